@@ -1,0 +1,281 @@
+"""Host-side structure ingest: PDB text -> atom table -> chain fragments -> SoA chain batch.
+
+Mirrors the host code that sits *above* the codec hot path in the reference:
+  * the fixed-column ATOM parser of the Python module (foldcomp/foldcomp.cxx:253-278),
+  * removeAlternativePosition (src/atom_coordinate.cpp:362-370),
+  * identifyChains / identifyDiscontinousResInd fragmenting (src/atom_coordinate.cpp:469-530,
+    used by the CLI at src/main.cpp:467-480),
+  * splitAtomByResidue (src/atom_coordinate.cpp:304-328) -> the residue->atom offsets of the batch.
+The output is the structure-of-arrays `fcz_chain_batch` of include/fcz_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from ._aa_tables import ATOM_NAMES, RES3
+
+ATOM_CODE = {n: i for i, n in enumerate(ATOM_NAMES)}
+ATOM_CODE_OTHER = 255
+ATOM_CODE_OXT = ATOM_CODE["OXT"]
+# names Foldcomp::compress accepts (AAS.at(name), src/sidechain.cpp:177): the 20 standard + literal UNK
+RES_CODE = {n: i for i, n in enumerate(RES3) if i < 20 or n == "UNK"}
+
+
+class StructureError(ValueError):
+    pass
+
+
+@dataclass
+class AtomTable:
+    """AoS-free atom records of one input file (the reference's std::vector<AtomCoordinate>)."""
+    atom: List[str]
+    residue: List[str]
+    chain: List[str]
+    atom_index: np.ndarray
+    res_index: np.ndarray
+    xyz: np.ndarray          # (n,3) float32
+    bfac: np.ndarray         # (n,) float32
+
+    def __len__(self):
+        return len(self.atom)
+
+    def take(self, sl: slice) -> "AtomTable":
+        return AtomTable(self.atom[sl], self.residue[sl], self.chain[sl], self.atom_index[sl],
+                         self.res_index[sl], self.xyz[sl], self.bfac[sl])
+
+    def keep(self, mask: np.ndarray) -> "AtomTable":
+        idx = np.nonzero(mask)[0]
+        return AtomTable([self.atom[i] for i in idx], [self.residue[i] for i in idx],
+                         [self.chain[i] for i in idx], self.atom_index[idx], self.res_index[idx],
+                         self.xyz[idx], self.bfac[idx])
+
+
+def parse_pdb(text: str, *, hetatm: bool = False, single_chain: bool = False) -> AtomTable:
+    """Fixed-column PDB ATOM parser (foldcomp/foldcomp.cxx:259-278).
+
+    single_chain=True reproduces the Python binding: a second chain id raises
+    StructureError("multiple chains") (flag 2 at foldcomp.cxx:264-266).
+    """
+    atom, residue, chain = [], [], []
+    ai, ri, xyz, bf = [], [], [], []
+    first_chain = None
+    for line in text.splitlines():
+        if line.startswith("ATOM") or (hetatm and line.startswith("HETATM")):
+            ch = line[21:22]
+            if first_chain is None:
+                first_chain = ch
+            if single_chain and ch != first_chain:
+                raise StructureError("multiple chains")
+            atom.append(line[12:16].strip())
+            residue.append(line[17:20].strip())
+            chain.append(ch)
+            ai.append(int(line[6:11]))
+            ri.append(int(line[22:26]))
+            xyz.append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
+            b = line[60:66].strip()
+            bf.append(float(b) if b else 0.0)
+    return AtomTable(atom, residue, chain, np.asarray(ai, np.int32), np.asarray(ri, np.int32),
+                     np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3),
+                     np.asarray(bf, np.float64).astype(np.float32))
+
+
+def remove_alternative_position(t: AtomTable) -> AtomTable:
+    """Drop an atom whose name equals the previous (kept) atom's name (atom_coordinate.cpp:362-370)."""
+    keep = np.ones(len(t), bool)
+    prev = None
+    for i, a in enumerate(t.atom):
+        if prev is not None and a == prev:
+            keep[i] = False
+        else:
+            prev = a
+    return t if keep.all() else t.keep(keep)
+
+
+def identify_chains(t: AtomTable) -> List[slice]:
+    """identifyChains (src/atom_coordinate.cpp:469-497): split where the chain id changes; the new
+    fragment must start at an atom named N, otherwise atoms are skipped up to the next N."""
+    out = []
+    n = len(t)
+    start = 0
+    i = 1
+    while i < n:
+        if t.chain[i] != t.chain[i - 1]:
+            if t.atom[i] == "N":
+                out.append(slice(start, i))
+                start = i
+            else:
+                j = next((j for j in range(i, n) if t.atom[j] == "N"), None)
+                if j is None:
+                    break  # (the reference would spin here; nothing compressible follows)
+                out.append(slice(start, i))
+                start = j
+                i = start
+        i += 1
+    out.append(slice(start, n))
+    return out
+
+
+def identify_discontinuous(t: AtomTable, sl: slice) -> List[slice]:
+    """identifyDiscontinousResInd (src/atom_coordinate.cpp:506-530): look only at N atoms and split
+    where consecutive residue numbers differ by more than 1; a fragment starts at its first N."""
+    n_idx = [i for i in range(sl.start, sl.stop) if t.atom[i] == "N"]
+    if not n_idx:
+        return []
+    out = []
+    start = n_idx[0]
+    for a, b in zip(n_idx[:-1], n_idx[1:]):
+        if int(t.res_index[b]) - int(t.res_index[a]) > 1:
+            out.append(slice(start, b))
+            start = b
+    out.append(slice(start, sl.stop))
+    return out
+
+
+@dataclass
+class Chain:
+    """One gap-free single-chain fragment = one FCZ record (one `Foldcomp` object in the reference)."""
+    title: str
+    atoms: AtomTable
+
+
+def split_residues(t: AtomTable) -> np.ndarray:
+    """Residue boundaries as atom offsets [n_res+1] (splitAtomByResidue, atom_coordinate.cpp:304-328:
+    a new residue starts where residue_index changes; the last atom always joins the open residue)."""
+    n = len(t)
+    if n == 0:
+        return np.zeros(1, np.uint32)
+    ri = t.res_index
+    change = np.nonzero(ri[1:] != ri[:-1])[0] + 1
+    change = change[change != n - 1]  # quirk: the final atom never opens a residue of its own
+    return np.concatenate(([0], change, [n])).astype(np.uint32)
+
+
+@dataclass
+class ChainBatch:
+    """SoA batch of chains == `fcz_chain_batch` (include/fcz_hip.h)."""
+    res_off: np.ndarray
+    atom_off: np.ndarray
+    x: np.ndarray
+    y: np.ndarray
+    z: np.ndarray
+    atom_code: np.ndarray
+    res_code: np.ndarray
+    bfac_ca: np.ndarray
+    first_res_index: np.ndarray
+    first_atom_index: np.ndarray
+    chain_id: np.ndarray      # uint8 (chars)
+    titles: np.ndarray        # uint8
+    title_off: np.ndarray
+    anchor_threshold: int = 25
+    _keep: list = field(default_factory=list, repr=False)
+
+    @property
+    def n_chains(self):
+        return len(self.res_off) - 1
+
+    @property
+    def n_residues(self):
+        return int(self.res_off[-1])
+
+    @property
+    def n_atoms(self):
+        return int(self.atom_off[-1])
+
+
+def build_batch(chains: Sequence[Chain], anchor_threshold: int = 25) -> ChainBatch:
+    res_off = [0]
+    atom_off_parts = []
+    xs, codes, rcodes, bfs = [], [], [], []
+    fri, fai, cid = [], [], []
+    titles = bytearray()
+    title_off = [0]
+    abase = 0
+    for ch in chains:
+        t = ch.atoms
+        if len(t) == 0:
+            raise StructureError("empty chain")
+        ro = split_residues(t)
+        nres = len(ro) - 1
+        ac = np.fromiter((ATOM_CODE.get(a, ATOM_CODE_OTHER) for a in t.atom), np.uint8, len(t))
+        rc = np.empty(nres, np.uint8)
+        bf = np.zeros(nres, np.float32)
+        for r in range(nres):
+            name = t.residue[ro[r]]
+            code = RES_CODE.get(name)
+            if code is None:
+                # the reference throws std::out_of_range here (src/sidechain.cpp:177)
+                raise StructureError(f"residue name {name!r} is not supported by the codec")
+            rc[r] = code
+            seg = ac[ro[r]:ro[r + 1]]
+            # N, CA, C must be present (backbone = filterBackbone order), ABI precondition
+            pos = [np.nonzero(seg == k)[0] for k in (0, 1, 2)]
+            if any(len(p) == 0 for p in pos) or not (pos[0][0] < pos[1][0] < pos[2][0]):
+                raise StructureError("residue without N, CA, C backbone atoms in order")
+            bf[r] = t.bfac[ro[r] + pos[1][0]]
+        atom_off_parts.append(ro[:-1] + abase)
+        abase += len(t)
+        res_off.append(res_off[-1] + nres)
+        xs.append(t.xyz); codes.append(ac); rcodes.append(rc); bfs.append(bf)
+        fri.append(int(t.res_index[0])); fai.append(int(t.atom_index[0]))
+        cid.append(ord(t.chain[0][0]) if t.chain[0] else ord(" "))
+        tb = ch.title.encode("latin-1", "replace")
+        titles += tb
+        title_off.append(len(titles))
+    xyz = np.concatenate(xs) if xs else np.zeros((0, 3), np.float32)
+    atom_off = np.concatenate(atom_off_parts + [np.asarray([abase])]).astype(np.uint32)
+    return ChainBatch(
+        res_off=np.asarray(res_off, np.uint32), atom_off=atom_off,
+        x=np.ascontiguousarray(xyz[:, 0]), y=np.ascontiguousarray(xyz[:, 1]), z=np.ascontiguousarray(xyz[:, 2]),
+        atom_code=np.concatenate(codes), res_code=np.concatenate(rcodes), bfac_ca=np.concatenate(bfs),
+        first_res_index=np.asarray(fri, np.int32), first_atom_index=np.asarray(fai, np.int32),
+        chain_id=np.asarray(cid, np.uint8), titles=np.frombuffer(bytes(titles) or b"\0", np.uint8).copy()[:len(titles)] if len(titles) else np.zeros(0, np.uint8),
+        title_off=np.asarray(title_off, np.uint32), anchor_threshold=anchor_threshold)
+
+
+# ---- ctypes view of the batch ---------------------------------------------------------------
+class CChainBatch(ctypes.Structure):
+    _fields_ = [
+        ("n_chains", ctypes.c_uint32), ("n_residues", ctypes.c_uint32), ("n_atoms", ctypes.c_uint32),
+        ("anchor_threshold", ctypes.c_int32),
+        ("res_off", ctypes.c_void_p), ("atom_off", ctypes.c_void_p),
+        ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("z", ctypes.c_void_p),
+        ("atom_code", ctypes.c_void_p), ("res_code", ctypes.c_void_p), ("bfac_ca", ctypes.c_void_p),
+        ("first_res_index", ctypes.c_void_p), ("first_atom_index", ctypes.c_void_p),
+        ("chain_id", ctypes.c_void_p), ("titles", ctypes.c_void_p), ("title_off", ctypes.c_void_p),
+    ]
+
+
+class CAtomsOut(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("z", ctypes.c_void_p),
+                ("bfac_res", ctypes.c_void_p), ("res_code", ctypes.c_void_p), ("atom_code", ctypes.c_void_p)]
+
+
+class CEntryInfo(ctypes.Structure):
+    _fields_ = [("n_residues", ctypes.c_uint32), ("n_atoms_out", ctypes.c_uint32),
+                ("n_atoms_header", ctypes.c_uint32), ("first_res_index", ctypes.c_int32),
+                ("first_atom_index", ctypes.c_int32), ("n_anchors", ctypes.c_uint32),
+                ("n_sidechain_torsions", ctypes.c_uint32), ("title_off", ctypes.c_uint32),
+                ("title_len", ctypes.c_uint32), ("chain_id", ctypes.c_char),
+                ("first_residue", ctypes.c_char), ("last_residue", ctypes.c_char),
+                ("has_oxt", ctypes.c_uint8), ("status", ctypes.c_int32)]
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    return a.ctypes.data if a.size else None
+
+
+def batch_as_c(b: ChainBatch) -> CChainBatch:
+    """Host-pointer view (numpy arrays must stay alive while the struct is in use)."""
+    s = CChainBatch()
+    s.n_chains, s.n_residues, s.n_atoms = b.n_chains, b.n_residues, b.n_atoms
+    s.anchor_threshold = int(b.anchor_threshold)
+    for name in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca",
+                 "first_res_index", "first_atom_index", "chain_id", "titles", "title_off"):
+        setattr(s, name, _ptr(getattr(b, name)))
+    return s

@@ -1,0 +1,181 @@
+/* fcz_hip.h -- C-ABI of the MI355X-native Foldcomp codec hot path (libfcz_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, integer status codes,
+ * no exceptions. The reference (steineggerlab/foldcomp) has no FFI for this path -- it is entered
+ * through the C++ class `Foldcomp`. Each entry point below names the reference interface it replaces
+ * (file:line under the reference tree); INTEGRATION.md shows the binding a maintainer would add.
+ *
+ *   reference                                              this ABI
+ *   ---------------------------------------------------    ------------------------------------------
+ *   Foldcomp::compress(span<AtomCoordinate>)               fcz_compress_batch / fcz_compress_batch_dev
+ *     src/foldcomp.cpp:562 (+preprocess :450)
+ *   Foldcomp::writeStream(ostream&)  src/foldcomp.cpp:1038   (the FCZ bytes are what compress returns)
+ *   Foldcomp::getSize()              src/foldcomp.cpp:1190   fcz_compress_sizes / fcz_compress_sizes_dev
+ *   Foldcomp::read(istream&)         src/foldcomp.cpp:904    fcz_decompress_sizes (+ header parse)
+ *   Foldcomp::decompress(vector<AtomCoordinate>&)          fcz_decompress_batch / fcz_decompress_batch_dev
+ *     src/foldcomp.cpp:779
+ *   Foldcomp::checkValidity()        src/foldcomp.cpp:1492   fcz_check
+ *
+ * Batch-first: one call handles C independent chains ("one wavefront per chain" on the device).
+ * Data layout is structure-of-arrays; all offsets are element indices, not bytes, unless noted.
+ *
+ * Threading: an fcz_ctx owns one HIP stream + device scratch on one GPU; use one ctx per host thread.
+ */
+#ifndef FCZ_HIP_H
+#define FCZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum fcz_status {
+    FCZ_OK = 0,
+    FCZ_E_INVALID_ARG = -1,
+    FCZ_E_NO_DEVICE = -2,       /* no HIP device / HIP runtime error; the library has NO CPU fallback */
+    FCZ_E_HIP = -3,
+    FCZ_E_BAD_MAGIC = -4,       /* Foldcomp::read returns -1 (src/foldcomp.cpp:911-915) */
+    FCZ_E_TRUNCATED = -5,       /* FCZ entry shorter than its header promises */
+    FCZ_E_RESIDUE = -6,         /* residue code the reference cannot process (AAS.at throws, src/sidechain.cpp:177) */
+    FCZ_E_TOO_SHORT = -7,       /* chain with < 2 residues: undefined in the reference */
+    FCZ_E_NOMEM = -8
+};
+
+/* ---- vocabulary --------------------------------------------------------------------------- */
+/* Residue codes: the reference's 5-bit codes (src/utility.h:133-206):
+ *   ALA0 ARG1 ASN2 ASP3 CYS4 GLN5 GLU6 GLY7 HIS8 ILE9 LEU10 LYS11 MET12 PHE13 PRO14 SER15 THR16
+ *   TRP17 TYR18 VAL19 ASX20 GLX21 STP22 UNK23.
+ * Atom codes: 0=N 1=CA 2=C 3=O 4=CB ... 35=OH, 36=OXT, 255=any other name (see fcz_atom_code_name).
+ */
+#define FCZ_ATOM_CODE_OXT 36
+#define FCZ_ATOM_CODE_OTHER 255
+
+/* Compress input: C chains, R residues in total, M atoms in total. Caller-owned.
+ * Replaces the tcb::span<AtomCoordinate> handed to Foldcomp::compress (src/main.cpp:485-488).
+ * Preconditions (the reference's input domain): every residue holds atoms
+ * named N, CA, C; residues of a chain are gap-free; residue names are the 20 standard ones or UNK. */
+typedef struct fcz_chain_batch {
+    uint32_t n_chains;              /* C */
+    uint32_t n_residues;            /* R */
+    uint32_t n_atoms;               /* M */
+    int32_t  anchor_threshold;      /* `-b`, Foldcomp::anchorThreshold (default 25) */
+    const uint32_t* res_off;        /* [C+1] residues of chain c = [res_off[c], res_off[c+1]) */
+    const uint32_t* atom_off;       /* [R+1] atoms of residue r = [atom_off[r], atom_off[r+1]) (input order) */
+    const float*    x;              /* [M] */
+    const float*    y;              /* [M] */
+    const float*    z;              /* [M] */
+    const uint8_t*  atom_code;      /* [M] */
+    const uint8_t*  res_code;       /* [R] */
+    const float*    bfac_ca;        /* [R] tempFactor of the residue's CA atom (src/foldcomp.cpp:543-547) */
+    const int32_t*  first_res_index;  /* [C] header.idxResidue (src/foldcomp.cpp:464) */
+    const int32_t*  first_atom_index; /* [C] header.idxAtom */
+    const char*     chain_id;       /* [C] */
+    const char*     titles;         /* concatenated titles, no NULs */
+    const uint32_t* title_off;      /* [C+1] byte offsets into titles */
+} fcz_chain_batch;
+
+/* Decompress output: SoA coordinates of all atoms of all chains in reference output order
+ * (canonical atom order of src/amino_acid.h, or the `-a` order), OXT last when present.
+ * Replaces the std::vector<AtomCoordinate>& filled by Foldcomp::decompress. Caller-owned. */
+typedef struct fcz_atoms_out {
+    float*    x;            /* [M] */
+    float*    y;            /* [M] */
+    float*    z;            /* [M] */
+    float*    bfac_res;     /* [R] de-quantised B-factor of each residue (src/foldcomp.cpp:884-892) */
+    uint8_t*  res_code;     /* [R] */
+    uint8_t*  atom_code;    /* [M] optional (may be NULL) */
+} fcz_atoms_out;
+
+/* Parsed per-entry header fields a caller needs to rebuild AtomCoordinate records / PDB text. */
+typedef struct fcz_entry_info {
+    uint32_t n_residues;
+    uint32_t n_atoms_out;       /* atoms the decompressor emits (incl. OXT) */
+    uint32_t n_atoms_header;    /* header.nAtom */
+    int32_t  first_res_index;
+    int32_t  first_atom_index;
+    uint32_t n_anchors;
+    uint32_t n_sidechain_torsions;
+    uint32_t title_off;         /* byte offset of the title inside the entry */
+    uint32_t title_len;
+    char     chain_id;
+    char     first_residue;     /* one-letter */
+    char     last_residue;
+    uint8_t  has_oxt;
+    int32_t  status;            /* FCZ_OK or the reason this entry is skipped */
+} fcz_entry_info;
+
+typedef struct fcz_ctx fcz_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int  fcz_ctx_create(int device, fcz_ctx** out);
+void fcz_ctx_destroy(fcz_ctx* ctx);
+/* hipStream_t of the ctx as an opaque pointer (all *_dev entry points enqueue on it). */
+void* fcz_ctx_stream(fcz_ctx* ctx);
+int  fcz_ctx_synchronize(fcz_ctx* ctx);
+const char* fcz_status_string(int status);
+const char* fcz_atom_code_name(int atom_code);     /* "N", "CA", ... "OXT"; NULL if out of range */
+int  fcz_atom_code_from_name(const char* name);    /* 255 for unknown names */
+int  fcz_res_code_from_name(const char* three_letter); /* -1 for names the reference rejects */
+const char* fcz_res_code_name(int res_code);
+int  fcz_res_code_natoms(int res_code);            /* atoms emitted per residue (3 for UNK) */
+/* canonical atom code of output position j of a residue (alt_order: the `-a` order) */
+int  fcz_res_code_atom(int res_code, int j, int alt_order);
+
+/* ---- compress ----------------------------------------------------------------------------- */
+/* Exact FCZ size of every chain -> exclusive prefix in out_off[C+1] (bytes). Host arrays.
+ * Pure host integer work (Foldcomp::getSize, src/foldcomp.cpp:1190-1214). */
+int fcz_compress_sizes(const fcz_chain_batch* in, uint64_t* out_off);
+
+/* Host-pointer convenience: copies the batch to the GPU, runs the kernels, copies FCZ bytes back
+ * into out[out_off[c] .. out_off[c+1]). status[c] (may be NULL) receives a per-chain fcz_status. */
+int fcz_compress_batch(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off,
+                       uint8_t* out, int32_t* status);
+
+/* Device-resident variant: every pointer inside `in`, plus out_off/out/status, is a device pointer
+ * (titles included). Work is enqueued on the ctx stream; no host synchronisation. `max_chain_res`
+ * is an upper bound of residues per chain (sizing of per-lane work), 0 = unknown (library scans). */
+int fcz_compress_sizes_dev(fcz_ctx* ctx, const fcz_chain_batch* in, uint64_t* out_off_dev);
+int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off_dev,
+                           uint8_t* out_dev, int32_t* status_dev);
+
+/* ---- decompress --------------------------------------------------------------------------- */
+/* Parse the n entries blob[off[i] .. off[i+1]) (trailing bytes such as the MMseqs '\0' are ignored,
+ * like Foldcomp::read). Fills info[n] and the exclusive prefixes res_off[n+1] / atom_off[n+1]
+ * that size the output arrays. Entries that fail validation get info[i].status != FCZ_OK and
+ * contribute zero residues/atoms. Host arrays. */
+int fcz_decompress_sizes(const uint8_t* blob, const uint64_t* off, uint32_t n,
+                         fcz_entry_info* info, uint32_t* res_off, uint32_t* atom_off);
+
+int fcz_decompress_batch(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n,
+                         const uint32_t* res_off, const uint32_t* atom_off, int alt_order,
+                         const fcz_atoms_out* out);
+
+/* Device-resident variants. fcz_decompress_sizes_dev fills res_off_dev/atom_off_dev (n+1 each)
+ * and returns the totals through pinned host words after a stream sync (the only sync on this path:
+ * the caller needs R and M to allocate outputs). */
+int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                             uint32_t* res_off_dev, uint32_t* atom_off_dev,
+                             uint32_t* total_res, uint32_t* total_atoms);
+int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                             const uint32_t* res_off_dev, const uint32_t* atom_off_dev, int alt_order,
+                             const fcz_atoms_out* out_dev);
+
+/* ---- check -------------------------------------------------------------------------------- */
+/* Foldcomp::checkValidity (src/foldcomp.cpp:1492-1532) on one entry; returns the reference's
+ * ValidityError value (0 = SUCCESS .. 6) or a negative fcz_status if the entry cannot be read. */
+int fcz_check(const uint8_t* entry, uint64_t len);
+
+/* ---- introspection for benchmarks --------------------------------------------------------- */
+/* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
+ * group since the last reset: "compress", "decompress_backbone", "decompress_sidechain", ... */
+int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
+int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
+void fcz_ctx_reset_timing(fcz_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCZ_HIP_H */

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Build the real reference hot path from its own sources, in place, into oracle/_ref/.
+# TEST INFRASTRUCTURE ONLY. Needs /root/reference (absent on the GPU box: there the prebuilt
+# oracle/_ref/libfoldcomp_ref.so that travelled with the snapshot is used).
+# Flags mirror the reference's Release build (CMakeLists.txt: -O3 -DNDEBUG, C++17, x86-64 baseline,
+# i.e. no -march: the binary contains no FMA), see SURVEY.md §4 [probe].
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${FOLDCOMP_REFERENCE:-/root/reference}"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/src" ]; then
+  echo "build_ref.sh: $REF/src not present; keeping prebuilt $OUT (if any)" >&2
+  exit 0
+fi
+mkdir -p "$OUT"
+SRCS="amino_acid atom_coordinate discretizer foldcomp nerf sidechain torsion_angle utility"
+OBJS=""
+for s in $SRCS; do
+  g++ -O3 -DNDEBUG -std=c++17 -fPIC -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" \
+      -c "$REF/src/$s.cpp" -o "$OUT/$s.o" &
+  OBJS="$OBJS $OUT/$s.o"
+done
+g++ -O3 -DNDEBUG -std=c++17 -fPIC -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" \
+    -c "$HERE/ref_shim.cpp" -o "$OUT/ref_shim.o" &
+wait
+g++ -shared -o "$OUT/libfoldcomp_ref.so" $OBJS "$OUT/ref_shim.o"
+rm -f "$OUT"/*.o
+echo "built $OUT/libfoldcomp_ref.so"

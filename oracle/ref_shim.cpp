@@ -1,0 +1,164 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+//
+// A thin extern "C" driver around the *unmodified* reference sources as they lie under
+// /root/reference/src (compiled in place by oracle/build_ref.sh; the result goes to oracle/_ref/).
+// It exposes the reference's own per-chain entry points
+//   Foldcomp::compress  (src/foldcomp.cpp:562)  + Foldcomp::writeStream (src/foldcomp.cpp:1038)
+//   Foldcomp::read      (src/foldcomp.cpp:904)  + Foldcomp::decompress  (src/foldcomp.cpp:779)
+// over plain arrays, so that tests can pin the C restatement (oracle/fcz_oracle.c) and the HIP path
+// against the real thing, and bench.py can time the reference's CPU path ("cpu_baseline.kind":"reference").
+// Nothing of the reference is copied here: this file only *calls* it.
+#include "foldcomp.h"
+#include "atom_coordinate.h"
+#include "amino_acid.h"
+
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+static std::string trim_name(const char* p, int width) {
+    int b = 0, e = width;
+    while (b < e && (p[b] == ' ' || p[b] == '\0')) b++;
+    while (e > b && (p[e - 1] == ' ' || p[e - 1] == '\0')) e--;
+    return std::string(p + b, p + e);
+}
+
+extern "C" {
+
+// atom_names: n_atoms x 4 chars (space/NUL padded), res_names: n_atoms x 3 chars.
+// Returns the FCZ size written to out (or -needed if out_cap is too small, -1 on failure).
+long ref_compress(int n_atoms, const char* atom_names, const char* res_names, const char* chain_ids,
+                  const int* atom_index, const int* res_index,
+                  const float* x, const float* y, const float* z, const float* bfac,
+                  const char* title, int title_len, int anchor_threshold,
+                  unsigned char* out, long out_cap) {
+    std::vector<AtomCoordinate> atoms;
+    atoms.reserve(n_atoms);
+    for (int i = 0; i < n_atoms; i++) {
+        atoms.emplace_back(trim_name(atom_names + 4 * i, 4), trim_name(res_names + 3 * i, 3),
+                           std::string(1, chain_ids[i]), atom_index[i], res_index[i],
+                           x[i], y[i], z[i], 1.0f, bfac[i]);
+    }
+    Foldcomp c;
+    c.strTitle = std::string(title, title + title_len);
+    c.anchorThreshold = anchor_threshold;
+    try {
+        tcb::span<AtomCoordinate> sp(atoms.data(), atoms.size());
+        c.compress(sp);
+    } catch (...) {
+        return -1;
+    }
+    std::ostringstream oss;
+    c.writeStream(oss);
+    std::string s = oss.str();
+    if ((long)s.size() > out_cap) return -(long)s.size();
+    memcpy(out, s.data(), s.size());
+    // The 4 struct-padding bytes of CompressedFileHeader are uninitialised in the reference
+    // (src/foldcomp.h:118-136, src/foldcomp.cpp:1341); zero them so outputs are comparable.
+    if (s.size() >= 24) { out[14] = out[15] = out[22] = out[23] = 0; }
+    return (long)s.size();
+}
+
+// Pre-quantisation angles of one chain (Foldcomp::preprocess, src/foldcomp.cpp:450).
+// out arrays need n_res entries each; returns number of values per array (n_res-1) or -1.
+int ref_angles(int n_atoms, const char* atom_names, const char* res_names, const char* chain_ids,
+               const int* atom_index, const int* res_index,
+               const float* x, const float* y, const float* z, const float* bfac,
+               float* phi, float* psi, float* omega, float* n_ca_c, float* ca_c_n, float* c_n_ca,
+               float* sc_torsions, int sc_cap, int* n_sc) {
+    std::vector<AtomCoordinate> atoms;
+    for (int i = 0; i < n_atoms; i++) {
+        atoms.emplace_back(trim_name(atom_names + 4 * i, 4), trim_name(res_names + 3 * i, 3),
+                           std::string(1, chain_ids[i]), atom_index[i], res_index[i],
+                           x[i], y[i], z[i], 1.0f, bfac[i]);
+    }
+    Foldcomp c;
+    try {
+        tcb::span<AtomCoordinate> sp(atoms.data(), atoms.size());
+        c.preprocess(sp);
+    } catch (...) {
+        return -1;
+    }
+    size_t n = c.phi.size();
+    for (size_t i = 0; i < n; i++) {
+        phi[i] = c.phi[i]; psi[i] = c.psi[i]; omega[i] = c.omega[i];
+        n_ca_c[i] = c.n_ca_c_angle[i]; ca_c_n[i] = c.ca_c_n_angle[i]; c_n_ca[i] = c.c_n_ca_angle[i];
+    }
+    int k = 0;
+    for (auto& v : c.sideChainAnglesPerResidue)
+        for (float f : v) { if (k < sc_cap) sc_torsions[k] = f; k++; }
+    *n_sc = k;
+    return (int)n;
+}
+
+// Returns number of atoms (or -needed if cap too small; -1000-k on read error k).
+int ref_decompress(const unsigned char* fcz, long len, int alt_order,
+                   float* x, float* y, float* z, float* bfac,
+                   char* atom_names /*4 per atom*/, char* res_names /*3 per atom*/,
+                   int* atom_index, int* res_index, char* chain_ids, int cap,
+                   char* title_out, int title_cap, int* title_len) {
+    std::string s((const char*)fcz, (size_t)len);
+    std::istringstream iss(s);
+    Foldcomp c;
+    int flag = c.read(iss);
+    if (flag != 0) return -1000 + flag;
+    c.useAltAtomOrder = alt_order != 0;
+    std::vector<AtomCoordinate> atoms;
+    try {
+        flag = c.decompress(atoms);
+    } catch (...) {
+        return -1003;
+    }
+    if (flag != 0) return -1004;
+    if (title_len) {
+        *title_len = (int)c.strTitle.size();
+        if (title_out) memcpy(title_out, c.strTitle.data(), std::min<size_t>(title_cap, c.strTitle.size()));
+    }
+    if ((int)atoms.size() > cap) return -(int)atoms.size();
+    for (size_t i = 0; i < atoms.size(); i++) {
+        x[i] = atoms[i].coordinate.x; y[i] = atoms[i].coordinate.y; z[i] = atoms[i].coordinate.z;
+        bfac[i] = atoms[i].tempFactor;
+        memset(atom_names + 4 * i, ' ', 4);
+        memcpy(atom_names + 4 * i, atoms[i].atom.data(), std::min<size_t>(4, atoms[i].atom.size()));
+        memset(res_names + 3 * i, ' ', 3);
+        memcpy(res_names + 3 * i, atoms[i].residue.data(), std::min<size_t>(3, atoms[i].residue.size()));
+        atom_index[i] = atoms[i].atom_index;
+        res_index[i] = atoms[i].residue_index;
+        chain_ids[i] = atoms[i].chain.empty() ? ' ' : atoms[i].chain[0];
+    }
+    return (int)atoms.size();
+}
+
+// PDB text of a decompressed structure exactly as the reference writes it
+// (writeAtomCoordinatesToPDB, src/atom_coordinate.cpp:220-291). Returns length or -needed.
+long ref_decompress_pdb(const unsigned char* fcz, long len, int alt_order, char* out, long out_cap) {
+    std::string s((const char*)fcz, (size_t)len);
+    std::istringstream iss(s);
+    Foldcomp c;
+    if (c.read(iss) != 0) return -1;
+    c.useAltAtomOrder = alt_order != 0;
+    std::vector<AtomCoordinate> atoms;
+    try { c.decompress(atoms); } catch (...) { return -1; }
+    std::ostringstream oss;
+    writeAtomCoordinatesToPDB(atoms, c.strTitle, oss);
+    std::string o = oss.str();
+    if ((long)o.size() > out_cap) return -(long)o.size();
+    memcpy(out, o.data(), o.size());
+    return (long)o.size();
+}
+
+// extract (src/foldcomp.cpp:1260): type 0 = plddt, 1 = fasta. Returns length or -needed.
+long ref_extract(const unsigned char* fcz, long len, int type, int digits, char* out, long out_cap) {
+    std::string s((const char*)fcz, (size_t)len);
+    std::istringstream iss(s);
+    Foldcomp c;
+    if (c.read(iss) != 0) return -1;
+    std::string data;
+    c.extract(data, type, digits);
+    if ((long)data.size() > out_cap) return -(long)data.size();
+    memcpy(out, data.data(), data.size());
+    return (long)data.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""Batch codec object over the C-ABI: the host-side mirror of the reference's `Foldcomp` class
+(src/foldcomp.h:267-402) for many chains at once.
+
+    Foldcomp::compress + writeStream   ->  Codec.compress_batch(ChainBatch)   -> FCZ blob + offsets
+    Foldcomp::read + decompress        ->  Codec.decompress_batch(blob, off)  -> SoA atoms
+
+Host numpy arrays in, host numpy arrays out (copies ride the ctx stream). The device-resident entry
+points used by bench.py take raw device pointers (e.g. torch tensors' .data_ptr()).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .structure import CAtomsOut, CChainBatch, CEntryInfo, ChainBatch, batch_as_c
+
+
+class Codec:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.fcz_ctx_create(int(device), ctypes.byref(h)), "fcz_ctx_create")
+        self.ctx = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.fcz_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.fcz_ctx_stream(self.ctx) or 0)
+
+    def synchronize(self):
+        _lib.check(self.lib.fcz_ctx_synchronize(self.ctx), "fcz_ctx_synchronize")
+
+    # ---- compress -------------------------------------------------------------------------------
+    def compress_sizes(self, b: ChainBatch) -> np.ndarray:
+        cb = batch_as_c(b)
+        off = np.zeros(b.n_chains + 1, np.uint64)
+        _lib.check(self.lib.fcz_compress_sizes(ctypes.byref(cb), off.ctypes.data), "fcz_compress_sizes")
+        return off
+
+    def compress_batch(self, b: ChainBatch, strict: bool = True):
+        """-> (blob uint8[...], off uint64[C+1], status int32[C])"""
+        off = self.compress_sizes(b)
+        cb = batch_as_c(b)
+        out = np.zeros(int(off[-1]), np.uint8)
+        st = np.zeros(b.n_chains, np.int32)
+        rc = self.lib.fcz_compress_batch(self.ctx, ctypes.byref(cb), off.ctypes.data, out.ctypes.data, st.ctypes.data)
+        if rc != 0 and (strict or rc in (-1, -2, -3, -8)):
+            _lib.check(rc, "fcz_compress_batch")
+        return out, off, st
+
+    # ---- decompress -----------------------------------------------------------------------------
+    def decompress_sizes(self, blob: np.ndarray, off: np.ndarray):
+        n = len(off) - 1
+        blob = np.ascontiguousarray(blob, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        info = (CEntryInfo * max(n, 1))()
+        res_off = np.zeros(n + 1, np.uint32)
+        atom_off = np.zeros(n + 1, np.uint32)
+        _lib.check(self.lib.fcz_decompress_sizes(blob.ctypes.data, off.ctypes.data, n, ctypes.addressof(info),
+                                                 res_off.ctypes.data, atom_off.ctypes.data), "fcz_decompress_sizes")
+        return info, res_off, atom_off
+
+    def decompress_batch(self, blob: np.ndarray, off: np.ndarray, alt_order: bool = False):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        info, res_off, atom_off = self.decompress_sizes(blob, off)
+        M, R = int(atom_off[-1]), int(res_off[-1])
+        x = np.zeros(M, np.float32); y = np.zeros(M, np.float32); z = np.zeros(M, np.float32)
+        bf = np.zeros(R, np.float32); rc = np.zeros(R, np.uint8); ac = np.zeros(M, np.uint8)
+        out = CAtomsOut(x.ctypes.data, y.ctypes.data, z.ctypes.data, bf.ctypes.data, rc.ctypes.data, ac.ctypes.data)
+        if M:
+            _lib.check(self.lib.fcz_decompress_batch(self.ctx, blob.ctypes.data, off.ctypes.data, n, res_off.ctypes.data,
+                                                     atom_off.ctypes.data, int(alt_order), ctypes.byref(out)),
+                       "fcz_decompress_batch")
+        return dict(x=x, y=y, z=z, bfac_res=bf, res_code=rc, atom_code=ac, res_off=res_off, atom_off=atom_off, info=info)
+
+    # ---- timing ---------------------------------------------------------------------------------
+    def enable_timing(self, on: bool = True):
+        self.lib.fcz_ctx_enable_timing(self.ctx, int(on))
+
+    def reset_timing(self):
+        self.lib.fcz_ctx_reset_timing(self.ctx)
+
+    def kernel_time(self, name: str):
+        ms = ctypes.c_double(0); n = ctypes.c_uint64(0)
+        self.lib.fcz_ctx_kernel_time(self.ctx, name.encode(), ctypes.byref(ms), ctypes.byref(n))
+        return ms.value, n.value
+
+    # ---- numerics self-test hook ------------------------------------------------------------------
+    def selftest_math(self, mode: int, start_bits: int, stride: int, count: int) -> np.ndarray:
+        out = np.zeros(count, np.float32)
+        _lib.check(self.lib.fcz_selftest_math(self.ctx, mode, start_bits, stride, count, out.ctypes.data), "fcz_selftest_math")
+        return out

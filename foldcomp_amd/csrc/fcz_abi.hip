@@ -1,0 +1,498 @@
+// fcz_abi.hip -- C-ABI (include/fcz_hip.h) over the gfx950 kernels. No torch, no C++ types cross the ABI.
+// There is deliberately NO CPU fallback in this library: without a HIP device every compute entry
+// point returns FCZ_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "fcz_kernels.h"
+
+// second, host-side instance of the generated tables (integer metadata for sizes/validation)
+namespace host_tab {
+#undef FCZ_TABLE_QUAL
+#undef FCZ_T
+#define FCZ_TABLE_QUAL static const
+#define FCZ_T(name) h_##name
+#include "aa_tables.inc"
+}  // namespace host_tab
+
+using namespace fcz;
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            fprintf(stderr, "fcz_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return FCZ_E_HIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+namespace {
+
+struct dev_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return FCZ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return FCZ_E_NOMEM; }
+        cap = want;
+        return FCZ_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct timed_span { std::string name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct fcz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // scratch
+    dev_buf ang;        // compress: 6 x R floats
+    dev_buf sizes;      // compress: C x u64
+    dev_buf cnt;        // decompress: 3 x n u32 counts + n i32 status
+    dev_buf seg_off;    // decompress: (n+1) u32
+    dev_buf fwd;        // decompress: forward atoms
+    dev_buf bb;         // decompress: blended backbone
+    // staging for the host-pointer entry points
+    dev_buf stage[20];
+    uint32_t* pinned = nullptr;  // 4 words
+    bool timing = false;
+    std::vector<timed_span> spans;
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+};
+
+namespace {
+
+struct span_guard {
+    fcz_ctx* ctx; hipEvent_t a = nullptr, b = nullptr; const char* name;
+    span_guard(fcz_ctx* c, const char* n) : ctx(c), name(n) {
+        if (ctx->timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+    }
+    ~span_guard() {
+        if (ctx->timing) { (void)hipEventRecord(b, ctx->stream); ctx->spans.push_back({name, a, b}); }
+    }
+};
+
+void drain_spans(fcz_ctx* ctx) {
+    if (ctx->spans.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto& e = ctx->acc[s.name]; e.first += ms; e.second += 1; }
+        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+    }
+    ctx->spans.clear();
+}
+
+inline unsigned grid_for(uint32_t items, unsigned per_block) { return (items + per_block - 1) / per_block; }
+
+}  // namespace
+
+extern "C" {
+
+const char* fcz_status_string(int s) {
+    switch (s) {
+        case FCZ_OK: return "ok";
+        case FCZ_E_INVALID_ARG: return "invalid argument";
+        case FCZ_E_NO_DEVICE: return "no HIP device (libfcz_hip has no CPU fallback)";
+        case FCZ_E_HIP: return "HIP runtime error";
+        case FCZ_E_BAD_MAGIC: return "not an FCZ entry (bad magic)";
+        case FCZ_E_TRUNCATED: return "truncated or inconsistent FCZ entry";
+        case FCZ_E_RESIDUE: return "residue code not supported by the codec";
+        case FCZ_E_TOO_SHORT: return "chain shorter than 2 residues";
+        case FCZ_E_NOMEM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const char* fcz_atom_code_name(int code) {
+    if (code < 0 || code >= FCZ_N_ATOM_CODES) return nullptr;
+    return host_tab::h_atom_name[code];
+}
+int fcz_atom_code_from_name(const char* name) {
+    for (int i = 0; i < FCZ_N_ATOM_CODES; i++) if (strcmp(host_tab::h_atom_name[i], name) == 0) return i;
+    return FCZ_ATOM_CODE_OTHER;
+}
+int fcz_res_code_from_name(const char* n3) {
+    for (int i = 0; i < FCZ_N_RES_CODES; i++)
+        if (strcmp(host_tab::h_res3[i], n3) == 0) return (i < 20 || i == 23) ? i : -1;
+    return -1;
+}
+const char* fcz_res_code_name(int rc) { return (rc >= 0 && rc < FCZ_N_RES_CODES) ? host_tab::h_res3[rc] : "UNK"; }
+int fcz_res_code_natoms(int rc) { return (rc >= 0 && rc < FCZ_N_RES_CODES) ? host_tab::h_res_natoms[rc] : 3; }
+int fcz_res_code_atom(int rc, int j, int alt) {
+    if (rc < 0 || rc >= FCZ_N_RES_CODES) rc = 23;
+    if (j < 0 || j >= host_tab::h_res_natoms[rc]) return FCZ_ATOM_CODE_OTHER;
+    int slot = alt ? host_tab::h_res_alt_slot[rc][j] : j;
+    return host_tab::h_res_atom[rc][slot];
+}
+
+int fcz_ctx_create(int device, fcz_ctx** out) {
+    if (!out) return FCZ_E_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FCZ_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FCZ_E_NO_DEVICE;
+    fcz_ctx* c = new fcz_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FCZ_E_HIP; }
+    if (hipHostMalloc((void**)&c->pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FCZ_E_HIP; }
+    *out = c;
+    return FCZ_OK;
+}
+
+void fcz_ctx_destroy(fcz_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    drain_spans(c);
+    (void)hipStreamSynchronize(c->stream);
+    c->ang.release(); c->sizes.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release();
+    for (auto& b : c->stage) b.release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* fcz_ctx_stream(fcz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int fcz_ctx_synchronize(fcz_ctx* c) {
+    if (!c) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FCZ_OK;
+}
+int fcz_ctx_enable_timing(fcz_ctx* c, int enable) { if (!c) return FCZ_E_INVALID_ARG; drain_spans(c); c->timing = enable != 0; return FCZ_OK; }
+void fcz_ctx_reset_timing(fcz_ctx* c) { if (!c) return; drain_spans(c); c->acc.clear(); }
+int fcz_ctx_kernel_time(fcz_ctx* c, const char* name, double* ms, uint64_t* launches) {
+    if (!c || !name) return FCZ_E_INVALID_ARG;
+    drain_spans(c);
+    auto it = c->acc.find(name);
+    if (ms) *ms = it == c->acc.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == c->acc.end() ? 0 : it->second.second;
+    return FCZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compress
+// ------------------------------------------------------------------------------------------------
+int fcz_compress_sizes(const fcz_chain_batch* in, uint64_t* out_off) {
+    if (!in || !out_off || in->anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    uint64_t o = 0;
+    for (uint32_t c = 0; c < in->n_chains; c++) {
+        out_off[c] = o;
+        const uint32_t r0 = in->res_off[c], n = in->res_off[c + 1] - r0;
+        uint32_t nsc = 0;
+        for (uint32_t k = 0; k < n; k++) { uint32_t rc = in->res_code[r0 + k]; nsc += host_tab::h_res_natoms[rc < 24 ? rc : 23] - 3; }
+        o += make_layout(n, n / (uint32_t)in->anchor_threshold + 2, in->title_off[c + 1] - in->title_off[c], nsc).size;
+    }
+    out_off[in->n_chains] = o;
+    return FCZ_OK;
+}
+
+int fcz_compress_sizes_dev(fcz_ctx* ctx, const fcz_chain_batch* in, uint64_t* out_off_dev) {
+    if (!ctx || !in || !out_off_dev || in->anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (in->n_chains == 0) { HIP_TRY(hipMemsetAsync(out_off_dev, 0, sizeof(uint64_t), ctx->stream)); return FCZ_OK; }
+    int rc = ctx->sizes.ensure(sizeof(uint64_t) * (size_t)in->n_chains);
+    if (rc) return rc;
+    span_guard g(ctx, "compress_sizes");
+    hipLaunchKernelGGL(k_compress_sizes, dim3(grid_for(in->n_chains, 256)), dim3(256), 0, ctx->stream, *in, ctx->sizes.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, ctx->stream, in->n_chains, ctx->sizes.as<uint64_t>(), out_off_dev);
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off_dev, uint8_t* out_dev,
+                           int32_t* status_dev) {
+    if (!ctx || !in || !out_off_dev || !out_dev) return FCZ_E_INVALID_ARG;
+    if (in->anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (in->n_chains == 0) return FCZ_OK;
+    int rc = ctx->ang.ensure(sizeof(float) * 6 * (size_t)std::max<uint32_t>(in->n_residues, 1));
+    if (rc) return rc;
+    span_guard g(ctx, "compress");
+    hipLaunchKernelGGL(k_compress, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in,
+                       out_off_dev, out_dev, status_dev, ctx->ang.as<float>());
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+int fcz_compress_batch(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off, uint8_t* out, int32_t* status) {
+    if (!ctx || !in || !out_off || !out) return FCZ_E_INVALID_ARG;
+    if (in->anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t C = in->n_chains, R = in->n_residues, M = in->n_atoms;
+    if (C == 0) return FCZ_OK;
+    const uint32_t TL = in->title_off[C];
+    const uint64_t out_bytes = out_off[C];
+    struct item { const void* src; size_t bytes; };
+    const item items[] = {
+        {in->res_off, sizeof(uint32_t) * (C + 1)}, {in->atom_off, sizeof(uint32_t) * (R + 1)},
+        {in->x, sizeof(float) * M}, {in->y, sizeof(float) * M}, {in->z, sizeof(float) * M},
+        {in->atom_code, (size_t)M}, {in->res_code, (size_t)R}, {in->bfac_ca, sizeof(float) * R},
+        {in->first_res_index, sizeof(int32_t) * C}, {in->first_atom_index, sizeof(int32_t) * C},
+        {in->chain_id, (size_t)C}, {in->titles, (size_t)TL}, {in->title_off, sizeof(uint32_t) * (C + 1)},
+        {out_off, sizeof(uint64_t) * (C + 1)},
+    };
+    void* d[14];
+    for (int i = 0; i < 14; i++) {
+        int rc = ctx->stage[i].ensure(std::max<size_t>(items[i].bytes, 16));
+        if (rc) return rc;
+        d[i] = ctx->stage[i].p;
+        if (items[i].bytes) HIP_TRY(hipMemcpyAsync(d[i], items[i].src, items[i].bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = ctx->stage[14].ensure(std::max<uint64_t>(out_bytes, 16)); if (rc) return rc;
+    rc = ctx->stage[15].ensure(sizeof(int32_t) * C); if (rc) return rc;
+    fcz_chain_batch dv = *in;
+    dv.res_off = (const uint32_t*)d[0]; dv.atom_off = (const uint32_t*)d[1];
+    dv.x = (const float*)d[2]; dv.y = (const float*)d[3]; dv.z = (const float*)d[4];
+    dv.atom_code = (const uint8_t*)d[5]; dv.res_code = (const uint8_t*)d[6]; dv.bfac_ca = (const float*)d[7];
+    dv.first_res_index = (const int32_t*)d[8]; dv.first_atom_index = (const int32_t*)d[9];
+    dv.chain_id = (const char*)d[10]; dv.titles = (const char*)d[11]; dv.title_off = (const uint32_t*)d[12];
+    rc = fcz_compress_batch_dev(ctx, &dv, (const uint64_t*)d[13], ctx->stage[14].as<uint8_t>(), ctx->stage[15].as<int32_t>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->stage[14].p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> st_host;
+    int32_t* st = status;
+    if (!st) { st_host.resize(C); st = st_host.data(); }
+    HIP_TRY(hipMemcpyAsync(st, ctx->stage[15].p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int worst = FCZ_OK;
+    for (uint32_t c = 0; c < C; c++) if (st[c] != FCZ_OK) worst = st[c];
+    return worst;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decompress
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t h_u16(const uint8_t* p) { return p[0] | (p[1] << 8); }
+static inline uint32_t h_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+static void parse_entry(const uint8_t* e, uint64_t len, fcz_entry_info* info) {
+    memset(info, 0, sizeof *info);
+    if (len < 76) { info->status = FCZ_E_TRUNCATED; return; }
+    if (memcmp(e, "FCMP", 4) != 0) { info->status = FCZ_E_BAD_MAGIC; return; }
+    const uint32_t n = h_u16(e + 4);
+    info->n_residues = n;
+    info->n_atoms_header = h_u16(e + 6);
+    info->first_res_index = (int32_t)h_u16(e + 8);
+    info->first_atom_index = (int32_t)h_u16(e + 10);
+    info->n_anchors = e[12];
+    info->chain_id = (char)e[13];
+    info->n_sidechain_torsions = h_u32(e + 16);
+    info->first_residue = (char)e[20];
+    info->last_residue = (char)e[21];
+    info->title_len = h_u32(e + 24);
+    info->title_off = 76 + 4 * info->n_anchors;
+    if (info->title_len > len || info->n_sidechain_torsions > len) { info->status = FCZ_E_TRUNCATED; return; }
+    const rec_layout L = make_layout(n, info->n_anchors, info->title_len, info->n_sidechain_torsions);
+    if ((uint64_t)L.size > len) { info->status = FCZ_E_TRUNCATED; return; }
+    if (n < 2 || info->n_anchors < 2) { info->status = FCZ_E_TOO_SHORT; return; }
+    info->has_oxt = e[L.o_oxt];
+    uint32_t na = 0, nsc = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t rc = e[L.o_words + 8 * k] >> 3;
+        if (k == 0) { rc = 23; for (int i = 0; i < 24; i++) if (host_tab::h_res1[i] == info->first_residue) { rc = i; break; } }
+        if (rc >= 24) rc = 23;
+        if (!(rc < 20 || rc == 23)) { info->status = FCZ_E_RESIDUE; return; }
+        na += host_tab::h_res_natoms[rc]; nsc += host_tab::h_res_natoms[rc] - 3;
+    }
+    if (nsc != info->n_sidechain_torsions) { info->status = FCZ_E_TRUNCATED; return; }
+    for (uint32_t s = 0; s + 1 < info->n_anchors; s++) {
+        const int a = (int)h_u32(e + L.o_aidx + 4 * s), b = (int)h_u32(e + L.o_aidx + 4 * (s + 1));
+        if (a < 0 || b < a || b > (int)n - 1 || (s == 0 && a != 0) || (s + 2 == info->n_anchors && b != (int)n - 1)) {
+            info->status = FCZ_E_TRUNCATED; return;
+        }
+    }
+    info->n_atoms_out = na + (info->has_oxt ? 1 : 0);
+    info->status = FCZ_OK;
+}
+
+int fcz_decompress_sizes(const uint8_t* blob, const uint64_t* off, uint32_t n, fcz_entry_info* info, uint32_t* res_off,
+                         uint32_t* atom_off) {
+    if (!blob || !off || !res_off || !atom_off) return FCZ_E_INVALID_ARG;
+    uint32_t r = 0, a = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        res_off[i] = r; atom_off[i] = a;
+        fcz_entry_info tmp;
+        fcz_entry_info* pi = info ? &info[i] : &tmp;
+        parse_entry(blob + off[i], off[i + 1] - off[i], pi);
+        if (pi->status == FCZ_OK) { r += pi->n_residues; a += pi->n_atoms_out; }
+    }
+    res_off[n] = r; atom_off[n] = a;
+    return FCZ_OK;
+}
+
+int fcz_check(const uint8_t* e, uint64_t len) {
+    fcz_entry_info info;
+    parse_entry(e, len, &info);
+    if (info.status == FCZ_E_BAD_MAGIC || info.status == FCZ_E_TRUNCATED) return info.status;
+    const rec_layout L = make_layout(info.n_residues, info.n_anchors, info.title_len, info.n_sidechain_torsions);
+    bool empty_bb = true, empty_sc = true, empty_t = true;
+    for (uint32_t k = 0; k < info.n_residues; k++) {
+        const uint8_t* b = e + L.o_words + 8 * k;
+        if ((b[0] & 7) | b[1] | b[2] | b[3] | b[4]) empty_bb = false;
+        if (e[L.o_tbytes + k]) empty_t = false;
+    }
+    for (uint32_t k = 0; k < info.n_sidechain_torsions; k++) if (e[L.o_sc + k]) empty_sc = false;
+    if (empty_bb) return 4;
+    if (empty_sc) return 5;
+    if (empty_t) return 6;
+    return 0;
+}
+
+int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                             uint32_t* res_off_dev, uint32_t* atom_off_dev, uint32_t* total_res, uint32_t* total_atoms) {
+    if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
+    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
+    {
+        span_guard g(ctx, "decompress_sizes");
+        if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st);
+        hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, ctx->stream, n, cr, res_off_dev, ca, atom_off_dev, cs, ctx->seg_off.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (total_res) *total_res = ctx->pinned[0];
+    if (total_atoms) *total_atoms = ctx->pinned[1];
+    return FCZ_OK;
+}
+
+// The segment prefix (seg_off) lives in the ctx: fcz_decompress_sizes_dev computes it; the batch call
+// recomputes it when it is called without a preceding sizes call on the same entries.
+static int ensure_segments(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res,
+                           uint32_t* total_seg) {
+    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
+    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
+    if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st);
+    // scans of residues (scratch, reusing cr in place is not possible: use stage[16]) and segments
+    rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, ctx->stream, n, cr, ctx->stage[16].as<uint32_t>(), (const uint32_t*)nullptr,
+                       (uint32_t*)nullptr, cs, ctx->seg_off.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], ctx->stage[16].as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *total_res = ctx->pinned[0]; *total_seg = ctx->pinned[2];
+    return FCZ_OK;
+}
+
+int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                             const uint32_t* res_off_dev, const uint32_t* atom_off_dev, int alt_order,
+                             const fcz_atoms_out* out_dev) {
+    if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev || !out_dev) return FCZ_E_INVALID_ARG;
+    if (!out_dev->x || !out_dev->y || !out_dev->z || !out_dev->bfac_res) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return FCZ_OK;
+    uint32_t R = 0, S = 0;
+    int rc = ensure_segments(ctx, blob_dev, off_dev, n, &R, &S);
+    if (rc) return rc;
+    if (R == 0) return FCZ_OK;
+    rc = ctx->fwd.ensure(sizeof(v3) * 3 * ((size_t)R + S)); if (rc) return rc;
+    rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
+    const uint32_t* seg_off = ctx->seg_off.as<uint32_t>();
+    {
+        span_guard g(ctx, "decompress_forward");
+        hipLaunchKernelGGL(k_forward_nerf, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
+                           seg_off, ctx->fwd.as<v3>());
+    }
+    {
+        span_guard g(ctx, "decompress_reverse");
+        hipLaunchKernelGGL(k_reverse_blend, dim3(grid_for(S, BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
+                           seg_off, ctx->fwd.as<v3>(), ctx->bb.as<v3>());
+    }
+    {
+        span_guard g(ctx, "decompress_sidechain");
+        hipLaunchKernelGGL(k_sidechain, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
+                           res_off_dev, atom_off_dev, ctx->bb.as<v3>(), alt_order, *out_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+int fcz_decompress_batch(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, const uint32_t* res_off,
+                         const uint32_t* atom_off, int alt_order, const fcz_atoms_out* out) {
+    if (!ctx || !blob || !off || !res_off || !atom_off || !out) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return FCZ_OK;
+    const uint64_t blob_bytes = off[n];
+    const uint32_t R = res_off[n], M = atom_off[n];
+    int rc;
+    if ((rc = ctx->stage[0].ensure(std::max<uint64_t>(blob_bytes, 16)))) return rc;
+    if ((rc = ctx->stage[1].ensure(sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ctx->stage[2].ensure(sizeof(uint32_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ctx->stage[3].ensure(sizeof(uint32_t) * ((size_t)n + 1)))) return rc;
+    for (int i = 4; i < 7; i++) if ((rc = ctx->stage[i].ensure(std::max<size_t>(sizeof(float) * (size_t)M, 16)))) return rc;
+    if ((rc = ctx->stage[7].ensure(std::max<size_t>(sizeof(float) * (size_t)R, 16)))) return rc;
+    if ((rc = ctx->stage[8].ensure(std::max<size_t>((size_t)R, 16)))) return rc;
+    if ((rc = ctx->stage[9].ensure(std::max<size_t>((size_t)M, 16)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->stage[0].p, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[1].p, off, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[2].p, res_off, sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[3].p, atom_off, sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    fcz_atoms_out dv;
+    dv.x = ctx->stage[4].as<float>(); dv.y = ctx->stage[5].as<float>(); dv.z = ctx->stage[6].as<float>();
+    dv.bfac_res = ctx->stage[7].as<float>();
+    dv.res_code = out->res_code ? ctx->stage[8].as<uint8_t>() : nullptr;
+    dv.atom_code = out->atom_code ? ctx->stage[9].as<uint8_t>() : nullptr;
+    rc = fcz_decompress_batch_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
+                                  ctx->stage[3].as<uint32_t>(), alt_order, &dv);
+    if (rc) return rc;
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(out->x, dv.x, sizeof(float) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out->y, dv.y, sizeof(float) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out->z, dv.z, sizeof(float) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->atom_code) HIP_TRY(hipMemcpyAsync(out->atom_code, dv.atom_code, (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (R) {
+        HIP_TRY(hipMemcpyAsync(out->bfac_res, dv.bfac_res, sizeof(float) * (size_t)R, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->res_code) HIP_TRY(hipMemcpyAsync(out->res_code, dv.res_code, (size_t)R, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-test hooks: run the device numerics over caller-chosen float bit patterns so tests can pin
+// them against the host libm (tests/test_device_math.py). mode 0: acos_deg, 1: sinf, 2: cosf
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace fcz {
+__global__ void k_selftest_math(int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* __restrict__ outv) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float x = __uint_as_float(start_bits + i * stride);
+    float r = (mode == 0) ? acos_deg(x) : (mode == 1) ? sinf_glibc(x) : cosf_glibc(x);
+    outv[i] = r;
+}
+}  // namespace fcz
+
+extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host) {
+    if (!ctx || !out_host || mode < 0 || mode > 2) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (count == 0) return FCZ_OK;
+    int rc = ctx->stage[17].ensure(sizeof(float) * (size_t)count); if (rc) return rc;
+    hipLaunchKernelGGL(fcz::k_selftest_math, dim3(grid_for(count, 256)), dim3(256), 0, ctx->stream, mode, start_bits, stride, count,
+                       ctx->stage[17].as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, ctx->stage[17].p, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}

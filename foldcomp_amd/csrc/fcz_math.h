@@ -1,0 +1,265 @@
+// fcz_math.h -- device numerics of the FCZ codec for gfx950.
+//
+// Contract: every value that reaches an FCZ byte or an output coordinate is bit-identical to what the
+// reference computes on x86-64/glibc 2.35. The reference mixes float and
+// double at fixed points; those promotion points are reproduced literally. Compile this file with
+// -ffp-contract=off (no implicit FMA); every fused operation below is an explicit __builtin_fma in
+// code whose result is provably independent of the fusion (double-double error terms).
+//
+// Two host-libm functions sit on the path:
+//   * acos(double) in the dihedral / bond-angle measurement (src/torsion_angle.cpp:77-84,
+//     src/float3d.h:63). Only (float)(acos((double)c)*180.0/M_PI) of a *float* c is observable.
+//     Device: fast double evaluation + a float-rounding safety test; inputs whose result lies within
+//     2^-48 (relative) of a float rounding boundary are re-evaluated exactly (correctly rounded
+//     double acos via a double-double cosine comparison). glibc's acos is correctly rounded except
+//     for ~2^-17 of inputs, so the two agree except with probability ~1e-14 per value.
+//   * sinf/cosf (float) in Nerf::place_atom (src/nerf.cpp:67-71). glibc 2.35 uses the
+//     "optimized-routines" algorithm (double polynomial after one-step reduction); it is restated
+//     here operation by operation. tests/test_oracle_trig.py shows the plain (non-FMA) evaluation
+//     equals both glibc ifunc variants for every float |x| < 17.27, which covers every angle the
+//     codec can produce.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fcz {
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+// crossProduct, reference src/float3d.h:19-24
+__device__ __forceinline__ v3 vcross(v3 a, v3 b) {
+    v3 r;
+    r.x = a.y * b.z - b.y * a.z;
+    r.y = a.z * b.x - b.z * a.x;
+    r.z = a.x * b.y - b.x * a.y;
+    return r;
+}
+
+// norm, reference src/float3d.h:32-34 (double pow/sqrt, float result)
+__device__ __forceinline__ float vnorm(v3 v) {
+    double s = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z;
+    return (float)__builtin_sqrt(s);
+}
+
+// getCosineTheta, reference src/float3d.h:36-43
+__device__ __forceinline__ float vcos_theta(v3 a, v3 b) {
+    float ip = (a.x * b.x) + (a.y * b.y) + (a.z * b.z);
+    float s1 = a.x * a.x + a.y * a.y + a.z * a.z;
+    float s2 = b.x * b.x + b.y * b.y + b.z * b.z;
+    float p = s1 * s2;
+    return (float)((double)ip / __builtin_sqrt((double)p));
+}
+
+// ---- double-double helpers (slow path only) ---------------------------------------------------
+struct dd { double hi, lo; };
+__device__ __forceinline__ dd dd_two_sum(double a, double b) {
+    double s = a + b, bb = s - a;
+    return dd{s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd dd_quick_two_sum(double a, double b) {
+    double s = a + b;
+    return dd{s, b - (s - a)};
+}
+__device__ __forceinline__ dd dd_two_prod(double a, double b) {
+    double p = a * b;
+    return dd{p, __builtin_fma(a, b, -p)};
+}
+__device__ __forceinline__ dd dd_add(dd a, dd b) {
+    dd s = dd_two_sum(a.hi, b.hi);
+    dd t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_quick_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_quick_two_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+__device__ __forceinline__ dd dd_mul(dd a, dd b) {
+    dd p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick_two_sum(p.hi, p.lo);
+}
+__device__ __forceinline__ dd dd_div_d(dd a, double b) {
+    double q1 = a.hi / b;
+    dd p = dd_two_prod(q1, b);
+    dd r = dd_add(a, dd_neg(p));
+    double q2 = r.hi / b;
+    p = dd_two_prod(q2, b);
+    r = dd_add(r, dd_neg(p));
+    double q3 = r.hi / b;
+    dd q = dd_quick_two_sum(q1, q2);
+    return dd_add(q, dd{q3, 0.0});
+}
+
+// cos(t) for a double-double t in [0, pi], ~100 bits: cos t = -sin(t - pi/2), Taylor series.
+__device__ __noinline__ dd dd_cos_0_pi(dd t) {
+    const dd half_pi = dd{0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54};
+    dd y = dd_add(t, dd_neg(half_pi));
+    dd y2 = dd_mul(y, y);
+    dd term = y, sum = y;
+    for (int k = 1; k <= 22; k++) {
+        term = dd_div_d(dd_mul(term, y2), (double)((2 * k) * (2 * k + 1)));
+        sum = (k & 1) ? dd_add(sum, dd_neg(term)) : dd_add(sum, term);
+    }
+    return dd_neg(sum);
+}
+
+__device__ __forceinline__ double d_next_up(double a) {   // a > 0 finite
+    return __longlong_as_double(__double_as_longlong(a) + 1);
+}
+__device__ __forceinline__ double d_next_down(double a) { // a > 0 finite
+    return __longlong_as_double(__double_as_longlong(a) - 1);
+}
+
+// Correctly rounded acos of a float c in (-1, 1), c != 0 excluded nowhere: start from an
+// approximation a0 and walk to the double nearest to acos(c) using exact midpoint tests
+// acos(c) < m  <=>  c > cos(m)  (cos is decreasing on [0, pi]).
+__device__ __noinline__ double acos_correctly_rounded(float c, double a0) {
+    double a = a0;
+    for (int it = 0; it < 8; it++) {
+        double up = d_next_up(a), dn = d_next_down(a);
+        // midpoints as exact double-doubles
+        dd m_up = dd_two_sum(a, 0.5 * (up - a));
+        dd m_dn = dd_two_sum(a, -0.5 * (a - dn));
+        dd cu = dd_cos_0_pi(m_up);
+        dd du = dd_add(cu, dd{-(double)c, 0.0});       // cos(m_up) - c
+        if (!(du.hi < 0.0 || (du.hi == 0.0 && du.lo < 0.0))) { a = up; continue; }   // acos c >= m_up
+        dd cd = dd_cos_0_pi(m_dn);
+        dd dl = dd_add(cd, dd{-(double)c, 0.0});       // cos(m_dn) - c
+        if (dl.hi < 0.0 || (dl.hi == 0.0 && dl.lo < 0.0)) { a = dn; continue; }       // acos c < m_dn
+        break;
+    }
+    return a;
+}
+
+// (float)(acos((double)c) * 180.0 / M_PI), the only way the reference observes acos.
+// Returns NaN for |c| > 1 or NaN input (callers apply the reference's NaN guard where it has one).
+__device__ __forceinline__ float acos_deg(float c) {
+    const double kPi = 3.14159265358979323846;
+    double A = __ocml_acos_f64((double)c);
+    double D = A * 180.0 / kPi;
+    float f = (float)D;
+    // float-rounding safety: distance of D to the rounding boundary on its side of f
+    double e = D - (double)f;
+    float other = __uint_as_float(__float_as_uint(f) + ((e > 0.0) ? 1 : -1));
+    double mid = 0.5 * ((double)f + (double)other);
+    double dist = __builtin_fabs(D - mid);
+    // 32 ulp(double) of D; D in (0, 180]. (f == 0 only for c == 1 where A is exactly 0.)
+    if (__builtin_expect(dist < D * 0x1p-47 && f > 0.0f, 0)) {
+        A = acos_correctly_rounded(c, A);
+        D = A * 180.0 / kPi;
+        f = (float)D;
+    }
+    return f;
+}
+
+// one window of getTorsionFromXYZ, reference src/torsion_angle.cpp:50-94
+__device__ __forceinline__ float dihedral_deg(v3 a, v3 b, v3 c, v3 d) {
+    v3 d1 = vsub(b, a), d2 = vsub(c, b), d3 = vsub(d, c);
+    v3 u1 = vcross(d1, d2), u2 = vcross(d2, d3);
+    float ct = vcos_theta(u1, u2);
+    float t = acos_deg(ct);
+    if (t != t) t = (ct < 0.0f) ? 180.0f : 0.0f;   // isnan(acos) guard, :77-84
+    v3 w = vcross(u2, d2);
+    if ((u1.x * w.x) + (u1.y * w.y) + (u1.z * w.z) < 0.0f) t = -1.0f * t;
+    return t;
+}
+
+// angle, reference src/float3d.h:55-65 (no NaN guard)
+__device__ __forceinline__ float bond_angle_deg(v3 a, v3 b, v3 c) {
+    v3 d1 = vsub(a, b), d2 = vsub(c, b);
+    return acos_deg(vcos_theta(d1, d2));
+}
+
+// ---- glibc 2.35 sinf/cosf, |x| < 120 (sysdeps/ieee754/flt-32/{s_sinf.c,s_cosf.c,sincosf.h}) -----
+__device__ __forceinline__ float sc_poly(double x, double x2, int n, bool neg_cos) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+        double x7 = x3 * x2;
+        double s = x + x3 * -0x1.555545995a603p-3;
+        return (float)(s + x7 * s1);
+    } else {
+        double sg = neg_cos ? -1.0 : 1.0;
+        double x4 = x2 * x2;
+        double c2 = sg * -0x1.6c087e89a359dp-10 + x2 * (sg * 0x1.99343027bf8c3p-16);
+        double c1 = sg * 0x1p0 + x2 * (sg * -0x1.ffffffd0c621cp-2);
+        double x6 = x4 * x2;
+        double c = c1 + x4 * (sg * 0x1.55553e1068f19p-5);
+        return (float)(c + x6 * c2);
+    }
+}
+__device__ __forceinline__ uint32_t abstop12(float f) { return (__float_as_uint(f) >> 20) & 0x7ffu; }
+
+// sin (is_cos = 0) or cos (is_cos = 1) of a float |y| < 120
+__device__ __forceinline__ float sincosf_glibc(float y, int is_cos) {
+    double x = (double)y;
+    if (abstop12(y) < 0x3f4u) {            // abstop12(pi/4)
+        double x2 = x * x;
+        if (abstop12(y) < 0x398u)          // abstop12(0x1p-12f)
+            return is_cos ? 1.0f : y;
+        return sc_poly(x, x2, is_cos, false);
+    }
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    double s = ((n + 1) & 2) ? -1.0 : 1.0;  // sign table {1,-1,-1,1}[n & 3]
+    return sc_poly(x * s, x * x, n ^ is_cos, (n & 2) != 0);
+}
+__device__ __forceinline__ float sinf_glibc(float y) { return sincosf_glibc(y, 0); }
+__device__ __forceinline__ float cosf_glibc(float y) { return sincosf_glibc(y, 1); }
+
+// degrees -> radians as Nerf::place_atom does (src/nerf.cpp:63-64): double multiply, double divide,
+// rounded to float on assignment
+__device__ __forceinline__ float deg2rad(float deg) {
+    const double kPi = 3.14159265358979323846;
+    return (float)((double)deg * kPi / 180.0);
+}
+
+// Nerf::place_atom, reference src/nerf.cpp:39-104, with the trigonometry hoisted: d2 is the
+// "curr_atm" vector (-L cos(ba), L cos(ta) sin(ba), L sin(ta) sin(ba)) (:66-70).
+__device__ __forceinline__ v3 place_atom_d2(v3 a, v3 b, v3 c, v3 d2) {
+    v3 ab = vsub(b, a), bc = vsub(c, b);
+    float bc_norm = vnorm(bc);
+    v3 bcn = v3{bc.x / bc_norm, bc.y / bc_norm, bc.z / bc_norm};
+    v3 n = vcross(ab, bcn);
+    float n_norm = vnorm(n);
+    n.x = n.x / n_norm; n.y = n.y / n_norm; n.z = n.z / n_norm;
+    v3 nbc = vcross(n, bcn);
+    v3 D = v3{0.0f, 0.0f, 0.0f};
+    D.x += (bcn.x * d2.x); D.x += (nbc.x * d2.y); D.x += (n.x * d2.z);
+    D.y += (bcn.y * d2.x); D.y += (nbc.y * d2.y); D.y += (n.y * d2.z);
+    D.z += (bcn.z * d2.x); D.z += (nbc.z * d2.y); D.z += (n.z * d2.z);
+    D.x += c.x; D.y += c.y; D.z += c.z;
+    return D;
+}
+
+__device__ __forceinline__ v3 nerf_d2(float L, float bond_angle_deg_, float torsion_deg) {
+    float ba = deg2rad(bond_angle_deg_), ta = deg2rad(torsion_deg);
+    float sb = sinf_glibc(ba);
+    v3 d2;
+    d2.x = -1.0f * L * cosf_glibc(ba);
+    d2.y = L * cosf_glibc(ta) * sb;
+    d2.z = L * sinf_glibc(ta) * sb;
+    return d2;
+}
+
+__device__ __forceinline__ v3 place_atom(v3 a, v3 b, v3 c, float L, float ba_deg, float ta_deg) {
+    return place_atom_d2(a, b, c, nerf_d2(L, ba_deg, ta_deg));
+}
+
+// ---- quantisers, reference src/discretizer.cpp ----------------------------------------------------
+// vector discretize (:43-53): float product, double +0.5, truncation; NaN -> 0 like x86-64 gcc
+__device__ __forceinline__ uint32_t quant_round(float v, float mn, float disc_f) {
+    double d = (double)((v - mn) * disc_f) + 0.5;
+    return (d != d) ? 0u : (uint32_t)(long long)d;
+}
+// scalar discretize (:55-57): truncation of the float product
+__device__ __forceinline__ uint32_t quant_trunc(float v, float mn, float disc_f) {
+    float f = (v - mn) * disc_f;
+    return (f != f) ? 0u : (uint32_t)(long long)f;
+}
+__device__ __forceinline__ float dequant(uint32_t q, float mn, float cont_f) { return ((float)q * cont_f) + mn; }
+
+}  // namespace fcz

@@ -700,3 +700,53 @@ int fcz_oracle_decompress_batch(const uint8_t* blob, const uint64_t* off, uint32
     }
     return FCZ_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * pins for the restated libm pieces (used by tests only)
+ * ------------------------------------------------------------------------------------------- */
+/* number of float bit patterns u in [lo_bits, hi_bits) (both signs) where the restated sinf/cosf differ
+ * from the host libm */
+long fcz_oracle_trig_mismatches(uint32_t lo_bits, uint32_t hi_bits, int n_threads) {
+    long bad = 0;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : bad) schedule(static, 1 << 18) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (uint32_t u = lo_bits; u < hi_bits; u++) {
+        for (int sg = 0; sg < 2; sg++) {
+            uint32_t v = u | ((uint32_t)sg << 31);
+            float x, a, b;
+            memcpy(&x, &v, 4);
+            a = sinf(x); b = fcz_oracle_sinf(x);
+            if (memcmp(&a, &b, 4)) bad++;
+            a = cosf(x); b = fcz_oracle_cosf(x);
+            if (memcmp(&a, &b, 4)) bad++;
+        }
+    }
+    return bad;
+}
+
+/* host evaluation of the only way the codec observes acos: (float)(acos((double)c)*180.0/M_PI)
+ * (src/torsion_angle.cpp:84, src/float3d.h:63) for count consecutive-by-stride float bit patterns */
+void fcz_oracle_acos_deg_sweep(uint32_t start_bits, uint32_t stride, uint32_t count, float* out, int n_threads) {
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1 << 16) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t v = start_bits + i * stride;
+        float c; memcpy(&c, &v, 4);
+        out[i] = (float)(acos((double)c) * 180.0 / M_PI);
+    }
+}
+void fcz_oracle_sincos_sweep(int is_cos, uint32_t start_bits, uint32_t stride, uint32_t count, float* out, int n_threads) {
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1 << 16) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t v = start_bits + i * stride;
+        float c; memcpy(&c, &v, 4);
+        out[i] = is_cos ? cosf(c) : sinf(c);
+    }
+}

@@ -1,0 +1,96 @@
+"""CPU: the C-ABI shared library loads, exports every function include/fcz_hip.h declares, its pure-host
+entry points (sizes, header parse, check, code tables) work, and compute entry points fail loudly without
+a GPU instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _harness as H
+from _cases import compress_cases, db_cases, entries_blob, golden_batch
+from foldcomp_amd import _lib
+from foldcomp_amd.structure import CEntryInfo, batch_as_c
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "fcz_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fcz_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_built_and_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "libfcz_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fcz_hip.h but not exported"
+    assert set(_lib.EXPORTS) <= set(names)
+
+
+def test_code_tables():
+    lib = _lib.load()
+    assert lib.fcz_atom_code_name(0) == b"N" and lib.fcz_atom_code_name(36) == b"OXT"
+    assert lib.fcz_atom_code_from_name(b"CA") == 1 and lib.fcz_atom_code_from_name(b"H1") == 255
+    assert lib.fcz_res_code_from_name(b"TRP") == 17 and lib.fcz_res_code_from_name(b"MSE") == -1
+    assert lib.fcz_res_code_from_name(b"UNK") == 23 and lib.fcz_res_code_from_name(b"ASX") == -1
+    assert lib.fcz_res_code_natoms(17) == 14 and lib.fcz_res_code_natoms(7) == 4 and lib.fcz_res_code_natoms(23) == 3
+    # ALA canonical N CA C O CB, `-a` order N CA C CB O (reference src/amino_acid.h:71-74)
+    assert [lib.fcz_res_code_atom(0, j, 0) for j in range(5)] == [0, 1, 2, 3, 4]
+    assert [lib.fcz_res_code_atom(0, j, 1) for j in range(5)] == [0, 1, 2, 4, 3]
+
+
+def test_host_sizes_match_reference_record_sizes(golden):
+    z, index = golden
+    lib = _lib.load()
+    for name in compress_cases(index):
+        b = golden_batch(z, name)
+        cb = batch_as_c(b)
+        off = np.zeros(2, np.uint64)
+        assert lib.fcz_compress_sizes(ctypes.byref(cb), off.ctypes.data) == 0
+        assert int(off[1]) == len(z[f"{name}/fcz"]), name
+
+
+def test_host_entry_parse_and_check(golden):
+    z, index = golden
+    lib = _lib.load()
+    names = compress_cases(index) + db_cases(index)
+    blob, off = entries_blob([z[f"{n}/fcz"].tobytes() for n in names])
+    n = len(names)
+    info = (CEntryInfo * n)()
+    ro = np.zeros(n + 1, np.uint32); ao = np.zeros(n + 1, np.uint32)
+    assert lib.fcz_decompress_sizes(blob.ctypes.data, off.ctypes.data, n, ctypes.addressof(info), ro.ctypes.data, ao.ctypes.data) == 0
+    for i, nm in enumerate(names):
+        assert info[i].status == 0, nm
+        assert info[i].n_atoms_out == len(z[f"{nm}/xyz0"]), nm
+        e = z[f"{nm}/fcz"].tobytes()
+        assert lib.fcz_check(e, len(e)) == H.load_oracle().fcz_oracle_check(e, len(e))
+    # same verdicts as the oracle's parser on damaged entries
+    e = z["pdb:test_af/fcz"].tobytes()
+    for bad, want in ((b"XXXX" + e[4:], -4), (e[:100], -5), (e[:40], -5)):
+        bb, oo = entries_blob([bad])
+        inf = (CEntryInfo * 1)()
+        lib.fcz_decompress_sizes(bb.ctypes.data, oo.ctypes.data, 1, ctypes.addressof(inf), ro.ctypes.data, ao.ctypes.data)
+        assert inf[0].status == want
+        assert ro[1] == 0 and ao[1] == 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """on a box without a HIP device ctx creation must fail; nothing computes on the CPU"""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.fcz_ctx_create(0, ctypes.byref(h)) == -2
+    from foldcomp_amd.codec import Codec
+    with pytest.raises(_lib.FczLibraryError):
+        Codec(0)

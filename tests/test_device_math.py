@@ -1,0 +1,68 @@
+"""GPU: the device numerics (fcz_math.h) against the host libm, bit for bit.
+ * acos_deg(c) == (float)(acos((double)c)*180.0/M_PI) on strided sweeps over every float in [-1,1]
+ * sinf/cosf restatement == libm sinf/cosf on sweeps over |x| < 8"""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import _harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _b(f):
+    return struct.unpack("<I", struct.pack("<f", f))[0]
+
+
+def _host_acos(start, stride, count):
+    lib = H.load_oracle()
+    lib.fcz_oracle_acos_deg_sweep.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+    out = np.zeros(count, np.float32)
+    lib.fcz_oracle_acos_deg_sweep(start, stride, count, out.ctypes.data, min(32, os.cpu_count() or 1))
+    return out
+
+
+def _host_sincos(is_cos, start, stride, count):
+    lib = H.load_oracle()
+    lib.fcz_oracle_sincos_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+    out = np.zeros(count, np.float32)
+    lib.fcz_oracle_sincos_sweep(is_cos, start, stride, count, out.ctypes.data, min(32, os.cpu_count() or 1))
+    return out
+
+
+@pytest.mark.parametrize("sign", [0, 0x80000000])
+def test_acos_deg_strided_sweep(codec, sign):
+    one = _b(1.0)
+    stride = 61                      # odd stride: hits every mantissa residue class over the sweep
+    count = one // stride + 1
+    dev = codec.selftest_math(0, sign, stride, count)
+    host = _host_acos(sign, stride, count)
+    a, b = dev.view(np.uint32), host.view(np.uint32)
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) == 0, (len(bad), [(hex(sign + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])
+
+
+def test_acos_deg_dense_near_one(codec):
+    """the steep end: every float in [0.999, 1] and [-1, -0.999] plus out-of-range / NaN inputs"""
+    for sign in (0, 0x80000000):
+        lo, hi = _b(0.999), _b(1.0)
+        dev = codec.selftest_math(0, sign + lo, 1, hi - lo + 8)
+        host = _host_acos(sign + lo, 1, hi - lo + 8)
+        a, b = dev.view(np.uint32), host.view(np.uint32)
+        nan = np.isnan(dev) & np.isnan(host)
+        assert ((a == b) | nan).all()
+
+
+@pytest.mark.parametrize("is_cos", [0, 1])
+def test_sincos_sweep(codec, is_cos):
+    for sign in (0, 0x80000000):
+        stride = 13
+        count = _b(8.0) // stride
+        dev = codec.selftest_math(1 + is_cos, sign, stride, count)
+        host = _host_sincos(is_cos, sign, stride, count)
+        a, b = dev.view(np.uint32), host.view(np.uint32)
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, (len(bad), [(hex(sign + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])

@@ -1,0 +1,100 @@
+"""CPU: the C restatement (oracle/) against vectors minted from the real reference (tests/golden/,
+made by tools/make_goldens.py) -- FCZ bytes bit-exact (4 uninitialised header pad bytes masked),
+pre-quantisation angles and decompressed float32 coordinates bit-exact."""
+import numpy as np
+import pytest
+
+import _harness as H
+from _cases import compress_cases, db_cases, entries_blob, golden_batch
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_golden_index(golden):
+    z, index = golden
+    assert len(index) >= 50
+    assert sum(n.startswith("db:") for n in index) == 24
+
+
+def test_oracle_compress_matches_reference_bytes(golden):
+    z, index = golden
+    for name in compress_cases(index):
+        b = golden_batch(z, name)
+        blob, off, st = H.oracle_compress(b)
+        assert st[0] == 0, name
+        assert blob.tobytes() == z[f"{name}/fcz"].tobytes(), name
+
+
+def test_oracle_decompress_matches_reference_bits(golden):
+    z, index = golden
+    names = compress_cases(index) + db_cases(index)
+    for alt in (0, 1):
+        use = [n for n in names if f"{n}/xyz{alt}" in z]
+        blob, off = entries_blob([z[f"{n}/fcz"].tobytes() for n in use])
+        d = H.oracle_decompress(blob, off, alt_order=bool(alt))
+        for i, n in enumerate(use):
+            a0, a1 = d["atom_off"][i], d["atom_off"][i + 1]
+            exp = z[f"{n}/xyz{alt}"]
+            assert a1 - a0 == len(exp), n
+            got = np.stack([d["x"][a0:a1], d["y"][a0:a1], d["z"][a0:a1]], 1)
+            assert np.array_equal(_bits(got), _bits(exp)), (n, alt)
+
+
+def test_oracle_decompress_restated_trig_is_identical(golden):
+    """the restated glibc sinf/cosf gives the same coordinates as the host libm"""
+    z, index = golden
+    use = [n for n in compress_cases(index) + db_cases(index)]
+    blob, off = entries_blob([z[f"{n}/fcz"].tobytes() for n in use])
+    a = H.oracle_decompress(blob, off)
+    b = H.oracle_decompress(blob, off, restated_trig=True)
+    for k in "xyz":
+        assert np.array_equal(_bits(a[k]), _bits(b[k]))
+
+
+def test_committed_reference_fcz_payload(golden):
+    """test/test_af.fcz was produced on another platform: its header floats differ by 1 ulp
+     but packed words, side-chain bytes and B-factor bytes must be identical."""
+    z, _ = golden
+    ref = z["fixture:test_af.fcz"].tobytes()
+    b = golden_batch(z, "pdb:test_af")
+    blob, off, st = H.oracle_compress(b)
+    mine = blob.tobytes()
+    n, na, tl_ref = 28, ref[12], int.from_bytes(ref[24:28], "little")
+    tl = int.from_bytes(mine[24:28], "little")
+    w_ref = 76 + 4 * na + tl_ref + 36 * na + 13
+    w = 76 + 4 * na + tl + 36 * na + 13
+    assert ref[w_ref:w_ref + 8 * n] == mine[w:w + 8 * n]
+    nsc = int.from_bytes(ref[16:20], "little")
+    assert ref[w_ref + 8 * n: w_ref + 8 * n + nsc] == mine[w + 8 * n: w + 8 * n + nsc]
+    assert ref[-n:] == mine[-n:]
+
+
+def test_oracle_check_and_errors(golden):
+    z, index = golden
+    lib = H.load_oracle()
+    e = z["pdb:test_af/fcz"].tobytes()
+    assert lib.fcz_oracle_check(e, len(e)) == 0
+    bad = b"XXXX" + e[4:]
+    assert lib.fcz_oracle_check(bad, len(bad)) == -4
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_vs_live_reference_on_fresh_synthetic():
+    """fresh seeds, not in the goldens: oracle == real reference, compress and decompress"""
+    from foldcomp_amd import synthetic
+    from tools_chain_table import chain_table
+    b = synthetic.to_chain_batch(synthetic.generate(6, [33, 150, 350, 351, 12, 77], seed=424242))
+    blob, off, st = H.oracle_compress(b)
+    assert (st == 0).all()
+    d = H.oracle_decompress(blob, off)
+    for c in range(b.n_chains):
+        t = chain_table(b, c)
+        title = bytes(b.titles[b.title_off[c]:b.title_off[c + 1]]).decode()
+        ref = H.mask_pad(H.ref_compress(t, title, b.anchor_threshold))
+        assert ref == blob[off[c]:off[c + 1]].tobytes()
+        r = H.ref_decompress(ref)
+        a0, a1 = d["atom_off"][c], d["atom_off"][c + 1]
+        for k in "xyz":
+            assert np.array_equal(_bits(r[k]), _bits(d[k][a0:a1]))

@@ -108,42 +108,53 @@ def main():
     ntors = [max(n - 3, 0) for n in natoms]
     assert ntors[:20] == [2,8,5,5,3,6,6,1,7,5,5,6,5,8,4,3,4,11,9,4], ntors
 
+    hdr = []
+    h = hdr.append
+    h("// GENERATED by tools/gen_tables.py -- do not edit. Amino-acid geometry tables in dense form.")
+    h("// Data source: reference src/amino_acid.h:69-406 (ideal geometry), src/utility.h:133-206 (codes).")
+    h("// The table bodies live in aa_tables.inc so that a translation unit can instantiate them twice")
+    h("// (e.g. a __device__ copy and a host copy) by redefining FCZ_TABLE_QUAL / FCZ_T.")
+    h("#pragma once")
+    h("#include <stdint.h>")
+    h("#define FCZ_N_RES_CODES 24")
+    h("#define FCZ_MAX_RES_ATOMS 14")
+    h("#define FCZ_N_ATOM_CODES 37")
+    h("#define FCZ_ATOM_OXT 36")
+    h("#define FCZ_ATOM_OTHER 255")
+    h("#define FCZ_RES_PRO 14")
+    h("#define FCZ_RES_UNK 23")
+    h("#ifndef FCZ_TABLE_QUAL")
+    h("#define FCZ_TABLE_QUAL static const")
+    h("#endif")
+    h("#ifndef FCZ_T")
+    h("#define FCZ_T(name) fcz_##name")
+    h("#endif")
+    h('#include "aa_tables.inc"')
+    open("foldcomp_amd/csrc/aa_tables.h", "w").write("\n".join(hdr) + "\n")
+
     out = []
     w = out.append
-    w("// GENERATED by tools/gen_tables.py -- do not edit. Amino-acid geometry tables in dense form.")
-    w("// Data source: reference src/amino_acid.h:69-406 (ideal geometry), src/utility.h:133-206 (codes).")
-    w("#pragma once")
-    w("#include <stdint.h>")
-    w("#define FCZ_N_RES_CODES 24")
-    w("#define FCZ_MAX_RES_ATOMS 14")
-    w("#define FCZ_N_ATOM_CODES 37")
-    w("#define FCZ_ATOM_OXT 36")
-    w("#define FCZ_ATOM_OTHER 255")
-    w("#define FCZ_RES_PRO 14")
-    w("#define FCZ_RES_UNK 23")
-    w("#ifndef FCZ_TABLE_QUAL")
-    w("#define FCZ_TABLE_QUAL static const")
-    w("#endif")
-    w('FCZ_TABLE_QUAL char fcz_res1[FCZ_N_RES_CODES + 1] = "%s";' % RES1)
-    w("FCZ_TABLE_QUAL char fcz_res3[FCZ_N_RES_CODES][4] = {%s};" % ",".join('"%s"' % r for r in RES3))
-    w("FCZ_TABLE_QUAL char fcz_atom_name[FCZ_N_ATOM_CODES][4] = {%s};" % ",".join('"%s"' % a for a in names))
+    w("// GENERATED by tools/gen_tables.py -- do not edit. Included by aa_tables.h (no include guard on purpose).")
+    w('FCZ_TABLE_QUAL char FCZ_T(res1)[FCZ_N_RES_CODES + 1] = "%s";' % RES1)
+    w("FCZ_TABLE_QUAL char FCZ_T(res3)[FCZ_N_RES_CODES][4] = {%s};" % ",".join('"%s"' % r for r in RES3))
+    w("FCZ_TABLE_QUAL char FCZ_T(atom_name)[FCZ_N_ATOM_CODES][4] = {%s};" % ",".join('"%s"' % a for a in names))
     w("// atoms per residue code (UNK/ASX/GLX/STP: backbone only)")
-    w("FCZ_TABLE_QUAL uint8_t fcz_res_natoms[FCZ_N_RES_CODES] = {%s};" % ",".join(map(str, natoms)))
+    w("FCZ_TABLE_QUAL uint8_t FCZ_T(res_natoms)[FCZ_N_RES_CODES] = {%s};" % ",".join(map(str, natoms)))
     def tab2(name, typ, rows, fmt):
-        w("FCZ_TABLE_QUAL %s %s[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS] = {" % (typ, name))
+        w("FCZ_TABLE_QUAL %s FCZ_T(%s)[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS] = {" % (typ, name))
         for r, row in zip(RES3, rows):
             w("  {%s}, // %s" % (",".join(fmt(v) for v in row), r))
         w("};")
     w("// canonical atom order: atom code of slot j")
-    tab2("fcz_res_atom", "uint8_t", atoms, str)
+    tab2("res_atom", "uint8_t", atoms, str)
     w("// `-a` output order: canonical slot printed at position j")
-    tab2("fcz_res_alt_slot", "uint8_t", alts, str)
+    tab2("res_alt_slot", "uint8_t", alts, str)
     w("// predecessor slots (p0,p1,p2) of slot j>=3, packed p0 | p1<<4 | p2<<8")
-    tab2("fcz_res_prev", "uint16_t", [[p[0] | p[1] << 4 | p[2] << 8 for p in row] for row in prev], lambda v: "0x%03x" % v)
+    tab2("res_prev", "uint16_t", [[p[0] | p[1] << 4 | p[2] << 8 for p in row] for row in prev], lambda v: "0x%03x" % v)
     w("// ideal bond length p2-j / bond angle p1-p2-j of slot j>=3, float32 bit patterns")
-    tab2("fcz_res_blen_bits", "uint32_t", blen, lambda v: "0x%08xu" % v)
-    tab2("fcz_res_bang_bits", "uint32_t", bang, lambda v: "0x%08xu" % v)
-    open("foldcomp_amd/csrc/aa_tables.h", "w").write("\n".join(out) + "\n")
+    tab2("res_blen_bits", "uint32_t", blen, lambda v: "0x%08xu" % v)
+    tab2("res_bang_bits", "uint32_t", bang, lambda v: "0x%08xu" % v)
+    open("foldcomp_amd/csrc/aa_tables.inc", "w").write("\n".join(out) + "\n")
 
     py = []
     py.append('"""GENERATED by tools/gen_tables.py -- do not edit."""')

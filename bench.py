@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- residues/s of the FCZ hot path (compress + decompress) on synthetic 350-residue chains.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: plain python; N>1: one rank per GPU
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   under torchrun)
+
+One "step" = one pass of the hot path over the rank's resident batch: compress every chain to FCZ, then
+decompress every FCZ record back to SoA atoms (round trip). Workload at N=1 = BASELINE.json configs[1]:
+1 000 000 synthetic 350-residue chains on one MI355X (inputs resident in HBM before the clock starts).
+N>1: every rank owns its own 1M-chain shard (weak scaling); the data path has no collective, the ranks
+only exchange the output index (per-record lengths -> global offsets) over RCCL after compressing.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
+HIP-event time measured here) and `cpu_baseline` (the reference's own CPU path, oracle/_ref, timed on a
+bounded sample of the same chains on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from foldcomp_amd import _lib, synthetic  # noqa: E402
+from foldcomp_amd.codec import Codec  # noqa: E402
+from foldcomp_amd.structure import CAtomsOut, CChainBatch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chains", type=int, default=1_000_000, help="chains per GPU")
+    ap.add_argument("--residues", type=int, default=350)
+    ap.add_argument("--anchor", type=int, default=25)
+    ap.add_argument("--gen-chunk", type=int, default=32768)
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="chains timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base):
+    """build the rank's batch on the GPU chunk by chunk -> dict of device tensors (fcz_chain_batch layout)"""
+    parts = []
+    done = 0
+    while done < n_chains:
+        c = min(chunk, n_chains - done)
+        parts.append(synthetic.generate(c, n_res, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
+                                        first_chain_id=seed_base + done))
+        done += c
+    if len(parts) == 1:
+        return parts[0]
+    out = {"anchor_threshold": anchor}
+    for k in ("x", "y", "z", "atom_code", "res_code", "bfac_ca", "first_res_index", "first_atom_index", "chain_id", "titles"):
+        out[k] = torch.cat([p[k] for p in parts])
+    for k, unit in (("res_off", "res_off"), ("atom_off", "atom_off"), ("title_off", "title_off")):
+        acc = []; base = 0
+        for p in parts:
+            v = p[k].to(torch.int64)
+            acc.append(v[:-1] + base); base += int(v[-1])
+        acc.append(torch.tensor([base], dtype=torch.int64, device=device))
+        out[k] = torch.cat(acc).to(torch.int32)
+    return out
+
+
+def c_batch(d) -> CChainBatch:
+    s = CChainBatch()
+    s.n_chains = d["res_off"].numel() - 1
+    s.n_residues = int(d["res_off"][-1])
+    s.n_atoms = int(d["atom_off"][-1])
+    s.anchor_threshold = int(d["anchor_threshold"])
+    for k in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca", "first_res_index", "first_atom_index",
+              "chain_id", "titles", "title_off"):
+        setattr(s, k, d[k].data_ptr())
+    return s
+
+
+def host_sample(d, n_sample):
+    """first n_sample chains of the device batch as a host ChainBatch"""
+    n_sample = min(n_sample, d["res_off"].numel() - 1)
+    r1 = int(d["res_off"][n_sample]); a1 = int(d["atom_off"][r1]); t1 = int(d["title_off"][n_sample])
+    sub = {k: d[k][:a1] for k in ("x", "y", "z", "atom_code")}
+    sub.update({k: d[k][:r1] for k in ("res_code", "bfac_ca")})
+    sub.update({k: d[k][:n_sample] for k in ("first_res_index", "first_atom_index", "chain_id")})
+    sub["res_off"] = d["res_off"][:n_sample + 1]; sub["atom_off"] = d["atom_off"][:r1 + 1]
+    sub["titles"] = d["titles"][:t1]; sub["title_off"] = d["title_off"][:n_sample + 1]
+    sub["anchor_threshold"] = d["anchor_threshold"]
+    return synthetic.to_chain_batch(sub)
+
+
+def cpu_baseline(hb, anchor):
+    """the reference's CPU path on this host (oracle/_ref, OpenMP over chains like `foldcomp -t`);
+    falls back to the C port (oracle/) only as a *baseline*, never as part of the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _harness as H
+    from foldcomp_amd._aa_tables import ATOM_NAMES, RES3
+    cores = os.cpu_count() or 1
+    R = hb.n_residues
+    sample = f"first {hb.n_chains} chains of the GPU workload ({R} residues), codec only (objects in, FCZ, objects out)"
+    if H.have_ref():
+        lib = H.load_ref()
+        an = np.zeros((37, 4), np.uint8); rn = np.zeros((24, 4), np.uint8)
+        for i, n in enumerate(ATOM_NAMES): an[i, :len(n)] = np.frombuffer(n.encode(), np.uint8)
+        for i, n in enumerate(RES3): rn[i, :3] = np.frombuffer(n.encode(), np.uint8)
+        lib.ref_bench_roundtrip.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+        tc = ctypes.c_double(); td = ctypes.c_double(); fb = ctypes.c_ulonglong(); ao = ctypes.c_ulonglong()
+        fail = lib.ref_bench_roundtrip(hb.n_chains, hb.res_off.ctypes.data, hb.atom_off.ctypes.data, hb.x.ctypes.data, hb.y.ctypes.data,
+                                       hb.z.ctypes.data, hb.atom_code.ctypes.data, hb.res_code.ctypes.data, hb.bfac_ca.ctypes.data,
+                                       an.ctypes.data, rn.ctypes.data, anchor, cores, ctypes.byref(tc), ctypes.byref(td),
+                                       ctypes.byref(fb), ctypes.byref(ao))
+        return {"value": R / (tc.value + td.value), "unit": "residues/s", "cores": cores, "kind": "reference", "sample": sample,
+                "compress_residues_per_s": R / tc.value, "decompress_residues_per_s": R / td.value, "failed_chains": int(fail)}
+    t0 = time.perf_counter(); blob, off, st = H.oracle_compress(hb, n_threads=cores)
+    t1 = time.perf_counter(); H.oracle_decompress(blob, off, n_threads=cores); t2 = time.perf_counter()
+    return {"value": R / (t2 - t0), "unit": "residues/s", "cores": cores, "kind": "port", "sample": sample,
+            "compress_residues_per_s": R / (t1 - t0), "decompress_residues_per_s": R / (t2 - t1)}
+
+
+def parity_sample(hb, blob_dev, off_dev, out_t, atom_off_host, n):
+    """GPU results of the first n chains against the oracle (checker only, outside the timed region)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _harness as H
+    oblob, ooff, ost = H.oracle_compress(hb, n_threads=os.cpu_count() or 1)
+    nb = int(ooff[-1])
+    got = blob_dev[:nb].cpu().numpy()
+    goff = off_dev[:n + 1].cpu().numpy().astype(np.uint64)
+    ok_c = bool(np.array_equal(goff, ooff) and got.tobytes() == oblob.tobytes())
+    o = H.oracle_decompress(oblob, ooff, n_threads=os.cpu_count() or 1)
+    na = int(o["atom_off"][-1])
+    ok_d = all(np.array_equal(out_t[k][:na].cpu().numpy().view(np.uint32), o[k].view(np.uint32)) for k in ("x", "y", "z"))
+    return ok_c, bool(ok_d)
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the FCZ hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    C, n_res = args.chains, args.residues
+    d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C)
+    R, M = int(d["res_off"][-1]), int(d["atom_off"][-1])
+    codec = Codec(local)
+    lib = codec.lib
+    cb = c_batch(d)
+
+    # output buffers (sizes are exact: Foldcomp::getSize on the device)
+    off_dev = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.fcz_compress_sizes_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr()), "sizes")
+    codec.synchronize()
+    fcz_bytes = int(off_dev[-1])
+    blob_dev = torch.zeros(fcz_bytes, dtype=torch.uint8, device=dev)
+    status_dev = torch.zeros(C, dtype=torch.int32, device=dev)
+    res_off_dev = torch.zeros(C + 1, dtype=torch.int32, device=dev)
+    atom_off_dev = torch.zeros(C + 1, dtype=torch.int32, device=dev)
+    out_t = {k: torch.zeros(M, dtype=torch.float32, device=dev) for k in ("x", "y", "z")}
+    out_t["bfac_res"] = torch.zeros(R, dtype=torch.float32, device=dev)
+    out_t["res_code"] = torch.zeros(R, dtype=torch.uint8, device=dev)
+    cout = CAtomsOut(out_t["x"].data_ptr(), out_t["y"].data_ptr(), out_t["z"].data_ptr(), out_t["bfac_res"].data_ptr(),
+                     out_t["res_code"].data_ptr(), None)
+    lengths_dev = torch.zeros(C, dtype=torch.int64, device=dev)
+    gathered = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+
+    def step():
+        # compress: SoA atoms -> FCZ records
+        _lib.check(lib.fcz_compress_sizes_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr()), "sizes")
+        _lib.check(lib.fcz_compress_batch_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr(), blob_dev.data_ptr(),
+                                              status_dev.data_ptr()), "compress")
+        if world > 1:
+            # the only exchange of the sharded job: per-record lengths -> rank 0 builds the global index
+            codec.synchronize()
+            torch.sub(off_dev[1:], off_dev[:-1], out=lengths_dev)
+            dist.gather(lengths_dev, gathered, dst=0)
+        # decompress: FCZ records -> SoA atoms
+        tr = ctypes.c_uint32(); ta = ctypes.c_uint32()
+        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
+                                                atom_off_dev.data_ptr(), ctypes.byref(tr), ctypes.byref(ta)), "dsizes")
+        assert tr.value == R and ta.value == M, (tr.value, R, ta.value, M)
+        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
+                                                atom_off_dev.data_ptr(), 0, ctypes.byref(cout)), "decompress")
+
+    for _ in range(args.warmup):
+        step()
+    codec.synchronize(); torch.cuda.synchronize()
+    codec.enable_timing(True); codec.reset_timing()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    codec.synchronize(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time (HIP events on the codec's own stream)
+    ktime = {}
+    for name in ("compress_sizes", "compress", "decompress_sizes", "decompress_forward", "decompress_reverse", "decompress_sidechain"):
+        ms, n = codec.kernel_time(name)
+        ktime[name] = (ms / n) if n else 0.0
+    codec.enable_timing(False)
+    bad_status = int((status_dev != 0).sum())
+
+    if rank == 0:
+        A = M / R                                   # atoms per residue
+        fcz_per_res = fcz_bytes / R
+        # algorithmic bytes: compress reads 13A+9, writes fcz; decompress reads fcz, writes 12A+4
+        bytes_compress = (13 * A + 9 + fcz_per_res) * R
+        bytes_decompress = (fcz_per_res + 12 * A + 4) * R
+        dec_ms = ktime["decompress_forward"] + ktime["decompress_reverse"] + ktime["decompress_sidechain"]
+        cands = {"k_compress": (bytes_compress, ktime["compress"]),
+                 "decompress(k_forward_nerf+k_reverse_blend+k_sidechain)": (bytes_decompress, dec_ms)}
+        dom = max(cands, key=lambda k: cands[k][1])
+        by, ms = cands[dom]
+        ach = by / (ms * 1e-3) / 1e9 if ms else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
+                    "kernel_ms": {k: round(v, 4) for k, v in ktime.items()}}
+        parity = None
+        hb = None
+        if not args.no_parity or args.cpu_sample:
+            hb = host_sample(d, max(256, args.cpu_sample))
+        if not args.no_parity:
+            n = min(256, hb.n_chains)
+            hb256 = host_sample(d, n)
+            ok_c, ok_d = parity_sample(hb256, blob_dev, off_dev, out_t, None, n)
+            parity = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": bad_status}
+        cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if args.cpu_sample else None
+        total_res = R * world * args.steps
+        line = {
+            "metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs",
+            "value": total_res / dt, "unit": "residues/s (round trip: each residue compressed and decompressed once)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 + u8 bitpack",
+            "data": "synthetic",
+            "config": {"workload": f"{C} synthetic {n_res}-residue chains per GPU, compress+decompress, anchor -b {args.anchor}",
+                       "chains_per_gpu": C, "residues_per_chain": n_res, "atoms_per_residue": round(A, 3),
+                       "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
+            "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
+            "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    codec.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,9 +20,9 @@ for s in $SRCS; do
       -c "$REF/src/$s.cpp" -o "$OUT/$s.o" &
   OBJS="$OBJS $OUT/$s.o"
 done
-g++ -O3 -DNDEBUG -std=c++17 -fPIC -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" \
+g++ -O3 -DNDEBUG -std=c++17 -fPIC -fopenmp -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" \
     -c "$HERE/ref_shim.cpp" -o "$OUT/ref_shim.o" &
 wait
-g++ -shared -o "$OUT/libfoldcomp_ref.so" $OBJS "$OUT/ref_shim.o"
+g++ -shared -fopenmp -o "$OUT/libfoldcomp_ref.so" $OBJS "$OUT/ref_shim.o"
 rm -f "$OUT"/*.o
 echo "built $OUT/libfoldcomp_ref.so"

@@ -12,6 +12,7 @@
 #include "atom_coordinate.h"
 #include "amino_acid.h"
 
+#include <chrono>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -159,6 +160,74 @@ long ref_extract(const unsigned char* fcz, long len, int type, int digits, char*
     if ((long)data.size() > out_cap) return -(long)data.size();
     memcpy(out, data.data(), data.size());
     return (long)data.size();
+}
+
+
+// ---- timed batch round trip for bench.py's cpu_baseline leg ("kind": "reference") ---------------------
+// SoA batch in (same arrays as fcz_chain_batch, atom/residue names through code->name tables), the
+// reference's own objects in between. AtomCoordinate vectors are built before the clock starts (the
+// reference's parsers produce them; they are not part of the codec path timed here). Timed:
+//   compress leg:   Foldcomp::compress + writeStream   (src/foldcomp.cpp:562, :1038)
+//   decompress leg: Foldcomp::read + decompress          (src/foldcomp.cpp:904, :779)
+// parallelised over chains with OpenMP exactly like the reference's `-t` (src/input_processor.h:85-89).
+int ref_bench_roundtrip(int n_chains, const unsigned* res_off, const unsigned* atom_off,
+                        const float* x, const float* y, const float* z,
+                        const unsigned char* atom_code, const unsigned char* res_code, const float* bfac_ca,
+                        const char* atom_names /*37 x 4, NUL padded*/, const char* res_names /*24 x 4*/,
+                        int anchor_threshold, int n_threads, double* t_compress, double* t_decompress,
+                        unsigned long long* fcz_bytes, unsigned long long* atoms_out) {
+    std::vector<std::vector<AtomCoordinate>> chains(n_chains);
+    for (int c = 0; c < n_chains; c++) {
+        unsigned r0 = res_off[c], r1 = res_off[c + 1];
+        int serial = 1;
+        for (unsigned r = r0; r < r1; r++)
+            for (unsigned a = atom_off[r]; a < atom_off[r + 1]; a++) {
+                int code = atom_code[a];
+                chains[c].emplace_back(std::string(code < 37 ? atom_names + 4 * code : "H"), std::string(res_names + 4 * res_code[r]),
+                                       std::string("A"), serial++, (int)(r - r0) + 1, x[a], y[a], z[a], 1.0f, bfac_ca[r]);
+            }
+    }
+    std::vector<std::string> fcz(n_chains);
+    int fail = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+#pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads)
+    for (int c = 0; c < n_chains; c++) {
+        try {
+            Foldcomp comp;
+            comp.strTitle = "synth_0000000000";
+            comp.anchorThreshold = anchor_threshold;
+            tcb::span<AtomCoordinate> sp(chains[c].data(), chains[c].size());
+            comp.compress(sp);
+            std::ostringstream oss;
+            comp.writeStream(oss);
+            fcz[c] = oss.str();
+        } catch (...) {
+#pragma omp atomic
+            fail++;
+        }
+    }
+    double t1 = now();
+    unsigned long long total_atoms = 0;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads) reduction(+ : total_atoms)
+    for (int c = 0; c < n_chains; c++) {
+        try {
+            std::istringstream iss(fcz[c]);
+            Foldcomp comp;
+            if (comp.read(iss) != 0) { continue; }
+            std::vector<AtomCoordinate> atoms;
+            comp.decompress(atoms);
+            total_atoms += atoms.size();
+        } catch (...) {
+#pragma omp atomic
+            fail++;
+        }
+    }
+    double t2 = now();
+    unsigned long long bytes = 0;
+    for (auto& s : fcz) bytes += s.size();
+    *t_compress = t1 - t0; *t_decompress = t2 - t1; *fcz_bytes = bytes; *atoms_out = total_atoms;
+    return fail;
 }
 
 }  // extern "C"

@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--residues", type=int, default=350)
     ap.add_argument("--anchor", type=int, default=25)
     ap.add_argument("--gen-chunk", type=int, default=32768)
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="chains timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="chains timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args()
 
@@ -78,8 +78,8 @@ def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base):
 def c_batch(d) -> CChainBatch:
     s = CChainBatch()
     s.n_chains = d["res_off"].numel() - 1
-    s.n_residues = int(d["res_off"][-1])
-    s.n_atoms = int(d["atom_off"][-1])
+    s.n_residues = int(d["res_off"][-1]) & 0xFFFFFFFF
+    s.n_atoms = int(d["atom_off"][-1]) & 0xFFFFFFFF      # uint32 carried in a torch int32
     s.anchor_threshold = int(d["anchor_threshold"])
     for k in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca", "first_res_index", "first_atom_index",
               "chain_id", "titles", "title_off"):
@@ -90,7 +90,7 @@ def c_batch(d) -> CChainBatch:
 def host_sample(d, n_sample):
     """first n_sample chains of the device batch as a host ChainBatch"""
     n_sample = min(n_sample, d["res_off"].numel() - 1)
-    r1 = int(d["res_off"][n_sample]); a1 = int(d["atom_off"][r1]); t1 = int(d["title_off"][n_sample])
+    r1 = int(d["res_off"][n_sample]); a1 = int(d["atom_off"][r1]) & 0xFFFFFFFF; t1 = int(d["title_off"][n_sample])
     sub = {k: d[k][:a1] for k in ("x", "y", "z", "atom_code")}
     sub.update({k: d[k][:r1] for k in ("res_code", "bfac_ca")})
     sub.update({k: d[k][:n_sample] for k in ("first_res_index", "first_atom_index", "chain_id")})
@@ -160,7 +160,7 @@ def main():
 
     C, n_res = args.chains, args.residues
     d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C)
-    R, M = int(d["res_off"][-1]), int(d["atom_off"][-1])
+    R, M = int(d["res_off"][-1]) & 0xFFFFFFFF, int(d["atom_off"][-1]) & 0xFFFFFFFF
     codec = Codec(local)
     lib = codec.lib
     cb = c_batch(d)

@@ -177,6 +177,7 @@ int ref_bench_roundtrip(int n_chains, const unsigned* res_off, const unsigned* a
                         int anchor_threshold, int n_threads, double* t_compress, double* t_decompress,
                         unsigned long long* fcz_bytes, unsigned long long* atoms_out) {
     std::vector<std::vector<AtomCoordinate>> chains(n_chains);
+#pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads)
     for (int c = 0; c < n_chains; c++) {
         unsigned r0 = res_off[c], r1 = res_off[c + 1];
         int serial = 1;

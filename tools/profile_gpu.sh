@@ -1,0 +1,47 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py; keeps only
+# the small CSV summaries under gpurun_out/prof_<tag>/ (copy the ones to be judged into profiles/).
+# usage: tools/profile_gpu.sh <tag> [bench args...]
+set -u
+TAG=${1:-r1}; shift || true
+ARGS=${@:-"--chains 262144 --steps 3 --warmup 1 --cpu-sample 0 --no-parity"}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { # name, extra rocprof flags...
+  local name=$1; shift
+  rm -rf /tmp/rp_$name
+  rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o $name -- python $REPO/bench.py $ARGS > $OUT/${name}_bench.json 2> $OUT/${name}_bench.err
+  find /tmp/rp_$name -name '*.csv' -size -8M -exec cp {} $OUT/ \;
+  rm -rf /tmp/rp_$name
+}
+run stats --kernel-trace --stats
+# PMC passes: counters only (no trace domains besides kernel dispatch), one group per pass
+run pmc_sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
+run pmc_fetch --pmc FETCH_SIZE
+run pmc_write --pmc WRITE_SIZE
+# kernel-trace rows can be huge: keep per-kernel aggregates only
+python3 - "$OUT" <<'PY'
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+for f in glob.glob(os.path.join(out, "pmc_*_counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    seen = set()
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (r["Dispatch_Id"], k)
+            if key not in seen: seen.add(key); cnt[k] += 1
+    with open(f.replace("_counter_collection.csv", "_per_kernel.csv"), "w") as o:
+        w = csv.writer(o); w.writerow(["kernel", "dispatches", "counter", "sum", "per_dispatch"])
+        for k in agg:
+            for c, v in agg[k].items():
+                w.writerow([k, cnt[k], c, v, v / max(cnt[k], 1)])
+    os.remove(f)
+for f in glob.glob(os.path.join(out, "*_kernel_trace.csv")):
+    os.remove(f)
+PY
+ls -la $OUT

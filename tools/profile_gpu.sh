@@ -13,35 +13,35 @@ run() { # name, extra rocprof flags...
   local name=$1; shift
   rm -rf /tmp/rp_$name
   rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o $name -- python $REPO/bench.py $ARGS > $OUT/${name}_bench.json 2> $OUT/${name}_bench.err
-  find /tmp/rp_$name -name '*.csv' -size -8M -exec cp {} $OUT/ \;
+  python3 - /tmp/rp_$name $OUT <<'PY'
+import csv, glob, os, sys, collections, shutil
+src, out = sys.argv[1], sys.argv[2]
+for f in glob.glob(os.path.join(src, "**", "*.csv"), recursive=True):
+    base = os.path.basename(f)
+    if base.endswith("_counter_collection.csv"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r["Kernel_Name"].split("(")[0]
+                if "fcz" not in k: continue
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                cnt[k].add(r["Dispatch_Id"])
+        with open(os.path.join(out, base.replace("_counter_collection.csv", "_per_kernel.csv")), "w") as o:
+            w = csv.writer(o); w.writerow(["kernel", "dispatches", "counter", "sum", "per_dispatch"])
+            for k in sorted(agg):
+                for c, v in sorted(agg[k].items()):
+                    w.writerow([k, len(cnt[k]), c, v, v / max(len(cnt[k]), 1)])
+    elif base.endswith("_kernel_trace.csv"):
+        continue
+    elif os.path.getsize(f) < (4 << 20):
+        shutil.copy(f, out)
+PY
   rm -rf /tmp/rp_$name
 }
 run stats --kernel-trace --stats
 # PMC passes: counters only (no trace domains besides kernel dispatch), one group per pass
-run pmc_sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
-run pmc_fetch --pmc FETCH_SIZE
-run pmc_write --pmc WRITE_SIZE
-# kernel-trace rows can be huge: keep per-kernel aggregates only
-python3 - "$OUT" <<'PY'
-import csv, glob, os, sys, collections
-out = sys.argv[1]
-for f in glob.glob(os.path.join(out, "pmc_*_counter_collection.csv")):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-    seen = set()
-    with open(f) as fh:
-        for r in csv.DictReader(fh):
-            k = r["Kernel_Name"].split("(")[0]
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            key = (r["Dispatch_Id"], k)
-            if key not in seen: seen.add(key); cnt[k] += 1
-    with open(f.replace("_counter_collection.csv", "_per_kernel.csv"), "w") as o:
-        w = csv.writer(o); w.writerow(["kernel", "dispatches", "counter", "sum", "per_dispatch"])
-        for k in agg:
-            for c, v in agg[k].items():
-                w.writerow([k, cnt[k], c, v, v / max(cnt[k], 1)])
-    os.remove(f)
-for f in glob.glob(os.path.join(out, "*_kernel_trace.csv")):
-    os.remove(f)
-PY
+run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run pmc_sq2 --kernel-include-regex "fcz" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
+run pmc_fetch --kernel-include-regex "fcz" --pmc FETCH_SIZE
+run pmc_write --kernel-include-regex "fcz" --pmc WRITE_SIZE
 ls -la $OUT

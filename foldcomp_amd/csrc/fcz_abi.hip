@@ -475,17 +475,44 @@ int fcz_decompress_batch(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off,
 }  // extern "C"
 
 namespace fcz {
+// inputs of the multi-argument self tests come from an integer hash of the index so that the host
+// checker (oracle/fcz_oracle.c: fcz_oracle_math_sweep) regenerates exactly the same floats
+__device__ __forceinline__ float st_hash_float(uint32_t u, uint32_t salt, float scale) {
+    uint32_t h = (u ^ salt) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    return (float)(int32_t)h * scale;
+}
 __global__ void k_selftest_math(int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* __restrict__ outv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    float x = __uint_as_float(start_bits + i * stride);
-    float r = (mode == 0) ? acos_deg(x) : (mode == 1) ? sinf_glibc(x) : cosf_glibc(x);
+    const uint32_t u = start_bits + i * stride;
+    const float x = __uint_as_float(u);
+    const float sc = 0x1p-29f;   // hashed coordinates in (-4, 4)
+    float r;
+    if (mode == 0) r = acos_deg(x);
+    else if (mode == 1) r = sinf_glibc(x);
+    else if (mode == 2) r = cosf_glibc(x);
+    else if (mode == 3) r = deg2rad(x);
+    else if (mode == 4) r = vnorm(v3{st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)});
+    else if (mode == 5) r = vcos_theta(v3{st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)},
+                                       v3{st_hash_float(u, 4, sc), st_hash_float(u, 5, sc), st_hash_float(u, 6, sc)});
+    else {
+        // modes 6..8: x / y / z of place_atom on hashed geometry
+        const v3 a{st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)};
+        const v3 b{st_hash_float(u, 4, sc), st_hash_float(u, 5, sc), st_hash_float(u, 6, sc)};
+        const v3 c{st_hash_float(u, 7, sc), st_hash_float(u, 8, sc), st_hash_float(u, 9, sc)};
+        const float L = 1.2f + __builtin_fabsf(st_hash_float(u, 10, 0x1p-33f));
+        const float ba = 90.0f + st_hash_float(u, 11, 0x1p-25f);          // (26, 154) degrees
+        const float ta = st_hash_float(u, 12, 0x1.6p-24f);                // (-176, 176) degrees
+        const v3 d = place_atom(a, b, c, L, ba, ta);
+        r = (mode == 6) ? d.x : (mode == 7) ? d.y : d.z;
+    }
     outv[i] = r;
 }
 }  // namespace fcz
 
 extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host) {
-    if (!ctx || !out_host || mode < 0 || mode > 2) return FCZ_E_INVALID_ARG;
+    if (!ctx || !out_host || mode < 0 || mode > 8) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (count == 0) return FCZ_OK;
     int rc = ctx->stage[17].ensure(sizeof(float) * (size_t)count); if (rc) return rc;

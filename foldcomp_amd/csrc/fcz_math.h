@@ -37,19 +37,63 @@ __device__ __forceinline__ v3 vcross(v3 a, v3 b) {
     return r;
 }
 
-// norm, reference src/float3d.h:32-34 (double pow/sqrt, float result)
-__device__ __forceinline__ float vnorm(v3 v) {
-    double s = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z;
-    return (float)__builtin_sqrt(s);
+// ---- "round to float" fast paths --------------------------------------------------------------------
+// Several reference expressions evaluate in double and are observed only after rounding to float
+// (norm, getCosineTheta, the acos->degrees conversion, the degrees->radians conversion). IEEE-exact
+// double sqrt/divide/acos cost 15-60 f64 instructions each on gfx950. Instead: evaluate a cheap double
+// approximation v (relative error <= 2^-46, using v_rsq_f64 + one Newton step, explicit FMAs), round it
+// to float, and prove the rounding is the one the exact expression would give: if v lies farther than
+// 2^-41*|v| from the nearest float rounding boundary, every value within 2^-41 relative of v -- the
+// exact double result included -- rounds to the same float. Otherwise (probability ~2^-17 per value)
+// the exact, reference-ordered evaluation runs. The test is conservative by construction: zero,
+// denormal and power-of-two results take the exact path more often than needed, never less.
+__device__ __forceinline__ bool round_to_float_is_safe(double v, float f) {
+    const double fd = (double)f;
+    const double e = v - fd;
+    const uint32_t fb = __float_as_uint(f);
+    // half ulp of f scaled by (1 - 2^-16); for a power of two the lower neighbour is half as far
+    const uint32_t c = ((fb & 0x7fffffu) == 0u) ? ((26u << 20) - 0xFFFE0u) : ((25u << 20) - 0xFFFE0u);
+    const uint32_t th = ((uint32_t)__double2hiint(fd) & 0x7ff00000u) - c;
+    const double t = __hiloint2double((int)th, 0);
+    return !(__builtin_fabs(e) > t);   // NaN/inf: comparison false -> "safe" (value propagates)
 }
 
-// getCosineTheta, reference src/float3d.h:36-43
-__device__ __forceinline__ float vcos_theta(v3 a, v3 b) {
-    float ip = (a.x * b.x) + (a.y * b.y) + (a.z * b.z);
-    float s1 = a.x * a.x + a.y * a.y + a.z * a.z;
-    float s2 = b.x * b.x + b.y * b.y + b.z * b.z;
-    float p = s1 * s2;
+// norm, reference src/float3d.h:32-34 (double pow/sqrt, float result)
+__device__ __noinline__ float vnorm_exact(float x, float y, float z) {
+    double s = (double)x * (double)x + (double)y * (double)y + (double)z * (double)z;
+    return (float)__builtin_sqrt(s);
+}
+__device__ __forceinline__ float vnorm(v3 v) {
+    const double x = v.x, y = v.y, z = v.z;
+    const double s = __builtin_fma(z, z, __builtin_fma(y, y, x * x));
+    double r = __builtin_amdgcn_rsq(s);
+    const double g = s * r;                       // ~sqrt(s)
+    const double h = 0.5 * r;
+    const double d = __builtin_fma(-g, h, 0.5);
+    const double n = __builtin_fma(g, d, g);      // one Newton step: relative error ~2^-51
+    float f = (float)n;
+    if (__builtin_expect(!round_to_float_is_safe(n, f), 0)) f = vnorm_exact(v.x, v.y, v.z);
+    return f;
+}
+
+// getCosineTheta, reference src/float3d.h:36-43: float dot products, double sqrt + divide, float result
+__device__ __noinline__ float cos_theta_exact(float ip, float p) {
     return (float)((double)ip / __builtin_sqrt((double)p));
+}
+__device__ __forceinline__ float vcos_theta(v3 a, v3 b) {
+    const float ip = (a.x * b.x) + (a.y * b.y) + (a.z * b.z);
+    const float s1 = a.x * a.x + a.y * a.y + a.z * a.z;
+    const float s2 = b.x * b.x + b.y * b.y + b.z * b.z;
+    const float p = s1 * s2;
+    const double pd = (double)p;
+    double r = __builtin_amdgcn_rsq(pd);
+    const double t = pd * r;
+    const double d = __builtin_fma(-t, r, 1.0);
+    r = __builtin_fma(0.5 * r, d, r);             // 1/sqrt(p), relative error ~2^-51
+    const double q = (double)ip * r;
+    float f = (float)q;
+    if (__builtin_expect(!round_to_float_is_safe(q, f), 0)) f = cos_theta_exact(ip, p);
+    return f;
 }
 
 // ---- double-double helpers (slow path only) ---------------------------------------------------
@@ -135,7 +179,7 @@ __device__ __noinline__ double acos_correctly_rounded(float c, double a0) {
 
 // (float)(acos((double)c) * 180.0 / M_PI), the only way the reference observes acos.
 // Returns NaN for |c| > 1 or NaN input (callers apply the reference's NaN guard where it has one).
-__device__ __forceinline__ float acos_deg(float c) {
+__device__ __noinline__ float acos_deg_exact(float c) {
     const double kPi = 3.14159265358979323846;
     double A = __ocml_acos_f64((double)c);
     double D = A * 180.0 / kPi;
@@ -151,6 +195,44 @@ __device__ __forceinline__ float acos_deg(float c) {
         D = A * 180.0 / kPi;
         f = (float)D;
     }
+    return f;
+}
+
+// Fast path of the same function: asin kernel polynomial (degree 10 in z, minimax-fitted with mpmath,
+// relative error 2^-50 on z in [0, 1/4]) with the usual reduction acos(x) = 2 asin(sqrt((1-|x|)/2)) for
+// |x| > 1/2, one multiply by 180/pi, then the float-rounding safety test. ~45 f64 instructions.
+__device__ __forceinline__ float acos_deg(float c) {
+    const double x = (double)c;
+    const double ax = __builtin_fabs(x);
+    const bool big = ax > 0.5;
+    const double z = big ? __builtin_fma(-0.5, ax, 0.5) : x * x;
+    double sq;
+    {
+        double r = __builtin_amdgcn_rsq(z);
+        const double g = z * r, h = 0.5 * r;
+        const double d = __builtin_fma(-g, h, 0.5);
+        sq = __builtin_fma(g, d, g);
+    }
+    const double s = big ? sq : ax;
+    double P = 0x1.c8a4a8d5d7026p-6;
+    P = __builtin_fma(P, z, -0x1.bf16e7c9f283cp-8);
+    P = __builtin_fma(P, z, 0x1.fa1b2b4831188p-7);
+    P = __builtin_fma(P, z, 0x1.512bc40e88a9ep-7);
+    P = __builtin_fma(P, z, 0x1.cf5ed14c7cb7ep-7);
+    P = __builtin_fma(P, z, 0x1.1c0d74beb3610p-6);
+    P = __builtin_fma(P, z, 0x1.6e8f34a32a3ecp-6);
+    P = __builtin_fma(P, z, 0x1.f1c6ff7f5507fp-6);
+    P = __builtin_fma(P, z, 0x1.6db6dba99e56dp-5);
+    P = __builtin_fma(P, z, 0x1.33333333030cfp-4);
+    P = __builtin_fma(P, z, 0x1.55555555555bbp-3);
+    const double as = __builtin_fma(s * z, P, s);          // asin(s)
+    const double kPi = 3.14159265358979323846, kPio2 = 1.57079632679489661923;
+    const double A = big ? ((x > 0.0) ? 2.0 * as : __builtin_fma(-2.0, as, kPi))
+                         : ((x > 0.0) ? kPio2 - as : kPio2 + as);
+    const double D = A * 57.29577951308232087680;          // 180/pi
+    float f = (float)D;
+    // |c| >= 1, NaN, and every result the safety test cannot certify go through the exact evaluation
+    if (__builtin_expect(!(ax < 1.0) || !round_to_float_is_safe(D, f), 0)) f = acos_deg_exact(c);
     return f;
 }
 
@@ -209,12 +291,37 @@ __device__ __forceinline__ float sincosf_glibc(float y, int is_cos) {
 }
 __device__ __forceinline__ float sinf_glibc(float y) { return sincosf_glibc(y, 0); }
 __device__ __forceinline__ float cosf_glibc(float y) { return sincosf_glibc(y, 1); }
+// sinf(y) and cosf(y) together: one reduction, both polynomials (bit-identical to the two calls)
+__device__ __forceinline__ void sincosf_pair(float y, float* sn, float* cs) {
+    double x = (double)y;
+    if (abstop12(y) < 0x3f4u) {
+        const double x2 = x * x;
+        if (abstop12(y) < 0x398u) { *sn = y; *cs = 1.0f; return; }
+        *sn = sc_poly(x, x2, 0, false);
+        *cs = sc_poly(x, x2, 1, false);
+        return;
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    const double sg = ((n + 1) & 2) ? -1.0 : 1.0;
+    const double xs = x * sg, x2 = x * x;
+    const bool neg = (n & 2) != 0;
+    *sn = sc_poly(xs, x2, n, neg);
+    *cs = sc_poly(xs, x2, n ^ 1, neg);
+}
 
 // degrees -> radians as Nerf::place_atom does (src/nerf.cpp:63-64): double multiply, double divide,
-// rounded to float on assignment
-__device__ __forceinline__ float deg2rad(float deg) {
+// rounded to float on assignment. Fast path: one multiply by pi/180 + the float-rounding safety test.
+__device__ __noinline__ float deg2rad_exact(float deg) {
     const double kPi = 3.14159265358979323846;
     return (float)((double)deg * kPi / 180.0);
+}
+__device__ __forceinline__ float deg2rad(float deg) {
+    const double r = (double)deg * 0.01745329251994329577;
+    float f = (float)r;
+    if (__builtin_expect(!round_to_float_is_safe(r, f), 0)) f = deg2rad_exact(deg);
+    return f;
 }
 
 // Nerf::place_atom, reference src/nerf.cpp:39-104, with the trigonometry hoisted: d2 is the
@@ -236,12 +343,14 @@ __device__ __forceinline__ v3 place_atom_d2(v3 a, v3 b, v3 c, v3 d2) {
 }
 
 __device__ __forceinline__ v3 nerf_d2(float L, float bond_angle_deg_, float torsion_deg) {
-    float ba = deg2rad(bond_angle_deg_), ta = deg2rad(torsion_deg);
-    float sb = sinf_glibc(ba);
+    const float ba = deg2rad(bond_angle_deg_), ta = deg2rad(torsion_deg);
+    float sb, cb, st, ct;
+    sincosf_pair(ba, &sb, &cb);
+    sincosf_pair(ta, &st, &ct);
     v3 d2;
-    d2.x = -1.0f * L * cosf_glibc(ba);
-    d2.y = L * cosf_glibc(ta) * sb;
-    d2.z = L * sinf_glibc(ta) * sb;
+    d2.x = -1.0f * L * cb;
+    d2.y = L * ct * sb;
+    d2.z = L * st * sb;
     return d2;
 }
 

@@ -750,3 +750,40 @@ void fcz_oracle_sincos_sweep(int is_cos, uint32_t start_bits, uint32_t stride, u
         out[i] = is_cos ? cosf(c) : sinf(c);
     }
 }
+
+/* host twin of k_selftest_math (foldcomp_amd/csrc/fcz_abi.hip): same hashed inputs, reference-ordered
+ * evaluation with the host libm. modes: 3 deg2rad, 4 norm, 5 getCosineTheta, 6..8 place_atom x/y/z */
+static float st_hash_float(uint32_t u, uint32_t salt, float scale) {
+    uint32_t h = (u ^ salt) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    return (float)(int32_t)h * scale;
+}
+void fcz_oracle_math_sweep(int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out, int n_threads) {
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1 << 16) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t u = start_bits + i * stride;
+        float x; memcpy(&x, &u, 4);
+        const float sc = 0x1p-29f;
+        float r;
+        if (mode == 3) r = (float)((double)x * M_PI / 180.0);
+        else if (mode == 4) { v3 v = {st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)}; r = v_norm(v); }
+        else if (mode == 5) {
+            v3 a = {st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)};
+            v3 b = {st_hash_float(u, 4, sc), st_hash_float(u, 5, sc), st_hash_float(u, 6, sc)};
+            r = v_cos_theta(a, b);
+        } else {
+            v3 a = {st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)};
+            v3 b = {st_hash_float(u, 4, sc), st_hash_float(u, 5, sc), st_hash_float(u, 6, sc)};
+            v3 c = {st_hash_float(u, 7, sc), st_hash_float(u, 8, sc), st_hash_float(u, 9, sc)};
+            float L = 1.2f + fabsf(st_hash_float(u, 10, 0x1p-33f));
+            float ba = 90.0f + st_hash_float(u, 11, 0x1p-25f);
+            float ta = st_hash_float(u, 12, 0x1.6p-24f);
+            v3 d = place_atom(a, b, c, L, ba, ta);
+            r = (mode == 6) ? d.x : (mode == 7) ? d.y : d.z;
+        }
+        out[i] = r;
+    }
+}

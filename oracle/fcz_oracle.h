@@ -48,6 +48,7 @@ int fcz_oracle_check(const uint8_t* entry, uint64_t len);
 float fcz_oracle_sinf(float x);   /* glibc 2.35 sinf algorithm, plain (non-FMA) double arithmetic */
 float fcz_oracle_cosf(float x);
 void  fcz_oracle_use_restated_trig(int on);
+void  fcz_oracle_math_sweep(int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out, int n_threads);
 long  fcz_oracle_trig_mismatches(uint32_t lo_bits, uint32_t hi_bits, int n_threads);
 void  fcz_oracle_acos_deg_sweep(uint32_t start_bits, uint32_t stride, uint32_t count, float* out, int n_threads);
 void  fcz_oracle_sincos_sweep(int is_cos, uint32_t start_bits, uint32_t stride, uint32_t count, float* out, int n_threads); /* decompress: 0 = host libm sinf/cosf (default), 1 = restated */

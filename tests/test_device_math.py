@@ -66,3 +66,37 @@ def test_sincos_sweep(codec, is_cos):
         a, b = dev.view(np.uint32), host.view(np.uint32)
         bad = np.nonzero(a != b)[0]
         assert len(bad) == 0, (len(bad), [(hex(sign + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])
+
+
+def _host_math(mode, start, stride, count):
+    lib = H.load_oracle()
+    lib.fcz_oracle_math_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+    out = np.zeros(count, np.float32)
+    lib.fcz_oracle_math_sweep(mode, start, stride, count, out.ctypes.data, min(32, os.cpu_count() or 1))
+    return out
+
+
+def _same(dev, host):
+    a, b = dev.view(np.uint32), host.view(np.uint32)
+    return (a == b) | (np.isnan(dev) & np.isnan(host))
+
+
+def test_deg2rad_sweep(codec):
+    """every 7th float with |x| < 400 degrees, both signs"""
+    for sign in (0, 0x80000000):
+        stride = 7
+        count = _b(400.0) // stride
+        dev = codec.selftest_math(3, sign, stride, count)
+        host = _host_math(3, sign, stride, count)
+        bad = np.nonzero(~_same(dev, host))[0]
+        assert len(bad) == 0, (len(bad), [hex(sign + int(i) * stride) for i in bad[:8]])
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
+def test_hashed_geometry_functions(codec, mode):
+    """norm / getCosineTheta / place_atom on 2^26 hashed inputs: device fast paths == host reference order"""
+    count = 1 << 26
+    dev = codec.selftest_math(mode, 12345, 1, count)
+    host = _host_math(mode, 12345, 1, count)
+    bad = np.nonzero(~_same(dev, host))[0]
+    assert len(bad) == 0, (mode, len(bad), [(int(i), float(dev[i]), float(host[i])) for i in bad[:8]])

@@ -38,10 +38,10 @@ for f in glob.glob(os.path.join(src, "**", "*.csv"), recursive=True):
 PY
   rm -rf /tmp/rp_$name
 }
-run stats --kernel-trace --stats
+if [ -z "${PMC_ONLY:-}" ]; then run stats --kernel-trace --stats; fi
 # PMC passes: counters only (no trace domains besides kernel dispatch), one group per pass
 run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --kernel-include-regex "fcz" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
-run pmc_fetch --kernel-include-regex "fcz" --pmc FETCH_SIZE
-run pmc_write --kernel-include-regex "fcz" --pmc WRITE_SIZE
+if [ -z "${NO_MEM:-}" ]; then run pmc_fetch --kernel-include-regex "fcz" --pmc FETCH_SIZE
+run pmc_write --kernel-include-regex "fcz" --pmc WRITE_SIZE; fi
 ls -la $OUT

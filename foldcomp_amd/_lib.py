@@ -51,6 +51,7 @@ def load():
         "fcz_res_code_atom": (i32, [i32, i32, i32]),
         "fcz_compress_sizes": (i32, [PB, vp]),
         "fcz_compress_batch": (i32, [vp, PB, vp, vp, vp]),
+        "fcz_compress_angles": (i32, [vp, PB, vp]),
         "fcz_compress_sizes_dev": (i32, [vp, PB, vp]),
         "fcz_compress_batch_dev": (i32, [vp, PB, vp, vp, vp]),
         "fcz_decompress_sizes": (i32, [vp, vp, u32, vp, vp, vp]),
@@ -74,7 +75,7 @@ def load():
 EXPORTS = ["fcz_ctx_create", "fcz_ctx_destroy", "fcz_ctx_stream", "fcz_ctx_synchronize", "fcz_status_string",
            "fcz_atom_code_name", "fcz_atom_code_from_name", "fcz_res_code_from_name", "fcz_res_code_name",
            "fcz_res_code_natoms", "fcz_res_code_atom", "fcz_compress_sizes", "fcz_compress_batch",
-           "fcz_compress_sizes_dev", "fcz_compress_batch_dev", "fcz_decompress_sizes", "fcz_decompress_batch",
+           "fcz_compress_angles", "fcz_compress_sizes_dev", "fcz_compress_batch_dev", "fcz_decompress_sizes", "fcz_decompress_batch",
            "fcz_decompress_sizes_dev", "fcz_decompress_batch_dev", "fcz_check", "fcz_ctx_enable_timing",
            "fcz_ctx_kernel_time", "fcz_ctx_reset_timing"]
 

@@ -68,6 +68,13 @@ class Codec:
             _lib.check(rc, "fcz_compress_batch")
         return out, off, st
 
+    def compress_angles(self, b: ChainBatch) -> np.ndarray:
+        """-> float32 [6, R]: phi, psi, omega, n_ca_c, ca_c_n, c_n_ca before quantisation"""
+        cb = batch_as_c(b)
+        out = np.zeros((6, b.n_residues), np.float32)
+        _lib.check(self.lib.fcz_compress_angles(self.ctx, ctypes.byref(cb), out.ctypes.data), "fcz_compress_angles")
+        return out
+
     # ---- decompress -----------------------------------------------------------------------------
     def decompress_sizes(self, blob: np.ndarray, off: np.ndarray):
         n = len(off) - 1

@@ -69,6 +69,7 @@ struct fcz_ctx {
     dev_buf stage[20];
     uint32_t* pinned = nullptr;  // 4 words
     bool timing = false;
+    bool keep_first_angle = false;
     std::vector<timed_span> spans;
     std::map<std::string, std::pair<double, uint64_t>> acc;
 };
@@ -222,7 +223,7 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
     if (rc) return rc;
     span_guard g(ctx, "compress");
     hipLaunchKernelGGL(k_compress, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in,
-                       out_off_dev, out_dev, status_dev, ctx->ang.as<float>());
+                       out_off_dev, out_dev, status_dev, ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
 }
@@ -270,6 +271,24 @@ int fcz_compress_batch(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* 
     int worst = FCZ_OK;
     for (uint32_t c = 0; c < C; c++) if (st[c] != FCZ_OK) worst = st[c];
     return worst;
+}
+
+// Pre-quantisation backbone angles of a host batch (what get_data() of the Python module reports for
+// PDB input, foldcomp/foldcomp.cxx:633-662): angles_out is [6][R] floats in the order phi, psi, omega,
+// n_ca_c, ca_c_n, c_n_ca; entry r0+k (k < n-1) belongs to packed word k of the chain starting at residue
+// r0; n_ca_c[r0+n-1] holds the first residue's N-CA-C angle that the FCZ format drops.
+int fcz_compress_angles(fcz_ctx* ctx, const fcz_chain_batch* in, float* angles_out) {
+    if (!ctx || !in || !angles_out) return FCZ_E_INVALID_ARG;
+    std::vector<uint64_t> off((size_t)in->n_chains + 1);
+    int rc = fcz_compress_sizes(in, off.data());
+    if (rc) return rc;
+    std::vector<uint8_t> out(off[in->n_chains] ? off[in->n_chains] : 1);
+    ctx->keep_first_angle = true;
+    rc = fcz_compress_batch(ctx, in, off.data(), out.data(), nullptr);
+    ctx->keep_first_angle = false;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(angles_out, ctx->ang.p, sizeof(float) * 6 * (size_t)in->n_residues, hipMemcpyDeviceToHost));
+    return FCZ_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -147,7 +147,7 @@ struct slot_store {
 // what it wrote itself, so no cross-lane ordering is needed).
 __global__ __launch_bounds__(BLOCK) void k_compress(fcz_chain_batch in, const uint64_t* __restrict__ out_off,
                                                     uint8_t* __restrict__ out, int32_t* __restrict__ status,
-                                                    float* __restrict__ ang) {
+                                                    float* __restrict__ ang, int keep_first_angle) {
     __shared__ float s_slots[WAVES_PER_BLOCK][FCZ_MAX_RES_ATOMS * 3 * WAVE];
     __shared__ uint8_t s_slot_of[FCZ_N_RES_CODES][40];  // atom code -> canonical slot, 255 = not in residue
 
@@ -239,6 +239,9 @@ __global__ __launch_bounds__(BLOCK) void k_compress(fcz_chain_batch in, const ui
             }
         }
         const v3 N0 = S.get(0), CA0 = S.get(1), C0 = S.get(2);
+        // the N-CA-C angle of the first residue is measured by the reference (getBondAngles output[0]) but
+        // never stored in the FCZ (src/foldcomp.cpp:497); kept in the unused slot n-1 for get_data()
+        if (keep_first_angle && k == 0) a_nca[n - 1] = bond_angle_deg(N0, CA0, C0);
 
         // anchors: raw backbone coordinates of residue i*interval (and of the last residue),
         // reference Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1053-1059

@@ -141,6 +141,12 @@ int fcz_compress_sizes_dev(fcz_ctx* ctx, const fcz_chain_batch* in, uint64_t* ou
 int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off_dev,
                            uint8_t* out_dev, int32_t* status_dev);
 
+/* Pre-quantisation backbone angles of a host batch -- what `get_data()` of the reference's Python module
+ * returns for PDB input (foldcomp/foldcomp.cxx:633-662). angles_out = [6][R] floats, order phi, psi, omega,
+ * n_ca_c, ca_c_n, c_n_ca; entry r0+k (k < n-1) belongs to packed word k; n_ca_c[r0+n-1] holds the first
+ * residue's N-CA-C angle, which the FCZ format never stores (src/foldcomp.cpp:497). */
+int fcz_compress_angles(fcz_ctx* ctx, const fcz_chain_batch* in, float* angles_out);
+
 /* ---- decompress --------------------------------------------------------------------------- */
 /* Parse the n entries blob[off[i] .. off[i+1]) (trailing bytes such as the MMseqs '\0' are ignored,
  * like Foldcomp::read). Fills info[n] and the exclusive prefixes res_off[n+1] / atom_off[n+1]

@@ -1,0 +1,126 @@
+"""GPU: the Python surface that mirrors the reference's `foldcomp` module (compress / decompress /
+get_data / open), end to end through libfcz_hip.so, against reference-minted goldens."""
+import numpy as np
+import pytest
+
+import foldcomp_amd as foldcomp
+from _cases import db_cases, golden_batch
+from foldcomp_amd import pdbio
+from foldcomp_amd._aa_tables import RES3
+from foldcomp_amd.database import DatabaseWriter
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _input_pdb_text(z, name):
+    """render the golden SoA input of a one-chain case as PDB text (what a user would pass in)"""
+    b = golden_batch(z, name)
+    n_at = b.n_atoms
+    res_of_atom = np.repeat(np.arange(b.n_residues), np.diff(b.atom_off.astype(np.int64)))
+    bf = b.bfac_ca[res_of_atom]
+    return pdbio.format_pdb("", b.atom_code, b.res_code[res_of_atom], int(b.first_res_index[0]) + res_of_atom, chr(b.chain_id[0]),
+                            int(b.first_atom_index[0]), b.x, b.y, b.z, bf), bytes(b.titles).decode()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _codec_for_api(codec):
+    from foldcomp_amd import api
+    api.set_codec(codec)
+    yield
+    api.set_codec(None)
+
+
+@pytest.mark.parametrize("name", ["pdb:test_af", "pdb:test", "pdb:multichainA", "syn:len350", "syn:len26"])
+def test_compress_matches_reference_bytes(golden, name):
+    z, _ = golden
+    text, title = _input_pdb_text(z, name)
+    thr = int(z[f"{name}/in/anchor_threshold"][0])
+    fcz = foldcomp.compress(title, text, anchor_residue_threshold=thr)
+    assert isinstance(fcz, bytes)
+    assert fcz == z[f"{name}/fcz"].tobytes()
+
+
+def test_compress_errors(golden):
+    with pytest.raises(foldcomp.error, match="No ATOM lines found"):
+        foldcomp.compress("x", "HEADER nothing\n")
+    z, _ = golden
+    text, _ = _input_pdb_text(z, "pdb:test_af")
+    two = text + text.replace(" A ", " B ")
+    with pytest.raises(foldcomp.error, match="Multiple chains"):
+        foldcomp.compress("x", two)
+    with pytest.raises(TypeError):
+        foldcomp.compress("x", text, anchor_residue_threshold="25")
+    assert len(foldcomp.split_pdb_by_chain(two)) == 2
+
+
+@pytest.mark.parametrize("name", ["pdb:test_af", "pdb:test", "pdb:multichainB_1", "syn:len350", "db:00", "db:13"])
+def test_decompress_matches_reference_text(golden, name):
+    z, _ = golden
+    title, pdb = foldcomp.decompress(z[f"{name}/fcz"].tobytes())
+    exp = z[f"{name}/pdb0"].tobytes().decode("latin-1")
+    assert pdb == exp
+    if exp.startswith("TITLE"):
+        assert exp.startswith("TITLE     " + title[:70])
+
+
+def test_decompress_error():
+    with pytest.raises(foldcomp.error):
+        foldcomp.decompress(b"not an fcz record at all, definitely not")
+
+
+def test_get_data_fcz(golden):
+    z, _ = golden
+    for name in ("pdb:test_af", "db:05"):
+        d = foldcomp.get_data(z[f"{name}/fcz"].tobytes())
+        exp = z[f"{name}/xyz0"]
+        got = np.asarray(d["coordinates"], np.float32)
+        assert np.array_equal(_bits(got), _bits(exp))
+        assert set(d) == {"phi", "psi", "omega", "torsion_angles", "bond_angles", "residues", "b_factors", "coordinates"}
+        assert d["residues"] == z[f"{name}/fasta"].tobytes().decode()
+
+
+def test_get_data_pdb_angles_bit_exact(golden):
+    z, _ = golden
+    for name in ("pdb:test_af", "pdb:test", "syn:len129"):
+        text, _ = _input_pdb_text(z, name)
+        d = foldcomp.get_data(text)
+        for k in ("phi", "psi", "omega"):
+            assert np.array_equal(_bits(np.asarray(d[k], np.float32)), _bits(z[f"{name}/angle/{k}"])), (name, k)
+        n = len(d["residues"])
+        assert len(d["bond_angles"]) == 3 * n - 2 and len(d["torsion_angles"]) == 3 * n - 3
+        ba = np.asarray(d["bond_angles"], np.float32)
+        assert np.array_equal(_bits(ba[1::3]), _bits(z[f"{name}/angle/ca_c_n"]))
+        assert np.array_equal(_bits(ba[3::3]), _bits(z[f"{name}/angle/n_ca_c"]))
+    with pytest.raises(ValueError):
+        foldcomp.get_data(b"")
+
+
+def test_open_database(tmp_path, golden):
+    z, index = golden
+    names = db_cases(index)
+    w = DatabaseWriter(str(tmp_path / "db"))
+    for i, n in enumerate(names):
+        # MMseqs2-made databases carry a trailing NUL per entry; the module strips one byte (foldcomp.cxx:66)
+        e = z[f"{n}/fcz"].tobytes()
+        w.append(e if e.endswith(b"\0") else e + b"\0", i, bytes(z[f"{n}/name"]).decode())
+    w.close()
+    with foldcomp.open(str(tmp_path / "db")) as db:
+        assert len(db) == 24
+        title, pdb = db[3]
+        assert pdb == z[f"{names[3]}/pdb0"].tobytes().decode("latin-1")
+        allp = list(db.decompress_all(batch=16))
+        assert len(allp) == 24 and allp[3][1] == pdb
+        with pytest.raises(IndexError):
+            db[24]
+    want = [bytes(z[f"{names[5]}/name"]).decode(), "missing_id", bytes(z[f"{names[1]}/name"]).decode()]
+    with foldcomp.open(tmp_path / "db", ids=want, decompress=False) as db:
+        assert len(db) == 2
+        assert db[0].rstrip(b"\0") == z[f"{names[5]}/fcz"].tobytes().rstrip(b"\0")
+    with pytest.raises(KeyError):
+        foldcomp.open(str(tmp_path / "db"), ids=want, err_on_missing=True)
+    with pytest.raises(TypeError):
+        foldcomp.open(str(tmp_path / "db"), ids="d1asha_")

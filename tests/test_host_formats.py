@@ -1,0 +1,126 @@
+"""CPU: host-side formats around the codec against reference-minted goldens --
+PDB text writer (writeAtomCoordinatesToPDB / fast_ftoa), `extract` strings (pLDDT digits 1-4, FASTA),
+get_data() angle lists of FCZ input, the database container, ingest (fragmenting) rules."""
+import os
+
+import numpy as np
+import pytest
+
+import _harness as H
+from _cases import compress_cases, db_cases, entries_blob
+from foldcomp_amd import fczfile, pdbio
+from foldcomp_amd._aa_tables import RES3, RES_NATOMS
+from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+
+
+def _pdb_text_from_oracle(z, name):
+    """coordinates from the oracle (checker), text from the product's formatter"""
+    from foldcomp_amd.api import _pdb_from_result
+    e = z[f"{name}/fcz"].tobytes()
+    blob, off = entries_blob([e])
+    d = H.oracle_decompress(blob, off)
+    rec = fczfile.parse(e)
+    return _pdb_from_result(rec, d, 0, False)
+
+
+def test_pdb_text_matches_reference(golden):
+    z, index = golden
+    for name in compress_cases(index) + db_cases(index):
+        got = _pdb_text_from_oracle(z, name)
+        exp = z[f"{name}/pdb0"].tobytes().decode("latin-1")
+        if got != exp:
+            gl, el = got.splitlines(), exp.splitlines()
+            bad = [(i, a, b) for i, (a, b) in enumerate(zip(gl, el)) if a != b][:3]
+            raise AssertionError((name, len(gl), len(el), bad))
+
+
+def test_fast_ftoa_edge_cases():
+    v = np.asarray([0.0, -0.0004, 0.0005, -0.0005, 1.0005, 9.9995, -12.3456, 123.4567, 99.995, -0.5], np.float32)
+    got = pdbio.fast_ftoa(v, 1000, 3)
+    assert got[0] == "0.000" and got[1] == "-0.000"
+    assert got[6] in ("-12.346", "-12.345")
+    assert pdbio.fast_ftoa(np.asarray([87.5, 100.0, 0.004], np.float32), 100, 2) == ["87.50", "100.00", "0.00"]
+
+
+def test_title_wrapping():
+    t = "X" * 150
+    s = pdbio.title_lines(t)
+    lines = s.splitlines()
+    assert lines[0] == "TITLE     " + "X" * 70
+    assert lines[1] == "TITLE    2" + "X" * 70
+    assert lines[2] == "TITLE    3" + "X" * 10
+
+
+def test_extract_strings_match_reference(golden):
+    z, index = golden
+    for name in compress_cases(index) + db_cases(index):
+        rec = fczfile.parse(z[f"{name}/fcz"].tobytes())
+        for d in (1, 2, 3, 4):
+            assert fczfile.extract_plddt(rec, d) == z[f"{name}/plddt{d}"].tobytes().decode("latin-1"), (name, d)
+        assert fczfile.sequence(rec) == z[f"{name}/fasta"].tobytes().decode("latin-1"), name
+
+
+def test_committed_plddt_fixtures(golden):
+    """test/test_af.plddt (digits 1) and test/test_af.plddt.tsv (digits 4) of the reference repo"""
+    z, _ = golden
+    rec = fczfile.parse(z["fixture:test_af.fcz"].tobytes())
+    fa = z["fixture:test_af.plddt"].tobytes().decode()
+    tsv = z["fixture:test_af.plddt.tsv"].tobytes().decode()
+    assert fczfile.fasta_like("test/test_af.fcz", fczfile.extract_plddt(rec, 1)) == fa
+    assert fczfile.tsv_line("test/test_af.fcz", rec.n_residues, fczfile.extract_plddt(rec, 4)) == tsv
+
+
+def test_get_data_fcz_lists_match_reference_angles(golden):
+    """de-quantised phi/psi/omega of a record stay within half a quantisation step of the reference's
+    pre-quantisation angles, and the list shapes are the reference's (n, n, n, 3n-3, 3n)"""
+    z, index = golden
+    for name in ["pdb:test", "pdb:test_af", "syn:len350"]:
+        rec = fczfile.parse(z[f"{name}/fcz"].tobytes())
+        a = fczfile.angle_lists(rec)
+        n = rec.n_residues
+        assert len(a["phi"]) == n and len(a["torsion_angles"]) == 3 * n - 3 and len(a["bond_angles"]) == 3 * n
+        for k, q in (("phi", 0), ("psi", 1), ("omega", 2)):
+            ref = z[f"{name}/angle/{k}"]
+            assert np.abs(a[k][:n - 1] - ref).max() <= rec.cont_fs[q] * 0.5 + 1e-3
+
+
+def test_database_roundtrip_and_reference_db(tmp_path, golden):
+    z, index = golden
+    names = db_cases(index)
+    w = DatabaseWriter(str(tmp_path / "db"))
+    for i, n in enumerate(names):
+        w.append(z[f"{n}/fcz"].tobytes(), i, bytes(z[f"{n}/name"]).decode())
+    w.close()
+    assert open(tmp_path / "db.dbtype", "rb").read() == b"\x0c\x00\x00\x00"
+    r = DatabaseReader(str(tmp_path / "db"))
+    assert len(r) == 24
+    for i, n in enumerate(names):
+        assert r.data(i) == z[f"{n}/fcz"].tobytes()
+        assert r.name(i) == bytes(z[f"{n}/name"]).decode()
+        assert r.id_of_name(r.name(i)) == i
+    assert r.id_of_name("nope") == -1
+    first = open(tmp_path / "db.index").readline()
+    assert first == "0\t0\t%d\n" % len(z[f"{names[0]}/fcz"])
+    r.close()
+
+
+def test_fragmenting_rules():
+    """identifyChains / identifyDiscontinousResInd on a two-chain file with a residue-number gap
+    (the shape of the reference's test/multichain.pdb: A, B_0, B_1)"""
+    from foldcomp_amd.structure import identify_chains, identify_discontinuous, parse_pdb, split_residues
+    def atom(serial, name, res, ch, num):
+        return "ATOM  %5d  %-3s %3s %s%4d    %8.3f%8.3f%8.3f  1.00 50.00           %s\n" % (serial, name, res, ch, num, serial, 0, 0, name[0])
+    txt = ""
+    s = 1
+    for ch, nums in (("A", [1, 2, 3]), ("B", [1, 2, 5, 6])):
+        for num in nums:
+            for nm in ("N", "CA", "C", "O"):
+                txt += atom(s, nm, "GLY", ch, num); s += 1
+    t = parse_pdb(txt)
+    chains = identify_chains(t)
+    assert [(c.start, c.stop) for c in chains] == [(0, 12), (12, 28)]
+    parts = identify_discontinuous(t, chains[1])
+    assert [(p.start, p.stop) for p in parts] == [(12, 20), (20, 28)]
+    assert list(split_residues(t.take(chains[0]))) == [0, 4, 8, 12]
+    with pytest.raises(Exception):
+        parse_pdb(txt, single_chain=True)

@@ -65,7 +65,16 @@ def add_batch_case(name, b, thr=25):
     a = H.ref_angles(t)
     for k, v in a.items():
         out[f"{name}/angle/{k}"] = v
+    add_text_goldens(name, fcz)
     index.append(name)
+
+
+def add_text_goldens(name, fcz):
+    """reference PDB text of the decompressed record and the `extract` strings"""
+    out[f"{name}/pdb0"] = np.frombuffer(H.ref_decompress_pdb(fcz, False).encode("latin-1"), np.uint8)
+    for dgt in (1, 2, 3, 4):
+        out[f"{name}/plddt{dgt}"] = np.frombuffer(H.ref_extract(fcz, 0, dgt).encode("latin-1"), np.uint8)
+    out[f"{name}/fasta"] = np.frombuffer(H.ref_extract(fcz, 1, 0).encode("latin-1"), np.uint8)
 
 
 # ---- reference fixtures ------------------------------------------------------------------------
@@ -102,9 +111,12 @@ for key, offs, ln in idx:
         d = H.ref_decompress(e, bool(alt))
         out[f"{name}/xyz{alt}"] = np.stack([d["x"], d["y"], d["z"]], 1)
     out[f"{name}/bfac"] = d["bfac"]
+    add_text_goldens(name, e)
     index.append(name)
 
 # ---- the committed reference output test_af.fcz -------------------------------------------------
+out["fixture:test_af.plddt"] = np.frombuffer(open(os.path.join(REF_TEST, "test_af.plddt"), "rb").read(), np.uint8)
+out["fixture:test_af.plddt.tsv"] = np.frombuffer(open(os.path.join(REF_TEST, "test_af.plddt.tsv"), "rb").read(), np.uint8)
 out["fixture:test_af.fcz"] = np.frombuffer(open(os.path.join(REF_TEST, "test_af.fcz"), "rb").read(), np.uint8)
 
 # ---- synthetic edge cases ----------------------------------------------------------------------

@@ -23,18 +23,18 @@ constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = WAVE * WAVES_PER_BLOCK;
 
-// ---- unaligned byte access (FCZ records are byte-packed at arbitrary offsets) -------------------
-__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
-__device__ __forceinline__ float ld_f32(const uint8_t* p) { return __uint_as_float(ld_u32(p)); }
-__device__ __forceinline__ void st_u16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
-__device__ __forceinline__ void st_u32(uint8_t* p, uint32_t v) {
-    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
-}
-__device__ __forceinline__ void st_f32(uint8_t* p, float v) { st_u32(p, __float_as_uint(v)); }
-__device__ __forceinline__ v3 ld_v3(const uint8_t* p) { return v3{ld_f32(p), ld_f32(p + 4), ld_f32(p + 8)}; }
+// ---- unaligned access (FCZ records are byte-packed at arbitrary offsets) ---------------------------
+// gfx950 under ROCm runs with unaligned global access enabled; the memcpy forms compile to single
+// global_load/store_dword[x2] instructions instead of byte-wise sequences.
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ float ld_f32(const uint8_t* p) { float v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ void st_u16(uint8_t* p, uint32_t v) { uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
+__device__ __forceinline__ void st_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void st_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void st_f32(uint8_t* p, float v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ v3 ld_v3(const uint8_t* p) { v3 v; __builtin_memcpy(&v, p, 12); return v; }
 
 // ---- wave-level primitives -----------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
@@ -513,6 +513,20 @@ __device__ __forceinline__ bb_params load_params(const uint8_t* e) {
     for (int q = 0; q < 6; q++) { P.mn[q] = ld_f32(e + 28 + 4 * q); P.cf[q] = ld_f32(e + 52 + 4 * q); }
     return P;
 }
+__device__ __forceinline__ bb_word decode_word(uint64_t raw, const bb_params& P) {
+    const uint32_t b0 = (uint32_t)raw & 0xffu, b1 = (uint32_t)(raw >> 8) & 0xffu, b2 = (uint32_t)(raw >> 16) & 0xffu,
+                   b3 = (uint32_t)(raw >> 24) & 0xffu, b4 = (uint32_t)(raw >> 32) & 0xffu;
+    bb_word r;
+    r.res = b0 >> 3;
+    const uint32_t om = ((b0 & 7u) << 8) | b1, ps = (b2 << 4) | (b3 >> 4), ph = ((b3 & 0xfu) << 8) | b4;
+    r.phi = dequant(ph, P.mn[0], P.cf[0]);
+    r.psi = dequant(ps, P.mn[1], P.cf[1]);
+    r.omega = dequant(om, P.mn[2], P.cf[2]);
+    r.nca = dequant((uint32_t)(raw >> 56) & 0xffu, P.mn[3], P.cf[3]);
+    r.can = dequant((uint32_t)(raw >> 40) & 0xffu, P.mn[4], P.cf[4]);
+    r.cna = dequant((uint32_t)(raw >> 48) & 0xffu, P.mn[5], P.cf[5]);
+    return r;
+}
 __device__ __forceinline__ bb_word load_word(const uint8_t* w, const bb_params& P) {
     const uint32_t b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3], b4 = w[4];
     bb_word r;
@@ -545,33 +559,45 @@ __global__ __launch_bounds__(BLOCK) void k_forward_nerf(const uint8_t* __restric
     const entry_view v = view_entry(e);
     const bb_params P = load_params(e);
     const uint8_t* words = e + v.L.o_words;
+    const uint8_t* last_word = words + 8 * (size_t)(v.n - 1);
     v3* F = fwd + 3 * (size_t)res_off[c] + 3 * (size_t)seg_off[c];
     v3 p0 = ld_v3(e + v.L.o_anchor), p1 = ld_v3(e + v.L.o_anchor + 12), p2 = ld_v3(e + v.L.o_anchor + 24);
     const uint32_t nseg = v.n_anchor - 1;
     int first = (int)ld_u32(e + v.L.o_aidx);
+    int next = (int)ld_u32(e + v.L.o_aidx + 4);
+    // software prefetch: every global load is issued two residues (or one segment) ahead of its use so the
+    // dependent chain of place_atom calls never waits on memory
+    const uint8_t* wp = words + 8 * (size_t)first;
+    uint64_t w_cur = ld_u64(wp);
+    uint64_t w_nxt = ld_u64(wp + 8 <= last_word ? wp + 8 : last_word);
     for (uint32_t s = 0; s < nseg; s++) {
-        const int next = (int)ld_u32(e + v.L.o_aidx + 4 * (s + 1));
         const int len = next - first + 1;
+        const int next2 = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)(s + 2 <= nseg ? s + 2 : nseg));
+        const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
+        const v3 A0 = ld_v3(anc), A1 = ld_v3(anc + 12), A2 = ld_v3(anc + 24);   // used after the residue loop
         v3* Fs = F + 3 * (size_t)first + 3 * (size_t)s;
         Fs[0] = p0; Fs[1] = p1; Fs[2] = p2;
         for (int i = 0; i + 1 < len; i++) {
-            const bb_word w = load_word(words + 8 * (size_t)(first + i), P);
+            const uint8_t* pf = wp + 16;
+            const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
+            const bb_word w = decode_word(w_cur, P);
             const v3 N = place_atom(p0, p1, p2, (float)1.3311, w.can, w.psi);
             const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
             const v3 CA = place_atom(p1, p2, N, l_nca, w.cna, w.omega);
             const v3 C = place_atom(p2, N, CA, (float)1.5281, w.nca, w.phi);
             Fs[3 * i + 3] = N; Fs[3 * i + 4] = CA; Fs[3 * i + 5] = C;
             p0 = N; p1 = CA; p2 = C;
+            w_cur = w_nxt; w_nxt = w_pre; wp += 8;
         }
+        // The next segment starts at word `next`; the loop consumed words first..next-1, so w_cur already
+        // holds word `next` (segments share their boundary residue).
         // carry: blended last three atoms (indices T-3..T-1 of this segment)
         const float T = (float)(3 * len);
-        const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
-        const v3 A0 = ld_v3(anc), A1 = ld_v3(anc + 12), A2 = ld_v3(anc + 24);
         const float j0 = (float)(3 * len - 3), j1 = (float)(3 * len - 2), j2 = (float)(3 * len - 1);
         p0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / T, ((p0.y * 3.0f) + (A0.y * j0)) / T, ((p0.z * 3.0f) + (A0.z * j0)) / T};
         p1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / T, ((p1.y * 2.0f) + (A1.y * j1)) / T, ((p1.z * 2.0f) + (A1.z * j1)) / T};
         p2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / T, ((p2.y * 1.0f) + (A2.y * j2)) / T, ((p2.z * 1.0f) + (A2.z * j2)) / T};
-        first = next;
+        first = next; next = next2;
     }
 }
 
@@ -613,22 +639,31 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
     if (T < 4) {
         return;
     }
+    // Walk the segment backwards one residue (= one packed word = three atoms) per iteration; the word and
+    // the three forward atoms of the NEXT iteration are loaded before the current one is computed.
     v3 f2 = Fs[T - 2], f1 = Fs[T - 3];  // forward atoms f+2, f+1 for f = T-4
-    bb_word w = load_word(words + 8 * (size_t)(first + (T - 4) / 3), P);
-    int w_idx = (T - 4) / 3;
-    for (int f = T - 4; f >= 0; f--) {
-        const v3 f0 = Fs[f];
-        const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
-        const int q = f % 3;
-        if (f / 3 != w_idx) { w_idx = f / 3; w = load_word(words + 8 * (size_t)(first + w_idx), P); }
-        const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
-        const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
-        // a = R[f+3], b = R[f+2], c = R[f+1]
-        const v3 R = place_atom(r3, r2, r1, Lb, ba, tor);
-        const float wf = (float)(T - f), wr = (float)f;
-        B[f] = v3{((f0.x * wf) + (R.x * wr)) / Tf, ((f0.y * wf) + (R.y * wr)) / Tf, ((f0.z * wf) + (R.z * wr)) / Tf};
-        r3 = r2; r2 = r1; r1 = R;
-        f2 = f1; f1 = f0;
+    int wi = len - 2;                   // word index of atoms f = 3wi+2, 3wi+1, 3wi
+    uint64_t w_raw = ld_u64(words + 8 * (size_t)(first + wi));
+    v3 fa = Fs[3 * wi + 2], fb = Fs[3 * wi + 1], fc = Fs[3 * wi];
+    for (; wi >= 0; wi--) {
+        const int wn = wi > 0 ? wi - 1 : 0;
+        const uint64_t w_pre = ld_u64(words + 8 * (size_t)(first + wn));
+        const v3 na = Fs[3 * wn + 2], nb = Fs[3 * wn + 1], nc = Fs[3 * wn];
+        const bb_word w = decode_word(w_raw, P);
+#pragma unroll
+        for (int q = 2; q >= 0; q--) {
+            const int f = 3 * wi + q;
+            const v3 f0 = (q == 2) ? fa : (q == 1) ? fb : fc;
+            const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
+            const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
+            const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
+            const v3 R = place_atom(r3, r2, r1, Lb, ba, tor);   // a = R[f+3], b = R[f+2], c = R[f+1]
+            const float wf = (float)(T - f), wr = (float)f;
+            B[f] = v3{((f0.x * wf) + (R.x * wr)) / Tf, ((f0.y * wf) + (R.y * wr)) / Tf, ((f0.z * wf) + (R.z * wr)) / Tf};
+            r3 = r2; r2 = r1; r1 = R;
+            f2 = f1; f1 = f0;
+        }
+        w_raw = w_pre; fa = na; fb = nb; fc = nc;
     }
 }
 
@@ -643,6 +678,12 @@ __global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__
     __shared__ float s_d2x[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];   // -1 * L * cos(ba)
     __shared__ float s_sb[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];    // sin(ba)
     __shared__ float s_slots[WAVES_PER_BLOCK][FCZ_MAX_RES_ATOMS * 3 * WAVE];
+    // per-lane table lookups (residue code varies per lane) come from LDS copies, not global memory
+    __shared__ uint16_t s_prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
+    __shared__ float s_blen[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
+    __shared__ uint8_t s_oslot[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];   // output position -> canonical slot
+    __shared__ uint8_t s_ratom[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
+    __shared__ uint8_t s_natoms[FCZ_N_RES_CODES];
     // trig tables: the side-chain torsion takes one of 256 values (fixed-angle quantiser) and the bond
     // angles are per-(residue, atom) constants, so every sinf/cosf of this kernel is precomputed here.
     {
@@ -657,6 +698,11 @@ __global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__
             const float ba = deg2rad(__uint_as_float(fcz_res_bang_bits[rc][j]));
             s_d2x[rc][j] = -1.0f * L * cosf_glibc(ba);
             s_sb[rc][j] = sinf_glibc(ba);
+            s_prev[rc][j] = fcz_res_prev[rc][j];
+            s_blen[rc][j] = L;
+            s_oslot[rc][j] = alt_order ? fcz_res_alt_slot[rc][j] : (uint8_t)j;
+            s_ratom[rc][j] = fcz_res_atom[rc][j];
+            if (j == 0) s_natoms[rc] = fcz_res_natoms[rc];
         }
     }
     __syncthreads();
@@ -679,23 +725,34 @@ __global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__
     for (uint32_t base = 0; base < n; base += WAVE) {
         const uint32_t k = base + lane;
         const bool act = k < n;
-        uint32_t rc = 23, na = 0;
+        uint32_t rc = 23, na = 0, tq = 0;
+        v3 b0{0.f, 0.f, 0.f}, b1 = b0, b2 = b0;
         if (act) {
+            // first batch of loads: residue code, B-factor byte, the three backbone atoms
             rc = words[8 * (size_t)k] >> 3;
+            tq = e[v.L.o_tbytes + k];
+            b0 = B[3 * k]; b1 = B[3 * k + 1]; b2 = B[3 * k + 2];
             if (k == 0) rc = (uint32_t)res_code_from_letter(e[20]);
             if (rc >= 24) rc = 23;
-            na = fcz_res_natoms[rc];
+            na = s_natoms[rc];
         }
         uint32_t tot_a, tot_s;
         const uint32_t a_off = atom_run + wave_excl_scan(na, lane, &tot_a);
         const uint32_t s_off = sc_run + wave_excl_scan(act ? na - 3 : 0, lane, &tot_s);
         atom_run += tot_a; sc_run += tot_s;
         if (!act) continue;
-        S.put(0, B[3 * k]); S.put(1, B[3 * k + 1]); S.put(2, B[3 * k + 2]);
+        // second batch: all (<= 11) side-chain torsion bytes of the residue as three unaligned dwords
+        // (reads at most 11 bytes past the last torsion byte: still inside the record, which continues
+        // with the 8-byte B-factor header and n B-factor bytes)
+        const uint8_t* sp = scb + s_off;
+        const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = (na > 11) ? ld_u32(sp + 8) : 0u;
+        S.put(0, b0); S.put(1, b1); S.put(2, b2);
         for (uint32_t j = 3; j < na; j++) {
-            const uint32_t pk = fcz_res_prev[rc][j];
-            const uint32_t q = scb[s_off + j - 3];
-            const float L = __uint_as_float(fcz_res_blen_bits[rc][j]);
+            const uint32_t pk = s_prev[rc][j];
+            const uint32_t jj = j - 3;
+            const uint32_t qw = (jj < 4) ? q0 : (jj < 8 ? q1 : q2);
+            const uint32_t q = (qw >> (8 * (jj & 3))) & 0xffu;
+            const float L = s_blen[rc][j];
             const float sb = s_sb[rc][j];
             v3 d2;
             d2.x = s_d2x[rc][j];
@@ -705,12 +762,12 @@ __global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__
         }
         const uint32_t a = abase + a_off;
         for (uint32_t j = 0; j < na; j++) {
-            const uint32_t slot = alt_order ? fcz_res_alt_slot[rc][j] : j;
+            const uint32_t slot = s_oslot[rc][j];
             const v3 p = S.get((int)slot);
             out.x[a + j] = p.x; out.y[a + j] = p.y; out.z[a + j] = p.z;
-            if (out.atom_code) out.atom_code[a + j] = fcz_res_atom[rc][slot];
+            if (out.atom_code) out.atom_code[a + j] = s_ratom[rc][slot];
         }
-        out.bfac_res[r0 + k] = dequant(e[v.L.o_tbytes + k], tmin, tcf);
+        out.bfac_res[r0 + k] = dequant(tq, tmin, tcf);
         if (out.res_code) out.res_code[r0 + k] = (uint8_t)rc;
     }
     if (lane == 0 && e[v.L.o_oxt]) {

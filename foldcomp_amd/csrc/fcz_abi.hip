@@ -548,3 +548,13 @@ extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, ui
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FCZ_OK;
 }
+
+#ifdef FCZ_PROFILE_PHASES
+extern "C" int fcz_debug_phase_cycles(fcz_ctx* ctx, unsigned long long* out16, int reset) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(fcz::g_phase_cycles), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_phase_cycles), z, sizeof z)); }
+    return FCZ_OK;
+}
+#endif

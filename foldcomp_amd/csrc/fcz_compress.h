@@ -19,6 +19,18 @@
 
 namespace fcz {
 
+// Optional phase timer (build with -DFCZ_PROFILE_PHASES): per-wave s_memtime deltas summed into g_phase_cycles.
+#ifdef FCZ_PROFILE_PHASES
+__device__ unsigned long long g_phase_cycles[16];
+#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(); unsigned long long ph_acc[10] = {0,0,0,0,0,0,0,0,0,0};
+#define PH_MARK(i) { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; }
+#define PH_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 10; i_++) atomicAdd(&g_phase_cycles[i_], ph_acc[i_]); }
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH
+#endif
+
 #ifndef FCZ_COMPRESS_MIN_WAVES
 #define FCZ_COMPRESS_MIN_WAVES 2
 #endif
@@ -64,6 +76,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= in.n_chains) return;
     compress_tile_lds& L = s_tile[wave];
+    PH_DECL
 
     const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
     const uint32_t title_len = in.title_off[c + 1] - in.title_off[c];
@@ -93,6 +106,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         return;
     }
     nsc = wave_sum(nsc);
+    PH_MARK(0)
 
     const uint32_t m = n - 1;
     const uint32_t n_anchor = n / thr + 2;
@@ -141,6 +155,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         if (lane == 0) { L.aoff[64] = (uint16_t)(o64 - A0); L.aoff[65] = (uint16_t)(o65 - A0); L.rc[64] = (uint8_t)rc_hi; }
         L.rc[lane] = (uint8_t)rc_lane;
 
+        PH_MARK(1)
         // ---- coalesced staging of the tile's atoms: 16-byte loads, all issued before the first use ----
         {
             constexpr int NV = CT_CAP / (4 * WAVE);   // float4 rounds (3)
@@ -182,6 +197,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
+        PH_MARK(2)
         // ---- slot index table: first atom of each canonical name ----
         for (uint32_t rr = lane; rr < nres_t; rr += WAVE) {
             const uint32_t rc = L.rc[rr];
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
 
+        PH_MARK(3)
         // ---- anchors (reference Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1045-1059) ----
         if ((uint32_t)lane < T) {
             const uint32_t k = base + lane;
@@ -229,6 +246,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
                 a_arr[3 * R + (n - 1)] = bond_angle_deg(tile_atom(L, 0, 0), tile_atom(L, 0, 1), tile_atom(L, 0, 2));
         }
 
+        PH_MARK(4)
         // ---- the flat work list of the tile ----
         // items [0,3W): backbone dihedrals (q = item / W: psi, omega, phi), [3W,6W): backbone bond angles
         // (ca_c_n, c_n_ca, n_ca_c), then the side-chain dihedrals. W = number of residue windows of the
@@ -280,8 +298,10 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         }
         sc_base += tile_sc;
         base += T;
+        PH_MARK(5)
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
+        PH_MARK(6)
     }
     __threadfence_block();
 
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         }
     }
 
+    PH_MARK(7)
     for (uint32_t i = lane; i < title_len; i += WAVE) rec[RL.o_title + i] = (uint8_t)in.titles[in.title_off[c] + i];
 
     // ---- header (CompressedFileHeader src/foldcomp.h:118-136; get_header src/foldcomp.cpp:1340) ----
@@ -393,6 +414,8 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         st_f32(rec + RL.o_tmp + 4, qcont[6]);
         if (status) status[c] = FCZ_OK;
     }
+    PH_MARK(8)
+    PH_FLUSH
 }
 
 }  // namespace fcz

@@ -62,6 +62,11 @@ struct fcz_ctx {
     // scratch
     dev_buf ang;        // compress: 6 x R floats
     dev_buf sizes;      // compress: C x u64
+    dev_buf scan_tmp;   // block partials of the device scans
+    // decompress: the segment/residue prefixes computed by fcz_decompress_sizes_dev are reused by the
+    // fcz_decompress_batch_dev call that follows on the same entries
+    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_S = 0;
+    bool sizes_fresh = false;
     dev_buf cnt;        // decompress: 3 x n u32 counts + n i32 status
     dev_buf seg_off;    // decompress: (n+1) u32
     dev_buf fwd;        // decompress: forward atoms
@@ -99,6 +104,21 @@ void drain_spans(fcz_ctx* ctx) {
 }
 
 inline unsigned grid_for(uint32_t items, unsigned per_block) { return (items + per_block - 1) / per_block; }
+
+// exclusive scan of n elements into out[n+1] on the ctx stream (three launches, any n)
+template <class T>
+int device_scan(fcz_ctx* ctx, const T* in, T* out, uint32_t n) {
+    if (n == 0) { if (hipMemsetAsync(out, 0, sizeof(T), ctx->stream) != hipSuccess) return FCZ_E_HIP; return FCZ_OK; }
+    const unsigned nb = grid_for(n, SCAN_CHUNK);
+    int rc = ctx->scan_tmp.ensure(sizeof(unsigned long long) * 2 * ((size_t)nb + 1));
+    if (rc) return rc;
+    unsigned long long* part = ctx->scan_tmp.as<unsigned long long>();
+    unsigned long long* part_ex = part + nb + 1;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<T>), dim3(nb), dim3(1024), 0, ctx->stream, n, in, part);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, ctx->stream, nb, (const uint64_t*)part, (uint64_t*)part_ex);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<T>), dim3(nb), dim3(1024), 0, ctx->stream, n, in, part_ex, out);
+    return FCZ_OK;
+}
 
 }  // namespace
 
@@ -160,7 +180,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->sizes.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release();
+    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -208,8 +228,9 @@ int fcz_compress_sizes_dev(fcz_ctx* ctx, const fcz_chain_batch* in, uint64_t* ou
     int rc = ctx->sizes.ensure(sizeof(uint64_t) * (size_t)in->n_chains);
     if (rc) return rc;
     span_guard g(ctx, "compress_sizes");
-    hipLaunchKernelGGL(k_compress_sizes, dim3(grid_for(in->n_chains, 256)), dim3(256), 0, ctx->stream, *in, ctx->sizes.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, ctx->stream, in->n_chains, ctx->sizes.as<uint64_t>(), out_off_dev);
+    hipLaunchKernelGGL(k_compress_sizes, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in, ctx->sizes.as<uint64_t>());
+    rc = device_scan<uint64_t>(ctx, ctx->sizes.as<uint64_t>(), out_off_dev, in->n_chains);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
 }
@@ -386,7 +407,9 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     {
         span_guard g(ctx, "decompress_sizes");
         if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st);
-        hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, ctx->stream, n, cr, res_off_dev, ca, atom_off_dev, cs, ctx->seg_off.as<uint32_t>());
+        if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
+        if ((rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
+        if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -395,6 +418,8 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (total_res) *total_res = ctx->pinned[0];
     if (total_atoms) *total_atoms = ctx->pinned[1];
+    ctx->sized_blob = blob_dev; ctx->sized_off = off_dev; ctx->sized_n = n;
+    ctx->sized_R = ctx->pinned[0]; ctx->sized_S = ctx->pinned[2]; ctx->sizes_fresh = true;
     return FCZ_OK;
 }
 
@@ -402,14 +427,19 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
 // recomputes it when it is called without a preceding sizes call on the same entries.
 static int ensure_segments(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res,
                            uint32_t* total_seg) {
+    if (ctx->sizes_fresh && ctx->sized_blob == blob_dev && ctx->sized_off == off_dev && ctx->sized_n == n) {
+        ctx->sizes_fresh = false;   // single use: the records may be rewritten before the next call
+        *total_res = ctx->sized_R; *total_seg = ctx->sized_S;
+        return FCZ_OK;
+    }
     int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
     rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
     if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st);
     // scans of residues (scratch, reusing cr in place is not possible: use stage[16]) and segments
     rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
-    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, ctx->stream, n, cr, ctx->stage[16].as<uint32_t>(), (const uint32_t*)nullptr,
-                       (uint32_t*)nullptr, cs, ctx->seg_off.as<uint32_t>());
+    if ((rc = device_scan<uint32_t>(ctx, cr, ctx->stage[16].as<uint32_t>(), n))) return rc;
+    if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], ctx->stage[16].as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,19 +1,20 @@
-// fcz_compress.h -- k_compress_tiled: the compress kernel, second generation.
+// fcz_compress.h -- k_compress_tiled: the compress kernel (Foldcomp::preprocess/compress/writeStream,
+// reference src/foldcomp.cpp:450-606, 1038-1109).
 //
-// One wavefront per chain. The chain is walked in tiles of up to 64 residues; per tile
+// One wavefront per chain. The chain is walked in tiles of up to 64 residues:
 //   1. the tile's atoms (a contiguous range of the SoA arrays, plus the next residue for the backbone
-//      windows that straddle the tile edge) are loaded with coalesced, lane-strided loads into LDS;
-//   2. every residue lane scans its atoms *in LDS* and records, per canonical slot, the index of the
-//      first atom with that name (findFirstAtomCoords semantics, reference src/sidechain.cpp:140-147;
-//      missing atoms read as (0,0,0));
-//   3. all angle evaluations of the tile form ONE flat work list -- 3 backbone dihedrals + 3 backbone
-//      bond angles per residue window, then one dihedral per side-chain atom -- and lanes take items
-//      round-robin, so every iteration has 64 busy lanes running the same code (the per-residue loop of
-//      the first-generation kernel idled half the lanes on the ragged side-chain counts). Side-chain
-//      items are numbered exactly like the FCZ side-chain byte stream, so their byte stores are
-//      consecutive across lanes.
+//      windows that straddle the tile edge) arrive with coalesced 16-byte loads that were issued one tile
+//      earlier (register prefetch) and are parked in LDS as {x, y, z, code} records;
+//   2. every residue lane reads its atoms' codes from LDS (all reads in flight at once) and records, per
+//      canonical slot, the index of the first atom with that name (findFirstAtomCoords semantics,
+//      reference src/sidechain.cpp:140-147); absent names point at an all-zero record, which is what the
+//      reference reads for a missing atom;
+//   3. all angle evaluations of the tile form ONE flat work list -- 3 backbone dihedrals + 3 backbone bond
+//      angles per residue window, then one dihedral per side-chain atom -- and lanes take items
+//      round-robin: every iteration has 64 busy lanes running the same code. Side-chain items are
+//      numbered exactly like the FCZ side-chain byte stream, so their byte stores are consecutive.
 // Backbone angles go to per-chain scratch (coalesced per angle type); after the tile loop the wave reduces
-// min/max per type (value, index) and quantises + packs the 8-byte words.
+// min/max per type and quantises + packs the 8-byte words from registers.
 #pragma once
 #include "fcz_kernels.h"
 
@@ -34,29 +35,54 @@ __device__ unsigned long long g_phase_cycles[16];
 #ifndef FCZ_COMPRESS_MIN_WAVES
 #define FCZ_COMPRESS_MIN_WAVES 2
 #endif
-constexpr int CT_CAP = 768;          // staged atoms per tile (typical tile: 65 residues * 8.4 atoms = 545)
-constexpr int CT_RES = 65;           // 64 residues + 1 look-ahead
-constexpr uint32_t CT_NONE = 0xffffu;
+constexpr int CT_CAP = 768;          // staged atom records per tile (typical tile: 65 residues * 8.4 atoms = 545)
+constexpr int CT_ZERO = CT_CAP;      // index of the all-zero record (missing atoms)
+constexpr int CT_NV = CT_CAP / (4 * WAVE);   // float4 staging rounds per array
+constexpr int CT_SB = 8;             // tiles per metadata super-block (512 residues)
 
 struct alignas(16) compress_tile_lds {
-    float x[CT_CAP], y[CT_CAP], z[CT_CAP];
-    uint16_t idx[FCZ_MAX_RES_ATOMS][CT_RES + 1];   // [slot][residue in tile] -> staged atom index
-    uint16_t aoff[CT_RES + 1];                     // tile-local atom offset of each residue
-    uint16_t scpre[CT_RES + 1];                    // tile-local exclusive prefix of side-chain torsion counts
-    alignas(16) uint8_t code[CT_CAP];
-    uint8_t rc[CT_RES + 3];
+    float4 atom[CT_CAP + 1];                       // {x, y, z, code bits}
+    uint16_t idx[66][16];                          // [residue in tile][canonical slot] -> atom record index
+    uint16_t scpre[66];                            // tile-local exclusive prefix of side-chain torsion counts
+    uint8_t rc[68];
     uint8_t item_res[64 * 11];                     // side-chain item -> residue in tile
 };
 
 __device__ __forceinline__ v3 tile_atom(const compress_tile_lds& L, uint32_t res, uint32_t slot) {
-    const uint32_t i = L.idx[slot][res];
-    if (i == CT_NONE) return v3{0.0f, 0.0f, 0.0f};
-    return v3{L.x[i], L.y[i], L.z[i]};
+    const float4 a = L.atom[L.idx[res][slot]];
+    return v3{a.x, a.y, a.z};
 }
 
-__global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off,
-                                                          uint8_t* __restrict__ out, int32_t* __restrict__ status,
-                                                          float* __restrict__ ang, int keep_first_angle) {
+// ---- wave reductions on the DPP cross-lane network (no LDS traffic) -------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = __builtin_fminf(v, dpp_f32<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
+    v = __builtin_fminf(v, dpp_f32<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
+    v = __builtin_fminf(v, dpp_f32<0x141, 0xf>(v));   // row_half_mirror
+    v = __builtin_fminf(v, dpp_f32<0x140, 0xf>(v));   // row_mirror
+    v = __builtin_fminf(v, dpp_f32<0x142, 0xa>(v));   // row_bcast:15 -> rows 1,3
+    v = __builtin_fminf(v, dpp_f32<0x143, 0xc>(v));   // row_bcast:31 -> rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = __builtin_fmaxf(v, dpp_f32<0xB1, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x4E, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x141, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x140, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x142, 0xa>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// tile geometry shared by the prefetch and the consumer
+struct tile_ext { uint32_t T, nres, A0, cnt; bool look; };
+
+__global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES)
+void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                      int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle) {
     __shared__ compress_tile_lds s_tile[WAVES_PER_BLOCK];
     __shared__ uint8_t s_slot_of[FCZ_N_RES_CODES][40];  // atom code -> canonical slot, 255 = not in residue
     __shared__ uint16_t s_prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
@@ -83,6 +109,11 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
     const uint32_t thr = (uint32_t)in.anchor_threshold;
     uint8_t* rec = out + out_off[c];
     const uint32_t rec_size = (uint32_t)(out_off[c + 1] - out_off[c]);
+    // header scalars: issued now, consumed at the very end
+    const int32_t h_first_res = in.first_res_index[c], h_first_atom = in.first_atom_index[c];
+    const char h_chain = in.chain_id[c];
+    const uint32_t a_first = in.atom_off[r0], a_end = in.atom_off[r0 + n];
+    const uint32_t h_rc_first = in.res_code[r0], h_rc_last = in.res_code[r0 + (n ? n - 1 : 0)];
 
     // ---- validation (the reference aborts on these inputs) + total side-chain torsion count ----
     int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
@@ -116,104 +147,159 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
     float* a_arr = ang + r0;   // array q of this chain = a_arr + q*R : phi psi omega n_ca_c ca_c_n c_n_ca
     const float sc_min = -180.0f, sc_disc = 255.0f / (180.0f - (-180.0f));  // FixedAngleDiscretizer(255)
 
-    uint32_t sc_base = 0;       // side-chain bytes emitted so far
-    uint32_t base = 0;
-    while (base < n) {
-        // ---- tile metadata, one round trip: atom offsets of residues base..base+65, residue codes ----
-        uint32_t T = (n - base < (uint32_t)WAVE) ? (n - base) : (uint32_t)WAVE;
-        const uint32_t o_lane = in.atom_off[r0 + ((base + lane <= n) ? base + lane : n)];            // start of residue `lane`
-        const uint32_t o_hi = (lane < 2) ? in.atom_off[r0 + ((base + 64 + lane <= n) ? base + 64 + lane : n)] : 0u;  // 64, 65
-        uint32_t rc_lane = (base + lane < n) ? in.res_code[r0 + base + lane] : 23u;
-        const uint32_t rc_hi = (lane == 0 && base + 64 < n) ? in.res_code[r0 + base + 64] : 23u;
-        const uint32_t A0 = __shfl(o_lane, 0, WAVE);
-        const uint32_t o64 = __shfl(o_hi, 0, WAVE), o65 = __shfl(o_hi, 1, WAVE);
-        uint32_t my_end = __shfl_down(o_lane, 1, WAVE);            // end of residue `lane`
-        if (lane == 63) my_end = o64;
-        bool look = base + T < n;
-        uint32_t A1;
-        {
-            const uint32_t last = T + (look ? 1u : 0u);            // atom_off index (relative) of the tile end
-            A1 = (last == 65) ? o65 : (last == 64 ? o64 : __shfl(o_lane, (int)last, WAVE));
-        }
-        if (A1 - A0 > (uint32_t)CT_CAP) {
+    if (lane == 0) L.atom[CT_ZERO] = float4{0.f, 0.f, 0.f, 0.f};
+
+    // Metadata registers of the current super-block, rotated so that index 0 is always the current tile:
+    // mo[u] = atom_off of residue (tile base + u*64 + lane), mr[u] = its residue code.
+    uint32_t mo[CT_SB + 1], mr[CT_SB + 1];
+    auto load_meta = [&](uint32_t sb_base) {
+#pragma unroll
+        for (int u = 0; u <= CT_SB; u++) { const uint32_t k = sb_base + u * WAVE + lane; mo[u] = in.atom_off[r0 + (k <= n ? k : n)]; }
+#pragma unroll
+        for (int u = 0; u <= CT_SB; u++) { const uint32_t k = sb_base + u * WAVE + lane; mr[u] = (k < n) ? in.res_code[r0 + k] : 23u; }
+    };
+    // extent of the tile that starts at residue `base` (metadata in o_lane = mo[0], o_next = mo[1])
+    auto tile_extent = [&](uint32_t base, uint32_t o_lane, uint32_t o_next) -> tile_ext {
+        tile_ext e;
+        e.T = (n - base < (uint32_t)WAVE) ? (n - base) : (uint32_t)WAVE;
+        e.A0 = __shfl(o_lane, 0, WAVE);
+        const uint32_t o64 = __shfl(o_next, 0, WAVE), o65 = __shfl(o_next, 1, WAVE);
+        e.look = base + e.T < n;
+        const uint32_t last = e.T + (e.look ? 1u : 0u);
+        uint32_t A1 = (last == 65) ? o65 : (last == 64 ? o64 : __shfl(o_lane, (int)(last & 63u), WAVE));
+        if (A1 - e.A0 > (uint32_t)CT_CAP) {
             // unusually atom-rich residues (e.g. explicit hydrogens): shrink the tile. Residues [0,t) plus the
             // look-ahead residue t fit iff the ends of residues 0..t all lie within the staging capacity.
-            const bool fits = (base + lane < n) && (my_end - A0 <= (uint32_t)CT_CAP);
+            uint32_t my_end = __shfl_down(o_lane, 1, WAVE);
+            if (lane == 63) my_end = o64;
+            const bool fits = (base + lane < n) && (my_end - e.A0 <= (uint32_t)CT_CAP);
             const unsigned long long fm = __ballot(fits);
             const uint32_t lead = (fm == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~fm);
-            if (lead < 2) {  // one residue plus its successor exceed the staging capacity: not a protein chain
-                for (uint32_t i = lane; i < rec_size; i += WAVE) rec[i] = 0;
-                if (lane == 0 && status) status[c] = FCZ_E_INVALID_ARG;
-                return;
-            }
-            T = lead - 1; look = true;
-            A1 = (T + 1 == 64) ? o64 : __shfl(o_lane, (int)(T + 1), WAVE);
+            if (lead < 2) { e.T = 0; e.nres = 0; e.cnt = 0; return e; }   // not a protein chain
+            e.T = lead - 1; e.look = true;
+            A1 = (e.T + 1 == 64) ? o64 : __shfl(o_lane, (int)(e.T + 1), WAVE);
         }
-        const uint32_t nres_t = T + (look ? 1u : 0u);
-        const uint32_t cnt = A1 - A0;
-        if ((uint32_t)lane <= nres_t) L.aoff[lane] = (uint16_t)(o_lane - A0);
-        if (lane == 0) { L.aoff[64] = (uint16_t)(o64 - A0); L.aoff[65] = (uint16_t)(o65 - A0); L.rc[64] = (uint8_t)rc_hi; }
-        L.rc[lane] = (uint8_t)rc_lane;
+        e.nres = e.T + (e.look ? 1u : 0u);
+        e.cnt = A1 - e.A0;
+        return e;
+    };
+    // coalesced 16-byte loads of a tile's atoms into registers
+    float4 px[CT_NV], py[CT_NV], pz[CT_NV];
+    uint32_t pc[CT_NV];
+    auto issue_atoms = [&](const tile_ext& e) {
+        const bool whole = (size_t)e.A0 + CT_CAP + 4 <= (size_t)in.n_atoms;   // 16-byte reads stay inside the arrays
+#pragma unroll
+        for (int u = 0; u < CT_NV; u++) {
+            const uint32_t i4 = 4 * (u * WAVE + lane);
+            px[u] = py[u] = pz[u] = float4{0.f, 0.f, 0.f, 0.f}; pc[u] = 0;
+            if (i4 < e.cnt) {
+                if (whole || (size_t)e.A0 + i4 + 4 <= (size_t)in.n_atoms) {
+                    __builtin_memcpy(&px[u], in.x + e.A0 + i4, 16);
+                    __builtin_memcpy(&py[u], in.y + e.A0 + i4, 16);
+                    __builtin_memcpy(&pz[u], in.z + e.A0 + i4, 16);
+                    __builtin_memcpy(&pc[u], in.atom_code + e.A0 + i4, 4);
+                } else {
+                    // last few atoms of the whole batch: element-wise, never past the end of the arrays
+                    const uint32_t a = e.A0 + i4;
+                    const bool h1 = i4 + 1 < e.cnt, h2 = i4 + 2 < e.cnt, h3 = i4 + 3 < e.cnt;
+                    px[u] = float4{in.x[a], h1 ? in.x[a + 1] : 0.f, h2 ? in.x[a + 2] : 0.f, h3 ? in.x[a + 3] : 0.f};
+                    py[u] = float4{in.y[a], h1 ? in.y[a + 1] : 0.f, h2 ? in.y[a + 2] : 0.f, h3 ? in.y[a + 3] : 0.f};
+                    pz[u] = float4{in.z[a], h1 ? in.z[a + 1] : 0.f, h2 ? in.z[a + 2] : 0.f, h3 ? in.z[a + 3] : 0.f};
+                    pc[u] = (uint32_t)in.atom_code[a] | (h1 ? (uint32_t)in.atom_code[a + 1] << 8 : 0u) |
+                            (h2 ? (uint32_t)in.atom_code[a + 2] << 16 : 0u) | (h3 ? (uint32_t)in.atom_code[a + 3] << 24 : 0u);
+                }
+            }
+        }
+    };
 
-        PH_MARK(1)
-        // ---- coalesced staging of the tile's atoms: 16-byte loads, all issued before the first use ----
-        {
-            constexpr int NV = CT_CAP / (4 * WAVE);   // float4 rounds (3)
-            float4 vx[NV], vy[NV], vz[NV];
-            uint32_t vc[NV];
-            const bool whole = (size_t)A0 + CT_CAP + 4 <= (size_t)in.n_atoms;   // 16-byte reads stay inside the arrays
+    uint32_t sc_base = 0;       // side-chain bytes emitted so far
+    uint32_t base = 0;
+    uint32_t slot_in_sb = 0;    // tiles consumed from the current super-block
+    load_meta(0);
+    tile_ext cur = tile_extent(0, mo[0], mo[1]);
+    if (cur.T) issue_atoms(cur);
+    PH_MARK(1)
+    uint32_t last_cnt = 1;      // staged atoms of the final tile (for the OXT test)
+    while (true) {
+        if (cur.T == 0) {  // one residue plus its successor exceed the staging capacity
+            for (uint32_t i = lane; i < rec_size; i += WAVE) rec[i] = 0;
+            if (lane == 0 && status) status[c] = FCZ_E_INVALID_ARG;
+            return;
+        }
+        const uint32_t T = cur.T, cnt = cur.cnt, A0 = cur.A0;
+        const bool look = cur.look;
+        const uint32_t o_lane = mo[0], rc_lane = mr[0];
+        const uint32_t o64r = __shfl(mo[1], 0, WAVE) - A0, o65r = __shfl(mo[1], 1, WAVE) - A0;
+        const uint32_t rc64 = __shfl(mr[1], 0, WAVE);          // code of residue base+64
+        // ---- park the prefetched atoms in LDS as {x,y,z,code} records ----
 #pragma unroll
-            for (int u = 0; u < NV; u++) {
-                const uint32_t i4 = 4 * (u * WAVE + lane);
-                vx[u] = vy[u] = vz[u] = float4{0.f, 0.f, 0.f, 0.f}; vc[u] = 0;
-                if (i4 < cnt) {
-                    if (whole || (size_t)A0 + i4 + 4 <= (size_t)in.n_atoms) {
-                        __builtin_memcpy(&vx[u], in.x + A0 + i4, 16);
-                        __builtin_memcpy(&vy[u], in.y + A0 + i4, 16);
-                        __builtin_memcpy(&vz[u], in.z + A0 + i4, 16);
-                        __builtin_memcpy(&vc[u], in.atom_code + A0 + i4, 4);
-                    } else {
-                        // last few atoms of the whole batch: element-wise, never past the end of the arrays
-                        const uint32_t a = A0 + i4;
-                        const bool h1 = i4 + 1 < cnt, h2 = i4 + 2 < cnt, h3 = i4 + 3 < cnt;
-                        vx[u] = float4{in.x[a], h1 ? in.x[a + 1] : 0.f, h2 ? in.x[a + 2] : 0.f, h3 ? in.x[a + 3] : 0.f};
-                        vy[u] = float4{in.y[a], h1 ? in.y[a + 1] : 0.f, h2 ? in.y[a + 2] : 0.f, h3 ? in.y[a + 3] : 0.f};
-                        vz[u] = float4{in.z[a], h1 ? in.z[a + 1] : 0.f, h2 ? in.z[a + 2] : 0.f, h3 ? in.z[a + 3] : 0.f};
-                        vc[u] = (uint32_t)in.atom_code[a] | (h1 ? (uint32_t)in.atom_code[a + 1] << 8 : 0u) |
-                                (h2 ? (uint32_t)in.atom_code[a + 2] << 16 : 0u) | (h3 ? (uint32_t)in.atom_code[a + 3] << 24 : 0u);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NV; u++) {
-                const uint32_t i4 = 4 * (u * WAVE + lane);
-                if (i4 < cnt) {
-                    *reinterpret_cast<float4*>(&L.x[i4]) = vx[u];
-                    *reinterpret_cast<float4*>(&L.y[i4]) = vy[u];
-                    *reinterpret_cast<float4*>(&L.z[i4]) = vz[u];
-                    *reinterpret_cast<uint32_t*>(&L.code[i4]) = vc[u];
-                }
+        for (int u = 0; u < CT_NV; u++) {
+            const uint32_t i4 = 4 * (u * WAVE + lane);
+            if (i4 < cnt) {
+                L.atom[i4 + 0] = float4{px[u].x, py[u].x, pz[u].x, __uint_as_float(pc[u] & 0xffu)};
+                L.atom[i4 + 1] = float4{px[u].y, py[u].y, pz[u].y, __uint_as_float((pc[u] >> 8) & 0xffu)};
+                L.atom[i4 + 2] = float4{px[u].z, py[u].z, pz[u].z, __uint_as_float((pc[u] >> 16) & 0xffu)};
+                L.atom[i4 + 3] = float4{px[u].w, py[u].w, pz[u].w, __uint_as_float(pc[u] >> 24)};
             }
         }
+        L.rc[lane] = (uint8_t)rc_lane;
+        // ---- metadata rotation + prefetch of the next tile (loads land while this tile computes) ----
+        const uint32_t base_next = base + T;
+        const bool have_next = base_next < n;
+        tile_ext nxt; nxt.T = 0; nxt.nres = 0; nxt.cnt = 0; nxt.A0 = 0; nxt.look = false;
+        if (have_next) {
+            if (T == (uint32_t)WAVE && slot_in_sb + 1 < CT_SB) {
+#pragma unroll
+                for (int u = 0; u < CT_SB; u++) { mo[u] = mo[u + 1]; mr[u] = mr[u + 1]; }
+                slot_in_sb++;
+            } else {
+                // super-block exhausted (or a shrunken tile shifted the grid): reload metadata at base_next
+                slot_in_sb = 0;
+                load_meta(base_next);
+            }
+            nxt = tile_extent(base_next, mo[0], mo[1]);
+            if (nxt.T) issue_atoms(nxt);
+        }
+        PH_MARK(2)
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        PH_MARK(2)
+
         // ---- slot index table: first atom of each canonical name ----
-        for (uint32_t rr = lane; rr < nres_t; rr += WAVE) {
-            const uint32_t rc = L.rc[rr];
+        {
+            const uint32_t a_lo = o_lane - A0;
+            uint32_t a_hi = __shfl_down(o_lane, 1, WAVE) - A0;
+            if (lane == 63) a_hi = o64r;
+            auto build = [&](uint32_t rr, uint32_t rc, uint32_t lo, uint32_t hi) {
+                // all code reads of the residue in flight together, then all slot lookups
+                uint32_t codes[16], slots[16];
 #pragma unroll
-            for (int s = 0; s < FCZ_MAX_RES_ATOMS; s++) L.idx[s][rr] = (uint16_t)CT_NONE;
-            uint32_t filled = 0;
-            const uint32_t e = L.aoff[rr + 1];
-            for (uint32_t i = L.aoff[rr]; i < e; i++) {
-                const uint32_t code = L.code[i];
-                const uint32_t slot = code < 40 ? s_slot_of[rc][code] : 255u;
-                if (slot != 255u && !((filled >> slot) & 1u)) { filled |= 1u << slot; L.idx[slot][rr] = (uint16_t)i; }
-            }
+                for (int j = 0; j < 16; j++) codes[j] = (lo + j < hi) ? __float_as_uint(L.atom[lo + j].w) : 255u;
+#pragma unroll
+                for (int j = 0; j < 16; j++) slots[j] = (codes[j] < 40u) ? s_slot_of[rc][codes[j]] : 255u;
+                const uint32_t zz = (uint32_t)CT_ZERO | ((uint32_t)CT_ZERO << 16);
+                uint4* row = reinterpret_cast<uint4*>(&L.idx[rr][0]);
+                row[0] = uint4{zz, zz, zz, zz};
+                row[1] = uint4{zz, zz, zz, zz};
+                uint32_t filled = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t sl = slots[j];
+                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; L.idx[rr][sl] = (uint16_t)(lo + j); }
+                }
+                for (uint32_t i = lo + 16; i < hi; i++) {   // residues with more than 16 atoms (explicit hydrogens)
+                    const uint32_t code = __float_as_uint(L.atom[i].w);
+                    const uint32_t sl = code < 40u ? s_slot_of[rc][code] : 255u;
+                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; L.idx[rr][sl] = (uint16_t)i; }
+                }
+            };
+            // lanes 0..T-1 own the tile's residues; the look-ahead residue T is built by the lane that holds its
+            // offsets: lane T when the tile is short, lane 0 (from the next metadata column) when T == 64
+            if ((uint32_t)lane < T || (look && (uint32_t)lane == T)) build(lane, rc_lane, a_lo, a_hi);
+            if (look && T == (uint32_t)WAVE && lane == 0) build(64, rc64, o64r, o65r);
         }
         // side-chain item numbering of this tile
         uint32_t my_cnt = 0;
-        if ((uint32_t)lane < T) my_cnt = s_natoms[L.rc[lane] & 31u] - 3;
+        if ((uint32_t)lane < T) my_cnt = s_natoms[rc_lane & 31u] - 3;
         uint32_t tile_sc;
         const uint32_t my_pre = wave_excl_scan(my_cnt, lane, &tile_sc);
         if ((uint32_t)lane < T) {
@@ -222,8 +308,8 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-
         PH_MARK(3)
+
         // ---- anchors (reference Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1045-1059) ----
         if ((uint32_t)lane < T) {
             const uint32_t k = base + lane;
@@ -245,63 +331,81 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
             if (keep_first_angle && k == 0)
                 a_arr[3 * R + (n - 1)] = bond_angle_deg(tile_atom(L, 0, 0), tile_atom(L, 0, 1), tile_atom(L, 0, 2));
         }
-
         PH_MARK(4)
+
         // ---- the flat work list of the tile ----
         // items [0,3W): backbone dihedrals (q = item / W: psi, omega, phi), [3W,6W): backbone bond angles
-        // (ca_c_n, c_n_ca, n_ca_c), then the side-chain dihedrals. W = number of residue windows of the
-        // tile = residues k with k < n-1.
+        // (ca_c_n, c_n_ca, n_ca_c), then the side-chain dihedrals. W = residue windows of the tile (k < n-1).
+        // Every item is "angle between two vectors": for a dihedral the two plane normals (getTorsionFromXYZ,
+        // reference src/torsion_angle.cpp:50-94), for a bond angle the two bond vectors (angle(),
+        // src/float3d.h:55-65; getBondAngles src/nerf.cpp:495-508); getCosineTheta + acos is one shared path.
         const uint32_t W = (base + T <= m) ? T : (m > base ? m - base : 0);
         const uint32_t n_items = 6 * W + tile_sc;
         for (uint32_t t0 = 0; t0 < n_items; t0 += WAVE) {
             const uint32_t t = t0 + lane;
             if (t >= n_items) continue;
-            if (t < 3 * W) {
-                // getTorsionFromXYZ window, reference src/torsion_angle.cpp:46-96; split src/foldcomp.cpp:488-492
-                const uint32_t q = (t >= 2 * W) ? 2u : (t >= W ? 1u : 0u);
-                const uint32_t res = t - q * W;
-                v3 P[4];
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const uint32_t g = q + p;
-                    P[p] = tile_atom(L, res + (g >= 3 ? 1u : 0u), g >= 3 ? g - 3 : g);
-                }
-                const float v = dihedral_deg(P[0], P[1], P[2], P[3]);
-                const uint32_t arr = (q == 0) ? 1u : (q == 1 ? 2u : 0u);      // psi, omega, phi
-                a_arr[arr * R + base + res] = v;
-            } else if (t < 6 * W) {
-                // getBondAngles, reference src/nerf.cpp:495-508; split src/foldcomp.cpp:497-505
-                const uint32_t tt = t - 3 * W;
+            uint32_t rA, sA, rB, sB, rC, sC, rD, sD;   // (residue in tile, slot) of the 4 (3) points
+            bool is_dih;
+            size_t dest;         // backbone: index into a_arr; side chain: byte index
+            const bool is_bb = t < 6 * W;
+            if (is_bb) {
+                is_dih = t < 3 * W;
+                const uint32_t tt = is_dih ? t : t - 3 * W;
                 const uint32_t q = (tt >= 2 * W) ? 2u : (tt >= W ? 1u : 0u);
                 const uint32_t res = tt - q * W;
-                v3 P[3];
-#pragma unroll
-                for (int p = 0; p < 3; p++) {
-                    const uint32_t g = q + 1 + p;
-                    P[p] = tile_atom(L, res + (g >= 3 ? 1u : 0u), g >= 3 ? g - 3 : g);
-                }
-                const float v = bond_angle_deg(P[0], P[1], P[2]);
-                const uint32_t arr = (q == 0) ? 4u : (q == 1 ? 5u : 3u);      // ca_c_n, c_n_ca, n_ca_c
-                a_arr[arr * R + base + res] = v;
+                const uint32_t g0 = is_dih ? q : q + 1;           // first backbone atom of the window (0=N0 .. 5=C1)
+                rA = res + (g0 >= 3 ? 1u : 0u);     sA = g0 >= 3 ? g0 - 3 : g0;
+                rB = res + (g0 + 1 >= 3 ? 1u : 0u); sB = g0 + 1 >= 3 ? g0 - 2 : g0 + 1;
+                rC = res + (g0 + 2 >= 3 ? 1u : 0u); sC = g0 + 2 >= 3 ? g0 - 1 : g0 + 2;
+                rD = res + 1u;                       sD = g0;         // atom g0+3 (dihedrals only)
+                // psi, omega, phi -> arrays 1, 2, 0 (split src/foldcomp.cpp:488-492);
+                // ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3 (split :497-505)
+                const uint32_t arr = is_dih ? ((q == 0) ? 1u : (q == 1 ? 2u : 0u)) : ((q == 0) ? 4u : (q == 1 ? 5u : 3u));
+                dest = (size_t)arr * R + base + res;
             } else {
-                // calculateTorsionAnglesInResidue, reference src/sidechain.cpp:149-168; truncating quantiser
-                // src/foldcomp.cpp:532-538
+                // calculateTorsionAnglesInResidue, reference src/sidechain.cpp:149-168
+                is_dih = true;
                 const uint32_t ts = t - 6 * W;
                 const uint32_t res = L.item_res[ts];
-                const uint32_t rc = L.rc[res];
                 const uint32_t j = 3 + ts - L.scpre[res];
-                const uint32_t pk = s_prev[rc][j];
-                const float v = dihedral_deg(tile_atom(L, res, pk & 15), tile_atom(L, res, (pk >> 4) & 15),
-                                             tile_atom(L, res, (pk >> 8) & 15), tile_atom(L, res, j));
-                rec[RL.o_sc + sc_base + ts] = (uint8_t)quant_trunc(v, sc_min, sc_disc);
+                const uint32_t pk = s_prev[L.rc[res]][j];
+                rA = rB = rC = rD = res;
+                sA = pk & 15u; sB = (pk >> 4) & 15u; sC = (pk >> 8) & 15u; sD = j;
+                dest = ts;
             }
+            const v3 a = tile_atom(L, rA, sA), b = tile_atom(L, rB, sB), cc = tile_atom(L, rC, sC);
+            v3 va, vb, d2;
+            v3 u1{0.f, 0.f, 0.f}, u2 = u1;
+            if (is_dih) {
+                const v3 d = tile_atom(L, rD, sD);
+                const v3 d1 = vsub(b, a);
+                d2 = vsub(cc, b);
+                const v3 d3 = vsub(d, cc);
+                u1 = vcross(d1, d2); u2 = vcross(d2, d3);
+                va = u1; vb = u2;
+            } else {
+                va = vsub(a, b); vb = vsub(cc, b);
+                d2 = va;
+            }
+            const float ct = vcos_theta(va, vb);
+            float v = acos_deg(ct);
+            if (is_dih) {
+                if (v != v) v = (ct < 0.0f) ? 180.0f : 0.0f;   // isnan(acos) guard, src/torsion_angle.cpp:77-84
+                const v3 w = vcross(u2, d2);
+                if ((u1.x * w.x) + (u1.y * w.y) + (u1.z * w.z) < 0.0f) v = -1.0f * v;
+            }
+            if (is_bb) a_arr[dest] = v;
+            else rec[RL.o_sc + sc_base + dest] = (uint8_t)quant_trunc(v, sc_min, sc_disc);   // src/foldcomp.cpp:532-538
         }
         sc_base += tile_sc;
-        base += T;
+        last_cnt = cnt;
+        base = base_next;
+        cur = nxt;
         PH_MARK(5)
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         PH_MARK(6)
+        if (!have_next) break;
     }
     __threadfence_block();
 
@@ -327,6 +431,14 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
         st_u64(rec + RL.o_words + 8 * (size_t)k, word);
         rec[RL.o_tbytes + k] = (uint8_t)quant_round(v6, qmin[6], qdisc[6]);
     };
+    // std::min_element / max_element keep the FIRST of equal elements (src/discretizer.cpp:27-28). Equal
+    // floats with different bits are only +0/-0, so the plain value reduction is exact unless the extremum
+    // is a zero; only then the (value, index) reduction runs.
+    auto finish_q = [&](int q, float lo, float hi, ext mn, ext mx) {
+        if (__builtin_expect(lo == 0.0f, 0)) lo = wave_ext_min(mn);
+        if (__builtin_expect(hi == 0.0f, 0)) hi = wave_ext_max(mx);
+        qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+    };
     constexpr int U = 8;
     if (n <= (uint32_t)(U * WAVE)) {
         // everything of the chain in registers: one batch of loads, no reload for the quantisation pass
@@ -343,26 +455,28 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
 #pragma unroll
         for (int q = 0; q < 7; q++) {
             ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
+            float lo = kInf, hi = -kInf;
             const uint32_t cntq = (q < 6) ? m : n;
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t k = u * WAVE + lane;
-                if (k < cntq) { ext_min_upd(mn, va[q][u], k); ext_max_upd(mx, va[q][u], k); }
+                if (k < cntq) {
+                    lo = (va[q][u] < lo) ? va[q][u] : lo; hi = (hi < va[q][u]) ? va[q][u] : hi;
+                    ext_min_upd(mn, va[q][u], k); ext_max_upd(mx, va[q][u], k);
+                }
             }
-            const float lo = wave_ext_min(mn), hi = wave_ext_max(mx);
-            qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), mn, mx);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t k = u * WAVE + lane;
-            if (k < n) {
-                pack_store(k, rcs[u], va[0][u], va[1][u], va[2][u], va[3][u], va[4][u], va[5][u], va[6][u]);
-            }
+            if (k < n) pack_store(k, rcs[u], va[0][u], va[1][u], va[2][u], va[3][u], va[4][u], va[5][u], va[6][u]);
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 7; q++) {
             ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
+            float lo = kInf, hi = -kInf;
             const float* src = (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0);
             const uint32_t cntq = (q < 6) ? m : n;
             for (uint32_t k0 = 0; k0 < cntq; k0 += U * WAVE) {
@@ -370,10 +484,12 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
 #pragma unroll
                 for (int u = 0; u < U; u++) { const uint32_t k = k0 + u * WAVE + lane; t[u] = (k < cntq) ? src[k] : 0.0f; }
 #pragma unroll
-                for (int u = 0; u < U; u++) { const uint32_t k = k0 + u * WAVE + lane; if (k < cntq) { ext_min_upd(mn, t[u], k); ext_max_upd(mx, t[u], k); } }
+                for (int u = 0; u < U; u++) {
+                    const uint32_t k = k0 + u * WAVE + lane;
+                    if (k < cntq) { lo = (t[u] < lo) ? t[u] : lo; hi = (hi < t[u]) ? t[u] : hi; ext_min_upd(mn, t[u], k); ext_max_upd(mx, t[u], k); }
+                }
             }
-            const float lo = wave_ext_min(mn), hi = wave_ext_max(mx);
-            qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), mn, mx);
         }
         for (uint32_t k = lane; k < n; k += WAVE) {
             const bool w = k < m;
@@ -387,29 +503,30 @@ __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES) void k_compress_tile
 
     // ---- header (CompressedFileHeader src/foldcomp.h:118-136; get_header src/foldcomp.cpp:1340) ----
     if (lane == 0) {
-        const uint32_t a_first = in.atom_off[r0], a_end = in.atom_off[r0 + n];
         rec[0] = 'F'; rec[1] = 'C'; rec[2] = 'M'; rec[3] = 'P';
         uint8_t* h = rec + 4;
         st_u16(h + 0, n);
         st_u16(h + 2, a_end - a_first);
-        st_u16(h + 4, (uint32_t)in.first_res_index[c]);
-        st_u16(h + 6, (uint32_t)in.first_atom_index[c]);
+        st_u16(h + 4, (uint32_t)h_first_res);
+        st_u16(h + 6, (uint32_t)h_first_atom);
         h[8] = (uint8_t)n_anchor;
-        h[9] = (uint8_t)in.chain_id[c];
+        h[9] = (uint8_t)h_chain;
         h[10] = 0; h[11] = 0;  // struct padding: the reference leaves it uninitialised
         st_u32(h + 12, nsc);
-        h[16] = (uint8_t)fcz_res1[in.res_code[r0]];
-        h[17] = (uint8_t)fcz_res1[in.res_code[r0 + n - 1]];
+        h[16] = (uint8_t)fcz_res1[h_rc_first];
+        h[17] = (uint8_t)fcz_res1[h_rc_last];
         h[18] = 0; h[19] = 0;
         st_u32(h + 20, title_len);
 #pragma unroll
         for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, qmin[q]); st_f32(h + 48 + 4 * q, qcont[q]); }
-        const bool has_oxt = in.atom_code[a_end - 1] == FCZ_ATOM_OXT;   // src/foldcomp.cpp:474-482
+        // OXT (src/foldcomp.cpp:474-482): the last atom of the span, still parked in LDS from the final tile
+        const float4 la = L.atom[last_cnt - 1];
+        const bool has_oxt = __float_as_uint(la.w) == FCZ_ATOM_OXT;
         uint8_t* o = rec + RL.o_oxt;
         o[0] = has_oxt ? 1 : 0;
-        st_f32(o + 1, has_oxt ? in.x[a_end - 1] : 0.0f);
-        st_f32(o + 5, has_oxt ? in.y[a_end - 1] : 0.0f);
-        st_f32(o + 9, has_oxt ? in.z[a_end - 1] : 0.0f);
+        st_f32(o + 1, has_oxt ? la.x : 0.0f);
+        st_f32(o + 5, has_oxt ? la.y : 0.0f);
+        st_f32(o + 9, has_oxt ? la.z : 0.0f);
         st_f32(rec + RL.o_tmp, qmin[6]);
         st_f32(rec + RL.o_tmp + 4, qcont[6]);
         if (status) status[c] = FCZ_OK;

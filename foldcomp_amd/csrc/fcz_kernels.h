@@ -103,18 +103,63 @@ __host__ __device__ __forceinline__ rec_layout make_layout(uint32_t n_res, uint3
 // compress
 // ==================================================================================================
 
-// FCZ size of every chain (Foldcomp::getSize). One thread per chain; sizes[c] in bytes.
-__global__ void k_compress_sizes(fcz_chain_batch in, uint64_t* __restrict__ sizes) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+// FCZ size of every chain (Foldcomp::getSize). One wavefront per chain (coalesced residue-code reads).
+__global__ __launch_bounds__(BLOCK) void k_compress_sizes(fcz_chain_batch in, uint64_t* __restrict__ sizes) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= in.n_chains) return;
-    uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
+    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
     uint32_t nsc = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        uint32_t rc = in.res_code[r0 + k];
+    for (uint32_t k = lane; k < n; k += WAVE) {
+        const uint32_t rc = in.res_code[r0 + k];
         nsc += fcz_res_natoms[rc < 24 ? rc : 23] - 3;
     }
-    uint32_t n_anchor = n / (uint32_t)in.anchor_threshold + 2;
-    sizes[c] = make_layout(n, n_anchor, in.title_off[c + 1] - in.title_off[c], nsc).size;
+    nsc = wave_sum(nsc);
+    if (lane == 0) {
+        const uint32_t n_anchor = n / (uint32_t)in.anchor_threshold + 2;
+        sizes[c] = make_layout(n, n_anchor, in.title_off[c + 1] - in.title_off[c], nsc).size;
+    }
+}
+
+// ---- multi-block exclusive scan: per-chunk sums -> single-block scan of the sums -> per-chunk rescan ----
+constexpr int SCAN_CHUNK = 4096;   // elements per block (1024 threads x 4)
+template <class T>
+__global__ __launch_bounds__(1024) void k_scan_reduce(uint32_t n, const T* __restrict__ in, unsigned long long* __restrict__ partial) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK;
+    unsigned long long v = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint32_t i = base + u * 1024 + threadIdx.x; if (i < n) v += (unsigned long long)in[i]; }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; w++) t += s_w[w]; partial[blockIdx.x] = t; }
+}
+template <class T>
+__global__ __launch_bounds__(1024) void k_scan_apply(uint32_t n, const T* __restrict__ in, const unsigned long long* __restrict__ partial_excl,
+                                                     T* __restrict__ out) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long carry = partial_excl[blockIdx.x];
+    for (int u = 0; u < 4; u++) {
+        const uint32_t i = base + u * 1024 + threadIdx.x;
+        const unsigned long long v = (i < n) ? (unsigned long long)in[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { unsigned long long t = __shfl_up(inc, d, WAVE); if (lane >= d) inc += t; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        unsigned long long pre = carry;
+        for (int w = 0; w < wave; w++) pre += s_w[w];
+        if (i < n) out[i] = (T)(pre + inc - v);
+        unsigned long long tot = 0;
+        for (int w = 0; w < 16; w++) tot += s_w[w];
+        carry += tot;
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = (T)carry;
 }
 
 // first atom with the given code inside [a0,a1) (findFirstAtomCoords, src/sidechain.cpp:140-147)

@@ -56,29 +56,53 @@ __device__ __forceinline__ v3 tile_atom(const compress_tile_lds& L, uint32_t res
 // ---- wave reductions on the DPP cross-lane network (no LDS traffic) -------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
+// four DPP steps leave every lane with the extremum of its row of 16; the four rows are combined through
+// scalar reads
 __device__ __forceinline__ float wave_min_f32(float v) {
     v = __builtin_fminf(v, dpp_f32<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
     v = __builtin_fminf(v, dpp_f32<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
     v = __builtin_fminf(v, dpp_f32<0x141, 0xf>(v));   // row_half_mirror
     v = __builtin_fminf(v, dpp_f32<0x140, 0xf>(v));   // row_mirror
-    v = __builtin_fminf(v, dpp_f32<0x142, 0xa>(v));   // row_bcast:15 -> rows 1,3
-    v = __builtin_fminf(v, dpp_f32<0x143, 0xc>(v));   // row_bcast:31 -> rows 2,3
-    return __builtin_amdgcn_readlane(v, 63);
+    const int b = __float_as_int(v);   // readlane is an integer intrinsic: move bits, not values
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return __builtin_fminf(__builtin_fminf(r0, r1), __builtin_fminf(r2, r3));
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
     v = __builtin_fmaxf(v, dpp_f32<0xB1, 0xf>(v));
     v = __builtin_fmaxf(v, dpp_f32<0x4E, 0xf>(v));
     v = __builtin_fmaxf(v, dpp_f32<0x141, 0xf>(v));
     v = __builtin_fmaxf(v, dpp_f32<0x140, 0xf>(v));
-    v = __builtin_fmaxf(v, dpp_f32<0x142, 0xa>(v));
-    v = __builtin_fmaxf(v, dpp_f32<0x143, 0xc>(v));
-    return __builtin_amdgcn_readlane(v, 63);
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
+}
+
+// std::min_element / std::max_element keep the FIRST of equal elements (reference src/discretizer.cpp:27-28).
+// Equal floats with different bits are only +0/-0, so a plain value reduction is exact unless the extremum is a
+// zero; only then this (value, index) reduction over the stored values runs.
+__device__ __noinline__ void first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, float* lo, float* hi) {
+    const float kInf = __builtin_huge_valf();
+    ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
+    for (uint32_t k = lane; k < cnt; k += WAVE) { const float v = src[k]; ext_min_upd(mn, v, k); ext_max_upd(mx, v, k); }
+    *lo = wave_ext_min(mn); *hi = wave_ext_max(mx);
 }
 
 // tile geometry shared by the prefetch and the consumer
 struct tile_ext { uint32_t T, nres, A0, cnt; bool look; };
+
+// last few atoms of the whole batch: element-wise loads that never run past the end of the arrays
+__device__ __noinline__ void load_atoms_tail(const fcz_chain_batch& in, uint32_t a, uint32_t left, float4* vx, float4* vy, float4* vz, uint32_t* vc) {
+    const bool h1 = left > 1, h2 = left > 2, h3 = left > 3;
+    *vx = float4{in.x[a], h1 ? in.x[a + 1] : 0.f, h2 ? in.x[a + 2] : 0.f, h3 ? in.x[a + 3] : 0.f};
+    *vy = float4{in.y[a], h1 ? in.y[a + 1] : 0.f, h2 ? in.y[a + 2] : 0.f, h3 ? in.y[a + 3] : 0.f};
+    *vz = float4{in.z[a], h1 ? in.z[a + 1] : 0.f, h2 ? in.z[a + 2] : 0.f, h3 ? in.z[a + 3] : 0.f};
+    *vc = (uint32_t)in.atom_code[a] | (h1 ? (uint32_t)in.atom_code[a + 1] << 8 : 0u) |
+          (h2 ? (uint32_t)in.atom_code[a + 2] << 16 : 0u) | (h3 ? (uint32_t)in.atom_code[a + 3] << 24 : 0u);
+}
 
 __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES)
 void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
@@ -199,14 +223,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
                     __builtin_memcpy(&pz[u], in.z + e.A0 + i4, 16);
                     __builtin_memcpy(&pc[u], in.atom_code + e.A0 + i4, 4);
                 } else {
-                    // last few atoms of the whole batch: element-wise, never past the end of the arrays
-                    const uint32_t a = e.A0 + i4;
-                    const bool h1 = i4 + 1 < e.cnt, h2 = i4 + 2 < e.cnt, h3 = i4 + 3 < e.cnt;
-                    px[u] = float4{in.x[a], h1 ? in.x[a + 1] : 0.f, h2 ? in.x[a + 2] : 0.f, h3 ? in.x[a + 3] : 0.f};
-                    py[u] = float4{in.y[a], h1 ? in.y[a + 1] : 0.f, h2 ? in.y[a + 2] : 0.f, h3 ? in.y[a + 3] : 0.f};
-                    pz[u] = float4{in.z[a], h1 ? in.z[a + 1] : 0.f, h2 ? in.z[a + 2] : 0.f, h3 ? in.z[a + 3] : 0.f};
-                    pc[u] = (uint32_t)in.atom_code[a] | (h1 ? (uint32_t)in.atom_code[a + 1] << 8 : 0u) |
-                            (h2 ? (uint32_t)in.atom_code[a + 2] << 16 : 0u) | (h3 ? (uint32_t)in.atom_code[a + 3] << 24 : 0u);
+                    load_atoms_tail(in, e.A0 + i4, e.cnt - i4, &px[u], &py[u], &pz[u], &pc[u]);
                 }
             }
         }
@@ -215,13 +232,13 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
     uint32_t sc_base = 0;       // side-chain bytes emitted so far
     uint32_t base = 0;
     uint32_t slot_in_sb = 0;    // tiles consumed from the current super-block
-    load_meta(0);
-    tile_ext cur = tile_extent(0, mo[0], mo[1]);
-    if (cur.T) issue_atoms(cur);
-    PH_MARK(1)
     uint32_t last_cnt = 1;      // staged atoms of the final tile (for the OXT test)
-    while (true) {
-        if (cur.T == 0) {  // one residue plus its successor exceed the staging capacity
+    tile_ext cur; cur.T = 0; cur.nres = 0; cur.cnt = 0; cur.A0 = 0; cur.look = false;
+    // Software pipeline with a single copy of every stage: pass -1 only prefetches tile 0; pass t >= 0 parks
+    // tile t in LDS, prefetches tile t+1 and then computes tile t.
+    for (int pass = -1;; pass++) {
+        const bool live = pass >= 0;
+        if (live && cur.T == 0) {  // one residue plus its successor exceed the staging capacity
             for (uint32_t i = lane; i < rec_size; i += WAVE) rec[i] = 0;
             if (lane == 0 && status) status[c] = FCZ_E_INVALID_ARG;
             return;
@@ -229,31 +246,34 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         const uint32_t T = cur.T, cnt = cur.cnt, A0 = cur.A0;
         const bool look = cur.look;
         const uint32_t o_lane = mo[0], rc_lane = mr[0];
-        const uint32_t o64r = __shfl(mo[1], 0, WAVE) - A0, o65r = __shfl(mo[1], 1, WAVE) - A0;
-        const uint32_t rc64 = __shfl(mr[1], 0, WAVE);          // code of residue base+64
-        // ---- park the prefetched atoms in LDS as {x,y,z,code} records ----
+        uint32_t o64r = 0, o65r = 0, rc64 = 23;
+        if (live) {
+            o64r = __shfl(mo[1], 0, WAVE) - A0; o65r = __shfl(mo[1], 1, WAVE) - A0;
+            rc64 = __shfl(mr[1], 0, WAVE);          // code of residue base+64
+            // ---- park the prefetched atoms in LDS as {x,y,z,code} records ----
 #pragma unroll
-        for (int u = 0; u < CT_NV; u++) {
-            const uint32_t i4 = 4 * (u * WAVE + lane);
-            if (i4 < cnt) {
-                L.atom[i4 + 0] = float4{px[u].x, py[u].x, pz[u].x, __uint_as_float(pc[u] & 0xffu)};
-                L.atom[i4 + 1] = float4{px[u].y, py[u].y, pz[u].y, __uint_as_float((pc[u] >> 8) & 0xffu)};
-                L.atom[i4 + 2] = float4{px[u].z, py[u].z, pz[u].z, __uint_as_float((pc[u] >> 16) & 0xffu)};
-                L.atom[i4 + 3] = float4{px[u].w, py[u].w, pz[u].w, __uint_as_float(pc[u] >> 24)};
+            for (int u = 0; u < CT_NV; u++) {
+                const uint32_t i4 = 4 * (u * WAVE + lane);
+                if (i4 < cnt) {
+                    L.atom[i4 + 0] = float4{px[u].x, py[u].x, pz[u].x, __uint_as_float(pc[u] & 0xffu)};
+                    L.atom[i4 + 1] = float4{px[u].y, py[u].y, pz[u].y, __uint_as_float((pc[u] >> 8) & 0xffu)};
+                    L.atom[i4 + 2] = float4{px[u].z, py[u].z, pz[u].z, __uint_as_float((pc[u] >> 16) & 0xffu)};
+                    L.atom[i4 + 3] = float4{px[u].w, py[u].w, pz[u].w, __uint_as_float(pc[u] >> 24)};
+                }
             }
+            L.rc[lane] = (uint8_t)rc_lane;
         }
-        L.rc[lane] = (uint8_t)rc_lane;
         // ---- metadata rotation + prefetch of the next tile (loads land while this tile computes) ----
-        const uint32_t base_next = base + T;
+        const uint32_t base_next = live ? base + T : 0u;
         const bool have_next = base_next < n;
         tile_ext nxt; nxt.T = 0; nxt.nres = 0; nxt.cnt = 0; nxt.A0 = 0; nxt.look = false;
         if (have_next) {
-            if (T == (uint32_t)WAVE && slot_in_sb + 1 < CT_SB) {
+            if (live && T == (uint32_t)WAVE && slot_in_sb + 1 < CT_SB) {
 #pragma unroll
                 for (int u = 0; u < CT_SB; u++) { mo[u] = mo[u + 1]; mr[u] = mr[u + 1]; }
                 slot_in_sb++;
             } else {
-                // super-block exhausted (or a shrunken tile shifted the grid): reload metadata at base_next
+                // first tile, super-block exhausted, or a shrunken tile shifted the grid: (re)load metadata
                 slot_in_sb = 0;
                 load_meta(base_next);
             }
@@ -261,15 +281,21 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
             if (nxt.T) issue_atoms(nxt);
         }
         PH_MARK(2)
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        if (!live) { cur = nxt; continue; }
+        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in issue order: no memory fence needed
 
         // ---- slot index table: first atom of each canonical name ----
         {
             const uint32_t a_lo = o_lane - A0;
             uint32_t a_hi = __shfl_down(o_lane, 1, WAVE) - A0;
             if (lane == 63) a_hi = o64r;
-            auto build = [&](uint32_t rr, uint32_t rc, uint32_t lo, uint32_t hi) {
+            const uint32_t nres_t = T + (look ? 1u : 0u);
+            // lanes 0..T-1 own the tile's residues; the look-ahead residue T is built by lane T when the tile is
+            // short, by lane 0 (second trip, offsets from the next metadata column) when T == 64
+            for (uint32_t rr = lane; rr < nres_t; rr += WAVE) {
+                const bool second = rr >= (uint32_t)WAVE;
+                const uint32_t rc = second ? rc64 : rc_lane;
+                const uint32_t lo = second ? o64r : a_lo, hi = second ? o65r : a_hi;
                 // all code reads of the residue in flight together, then all slot lookups
                 uint32_t codes[16], slots[16];
 #pragma unroll
@@ -291,11 +317,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
                     const uint32_t sl = code < 40u ? s_slot_of[rc][code] : 255u;
                     if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; L.idx[rr][sl] = (uint16_t)i; }
                 }
-            };
-            // lanes 0..T-1 own the tile's residues; the look-ahead residue T is built by the lane that holds its
-            // offsets: lane T when the tile is short, lane 0 (from the next metadata column) when T == 64
-            if ((uint32_t)lane < T || (look && (uint32_t)lane == T)) build(lane, rc_lane, a_lo, a_hi);
-            if (look && T == (uint32_t)WAVE && lane == 0) build(64, rc64, o64r, o65r);
+            }
         }
         // side-chain item numbering of this tile
         uint32_t my_cnt = 0;
@@ -307,7 +329,6 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
             for (uint32_t j = 0; j < my_cnt; j++) L.item_res[my_pre + j] = (uint8_t)lane;
         }
         __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
         PH_MARK(3)
 
         // ---- anchors (reference Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1045-1059) ----
@@ -403,7 +424,6 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         cur = nxt;
         PH_MARK(5)
         __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
         PH_MARK(6)
         if (!have_next) break;
     }
@@ -431,12 +451,8 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         st_u64(rec + RL.o_words + 8 * (size_t)k, word);
         rec[RL.o_tbytes + k] = (uint8_t)quant_round(v6, qmin[6], qdisc[6]);
     };
-    // std::min_element / max_element keep the FIRST of equal elements (src/discretizer.cpp:27-28). Equal
-    // floats with different bits are only +0/-0, so the plain value reduction is exact unless the extremum
-    // is a zero; only then the (value, index) reduction runs.
-    auto finish_q = [&](int q, float lo, float hi, ext mn, ext mx) {
-        if (__builtin_expect(lo == 0.0f, 0)) lo = wave_ext_min(mn);
-        if (__builtin_expect(hi == 0.0f, 0)) hi = wave_ext_max(mx);
+    auto finish_q = [&](int q, float lo, float hi, const float* src, uint32_t cntq) {
+        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) first_extrema(src, cntq, lane, &lo, &hi);
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
     };
     constexpr int U = 8;
@@ -454,18 +470,15 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         }
 #pragma unroll
         for (int q = 0; q < 7; q++) {
-            ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
             float lo = kInf, hi = -kInf;
             const uint32_t cntq = (q < 6) ? m : n;
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t k = u * WAVE + lane;
-                if (k < cntq) {
-                    lo = (va[q][u] < lo) ? va[q][u] : lo; hi = (hi < va[q][u]) ? va[q][u] : hi;
-                    ext_min_upd(mn, va[q][u], k); ext_max_upd(mx, va[q][u], k);
-                }
+                const bool on = (uint32_t)(u * WAVE + lane) < cntq;
+                lo = __builtin_fminf(lo, on ? va[q][u] : kInf);
+                hi = __builtin_fmaxf(hi, on ? va[q][u] : -kInf);
             }
-            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), mn, mx);
+            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), cntq);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -473,9 +486,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
             if (k < n) pack_store(k, rcs[u], va[0][u], va[1][u], va[2][u], va[3][u], va[4][u], va[5][u], va[6][u]);
         }
     } else {
-#pragma unroll
         for (int q = 0; q < 7; q++) {
-            ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
             float lo = kInf, hi = -kInf;
             const float* src = (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0);
             const uint32_t cntq = (q < 6) ? m : n;
@@ -485,11 +496,13 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
                 for (int u = 0; u < U; u++) { const uint32_t k = k0 + u * WAVE + lane; t[u] = (k < cntq) ? src[k] : 0.0f; }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const uint32_t k = k0 + u * WAVE + lane;
-                    if (k < cntq) { lo = (t[u] < lo) ? t[u] : lo; hi = (hi < t[u]) ? t[u] : hi; ext_min_upd(mn, t[u], k); ext_max_upd(mx, t[u], k); }
+                    const bool on = k0 + u * WAVE + lane < cntq;
+                    lo = __builtin_fminf(lo, on ? t[u] : kInf); hi = __builtin_fmaxf(hi, on ? t[u] : -kInf);
                 }
             }
-            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), mn, mx);
+            float lo_w = wave_min_f32(lo), hi_w = wave_max_f32(hi);
+            if (__builtin_expect(lo_w == 0.0f || hi_w == 0.0f, 0)) first_extrema(src, cntq, lane, &lo_w, &hi_w);
+            qmin[q] = lo_w; qdisc[q] = nbins[q] / (hi_w - lo_w); qcont[q] = (hi_w - lo_w) / nbins[q];
         }
         for (uint32_t k = lane; k < n; k += WAVE) {
             const bool w = k < m;

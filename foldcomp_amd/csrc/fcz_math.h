@@ -361,13 +361,14 @@ __device__ __forceinline__ v3 place_atom(v3 a, v3 b, v3 c, float L, float ba_deg
 // ---- quantisers, reference src/discretizer.cpp ----------------------------------------------------
 // vector discretize (:43-53): float product, double +0.5, truncation; NaN -> 0 like x86-64 gcc
 __device__ __forceinline__ uint32_t quant_round(float v, float mn, float disc_f) {
+    // operand is in [0.5, n_bins + 1): the direct unsigned conversion equals gcc's cvttsd2si+truncate
     double d = (double)((v - mn) * disc_f) + 0.5;
-    return (d != d) ? 0u : (uint32_t)(long long)d;
+    return (d != d) ? 0u : __double2uint_rz(d);
 }
 // scalar discretize (:55-57): truncation of the float product
 __device__ __forceinline__ uint32_t quant_trunc(float v, float mn, float disc_f) {
     float f = (v - mn) * disc_f;
-    return (f != f) ? 0u : (uint32_t)(long long)f;
+    return (f != f) ? 0u : __float2uint_rz(f);
 }
 __device__ __forceinline__ float dequant(uint32_t q, float mn, float cont_f) { return ((float)q * cont_f) + mn; }
 

@@ -46,6 +46,8 @@ struct alignas(16) compress_tile_lds {
     uint16_t scpre[66];                            // tile-local exclusive prefix of side-chain torsion counts
     uint8_t rc[68];
     uint8_t item_res[64 * 11];                     // side-chain item -> residue in tile
+    float out_bb[6][WAVE];                         // backbone angles of the tile, flushed with coalesced stores
+    alignas(4) uint8_t out_sc[64 * 11 + 4];        // side-chain bytes of the tile
 };
 
 __device__ __forceinline__ v3 tile_atom(const compress_tile_lds& L, uint32_t res, uint32_t slot) {
@@ -367,7 +369,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
             if (t >= n_items) continue;
             uint32_t rA, sA, rB, sB, rC, sC, rD, sD;   // (residue in tile, slot) of the 4 (3) points
             bool is_dih;
-            size_t dest;         // backbone: index into a_arr; side chain: byte index
+            uint32_t dest;       // backbone: arr * 64 + residue in tile; side chain: byte index in the tile
             const bool is_bb = t < 6 * W;
             if (is_bb) {
                 is_dih = t < 3 * W;
@@ -382,7 +384,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
                 // psi, omega, phi -> arrays 1, 2, 0 (split src/foldcomp.cpp:488-492);
                 // ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3 (split :497-505)
                 const uint32_t arr = is_dih ? ((q == 0) ? 1u : (q == 1 ? 2u : 0u)) : ((q == 0) ? 4u : (q == 1 ? 5u : 3u));
-                dest = (size_t)arr * R + base + res;
+                dest = arr * WAVE + res;
             } else {
                 // calculateTorsionAnglesInResidue, reference src/sidechain.cpp:149-168
                 is_dih = true;
@@ -415,8 +417,27 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
                 const v3 w = vcross(u2, d2);
                 if ((u1.x * w.x) + (u1.y * w.y) + (u1.z * w.z) < 0.0f) v = -1.0f * v;
             }
-            if (is_bb) a_arr[dest] = v;
-            else rec[RL.o_sc + sc_base + dest] = (uint8_t)quant_trunc(v, sc_min, sc_disc);   // src/foldcomp.cpp:532-538
+            if (is_bb) (&L.out_bb[0][0])[dest] = v;
+            else L.out_sc[dest] = (uint8_t)quant_trunc(v, sc_min, sc_disc);   // src/foldcomp.cpp:532-538
+        }
+        // ---- flush the tile's results: 6 coalesced float stores + the side-chain bytes as (unaligned) dwords.
+        //      No global store inside the item loop keeps the wave's VMEM queue short, so the wait for the
+        //      prefetched next tile never has to drain stores.
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < W) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) a_arr[(size_t)q * R + base + lane] = L.out_bb[q][lane];
+        }
+        {
+            uint8_t* dstp = rec + RL.o_sc + sc_base;
+            const uint32_t nd = tile_sc >> 2;
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const uint32_t d = u * WAVE + lane;
+                if (d < nd) st_u32(dstp + 4 * d, *reinterpret_cast<const uint32_t*>(&L.out_sc[4 * d]));
+            }
+            const uint32_t tail = tile_sc & 3u;
+            if ((uint32_t)lane < tail) dstp[4 * nd + lane] = L.out_sc[4 * nd + lane];
         }
         sc_base += tile_sc;
         last_cnt = cnt;

@@ -86,24 +86,30 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // std::min_element / std::max_element keep the FIRST of equal elements (reference src/discretizer.cpp:27-28).
 // Equal floats with different bits are only +0/-0, so a plain value reduction is exact unless the extremum is a
 // zero; only then this (value, index) reduction over the stored values runs.
-__device__ __noinline__ void first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, float* lo, float* hi) {
+struct lo_hi { float lo, hi; };
+__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane) {
     const float kInf = __builtin_huge_valf();
     ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
     for (uint32_t k = lane; k < cnt; k += WAVE) { const float v = src[k]; ext_min_upd(mn, v, k); ext_max_upd(mx, v, k); }
-    *lo = wave_ext_min(mn); *hi = wave_ext_max(mx);
+    return lo_hi{wave_ext_min(mn), wave_ext_max(mx)};
 }
 
 // tile geometry shared by the prefetch and the consumer
 struct tile_ext { uint32_t T, nres, A0, cnt; bool look; };
 
-// last few atoms of the whole batch: element-wise loads that never run past the end of the arrays
-__device__ __noinline__ void load_atoms_tail(const fcz_chain_batch& in, uint32_t a, uint32_t left, float4* vx, float4* vy, float4* vz, uint32_t* vc) {
+// last few atoms of the whole batch: element-wise loads that never run past the end of the arrays.
+// Returned by value: taking the address of the prefetch registers would demote them to scratch memory.
+struct atom_quad { float4 x, y, z; uint32_t c; };
+__device__ __noinline__ atom_quad load_atoms_tail(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                  const uint8_t* __restrict__ code, uint32_t a, uint32_t left) {
     const bool h1 = left > 1, h2 = left > 2, h3 = left > 3;
-    *vx = float4{in.x[a], h1 ? in.x[a + 1] : 0.f, h2 ? in.x[a + 2] : 0.f, h3 ? in.x[a + 3] : 0.f};
-    *vy = float4{in.y[a], h1 ? in.y[a + 1] : 0.f, h2 ? in.y[a + 2] : 0.f, h3 ? in.y[a + 3] : 0.f};
-    *vz = float4{in.z[a], h1 ? in.z[a + 1] : 0.f, h2 ? in.z[a + 2] : 0.f, h3 ? in.z[a + 3] : 0.f};
-    *vc = (uint32_t)in.atom_code[a] | (h1 ? (uint32_t)in.atom_code[a + 1] << 8 : 0u) |
-          (h2 ? (uint32_t)in.atom_code[a + 2] << 16 : 0u) | (h3 ? (uint32_t)in.atom_code[a + 3] << 24 : 0u);
+    atom_quad q;
+    q.x = float4{x[a], h1 ? x[a + 1] : 0.f, h2 ? x[a + 2] : 0.f, h3 ? x[a + 3] : 0.f};
+    q.y = float4{y[a], h1 ? y[a + 1] : 0.f, h2 ? y[a + 2] : 0.f, h3 ? y[a + 3] : 0.f};
+    q.z = float4{z[a], h1 ? z[a + 1] : 0.f, h2 ? z[a + 2] : 0.f, h3 ? z[a + 3] : 0.f};
+    q.c = (uint32_t)code[a] | (h1 ? (uint32_t)code[a + 1] << 8 : 0u) | (h2 ? (uint32_t)code[a + 2] << 16 : 0u) |
+          (h3 ? (uint32_t)code[a + 3] << 24 : 0u);
+    return q;
 }
 
 __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES)
@@ -220,12 +226,13 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
             px[u] = py[u] = pz[u] = float4{0.f, 0.f, 0.f, 0.f}; pc[u] = 0;
             if (i4 < e.cnt) {
                 if (whole || (size_t)e.A0 + i4 + 4 <= (size_t)in.n_atoms) {
-                    __builtin_memcpy(&px[u], in.x + e.A0 + i4, 16);
-                    __builtin_memcpy(&py[u], in.y + e.A0 + i4, 16);
-                    __builtin_memcpy(&pz[u], in.z + e.A0 + i4, 16);
-                    __builtin_memcpy(&pc[u], in.atom_code + e.A0 + i4, 4);
+                    px[u] = ld_f4(in.x + e.A0 + i4);
+                    py[u] = ld_f4(in.y + e.A0 + i4);
+                    pz[u] = ld_f4(in.z + e.A0 + i4);
+                    pc[u] = ld_u32(in.atom_code + e.A0 + i4);
                 } else {
-                    load_atoms_tail(in, e.A0 + i4, e.cnt - i4, &px[u], &py[u], &pz[u], &pc[u]);
+                    const atom_quad q = load_atoms_tail(in.x, in.y, in.z, in.atom_code, e.A0 + i4, e.cnt - i4);
+                    px[u] = q.x; py[u] = q.y; pz[u] = q.z; pc[u] = q.c;
                 }
             }
         }
@@ -473,7 +480,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         rec[RL.o_tbytes + k] = (uint8_t)quant_round(v6, qmin[6], qdisc[6]);
     };
     auto finish_q = [&](int q, float lo, float hi, const float* src, uint32_t cntq) {
-        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) first_extrema(src, cntq, lane, &lo, &hi);
+        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane); lo = e.lo; hi = e.hi; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
     };
     constexpr int U = 8;
@@ -522,7 +529,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
                 }
             }
             float lo_w = wave_min_f32(lo), hi_w = wave_max_f32(hi);
-            if (__builtin_expect(lo_w == 0.0f || hi_w == 0.0f, 0)) first_extrema(src, cntq, lane, &lo_w, &hi_w);
+            if (__builtin_expect(lo_w == 0.0f || hi_w == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane); lo_w = e.lo; hi_w = e.hi; }
             qmin[q] = lo_w; qdisc[q] = nbins[q] / (hi_w - lo_w); qcont[q] = (hi_w - lo_w) / nbins[q];
         }
         for (uint32_t k = lane; k < n; k += WAVE) {

@@ -35,6 +35,9 @@ __device__ __forceinline__ void st_u32(uint8_t* p, uint32_t v) { __builtin_memcp
 __device__ __forceinline__ void st_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ void st_f32(uint8_t* p, float v) { __builtin_memcpy(p, &v, 4); }
 __device__ __forceinline__ v3 ld_v3(const uint8_t* p) { v3 v; __builtin_memcpy(&v, p, 12); return v; }
+// 16-byte load from a 4-byte aligned float address
+struct __attribute__((packed, aligned(4))) f4_u { float x, y, z, w; };
+__device__ __forceinline__ float4 ld_f4(const float* p) { const f4_u t = *reinterpret_cast<const f4_u*>(p); return float4{t.x, t.y, t.z, t.w}; }
 
 // ---- wave-level primitives -----------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {

@@ -715,12 +715,6 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
     }
 }
 
-constexpr int SC_CHUNK = 512;
-struct sidechain_meta {
-    uint16_t aoff[SC_CHUNK], soff[SC_CHUNK], perm[SC_CHUNK];
-    uint8_t rc[SC_CHUNK];
-};
-
 // Side chains + final output, one wavefront per chain, lane = residue.
 // Reference: Nerf::reconstructAminoAcid (src/nerf.cpp:106-155), side-chain torsion de-quantisation
 // (src/foldcomp.cpp:338-369), B-factors and OXT (:884-898), `-a` order _reorderAtoms (:1563-1577).
@@ -732,7 +726,6 @@ __global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__
     __shared__ float s_d2x[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];   // -1 * L * cos(ba)
     __shared__ float s_sb[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];    // sin(ba)
     __shared__ float s_slots[WAVES_PER_BLOCK][FCZ_MAX_RES_ATOMS * 3 * WAVE];
-    __shared__ sidechain_meta s_meta[WAVES_PER_BLOCK];
     // per-lane table lookups (residue code varies per lane) come from LDS copies, not global memory
     __shared__ uint16_t s_prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
     __shared__ float s_blen[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
@@ -776,104 +769,54 @@ __global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__
     const uint32_t abase = atom_off[c];
     slot_store S{&s_slots[wave][0], lane};
 
-    // Residues are processed in chunks of SC_CHUNK; inside a chunk they are visited in order of decreasing
-    // atom count (counting sort on the 12 possible counts), so the 64 lanes of an iteration grow side chains
-    // of (nearly) the same length instead of idling behind the longest one.
-    sidechain_meta& M = s_meta[wave];
     uint32_t atom_run = 0, sc_run = 0;
-    for (uint32_t cbase = 0; cbase < n; cbase += SC_CHUNK) {
-        const uint32_t cn = (n - cbase < (uint32_t)SC_CHUNK) ? (n - cbase) : (uint32_t)SC_CHUNK;
-        // ---- pass A: residue codes -> atom / torsion-byte offsets (chunk-relative), counts per atom count ----
-        uint32_t binc[12];
-#pragma unroll
-        for (int b = 0; b < 12; b++) binc[b] = 0;
-        uint32_t a_run = 0, s_run = 0;
-        for (uint32_t t0 = 0; t0 < cn; t0 += WAVE) {
-            const uint32_t i = t0 + lane, k = cbase + i;
-            const bool act = i < cn;
-            uint32_t rc = 23, na = 0;
-            if (act) {
-                rc = words[8 * (size_t)k] >> 3;
-                if (k == 0) rc = (uint32_t)res_code_from_letter(e[20]);
-                if (rc >= 24) rc = 23;
-                na = s_natoms[rc];
-            }
-            uint32_t tot_a, tot_s;
-            const uint32_t ao = a_run + wave_excl_scan(na, lane, &tot_a);
-            const uint32_t so = s_run + wave_excl_scan(act ? na - 3 : 0, lane, &tot_s);
-            a_run += tot_a; s_run += tot_s;
-            if (act) { M.aoff[i] = (uint16_t)ao; M.soff[i] = (uint16_t)so; M.rc[i] = (uint8_t)rc; }
-#pragma unroll
-            for (int b = 0; b < 12; b++) binc[b] += (uint32_t)__popcll(__ballot(act && na == (uint32_t)(14 - b)));
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t k = base + lane;
+        const bool act = k < n;
+        uint32_t rc = 23, na = 0, tq = 0;
+        v3 b0{0.f, 0.f, 0.f}, b1 = b0, b2 = b0;
+        if (act) {
+            // first batch of loads: residue code, B-factor byte, the three backbone atoms
+            rc = words[8 * (size_t)k] >> 3;
+            tq = e[v.L.o_tbytes + k];
+            b0 = B[3 * k]; b1 = B[3 * k + 1]; b2 = B[3 * k + 2];
+            if (k == 0) rc = (uint32_t)res_code_from_letter(e[20]);
+            if (rc >= 24) rc = 23;
+            na = s_natoms[rc];
         }
-        // bin b holds residues with 14-b atoms; bins are laid out in that (descending) order
-        uint32_t binstart[12];
-        {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int b = 0; b < 12; b++) { binstart[b] = acc; acc += binc[b]; }
+        uint32_t tot_a, tot_s;
+        const uint32_t a_off = atom_run + wave_excl_scan(na, lane, &tot_a);
+        const uint32_t s_off = sc_run + wave_excl_scan(act ? na - 3 : 0, lane, &tot_s);
+        atom_run += tot_a; sc_run += tot_s;
+        if (!act) continue;
+        // second batch: all (<= 11) side-chain torsion bytes of the residue as three unaligned dwords
+        // (reads at most 11 bytes past the last torsion byte: still inside the record, which continues
+        // with the 8-byte B-factor header and n B-factor bytes)
+        const uint8_t* sp = scb + s_off;
+        const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = (na > 11) ? ld_u32(sp + 8) : 0u;
+        S.put(0, b0); S.put(1, b1); S.put(2, b2);
+        for (uint32_t j = 3; j < na; j++) {
+            const uint32_t pk = s_prev[rc][j];
+            const uint32_t jj = j - 3;
+            const uint32_t qw = (jj < 4) ? q0 : (jj < 8 ? q1 : q2);
+            const uint32_t q = (qw >> (8 * (jj & 3))) & 0xffu;
+            const float L = s_blen[rc][j];
+            const float sb = s_sb[rc][j];
+            v3 d2;
+            d2.x = s_d2x[rc][j];
+            d2.y = L * s_tor_cos[q] * sb;
+            d2.z = L * s_tor_sin[q] * sb;
+            S.put((int)j, place_atom_d2(S.get(pk & 15), S.get((pk >> 4) & 15), S.get((pk >> 8) & 15), d2));
         }
-        // ---- pass B: stable counting sort -> perm ----
-        for (uint32_t t0 = 0; t0 < cn; t0 += WAVE) {
-            const uint32_t i = t0 + lane;
-            const bool act = i < cn;
-            const uint32_t na = act ? (uint32_t)s_natoms[M.rc[i]] : 0u;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-            for (int b = 0; b < 12; b++) {
-                const unsigned long long mk = __ballot(act && na == (uint32_t)(14 - b));
-                if (act && na == (uint32_t)(14 - b)) M.perm[binstart[b] + (uint32_t)__popcll(mk & lt)] = (uint16_t)i;
-                binstart[b] += (uint32_t)__popcll(mk);
-            }
+        const uint32_t a = abase + a_off;
+        for (uint32_t j = 0; j < na; j++) {
+            const uint32_t slot = s_oslot[rc][j];
+            const v3 p = S.get((int)slot);
+            out.x[a + j] = p.x; out.y[a + j] = p.y; out.z[a + j] = p.z;
+            if (out.atom_code) out.atom_code[a + j] = s_ratom[rc][slot];
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- grow side chains, 64 residues of similar size per iteration ----
-        for (uint32_t t0 = 0; t0 < cn; t0 += WAVE) {
-            const bool act = t0 + lane < cn;
-            const uint32_t i = act ? (uint32_t)M.perm[t0 + lane] : 0u;
-            const uint32_t k = cbase + i;
-            const uint32_t rc = act ? (uint32_t)M.rc[i] : 23u;
-            const uint32_t na = act ? (uint32_t)s_natoms[rc] : 0u;
-            const uint32_t na_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)na);   // sorted: lane 0 holds the largest
-            uint32_t tq = 0, q0 = 0, q1 = 0, q2 = 0;
-            v3 b0{0.f, 0.f, 0.f}, b1 = b0, b2 = b0;
-            if (act) {
-                // one batch of loads: B-factor byte, the three backbone atoms, all (<= 11) torsion bytes as three
-                // unaligned dwords (reads at most 11 bytes past the residue's last torsion byte: still inside the
-                // record, which continues with the 8-byte B-factor header and n B-factor bytes)
-                tq = e[v.L.o_tbytes + k];
-                b0 = B[3 * k]; b1 = B[3 * k + 1]; b2 = B[3 * k + 2];
-                const uint8_t* sp = scb + sc_run + M.soff[i];
-                q0 = ld_u32(sp); q1 = ld_u32(sp + 4); q2 = (na > 11) ? ld_u32(sp + 8) : 0u;
-            }
-            S.put(0, b0); S.put(1, b1); S.put(2, b2);
-            for (uint32_t j = 3; j < na_max; j++) {
-                if (j >= na) continue;
-                const uint32_t pk = s_prev[rc][j];
-                const uint32_t jj = j - 3;
-                const uint32_t qw = (jj < 4) ? q0 : (jj < 8 ? q1 : q2);
-                const uint32_t q = (qw >> (8 * (jj & 3))) & 0xffu;
-                const float Lb = s_blen[rc][j];
-                const float sb = s_sb[rc][j];
-                v3 d2;
-                d2.x = s_d2x[rc][j];
-                d2.y = Lb * s_tor_cos[q] * sb;
-                d2.z = Lb * s_tor_sin[q] * sb;
-                S.put((int)j, place_atom_d2(S.get(pk & 15), S.get((pk >> 4) & 15), S.get((pk >> 8) & 15), d2));
-            }
-            if (!act) continue;
-            const uint32_t a = abase + atom_run + M.aoff[i];
-            for (uint32_t j = 0; j < na; j++) {
-                const uint32_t slot = s_oslot[rc][j];
-                const v3 p = S.get((int)slot);
-                out.x[a + j] = p.x; out.y[a + j] = p.y; out.z[a + j] = p.z;
-                if (out.atom_code) out.atom_code[a + j] = s_ratom[rc][slot];
-            }
-            out.bfac_res[r0 + k] = dequant(tq, tmin, tcf);
-            if (out.res_code) out.res_code[r0 + k] = (uint8_t)rc;
-        }
-        atom_run += a_run; sc_run += s_run;
-        __builtin_amdgcn_wave_barrier();
+        out.bfac_res[r0 + k] = dequant(tq, tmin, tcf);
+        if (out.res_code) out.res_code[r0 + k] = (uint8_t)rc;
     }
     if (lane == 0 && e[v.L.o_oxt]) {
         const uint32_t a = abase + atom_run;

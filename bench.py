@@ -224,7 +224,7 @@ def main():
 
     # per-kernel device time (HIP events on the codec's own stream)
     ktime = {}
-    for name in ("compress_sizes", "compress", "decompress_sizes", "decompress_forward", "decompress_reverse", "decompress_sidechain"):
+    for name in ("compress_sizes", "compress", "decompress_sizes", "decompress_backbone", "decompress_sidechain"):
         ms, n = codec.kernel_time(name)
         ktime[name] = (ms / n) if n else 0.0
     codec.enable_timing(False)
@@ -236,9 +236,9 @@ def main():
         # algorithmic bytes: compress reads 13A+9, writes fcz; decompress reads fcz, writes 12A+4
         bytes_compress = (13 * A + 9 + fcz_per_res) * R
         bytes_decompress = (fcz_per_res + 12 * A + 4) * R
-        dec_ms = ktime["decompress_forward"] + ktime["decompress_reverse"] + ktime["decompress_sidechain"]
-        cands = {"k_compress": (bytes_compress, ktime["compress"]),
-                 "decompress(k_forward_nerf+k_reverse_blend+k_sidechain)": (bytes_decompress, dec_ms)}
+        dec_ms = ktime["decompress_backbone"] + ktime["decompress_sidechain"]
+        cands = {"k_compress_tiled": (bytes_compress, ktime["compress"]),
+                 "decompress(k_backbone+k_sidechain)": (bytes_decompress, dec_ms)}
         dom = max(cands, key=lambda k: cands[k][1])
         by, ms = cands[dom]
         ach = by / (ms * 1e-3) / 1e9 if ms else 0.0

@@ -65,11 +65,12 @@ struct fcz_ctx {
     dev_buf scan_tmp;   // block partials of the device scans
     // decompress: the segment/residue prefixes computed by fcz_decompress_sizes_dev are reused by the
     // fcz_decompress_batch_dev call that follows on the same entries
-    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_S = 0;
+    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_S = 0, sized_maxseg = 0;
     bool sizes_fresh = false;
     dev_buf cnt;        // decompress: 3 x n u32 counts + n i32 status
     dev_buf seg_off;    // decompress: (n+1) u32
-    dev_buf fwd;        // decompress: forward atoms
+    dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
+    dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
     dev_buf bb;         // decompress: blended backbone
     // staging for the host-pointer entry points
     dev_buf stage[20];
@@ -180,7 +181,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release();
+    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -404,9 +405,12 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
     rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
+    if ((rc = ctx->maxseg.ensure(16))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
     {
         span_guard g(ctx, "decompress_sizes");
-        if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st);
+        if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st,
+                                  ctx->maxseg.as<uint32_t>());
         if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
         if ((rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
         if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
@@ -415,27 +419,31 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (total_res) *total_res = ctx->pinned[0];
     if (total_atoms) *total_atoms = ctx->pinned[1];
     ctx->sized_blob = blob_dev; ctx->sized_off = off_dev; ctx->sized_n = n;
-    ctx->sized_R = ctx->pinned[0]; ctx->sized_S = ctx->pinned[2]; ctx->sizes_fresh = true;
+    ctx->sized_R = ctx->pinned[0]; ctx->sized_S = ctx->pinned[2]; ctx->sized_maxseg = ctx->pinned[3]; ctx->sizes_fresh = true;
     return FCZ_OK;
 }
 
 // The segment prefix (seg_off) lives in the ctx: fcz_decompress_sizes_dev computes it; the batch call
 // recomputes it when it is called without a preceding sizes call on the same entries.
 static int ensure_segments(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res,
-                           uint32_t* total_seg) {
+                           uint32_t* total_seg, uint32_t* max_seg_len) {
     if (ctx->sizes_fresh && ctx->sized_blob == blob_dev && ctx->sized_off == off_dev && ctx->sized_n == n) {
         ctx->sizes_fresh = false;   // single use: the records may be rewritten before the next call
-        *total_res = ctx->sized_R; *total_seg = ctx->sized_S;
+        *total_res = ctx->sized_R; *total_seg = ctx->sized_S; *max_seg_len = ctx->sized_maxseg;
         return FCZ_OK;
     }
     int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
     rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
-    if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st);
+    if ((rc = ctx->maxseg.ensure(16))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st,
+                              ctx->maxseg.as<uint32_t>());
     // scans of residues (scratch, reusing cr in place is not possible: use stage[16]) and segments
     rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     if ((rc = device_scan<uint32_t>(ctx, cr, ctx->stage[16].as<uint32_t>(), n))) return rc;
@@ -443,8 +451,9 @@ static int ensure_segments(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], ctx->stage[16].as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *total_res = ctx->pinned[0]; *total_seg = ctx->pinned[2];
+    *total_res = ctx->pinned[0]; *total_seg = ctx->pinned[2]; *max_seg_len = ctx->pinned[3];
     return FCZ_OK;
 }
 
@@ -455,22 +464,18 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     if (!out_dev->x || !out_dev->y || !out_dev->z || !out_dev->bfac_res) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) return FCZ_OK;
-    uint32_t R = 0, S = 0;
-    int rc = ensure_segments(ctx, blob_dev, off_dev, n, &R, &S);
+    uint32_t R = 0, S = 0, max_seg = 0;
+    int rc = ensure_segments(ctx, blob_dev, off_dev, n, &R, &S, &max_seg);
     if (rc) return rc;
     if (R == 0) return FCZ_OK;
-    rc = ctx->fwd.ensure(sizeof(v3) * 3 * ((size_t)R + S)); if (rc) return rc;
+    const uint32_t groups = grid_for(n, WAVE);
+    const uint32_t ring_rows = 3 * (max_seg ? max_seg : 1);
+    rc = ctx->fwd.ensure(sizeof(v3) * (size_t)groups * ring_rows * WAVE); if (rc) return rc;
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
-    const uint32_t* seg_off = ctx->seg_off.as<uint32_t>();
     {
-        span_guard g(ctx, "decompress_forward");
-        hipLaunchKernelGGL(k_forward_nerf, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
-                           seg_off, ctx->fwd.as<v3>());
-    }
-    {
-        span_guard g(ctx, "decompress_reverse");
-        hipLaunchKernelGGL(k_reverse_blend, dim3(grid_for(S, BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
-                           seg_off, ctx->fwd.as<v3>(), ctx->bb.as<v3>());
+        span_guard g(ctx, "decompress_backbone");
+        hipLaunchKernelGGL(k_backbone, dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
+                           ctx->fwd.as<v3>(), ring_rows, ctx->bb.as<v3>());
     }
     {
         span_guard g(ctx, "decompress_sidechain");

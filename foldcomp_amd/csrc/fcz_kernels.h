@@ -442,10 +442,11 @@ __device__ __forceinline__ int res_code_from_letter(uint8_t ch) {
 __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                        uint32_t n_entries, uint32_t* __restrict__ cnt_res,
                                                        uint32_t* __restrict__ cnt_atoms, uint32_t* __restrict__ cnt_seg,
-                                                       int32_t* __restrict__ status) {
+                                                       int32_t* __restrict__ status, uint32_t* __restrict__ max_seg_len) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (i >= n_entries) return;
+    uint32_t seg_max = 0;
     const uint8_t* e = blob + off[i];
     const uint64_t len = off[i + 1] - off[i];
     int st = FCZ_OK;
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
                 if (a < 0 || b < a || b > (int)n - 1) bad = 2;
                 if (s == 0 && a != 0) bad = 2;
                 if (s + 2 == v.n_anchor && b != (int)n - 1) bad = 2;
+                if (b >= a && (uint32_t)(b - a + 1) > seg_max) seg_max = (uint32_t)(b - a + 1);
             }
             na = wave_sum(na); nsc = wave_sum(nsc);
             if (__any(bad == 1)) st = FCZ_E_RESIDUE;
@@ -479,10 +481,13 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
             else { na_total = na + (e[v.L.o_oxt] ? 1 : 0); nseg = v.n_anchor - 1; }
         }
     }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(seg_max, d, WAVE); seg_max = o > seg_max ? o : seg_max; }
     if (lane == 0) {
         const bool ok = st == FCZ_OK;
         cnt_res[i] = ok ? n : 0; cnt_atoms[i] = ok ? na_total : 0; cnt_seg[i] = ok ? nseg : 0;
         status[i] = st;
+        if (ok && max_seg_len) atomicMax(max_seg_len, seg_max);
     }
 }
 
@@ -712,6 +717,122 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
             f2 = f1; f1 = f0;
         }
         w_raw = w_pre; fa = na; fb = nb; fc = nc;
+    }
+}
+
+// Backbone reconstruction, one wavefront per group of 64 consecutive entries, lane = chain.
+// Reference: segment loop of Foldcomp::decompress (src/foldcomp.cpp:814-858): per anchor segment a forward
+// NeRF (reconstructBackboneAtoms :167-246), then reconstructBackboneReverse (:248-273: bond angles re-measured
+// on the forward atoms, Nerf::reconstructWithReversed src/nerf.cpp:342-379 from the next anchor, weightedAverage
+// src/atom_coordinate.cpp:145-163); the next segment starts from the blended last three atoms (:855-857).
+// The forward atoms of the current segment live in a per-group ring [atom][lane] (every lane only ever
+// re-reads its own column, the transposed layout is purely for coalescing: one 768-byte row per step), so the
+// intermediate never makes a strided trip through HBM. bb receives the final backbone (3 atoms per residue,
+// chain-major).
+__global__ __launch_bounds__(WAVE) void k_backbone(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
+                                                   uint32_t n_entries, const uint32_t* __restrict__ res_off,
+                                                   v3* __restrict__ ring, uint32_t ring_rows, v3* __restrict__ bb) {
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * WAVE + lane;
+    const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
+    v3* Rg = ring + (size_t)blockIdx.x * ring_rows * WAVE + lane;   // row j at Rg[j * WAVE]
+    const uint8_t* e = blob + (valid ? off[c] : off[0]);
+    entry_view v; v.n = 0; v.n_anchor = 1; v.e = e; v.L = make_layout(0, 0, 0, 0);
+    bb_params P{};
+    if (valid) { v = view_entry(e); P = load_params(e); }
+    const uint8_t* words = e + v.L.o_words;
+    const uint8_t* last_word = words + 8 * (size_t)(v.n ? v.n - 1 : 0);
+    const uint32_t nseg = valid ? v.n_anchor - 1 : 0;
+    uint32_t maxseg = nseg;
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(maxseg, d, WAVE); maxseg = o > maxseg ? o : maxseg; }
+    v3* Bc = bb + 3 * (size_t)(valid ? res_off[c] : 0);
+    v3 p0{0.f, 0.f, 0.f}, p1 = p0, p2 = p0;
+    int first = 0, next = 0;
+    const uint8_t* wp = words;
+    uint64_t w_cur = 0, w_nxt = 0;
+    if (valid) {
+        p0 = ld_v3(e + v.L.o_anchor); p1 = ld_v3(e + v.L.o_anchor + 12); p2 = ld_v3(e + v.L.o_anchor + 24);
+        first = (int)ld_u32(e + v.L.o_aidx); next = (int)ld_u32(e + v.L.o_aidx + 4);
+        wp = words + 8 * (size_t)first;
+        w_cur = ld_u64(wp);
+        w_nxt = ld_u64(wp + 8 <= last_word ? wp + 8 : last_word);
+    }
+    for (uint32_t s = 0; s < maxseg; s++) {
+        const bool act = s < nseg;
+        const int len = act ? next - first + 1 : 0;
+        int maxlen = len;
+#pragma unroll
+        for (int d = WAVE / 2; d > 0; d >>= 1) { const int o = __shfl_xor(maxlen, d, WAVE); maxlen = o > maxlen ? o : maxlen; }
+        int next2 = next;
+        v3 A0{0.f, 0.f, 0.f}, A1 = A0, A2 = A0;
+        if (act) {
+            next2 = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)(s + 2 <= nseg ? s + 2 : nseg));
+            const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
+            A0 = ld_v3(anc); A1 = ld_v3(anc + 12); A2 = ld_v3(anc + 24);   // next anchor: carry + reverse start
+            Rg[0] = p0; Rg[WAVE] = p1; Rg[2 * WAVE] = p2;
+        }
+        // ---- forward NeRF of the segment ----
+        for (int i = 0; i + 1 < maxlen; i++) {
+            if (i + 1 >= len) continue;
+            const uint8_t* pf = wp + 16;
+            const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
+            const bb_word w = decode_word(w_cur, P);
+            const v3 N = place_atom(p0, p1, p2, (float)1.3311, w.can, w.psi);
+            const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
+            const v3 CA = place_atom(p1, p2, N, l_nca, w.cna, w.omega);
+            const v3 C = place_atom(p2, N, CA, (float)1.5281, w.nca, w.phi);
+            Rg[(size_t)(3 * i + 3) * WAVE] = N; Rg[(size_t)(3 * i + 4) * WAVE] = CA; Rg[(size_t)(3 * i + 5) * WAVE] = C;
+            p0 = N; p1 = CA; p2 = C;
+            w_cur = w_nxt; w_nxt = w_pre; wp += 8;
+        }
+        // ---- reverse NeRF + blend of the same segment ----
+        const int T = 3 * len;
+        const float Tf = (float)T;
+        if (act) {
+            v3* B = Bc + 3 * (size_t)first;
+            v3 r3 = A2, r2 = A1, r1 = A0;   // R[T-1], R[T-2], R[T-3]: the anchor itself
+            if (s + 1 == nseg) {             // only the last segment keeps its final three atoms (src/foldcomp.cpp:847-851)
+                const float j0 = (float)(T - 3), j1 = (float)(T - 2), j2 = (float)(T - 1);
+                B[T - 3] = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
+                B[T - 2] = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
+                B[T - 1] = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
+            }
+            if (len >= 2) {
+                // forward atoms f+2, f+1 for f = T-4 are the last-but-one and last-but-two forward atoms = p1, p0
+                v3 f2 = p1, f1 = p0;
+                const uint8_t* seg_words = words + 8 * (size_t)first;
+                int wi = len - 2;
+                uint64_t w_raw = ld_u64(seg_words + 8 * (size_t)wi);
+                v3 fa = Rg[(size_t)(3 * wi + 2) * WAVE], fb = Rg[(size_t)(3 * wi + 1) * WAVE], fc = Rg[(size_t)(3 * wi) * WAVE];
+                for (; wi >= 0; wi--) {
+                    const int wn = wi > 0 ? wi - 1 : 0;
+                    const uint64_t w_pre = ld_u64(seg_words + 8 * (size_t)wn);
+                    const v3 na = Rg[(size_t)(3 * wn + 2) * WAVE], nb = Rg[(size_t)(3 * wn + 1) * WAVE], nc = Rg[(size_t)(3 * wn) * WAVE];
+                    const bb_word w = decode_word(w_raw, P);
+#pragma unroll
+                    for (int q = 2; q >= 0; q--) {
+                        const int f = 3 * wi + q;
+                        const v3 f0 = (q == 2) ? fa : (q == 1) ? fb : fc;
+                        const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
+                        const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
+                        const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
+                        const v3 Rv = place_atom(r3, r2, r1, Lb, ba, tor);   // a = R[f+3], b = R[f+2], c = R[f+1]
+                        const float wf = (float)(T - f), wr = (float)f;
+                        B[f] = v3{((f0.x * wf) + (Rv.x * wr)) / Tf, ((f0.y * wf) + (Rv.y * wr)) / Tf, ((f0.z * wf) + (Rv.z * wr)) / Tf};
+                        r3 = r2; r2 = r1; r1 = Rv;
+                        f2 = f1; f1 = f0;
+                    }
+                    w_raw = w_pre; fa = na; fb = nb; fc = nc;
+                }
+            }
+            // carry into the next segment: blended last three atoms (indices T-3..T-1)
+            const float j0 = (float)(T - 3), j1 = (float)(T - 2), j2 = (float)(T - 1);
+            p0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
+            p1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
+            p2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
+            first = next; next = next2;
+        }
     }
 }
 

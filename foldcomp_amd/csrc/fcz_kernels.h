@@ -487,7 +487,8 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
         const bool ok = st == FCZ_OK;
         cnt_res[i] = ok ? n : 0; cnt_atoms[i] = ok ? na_total : 0; cnt_seg[i] = ok ? nseg : 0;
         status[i] = st;
-        if (ok && max_seg_len) atomicMax(max_seg_len, seg_max);
+        // one contended atomic per entry would serialise (~88 atomics/us on one address): only the rare raisers go through
+        if (ok && max_seg_len && seg_max > __builtin_nontemporal_load(max_seg_len)) atomicMax(max_seg_len, seg_max);
     }
 }
 
@@ -720,6 +721,9 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
     }
 }
 
+#ifndef FCZ_BACKBONE_MIN_WAVES
+#define FCZ_BACKBONE_MIN_WAVES 3
+#endif
 // Backbone reconstruction, one wavefront per group of 64 consecutive entries, lane = chain.
 // Reference: segment loop of Foldcomp::decompress (src/foldcomp.cpp:814-858): per anchor segment a forward
 // NeRF (reconstructBackboneAtoms :167-246), then reconstructBackboneReverse (:248-273: bond angles re-measured
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
 // re-reads its own column, the transposed layout is purely for coalescing: one 768-byte row per step), so the
 // intermediate never makes a strided trip through HBM. bb receives the final backbone (3 atoms per residue,
 // chain-major).
-__global__ __launch_bounds__(WAVE) void k_backbone(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
+__global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                    uint32_t n_entries, const uint32_t* __restrict__ res_off,
                                                    v3* __restrict__ ring, uint32_t ring_rows, v3* __restrict__ bb) {
     const int lane = threadIdx.x;

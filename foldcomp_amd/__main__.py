@@ -1,0 +1,433 @@
+"""`python -m foldcomp_amd` -- the reference CLI surface (src/main.cpp) over the batch GPU codec.
+
+    foldcomp compress   [-t N] [-b B] [-d|-z] [-y] [-r] [-f] [--skip-discontinuous] <pdb|cif|dir|tar(.gz)|db> [<out>]
+    foldcomp decompress [-t N] [-a] [-d|-z] [-y] [--check] [-l ids [-m 0|1]] <fcz|dir|tar(.gz)|db> [<out>]
+    foldcomp extract    [--plddt|--fasta|--amino-acid] [-p digits] [--no-merge] [--use-title] <fcz|dir|tar|db> [<out>]
+    foldcomp check      <fcz|dir|tar|db>
+    foldcomp rmsd       <pdb|cif> <pdb|cif>
+
+Same flags, defaults, output naming (src/main.cpp:356-368, 444-508, 643-654) and exit-code behaviour (always
+0 once arguments parse, errors go to stderr). `-t` only sizes the host-side parse/format pool: the codec
+itself runs on the GPU in batches. Text parsing/formatting stays on the host; all geometry runs in
+libfcz_hip.so.
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import io
+import os
+import sys
+import tarfile
+from typing import Iterable, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from . import fczfile
+from .api import decompress_many, default_codec
+from .database import DatabaseReader, DatabaseWriter
+from .structure import (AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb,
+                        remove_alternative_position)
+
+VERSION = "0.1.0"
+BATCH_CHAINS = 16384
+
+
+# ---- structure files -----------------------------------------------------------------------------------
+def _parse_cif(text: str) -> Tuple[AtomTable, str]:
+    """minimal mmCIF reader: the _atom_site loop (what gemmi hands to StructureReader::updateStructure,
+    src/structure_reader.cpp:31-61) and _entry.id"""
+    title = ""
+    cols: List[str] = []
+    rows: List[List[str]] = []
+    in_loop = False
+    in_site = False
+    for line in text.splitlines():
+        s = line.strip()
+        if s.startswith("_entry.id"):
+            title = s.split(None, 1)[1].strip().strip("'\"") if len(s.split(None, 1)) > 1 else ""
+        if s == "loop_":
+            in_loop, in_site, cols = True, False, []
+            continue
+        if in_loop and s.startswith("_atom_site."):
+            cols.append(s.split(".", 1)[1].split()[0]); in_site = True
+            continue
+        if in_loop and s.startswith("_"):
+            in_site = False
+            continue
+        if in_site and cols:
+            if not s or s.startswith("#"):
+                in_loop = in_site = False
+                continue
+            rows.append(_cif_split(s))
+    ix = {c: i for i, c in enumerate(cols)}
+    def col(*names):
+        for n in names:
+            if n in ix:
+                return ix[n]
+        return None
+    c_atom, c_res = col("label_atom_id", "auth_atom_id"), col("label_comp_id", "auth_comp_id")
+    c_chain, c_seq = col("auth_asym_id", "label_asym_id"), col("auth_seq_id", "label_seq_id")
+    c_id, c_b = col("id"), col("B_iso_or_equiv")
+    cx, cy, cz = col("Cartn_x"), col("Cartn_y"), col("Cartn_z")
+    atom, res, chain, ai, ri, xyz, bf = [], [], [], [], [], [], []
+    for r in rows:
+        if len(r) < len(cols):
+            continue
+        atom.append(r[c_atom].strip('"')); res.append(r[c_res]); chain.append(r[c_chain])
+        ai.append(int(r[c_id]) if c_id is not None else len(ai) + 1)
+        ri.append(int(r[c_seq]) if r[c_seq] not in (".", "?") else 0)
+        xyz.append((float(r[cx]), float(r[cy]), float(r[cz])))
+        bf.append(float(r[c_b]) if c_b is not None and r[c_b] not in (".", "?") else 0.0)
+    t = AtomTable(atom, res, chain, np.asarray(ai, np.int32), np.asarray(ri, np.int32),
+                  np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3), np.asarray(bf, np.float64).astype(np.float32))
+    return t, title
+
+
+def _cif_split(s: str) -> List[str]:
+    out, i, n = [], 0, len(s)
+    while i < n:
+        if s[i].isspace():
+            i += 1; continue
+        if s[i] in "'\"":
+            q = s[i]; j = i + 1
+            while j < n and not (s[j] == q and (j + 1 == n or s[j + 1].isspace())):
+                j += 1
+            out.append(s[i + 1:j]); i = j + 1
+        else:
+            j = i
+            while j < n and not s[j].isspace():
+                j += 1
+            out.append(s[i:j]); i = j
+    return out
+
+
+def _pdb_title(text: str) -> str:
+    """gemmi: _entry.id = HEADER id code (cols 63-66), else _struct.title = TITLE records"""
+    title_parts = []
+    for line in text.splitlines():
+        if line.startswith("HEADER") and len(line) >= 66 and line[62:66].strip():
+            return line[62:66].strip()
+        if line.startswith("TITLE"):
+            title_parts.append(line[10:80].rstrip() if len(title_parts) == 0 else line[10:80].rstrip())
+        if line.startswith("ATOM"):
+            break
+    return " ".join(p.strip() for p in title_parts).strip() if title_parts else ""
+
+
+def load_structure(name: str, data: bytes) -> Tuple[AtomTable, str]:
+    base = os.path.basename(name)
+    if base.endswith(".gz"):
+        data = gzip.decompress(data); base_nogz = base[:-3]
+    else:
+        base_nogz = base
+    text = data.decode("latin-1")
+    if base_nogz.endswith(".cif"):
+        t, title = _parse_cif(text)
+    else:
+        t, title = parse_pdb(text, hetatm=True), _pdb_title(text)
+    return t, (title if title else base)
+
+
+def is_compressible(ext: str) -> bool:
+    return ext in ("pdb", "cif", "pdb.gz", "cif.gz")      # utility.cpp:129-140
+
+
+def file_parts(base: str) -> Tuple[str, str]:
+    """getFileParts (utility.cpp:118-127): split at the last '.', keeping a trailing .gz with the extension"""
+    stem, ext = base, ""
+    if base.endswith(".gz"):
+        stem = base[:-3]; ext = ".gz"
+    if "." in stem:
+        i = stem.rfind(".")
+        return stem[:i], stem[i + 1:] + ext
+    return stem, ext.lstrip(".")
+
+
+# ---- entry sources -------------------------------------------------------------------------------------
+def iter_entries(inp: str, recursive: bool, id_list: Optional[str], id_mode: int) -> Iterator[Tuple[str, bytes]]:
+    if os.path.exists(inp + ".dbtype"):
+        r = DatabaseReader(inp)
+        ids = range(len(r))
+        if id_list:
+            want = [l.strip() for l in open(id_list) if l.strip()]
+            ids = [r.id_of_key(int(w)) if id_mode == 0 else r.id_of_name(w) for w in want]
+            ids = [i for i in ids if i >= 0]
+        for i in ids:
+            yield r.name(i), r.data(i).rstrip(b"\0")
+        r.close()
+    elif inp.endswith((".tar", ".tar.gz", ".tgz")):
+        with tarfile.open(inp) as tf:
+            for m in tf:
+                if m.isfile():
+                    yield m.name, tf.extractfile(m).read()
+    elif os.path.isdir(inp):
+        for root, dirs, files in os.walk(inp):
+            dirs.sort()
+            for f in sorted(files):
+                p = os.path.join(root, f)
+                yield p, open(p, "rb").read()
+            if not recursive:
+                break
+    else:
+        yield inp, open(inp, "rb").read()
+
+
+class Sink:
+    """file / directory / tar / database outputs (src/main.cpp:510-530, 656-687)"""
+
+    def __init__(self, output: str, kind: str, overwrite: bool):
+        self.kind, self.output, self.overwrite = kind, output, overwrite
+        self.key = 0
+        if kind == "db":
+            self.db = DatabaseWriter(output)
+        elif kind == "tar":
+            self.tar = tarfile.open(output, "w")
+        elif kind == "dir":
+            os.makedirs(output, exist_ok=True)
+
+    def put(self, name: str, data: bytes, db_name: Optional[str] = None, nul: bool = False):
+        if self.kind == "db":
+            self.db.append(data + (b"\0" if nul else b""), self.key, db_name or name); self.key += 1
+        elif self.kind == "tar":
+            ti = tarfile.TarInfo(os.path.basename(name)); ti.size = len(data)
+            self.tar.addfile(ti, io.BytesIO(data))
+        else:
+            path = name if self.kind == "file" else os.path.join(self.output, os.path.basename(name))
+            if os.path.exists(path) and not self.overwrite:
+                print(f"[Error] Output file already exists: {os.path.basename(path)}", file=sys.stderr)
+                return
+            with open(path, "wb") as f:
+                f.write(data)
+
+    def close(self):
+        if self.kind == "db":
+            self.db.close()
+        elif self.kind == "tar":
+            self.tar.close()
+
+
+# ---- modes ---------------------------------------------------------------------------------------------
+def run_compress(a, inputs, output, kind, single):
+    sink = Sink(output, kind, a.overwrite)
+    pending: List[Tuple[str, str, Chain]] = []   # (file name, db name, chain)
+
+    def flush():
+        if not pending:
+            return
+        try:
+            batch = build_batch([p[2] for p in pending], a.brk)
+        except StructureError as e:
+            # isolate the offending chains one by one
+            good = []
+            for p in pending:
+                try:
+                    build_batch([p[2]], a.brk); good.append(p)
+                except StructureError as ee:
+                    print(f"[Error] compressing {p[0]}: {ee}", file=sys.stderr)
+            pending[:] = good
+            if not pending:
+                return
+            batch = build_batch([p[2] for p in pending], a.brk)
+        blob, off, st = default_codec().compress_batch(batch, strict=False)
+        for i, (fname, dbname, _) in enumerate(pending):
+            if st[i] != 0:
+                print(f"[Error] compressing {fname}", file=sys.stderr); continue
+            sink.put(fname, blob[off[i]:off[i + 1]].tobytes(), db_name=dbname)
+        pending.clear()
+
+    for inp in inputs:
+        for name, data in iter_entries(inp, a.recursive, None, 1):
+            base = os.path.basename(name)
+            stem, ext = file_parts(base)
+            if kind in ("tar", "db"):
+                out_file = stem
+            elif single:
+                out_file = file_parts(output)[0]
+            else:
+                out_file = stem
+            try:
+                t, title = load_structure(name, data)
+            except Exception as e:  # noqa: BLE001 - parse errors are reported and skipped like the reference
+                print(f"[Error] {base}: {e}", file=sys.stderr); continue
+            if len(t) == 0:
+                print(f"[Error] No atoms found in the input file: {base}", file=sys.stderr); continue
+            if title == base:
+                title = out_file            # src/main.cpp:465
+            t = remove_alternative_position(t)
+            chains = identify_chains(t)
+            for cs in chains:
+                frags = identify_discontinuous(t, cs)
+                if a.skip_discontinuous and len(frags) > 1:
+                    print(f"Skipping discontinuous chain: {base}", file=sys.stderr); continue
+                for j, sl in enumerate(frags):
+                    fname = out_file + (t.chain[cs.start] if len(chains) > 1 else "")
+                    if len(frags) > 1:
+                        fname += f"_{j}"
+                    if kind != "db":
+                        fname += ".fcz" if is_compressible(ext) else ("." + ext if ext else "")
+                    pending.append((fname, out_file, Chain(title, t.take(sl))))
+            if len(pending) >= BATCH_CHAINS:
+                flush()
+    flush()
+    sink.close()
+
+
+def run_decompress(a, inputs, output, kind, single):
+    sink = Sink(output, kind, a.overwrite)
+    names, ents = [], []
+
+    def flush():
+        if not ents:
+            return
+        res = decompress_many(ents, alt_order=a.alt, skip_bad=True)
+        for nm, r in zip(names, res):
+            if r is None:
+                print(f"[Error] decompressing {nm}", file=sys.stderr); continue
+            stem, ext = file_parts(os.path.basename(nm))
+            fname = file_parts(output)[0] + ".pdb" if single and kind == "file" else stem + (".pdb" if ext in ("fcz", "") else "." + ext)
+            if single and kind == "file":
+                fname = output
+            sink.put(fname, r[1].encode("latin-1"), db_name=stem, nul=True)
+        names.clear(); ents.clear()
+
+    for inp in inputs:
+        for name, data in iter_entries(inp, a.recursive, a.id_list, a.id_mode):
+            if a.check:
+                from . import _lib
+                arr = np.frombuffer(data, np.uint8)
+                if _lib.load().fcz_check(arr.ctypes.data, len(arr)) != 0:
+                    print(f"[Error] invalid FCZ entry skipped: {name}", file=sys.stderr); continue
+            names.append(name); ents.append(data)
+            if len(ents) >= BATCH_CHAINS:
+                flush()
+    flush()
+    sink.close()
+
+
+def run_extract(a, inputs, output, kind, single):
+    merged = [] if (a.merge and not single) else None
+    out_dir_made = False
+    for inp in inputs:
+        for name, data in iter_entries(inp, a.recursive, a.id_list, a.id_mode):
+            try:
+                rec = fczfile.parse(data)
+            except fczfile.FczFormatError:
+                print(f"[Error] reading {name}", file=sys.stderr); continue
+            title = rec.title if a.use_title else os.path.basename(name)
+            if a.ext_mode == 0:
+                s = fczfile.extract_plddt(rec, a.plddt_digits)
+                text = fczfile.fasta_like(title, s) if a.plddt_digits == 1 else fczfile.tsv_line(title, rec.n_residues, s)
+            else:
+                text = fczfile.fasta_like(title, fczfile.sequence(rec))
+            if single:
+                open(output, "w").write(text)
+            elif merged is not None:
+                merged.append(text)
+            else:
+                if not out_dir_made:
+                    os.makedirs(output, exist_ok=True); out_dir_made = True
+                open(os.path.join(output, file_parts(os.path.basename(name))[0] + "." + a.suffix), "w").write(text)
+    if merged is not None:
+        open(output.rstrip("/") if not output.endswith("/") else output.rstrip("/") + "." + a.suffix, "w").write("".join(merged))
+
+
+def run_check(a, inputs):
+    from . import _lib
+    lib = _lib.load()
+    msgs = {1: "backbone count mismatch", 2: "side chain count mismatch", 3: "temperature factor count mismatch",
+            4: "empty backbone angles", 5: "empty side chain angles", 6: "empty temperature factors"}
+    for inp in inputs:
+        for name, data in iter_entries(inp, a.recursive, a.id_list, a.id_mode):
+            arr = np.frombuffer(data, np.uint8)
+            rc = lib.fcz_check(arr.ctypes.data, len(arr)) if len(arr) else -5
+            if rc == 0:
+                print(f"[Info] {name} is valid.")
+            else:
+                print(f"[Error] {name}: {msgs.get(rc, 'not a valid FCZ entry')}", file=sys.stderr)
+
+
+def run_rmsd(a, p1, p2):
+    t1, _ = load_structure(p1, open(p1, "rb").read()); t2, _ = load_structure(p2, open(p2, "rb").read())
+    if len(t1) != len(t2):
+        print("[Error] The number of atoms in the two structures differ.", file=sys.stderr); return
+    def rms(m):   # atom_coordinate.cpp:424-434: float accumulation, no superposition
+        d = (t1.xyz[m] - t2.xyz[m]).astype(np.float32)
+        return float(np.sqrt(np.float32(np.sum(d * d, dtype=np.float32)) / np.float32(max(int(m.sum()), 1))))
+    bbm = np.asarray([x in ("N", "CA", "C") for x in t1.atom])
+    n_res = len(set(zip(t1.chain, t1.res_index.tolist())))
+    print(f"{p1}\t{p2}\t{n_res}\t{len(t1)}\t{rms(bbm):g}\t{rms(np.ones(len(t1), bool)):g}")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="foldcomp", add_help=True)
+    ap.add_argument("-v", "--version", action="store_true")
+    ap.add_argument("-t", "--threads", type=int, default=1)
+    ap.add_argument("-r", "--recursive", action="store_true")
+    ap.add_argument("-f", "--file", action="store_true", dest="file_input")
+    ap.add_argument("-a", "--alt", action="store_true")
+    ap.add_argument("-b", "--break", type=int, default=25, dest="brk")
+    ap.add_argument("-z", "--tar", action="store_true")
+    ap.add_argument("-d", "--db", action="store_true")
+    ap.add_argument("-y", "--overwrite", action="store_true")
+    ap.add_argument("-l", "--id-list", default=None)
+    ap.add_argument("-m", "--id-mode", type=int, default=1)
+    ap.add_argument("--skip-discontinuous", action="store_true")
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--plddt", action="store_const", const=0, dest="ext_mode", default=0)
+    ap.add_argument("--fasta", "--amino-acid", action="store_const", const=1, dest="ext_mode")
+    ap.add_argument("-p", "--plddt-digits", type=int, default=1)
+    ap.add_argument("--no-merge", action="store_false", dest="merge")
+    ap.add_argument("--use-title", action="store_true")
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--use-cache", action="store_true")
+    ap.add_argument("mode", nargs="?")
+    ap.add_argument("input", nargs="?")
+    ap.add_argument("output", nargs="?")
+    a = ap.parse_args(argv)
+    if a.version:
+        print(f"foldcomp {VERSION}"); return 0
+    if a.mode not in ("compress", "decompress", "extract", "check", "rmsd") or a.input is None:
+        ap.print_usage(); return 0
+    inp = a.input.rstrip("/")
+    if not os.path.exists(inp):
+        print(f"[Error] {inp} does not exist.", file=sys.stderr); return 1
+    if a.mode == "rmsd":
+        run_rmsd(a, inp, a.output); return 0
+    a.plddt_digits = min(max(a.plddt_digits, 1), 4)
+    a.suffix = {"compress": "fcz", "decompress": "pdb", "check": ""}.get(a.mode) if a.mode != "extract" else (
+        "fasta" if a.ext_mode == 1 else ("plddt" if a.plddt_digits == 1 else "plddt.tsv"))
+    inputs, singles = [inp], []
+    if a.file_input:
+        inputs = []
+        for line in open(inp).read().splitlines():
+            (singles if line.endswith((".pdb", ".pdb.gz", ".cif", ".cif.gz", ".fcz")) else inputs).append(line)
+        inputs += singles
+    single = (not a.file_input and os.path.isfile(inp) and not inp.endswith((".tar", ".tar.gz", ".tgz"))
+              and not os.path.exists(inp + ".dbtype"))
+    output = a.output.rstrip("/") if a.output else None
+    if output and output.endswith(".tar"):
+        a.tar = True
+    if output is None and a.mode != "check":
+        if a.db:
+            output = inp + "_db"
+        elif a.tar:
+            output = f"{inp}.{a.suffix}.tar"
+        elif single:
+            output = os.path.splitext(inp)[0] + "." + a.suffix
+        else:
+            output = f"{inp}_{a.suffix}/"
+    kind = "db" if a.db else "tar" if a.tar else ("file" if single else "dir")
+    if a.mode == "compress":
+        run_compress(a, inputs, output.rstrip("/") if kind != "file" else output, kind, single)
+    elif a.mode == "decompress":
+        run_decompress(a, inputs, output.rstrip("/") if kind != "file" else output, kind, single)
+    elif a.mode == "extract":
+        run_extract(a, inputs, output, kind, single)
+    else:
+        run_check(a, inputs)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -384,7 +384,7 @@ def main(argv=None):
     ap.add_argument("mode", nargs="?")
     ap.add_argument("input", nargs="?")
     ap.add_argument("output", nargs="?")
-    a = ap.parse_args(argv)
+    a = ap.parse_intermixed_args(argv)
     if a.version:
         print(f"foldcomp {VERSION}"); return 0
     if a.mode not in ("compress", "decompress", "extract", "check", "rmsd") or a.input is None:

@@ -71,6 +71,7 @@ struct fcz_ctx {
     dev_buf seg_off;    // decompress: (n+1) u32
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
+    dev_buf wring;      // decompress: per-group ring of the segment's packed words
     dev_buf bb;         // decompress: blended backbone
     // staging for the host-pointer entry points
     dev_buf stage[20];
@@ -181,7 +182,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release();
+    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -471,11 +472,12 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     const uint32_t groups = grid_for(n, WAVE);
     const uint32_t ring_rows = 3 * (max_seg ? max_seg : 1);
     rc = ctx->fwd.ensure(sizeof(v3) * (size_t)groups * ring_rows * WAVE); if (rc) return rc;
+    rc = ctx->wring.ensure(sizeof(uint64_t) * (size_t)groups * (ring_rows / 3) * WAVE); if (rc) return rc;
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     {
         span_guard g(ctx, "decompress_backbone");
         hipLaunchKernelGGL(k_backbone, dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
-                           ctx->fwd.as<v3>(), ring_rows, ctx->bb.as<v3>());
+                           ctx->fwd.as<v3>(), ctx->wring.as<uint64_t>(), ring_rows, ctx->bb.as<v3>());
     }
     {
         span_guard g(ctx, "decompress_sidechain");

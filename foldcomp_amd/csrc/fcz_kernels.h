@@ -733,13 +733,24 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
 // re-reads its own column, the transposed layout is purely for coalescing: one 768-byte row per step), so the
 // intermediate never makes a strided trip through HBM. bb receives the final backbone (3 atoms per residue,
 // chain-major).
-__global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
-                                                   uint32_t n_entries, const uint32_t* __restrict__ res_off,
-                                                   v3* __restrict__ ring, uint32_t ring_rows, v3* __restrict__ bb) {
+// window of blended backbone atoms per lane, flushed with wave-cooperative contiguous stores
+constexpr int BW = 16;                      // atoms per lane and window
+struct backbone_lds {
+    float atom[WAVE][BW * 3 + 3];           // [lane][slot*3+comp], odd dword stride: conflict-free
+    unsigned long long base[WAVE];          // byte address of slot 0 of the lane's window (chain-major bb)
+    int lo[WAVE], hi[WAVE];                 // filled slots [lo, hi)
+};
+
+__global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
+        const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries,
+        const uint32_t* __restrict__ res_off, v3* __restrict__ ring, uint64_t* __restrict__ wring, uint32_t ring_rows,
+        v3* __restrict__ bb) {
+    __shared__ backbone_lds S;
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x * WAVE + lane;
     const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
-    v3* Rg = ring + (size_t)blockIdx.x * ring_rows * WAVE + lane;   // row j at Rg[j * WAVE]
+    v3* Rg = ring + (size_t)blockIdx.x * ring_rows * WAVE + lane;            // atom row j at Rg[j * WAVE]
+    uint64_t* Wg = wring + (size_t)blockIdx.x * (ring_rows / 3) * WAVE + lane;   // word row i at Wg[i * WAVE]
     const uint8_t* e = blob + (valid ? off[c] : off[0]);
     entry_view v; v.n = 0; v.n_anchor = 1; v.e = e; v.L = make_layout(0, 0, 0, 0);
     bb_params P{};
@@ -762,6 +773,32 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(const
         w_cur = ld_u64(wp);
         w_nxt = ld_u64(wp + 8 <= last_word ? wp + 8 : last_word);
     }
+    // ---- output window: blended atoms are parked in LDS and leave as contiguous runs per chain ----
+    long long win = -1;           // window index (chain-major atom index / BW) this lane is filling, -1 = none
+    S.lo[lane] = 0; S.hi[lane] = 0;
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < BW * 3; t++) {               // 64 lanes x 48 rounds cover 64 chains x 48 dwords
+            const int flat = t * WAVE + lane;
+            const int cl = flat / (BW * 3), d = flat - cl * (BW * 3);
+            const int slot = d / 3;
+            if (slot >= S.lo[cl] && slot < S.hi[cl])
+                *reinterpret_cast<float*>(S.base[cl] + 4ull * (unsigned)d) = S.atom[cl][d];
+        }
+        __builtin_amdgcn_wave_barrier();
+        S.lo[lane] = 0; S.hi[lane] = 0;
+        win = -1;
+    };
+    auto emit = [&](bool on, long long bi, v3 a) {       // every lane calls (wave-uniform control flow)
+        const long long w = on ? bi / BW : win;
+        if (__any(on && win >= 0 && w != win)) flush();
+        if (on) {
+            const int slot = (int)(bi - w * BW);
+            if (win < 0) { win = w; S.base[lane] = (unsigned long long)(Bc + w * BW); S.lo[lane] = slot; S.hi[lane] = slot + 1; }
+            else { if (slot < S.lo[lane]) S.lo[lane] = slot; if (slot + 1 > S.hi[lane]) S.hi[lane] = slot + 1; }
+            S.atom[lane][3 * slot] = a.x; S.atom[lane][3 * slot + 1] = a.y; S.atom[lane][3 * slot + 2] = a.z;
+        }
+    };
     for (uint32_t s = 0; s < maxseg; s++) {
         const bool act = s < nseg;
         const int len = act ? next - first + 1 : 0;
@@ -781,6 +818,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(const
             if (i + 1 >= len) continue;
             const uint8_t* pf = wp + 16;
             const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
+            Wg[(size_t)i * WAVE] = w_cur;                 // the reverse pass re-reads the word from the ring (coalesced)
             const bb_word w = decode_word(w_cur, P);
             const v3 N = place_atom(p0, p1, p2, (float)1.3311, w.can, w.psi);
             const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
@@ -793,51 +831,62 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(const
         // ---- reverse NeRF + blend of the same segment ----
         const int T = 3 * len;
         const float Tf = (float)T;
-        if (act) {
-            v3* B = Bc + 3 * (size_t)first;
-            v3 r3 = A2, r2 = A1, r1 = A0;   // R[T-1], R[T-2], R[T-3]: the anchor itself
-            if (s + 1 == nseg) {             // only the last segment keeps its final three atoms (src/foldcomp.cpp:847-851)
-                const float j0 = (float)(T - 3), j1 = (float)(T - 2), j2 = (float)(T - 1);
-                B[T - 3] = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
-                B[T - 2] = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
-                B[T - 1] = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
+        const long long b0 = 3ll * first;               // chain-major index of the segment's atom 0
+        v3 r3 = A2, r2 = A1, r1 = A0;                   // R[T-1], R[T-2], R[T-3]: the anchor itself
+        const float j0 = (float)(T - 3), j1 = (float)(T - 2), j2 = (float)(T - 1);
+        const v3 c0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
+        const v3 c1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
+        const v3 c2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
+        {
+            // only the last segment keeps its final three atoms (src/foldcomp.cpp:847-851)
+            const bool fin = act && (s + 1 == nseg);
+            emit(fin, b0 + T - 1, c2); emit(fin, b0 + T - 2, c1); emit(fin, b0 + T - 3, c0);
+        }
+        // forward atoms f+2, f+1 for f = T-4 are the last-but-one and last-but-two forward atoms = p1, p0
+        v3 f2 = p1, f1 = p0;
+        int wi0 = len - 2;
+        uint64_t w_raw = 0;
+        v3 fa{0.f, 0.f, 0.f}, fb = fa, fc = fa;
+        if (wi0 >= 0) {
+            w_raw = Wg[(size_t)wi0 * WAVE];
+            fa = Rg[(size_t)(3 * wi0 + 2) * WAVE]; fb = Rg[(size_t)(3 * wi0 + 1) * WAVE]; fc = Rg[(size_t)(3 * wi0) * WAVE];
+        }
+        for (int wi = maxlen - 2; wi >= 0; wi--) {       // wave-uniform trip count; lanes join when wi <= len-2
+            const bool on = wi <= wi0;
+            uint64_t w_pre = w_raw;
+            v3 na = fa, nb = fb, nc = fc;
+            if (on) {
+                const int wn = wi > 0 ? wi - 1 : 0;
+                w_pre = Wg[(size_t)wn * WAVE];
+                na = Rg[(size_t)(3 * wn + 2) * WAVE]; nb = Rg[(size_t)(3 * wn + 1) * WAVE]; nc = Rg[(size_t)(3 * wn) * WAVE];
             }
-            if (len >= 2) {
-                // forward atoms f+2, f+1 for f = T-4 are the last-but-one and last-but-two forward atoms = p1, p0
-                v3 f2 = p1, f1 = p0;
-                const uint8_t* seg_words = words + 8 * (size_t)first;
-                int wi = len - 2;
-                uint64_t w_raw = ld_u64(seg_words + 8 * (size_t)wi);
-                v3 fa = Rg[(size_t)(3 * wi + 2) * WAVE], fb = Rg[(size_t)(3 * wi + 1) * WAVE], fc = Rg[(size_t)(3 * wi) * WAVE];
-                for (; wi >= 0; wi--) {
-                    const int wn = wi > 0 ? wi - 1 : 0;
-                    const uint64_t w_pre = ld_u64(seg_words + 8 * (size_t)wn);
-                    const v3 na = Rg[(size_t)(3 * wn + 2) * WAVE], nb = Rg[(size_t)(3 * wn + 1) * WAVE], nc = Rg[(size_t)(3 * wn) * WAVE];
-                    const bb_word w = decode_word(w_raw, P);
+            const bb_word w = decode_word(w_raw, P);
 #pragma unroll
-                    for (int q = 2; q >= 0; q--) {
-                        const int f = 3 * wi + q;
-                        const v3 f0 = (q == 2) ? fa : (q == 1) ? fb : fc;
-                        const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
-                        const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
-                        const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
-                        const v3 Rv = place_atom(r3, r2, r1, Lb, ba, tor);   // a = R[f+3], b = R[f+2], c = R[f+1]
-                        const float wf = (float)(T - f), wr = (float)f;
-                        B[f] = v3{((f0.x * wf) + (Rv.x * wr)) / Tf, ((f0.y * wf) + (Rv.y * wr)) / Tf, ((f0.z * wf) + (Rv.z * wr)) / Tf};
-                        r3 = r2; r2 = r1; r1 = Rv;
-                        f2 = f1; f1 = f0;
-                    }
-                    w_raw = w_pre; fa = na; fb = nb; fc = nc;
+            for (int q = 2; q >= 0; q--) {
+                const int f = 3 * wi + q;
+                const v3 f0 = (q == 2) ? fa : (q == 1) ? fb : fc;
+                v3 Bv{0.f, 0.f, 0.f};
+                if (on) {
+                    const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
+                    const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
+                    const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
+                    const v3 Rv = place_atom(r3, r2, r1, Lb, ba, tor);   // a = R[f+3], b = R[f+2], c = R[f+1]
+                    const float wf = (float)(T - f), wr = (float)f;
+                    Bv = v3{((f0.x * wf) + (Rv.x * wr)) / Tf, ((f0.y * wf) + (Rv.y * wr)) / Tf, ((f0.z * wf) + (Rv.z * wr)) / Tf};
+                    r3 = r2; r2 = r1; r1 = Rv;
+                    f2 = f1; f1 = f0;
                 }
+                emit(on, b0 + f, Bv);
             }
+            if (on) { w_raw = w_pre; fa = na; fb = nb; fc = nc; }
+        }
+        if (act) {
             // carry into the next segment: blended last three atoms (indices T-3..T-1)
-            const float j0 = (float)(T - 3), j1 = (float)(T - 2), j2 = (float)(T - 1);
-            p0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
-            p1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
-            p2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
+            p0 = c0; p1 = c1; p2 = c2;
             first = next; next = next2;
         }
     }
+    if (__any(win >= 0)) flush();
 }
 
 // Side chains + final output, one wavefront per chain, lane = residue.

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restri
 }
 
 #ifndef FCZ_BACKBONE_MIN_WAVES
-#define FCZ_BACKBONE_MIN_WAVES 3
+#define FCZ_BACKBONE_MIN_WAVES 2
 #endif
 // Backbone reconstruction, one wavefront per group of 64 consecutive entries, lane = chain.
 // Reference: segment loop of Foldcomp::decompress (src/foldcomp.cpp:814-858): per anchor segment a forward

@@ -324,15 +324,47 @@ __device__ __forceinline__ float deg2rad(float deg) {
     return f;
 }
 
+// x/d, y/d, z/d with ONE reciprocal. This is the unscaled core of the IEEE-correct float division the
+// compiler emits for '/' (v_rcp_f32, one FMA refinement of the reciprocal, two of the quotient, final FMA;
+// LLVM AMDGPU LowerFDIV32 between v_div_scale and v_div_fixup); those two wrappers only rescale operands whose
+// quotient or intermediates could leave the normal range. The guard below sends every such case -- and zero,
+// infinite or NaN denominators -- to the plain division, so results are bit-identical to three '/'.
+__device__ __forceinline__ v3 vdiv3(v3 n, float d) {
+    const uint32_t ed = (__float_as_uint(d) >> 23) & 0xffu;
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    v3 q;
+    {
+        float t = n.x * r; float e2 = __builtin_fmaf(-d, t, n.x); t = __builtin_fmaf(e2, r, t);
+        const float e3 = __builtin_fmaf(-d, t, n.x); q.x = __builtin_fmaf(e3, r, t);
+    }
+    {
+        float t = n.y * r; float e2 = __builtin_fmaf(-d, t, n.y); t = __builtin_fmaf(e2, r, t);
+        const float e3 = __builtin_fmaf(-d, t, n.y); q.y = __builtin_fmaf(e3, r, t);
+    }
+    {
+        float t = n.z * r; float e2 = __builtin_fmaf(-d, t, n.z); t = __builtin_fmaf(e2, r, t);
+        const float e3 = __builtin_fmaf(-d, t, n.z); q.z = __builtin_fmaf(e3, r, t);
+    }
+    // safe iff the denominator is comfortably normal and no quotient is tiny-but-nonzero or huge
+    const float ax = __builtin_fabsf(q.x), ay = __builtin_fabsf(q.y), az = __builtin_fabsf(q.z);
+    const bool den_ok = (ed - 32u) < 192u;                                   // 2^-95 <= |d| < 2^97
+    const bool q_ok = (ax == 0.0f || ax > 0x1p-90f) && (ay == 0.0f || ay > 0x1p-90f) && (az == 0.0f || az > 0x1p-90f) &&
+                      ax < 0x1p90f && ay < 0x1p90f && az < 0x1p90f;          // also false for NaN
+    if (__builtin_expect(!(den_ok && q_ok), 0)) q = v3{n.x / d, n.y / d, n.z / d};
+    return q;
+}
+
 // Nerf::place_atom, reference src/nerf.cpp:39-104, with the trigonometry hoisted: d2 is the
 // "curr_atm" vector (-L cos(ba), L cos(ta) sin(ba), L sin(ta) sin(ba)) (:66-70).
 __device__ __forceinline__ v3 place_atom_d2(v3 a, v3 b, v3 c, v3 d2) {
     v3 ab = vsub(b, a), bc = vsub(c, b);
     float bc_norm = vnorm(bc);
-    v3 bcn = v3{bc.x / bc_norm, bc.y / bc_norm, bc.z / bc_norm};
+    v3 bcn = vdiv3(bc, bc_norm);
     v3 n = vcross(ab, bcn);
     float n_norm = vnorm(n);
-    n.x = n.x / n_norm; n.y = n.y / n_norm; n.z = n.z / n_norm;
+    n = vdiv3(n, n_norm);
     v3 nbc = vcross(n, bcn);
     v3 D = v3{0.0f, 0.0f, 0.0f};
     D.x += (bcn.x * d2.x); D.x += (nbc.x * d2.y); D.x += (n.x * d2.z);

@@ -246,13 +246,8 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
     int rc = ctx->ang.ensure(sizeof(float) * 6 * (size_t)std::max<uint32_t>(in->n_residues, 1));
     if (rc) return rc;
     span_guard g(ctx, "compress");
-    static const bool use_v1 = getenv("FCZ_COMPRESS_V1") != nullptr;   // first-generation kernel, kept for A/B runs
-    if (use_v1)
-        hipLaunchKernelGGL(k_compress, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in,
-                           out_off_dev, out_dev, status_dev, ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_compress_tiled, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in,
-                           out_off_dev, out_dev, status_dev, ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
+    hipLaunchKernelGGL(k_compress_tiled, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in,
+                       out_off_dev, out_dev, status_dev, ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
 }

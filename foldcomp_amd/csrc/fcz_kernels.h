@@ -1,12 +1,13 @@
-// fcz_kernels.h -- HIP kernels of the FCZ codec for gfx950 (wave64).
+// fcz_kernels.h -- HIP kernels of the FCZ codec for gfx950 (wave64): shared primitives + the decompress side.
 //
 // compress  (Foldcomp::preprocess/compress/writeStream, reference src/foldcomp.cpp:450-606,1038-1109)
-//   k_compress:           one wavefront per chain, lane = residue (stride 64)
+//   k_compress_sizes:     one wavefront per chain: exact record size (Foldcomp::getSize)
+//   k_compress_tiled:     fcz_compress.h
 // decompress (Foldcomp::read/decompress, reference src/foldcomp.cpp:779-1036)
 //   k_entry_sizes:        one wavefront per entry: header validation, residue/atom/segment counts
-//   k_forward_nerf:       lane = chain  (the forward NeRF is one dependent chain per structure)
-//   k_reverse_blend:      lane = anchor segment (reverse NeRF + blend are independent per segment)
+//   k_backbone:           one wavefront per 64 entries, lane = chain: forward NeRF, reverse NeRF, blend
 //   k_sidechain:          one wavefront per chain, lane = residue; emits the final SoA atoms
+//   k_scan_reduce / k_scan_u64 / k_scan_apply: exclusive scans (offsets)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -165,18 +166,6 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t n, const T* __rest
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = (T)carry;
 }
 
-// first atom with the given code inside [a0,a1) (findFirstAtomCoords, src/sidechain.cpp:140-147)
-__device__ __forceinline__ v3 find_atom(const fcz_chain_batch& in, uint32_t a0, uint32_t a1, uint32_t code, uint32_t hint) {
-    // fast path: standard files list N, CA, C first
-    if (a0 + hint < a1 && in.atom_code[a0 + hint] == code) {
-        uint32_t a = a0 + hint;
-        return v3{in.x[a], in.y[a], in.z[a]};
-    }
-    for (uint32_t a = a0; a < a1; a++)
-        if (in.atom_code[a] == code) return v3{in.x[a], in.y[a], in.z[a]};
-    return v3{0.0f, 0.0f, 0.0f};
-}
-
 // LDS slot store of one lane's residue: [slot][comp][lane] floats -> conflict-free
 struct slot_store {
     float* base;  // this wave's region: 14 * 3 * 64 floats
@@ -190,228 +179,6 @@ struct slot_store {
         return v3{base[(slot * 3 + 0) * WAVE + lane], base[(slot * 3 + 1) * WAVE + lane], base[(slot * 3 + 2) * WAVE + lane]};
     }
 };
-
-// One wavefront per chain. ang = 6 x n_residues floats of device scratch (each lane re-reads only
-// what it wrote itself, so no cross-lane ordering is needed).
-__global__ __launch_bounds__(BLOCK) void k_compress(fcz_chain_batch in, const uint64_t* __restrict__ out_off,
-                                                    uint8_t* __restrict__ out, int32_t* __restrict__ status,
-                                                    float* __restrict__ ang, int keep_first_angle) {
-    __shared__ float s_slots[WAVES_PER_BLOCK][FCZ_MAX_RES_ATOMS * 3 * WAVE];
-    __shared__ uint8_t s_slot_of[FCZ_N_RES_CODES][40];  // atom code -> canonical slot, 255 = not in residue
-
-    // build the (residue code, atom code) -> slot map once per block
-    for (int i = threadIdx.x; i < FCZ_N_RES_CODES * 40; i += BLOCK) (&s_slot_of[0][0])[i] = 255;
-    __syncthreads();
-    for (int i = threadIdx.x; i < FCZ_N_RES_CODES * FCZ_MAX_RES_ATOMS; i += BLOCK) {
-        int rc = i / FCZ_MAX_RES_ATOMS, j = i % FCZ_MAX_RES_ATOMS;
-        if (j < fcz_res_natoms[rc]) s_slot_of[rc][fcz_res_atom[rc][j]] = (uint8_t)j;
-    }
-    __syncthreads();
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (c >= in.n_chains) return;
-
-    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
-    const uint32_t title_len = in.title_off[c + 1] - in.title_off[c];
-    const uint32_t thr = (uint32_t)in.anchor_threshold;
-    uint8_t* rec = out + out_off[c];
-    const uint32_t rec_size = (uint32_t)(out_off[c + 1] - out_off[c]);
-
-    // ---- validation (the reference aborts on these inputs) ----
-    int bad = 0;
-    if (n < 2 || thr < 2) bad = (n < 2) ? FCZ_E_TOO_SHORT : FCZ_E_INVALID_ARG;
-    for (uint32_t k = lane; k < n && !bad; k += WAVE)
-        if (!res_code_ok(in.res_code[r0 + k])) bad = FCZ_E_RESIDUE;
-    bad = __any(bad != 0) ? (bad ? bad : 1) : 0;
-    if (bad) {
-        // make the verdict uniform: take the smallest (most negative) code
-        int b = bad == 1 ? 0 : bad;
-#pragma unroll
-        for (int d = WAVE / 2; d > 0; d >>= 1) { int o = __shfl_xor(b, d, WAVE); b = o < b ? o : b; }
-        for (uint32_t i = lane; i < rec_size; i += WAVE) rec[i] = 0;
-        if (lane == 0 && status) status[c] = b;
-        return;
-    }
-
-    const uint32_t m = n - 1;  // number of (psi, omega, phi) triples / angle triples
-    const uint32_t n_anchor = n / thr + 2;
-    const uint32_t interval = n / (n_anchor - 1);
-    float* a_phi = ang + 0 * (size_t)in.n_residues + r0;
-    float* a_psi = ang + 1 * (size_t)in.n_residues + r0;
-    float* a_omg = ang + 2 * (size_t)in.n_residues + r0;
-    float* a_nca = ang + 3 * (size_t)in.n_residues + r0;
-    float* a_can = ang + 4 * (size_t)in.n_residues + r0;
-    float* a_cna = ang + 5 * (size_t)in.n_residues + r0;
-
-    // total side-chain torsions first (fixes the record layout)
-    uint32_t nsc = 0;
-    for (uint32_t k = lane; k < n; k += WAVE) nsc += fcz_res_natoms[in.res_code[r0 + k]] - 3;
-    nsc = wave_sum(nsc);
-    const rec_layout L = make_layout(n, n_anchor, title_len, nsc);
-
-    const float kInf = __builtin_huge_valf();
-    ext mn[7], mx[7];
-#pragma unroll
-    for (int q = 0; q < 7; q++) { mn[q] = ext{kInf, 0xffffffffu}; mx[q] = ext{-kInf, 0xffffffffu}; }
-
-    slot_store S{&s_slots[wave][0], lane};
-    // FixedAngleDiscretizer(255), reference src/discretizer.h:89-96
-    const float sc_min = -180.0f, sc_disc = 255.0f / (180.0f - (-180.0f));
-
-    uint32_t sc_base = 0;
-    for (uint32_t base = 0; base < n; base += WAVE) {
-        const uint32_t k = base + lane;
-        const bool act = k < n;
-        uint32_t rc = 23, na = 3, a0 = 0, a1 = 0;
-        if (act) {
-            rc = in.res_code[r0 + k];
-            na = fcz_res_natoms[rc];
-            a0 = in.atom_off[r0 + k];
-            a1 = in.atom_off[r0 + k + 1];
-        }
-        uint32_t tile_total;
-        const uint32_t sc_off = sc_base + wave_excl_scan(act ? na - 3 : 0, lane, &tile_total);
-        sc_base += tile_total;
-        if (!act) continue;
-
-        // gather this residue's atoms into canonical slots (first occurrence of a name wins)
-        uint32_t filled = 0;
-        for (int j = 0; j < FCZ_MAX_RES_ATOMS; j++) S.put(j, v3{0.0f, 0.0f, 0.0f});
-        for (uint32_t a = a0; a < a1; a++) {
-            uint32_t code = in.atom_code[a];
-            uint32_t slot = code < 40 ? s_slot_of[rc][code] : 255u;
-            if (slot != 255u && !((filled >> slot) & 1u)) {
-                filled |= 1u << slot;
-                S.put((int)slot, v3{in.x[a], in.y[a], in.z[a]});
-            }
-        }
-        const v3 N0 = S.get(0), CA0 = S.get(1), C0 = S.get(2);
-        // the N-CA-C angle of the first residue is measured by the reference (getBondAngles output[0]) but
-        // never stored in the FCZ (src/foldcomp.cpp:497); kept in the unused slot n-1 for get_data()
-        if (keep_first_angle && k == 0) a_nca[n - 1] = bond_angle_deg(N0, CA0, C0);
-
-        // anchors: raw backbone coordinates of residue i*interval (and of the last residue),
-        // reference Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1053-1059
-        {
-            uint32_t i = k / interval;
-            if (k % interval == 0 && i < n_anchor - 1) {
-                uint8_t* p = rec + L.o_anchor + 36 * i;
-                st_f32(p, N0.x); st_f32(p + 4, N0.y); st_f32(p + 8, N0.z);
-                st_f32(p + 12, CA0.x); st_f32(p + 16, CA0.y); st_f32(p + 20, CA0.z);
-                st_f32(p + 24, C0.x); st_f32(p + 28, C0.y); st_f32(p + 32, C0.z);
-                st_u32(rec + L.o_aidx + 4 * i, k);
-            }
-            if (k == n - 1) {
-                uint8_t* p = rec + L.o_anchor + 36 * (n_anchor - 1);
-                st_f32(p, N0.x); st_f32(p + 4, N0.y); st_f32(p + 8, N0.z);
-                st_f32(p + 12, CA0.x); st_f32(p + 16, CA0.y); st_f32(p + 20, CA0.z);
-                st_f32(p + 24, C0.x); st_f32(p + 28, C0.y); st_f32(p + 32, C0.z);
-                st_u32(rec + L.o_aidx + 4 * (n_anchor - 1), k);
-            }
-        }
-
-        // backbone dihedrals and bond angles of the window (residue k, residue k+1):
-        // getTorsionFromXYZ src/torsion_angle.cpp:46-96 split at src/foldcomp.cpp:488-492;
-        // getBondAngles src/nerf.cpp:495-508 split at src/foldcomp.cpp:497-505
-        if (k < m) {
-            const uint32_t b0 = a1, b1 = in.atom_off[r0 + k + 2];
-            const v3 N1 = find_atom(in, b0, b1, 0, 0), CA1 = find_atom(in, b0, b1, 1, 1), C1 = find_atom(in, b0, b1, 2, 2);
-            const float psi = dihedral_deg(N0, CA0, C0, N1);
-            const float omg = dihedral_deg(CA0, C0, N1, CA1);
-            const float phi = dihedral_deg(C0, N1, CA1, C1);
-            const float can = bond_angle_deg(CA0, C0, N1);
-            const float cna = bond_angle_deg(C0, N1, CA1);
-            const float nca = bond_angle_deg(N1, CA1, C1);
-            a_phi[k] = phi; a_psi[k] = psi; a_omg[k] = omg; a_nca[k] = nca; a_can[k] = can; a_cna[k] = cna;
-            ext_min_upd(mn[0], phi, k); ext_max_upd(mx[0], phi, k);
-            ext_min_upd(mn[1], psi, k); ext_max_upd(mx[1], psi, k);
-            ext_min_upd(mn[2], omg, k); ext_max_upd(mx[2], omg, k);
-            ext_min_upd(mn[3], nca, k); ext_max_upd(mx[3], nca, k);
-            ext_min_upd(mn[4], can, k); ext_max_upd(mx[4], can, k);
-            ext_min_upd(mn[5], cna, k); ext_max_upd(mx[5], cna, k);
-        }
-        {
-            const float bf = in.bfac_ca[r0 + k];
-            ext_min_upd(mn[6], bf, k); ext_max_upd(mx[6], bf, k);
-        }
-
-        // side-chain torsions: calculateTorsionAnglesInResidue src/sidechain.cpp:149-168, truncating
-        // quantiser src/foldcomp.cpp:532-538
-        uint8_t* scp = rec + L.o_sc + sc_off;
-        for (uint32_t j = 3; j < na; j++) {
-            const uint32_t pk = fcz_res_prev[rc][j];
-            const float t = dihedral_deg(S.get(pk & 15), S.get((pk >> 4) & 15), S.get((pk >> 8) & 15), S.get((int)j));
-            scp[j - 3] = (uint8_t)quant_trunc(t, sc_min, sc_disc);
-        }
-    }
-
-    // ---- per-chain quantiser parameters: Discretizer::Discretizer src/discretizer.cpp:22-33 ----
-    float qmin[7], qdisc[7], qcont[7];
-    const float nbins[7] = {4095.0f, 4095.0f, 2047.0f, 255.0f, 255.0f, 255.0f, 255.0f};
-#pragma unroll
-    for (int q = 0; q < 7; q++) {
-        const float lo = wave_ext_min(mn[q]), hi = wave_ext_max(mx[q]);
-        qmin[q] = lo;
-        qdisc[q] = nbins[q] / (hi - lo);
-        qcont[q] = (hi - lo) / nbins[q];
-    }
-
-    // ---- packed words (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52) + B-factors --
-    for (uint32_t k = lane; k < n; k += WAVE) {
-        uint32_t res = in.res_code[r0 + k], om = 0, ps = 0, ph = 0, b1 = 0, b2 = 0, b3 = 0;
-        if (k < m) {
-            ph = quant_round(a_phi[k], qmin[0], qdisc[0]) & 0xfffu;
-            ps = quant_round(a_psi[k], qmin[1], qdisc[1]) & 0xfffu;
-            om = quant_round(a_omg[k], qmin[2], qdisc[2]) & 0x7ffu;
-            b3 = quant_round(a_nca[k], qmin[3], qdisc[3]) & 0xffu;
-            b1 = quant_round(a_can[k], qmin[4], qdisc[4]) & 0xffu;
-            b2 = quant_round(a_cna[k], qmin[5], qdisc[5]) & 0xffu;
-        }
-        uint8_t* w = rec + L.o_words + 8 * k;
-        w[0] = (uint8_t)(((res & 0x1fu) << 3) | (om >> 8));
-        w[1] = (uint8_t)(om & 0xffu);
-        w[2] = (uint8_t)(ps >> 4);
-        w[3] = (uint8_t)(((ps & 0xfu) << 4) | (ph >> 8));
-        w[4] = (uint8_t)(ph & 0xffu);
-        w[5] = (uint8_t)b1; w[6] = (uint8_t)b2; w[7] = (uint8_t)b3;
-        rec[L.o_tbytes + k] = (uint8_t)quant_round(in.bfac_ca[r0 + k], qmin[6], qdisc[6]);
-    }
-
-    // ---- title ----
-    for (uint32_t i = lane; i < title_len; i += WAVE) rec[L.o_title + i] = (uint8_t)in.titles[in.title_off[c] + i];
-
-    // ---- header (CompressedFileHeader src/foldcomp.h:118-136; get_header src/foldcomp.cpp:1340) ----
-    if (lane == 0) {
-        const uint32_t a_first = in.atom_off[r0], a_end = in.atom_off[r0 + n];
-        rec[0] = 'F'; rec[1] = 'C'; rec[2] = 'M'; rec[3] = 'P';
-        uint8_t* h = rec + 4;
-        st_u16(h + 0, n);
-        st_u16(h + 2, a_end - a_first);
-        st_u16(h + 4, (uint32_t)in.first_res_index[c]);
-        st_u16(h + 6, (uint32_t)in.first_atom_index[c]);
-        h[8] = (uint8_t)n_anchor;
-        h[9] = (uint8_t)in.chain_id[c];
-        h[10] = 0; h[11] = 0;  // struct padding: the reference leaves it uninitialised
-        st_u32(h + 12, nsc);
-        h[16] = (uint8_t)fcz_res1[in.res_code[r0]];
-        h[17] = (uint8_t)fcz_res1[in.res_code[r0 + n - 1]];
-        h[18] = 0; h[19] = 0;
-        st_u32(h + 20, title_len);
-#pragma unroll
-        for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, qmin[q]); st_f32(h + 48 + 4 * q, qcont[q]); }
-        // OXT (src/foldcomp.cpp:474-482, written :1061-1064): last atom of the span named OXT
-        const bool has_oxt = in.atom_code[a_end - 1] == FCZ_ATOM_OXT;
-        uint8_t* o = rec + L.o_oxt;
-        o[0] = has_oxt ? 1 : 0;
-        st_f32(o + 1, has_oxt ? in.x[a_end - 1] : 0.0f);
-        st_f32(o + 5, has_oxt ? in.y[a_end - 1] : 0.0f);
-        st_f32(o + 9, has_oxt ? in.z[a_end - 1] : 0.0f);
-        st_f32(rec + L.o_tmp, qmin[6]);
-        st_f32(rec + L.o_tmp + 4, qcont[6]);
-        if (status) status[c] = FCZ_OK;
-    }
-}
 
 // ==================================================================================================
 // decompress
@@ -492,44 +259,6 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
     }
 }
 
-// Exclusive scan of up to three uint32 arrays in one single-block launch (n+1 outputs each).
-__global__ __launch_bounds__(1024) void k_scan3(uint32_t n, const uint32_t* a0, uint32_t* o0, const uint32_t* a1,
-                                                uint32_t* o1, const uint32_t* a2, uint32_t* o2) {
-    __shared__ uint32_t s_w[3][16];
-    __shared__ uint32_t s_carry[3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 3) s_carry[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t* in[3] = {a0, a1, a2};
-    uint32_t* out[3] = {o0, o1, o2};
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        uint32_t ex[3], v[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            v[q] = (in[q] && i < n) ? in[q][i] : 0;
-            uint32_t tot;
-            ex[q] = wave_excl_scan(v[q], lane, &tot);
-            if (lane == 63) s_w[q][wave] = tot;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            uint32_t pre = s_carry[q];
-            for (int w = 0; w < wave; w++) pre += s_w[q][w];
-            if (out[q] && i < n) out[q][i] = pre + ex[q];
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            uint32_t t = s_carry[threadIdx.x];
-            for (int w = 0; w < 16; w++) t += s_w[threadIdx.x][w];
-            s_carry[threadIdx.x] = t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 3 && out[threadIdx.x]) out[threadIdx.x][n] = s_carry[threadIdx.x];
-}
-
 // uint64 exclusive scan (FCZ byte offsets), single block
 __global__ __launch_bounds__(1024) void k_scan_u64(uint32_t n, const uint64_t* in, uint64_t* out) {
     __shared__ unsigned long long s_w[16];
@@ -580,145 +309,6 @@ __device__ __forceinline__ bb_word decode_word(uint64_t raw, const bb_params& P)
     r.can = dequant((uint32_t)(raw >> 40) & 0xffu, P.mn[4], P.cf[4]);
     r.cna = dequant((uint32_t)(raw >> 48) & 0xffu, P.mn[5], P.cf[5]);
     return r;
-}
-__device__ __forceinline__ bb_word load_word(const uint8_t* w, const bb_params& P) {
-    const uint32_t b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3], b4 = w[4];
-    bb_word r;
-    r.res = b0 >> 3;
-    const uint32_t om = ((b0 & 7u) << 8) | b1, ps = (b2 << 4) | (b3 >> 4), ph = ((b3 & 0xfu) << 8) | b4;
-    r.phi = dequant(ph, P.mn[0], P.cf[0]);
-    r.psi = dequant(ps, P.mn[1], P.cf[1]);
-    r.omega = dequant(om, P.mn[2], P.cf[2]);
-    r.nca = dequant(w[7], P.mn[3], P.cf[3]);
-    r.can = dequant(w[5], P.mn[4], P.cf[4]);
-    r.cna = dequant(w[6], P.mn[5], P.cf[5]);
-    return r;
-}
-
-// Forward NeRF, lane = chain. Reference: segment loop of Foldcomp::decompress (src/foldcomp.cpp:814-858),
-// reconstructBackboneAtoms (:167-246). Each segment s covers words [aidx[s], aidx[s+1]] and starts
-// from the blended last three atoms of segment s-1 (:855-857); those depend only on the forward
-// atoms and the stored anchor (weightedAverage, src/atom_coordinate.cpp:145-163, reverse atoms
-// T-3..T-1 are the anchor itself), so the whole forward chain runs without the reverse pass.
-// fwd holds, per chain, the forward atoms of every segment back to back:
-//   chain base = 3*res_off[c] + 3*seg_off[c] atoms; segment s at + 3*aidx[s] + 3*s
-//   (3*(R + total segments) atoms in all).
-__global__ __launch_bounds__(BLOCK) void k_forward_nerf(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
-                                                        uint32_t n_entries, const uint32_t* __restrict__ res_off,
-                                                        const uint32_t* __restrict__ seg_off, v3* __restrict__ fwd) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_entries) return;
-    if (res_off[c + 1] == res_off[c]) return;  // skipped entry
-    const uint8_t* e = blob + off[c];
-    const entry_view v = view_entry(e);
-    const bb_params P = load_params(e);
-    const uint8_t* words = e + v.L.o_words;
-    const uint8_t* last_word = words + 8 * (size_t)(v.n - 1);
-    v3* F = fwd + 3 * (size_t)res_off[c] + 3 * (size_t)seg_off[c];
-    v3 p0 = ld_v3(e + v.L.o_anchor), p1 = ld_v3(e + v.L.o_anchor + 12), p2 = ld_v3(e + v.L.o_anchor + 24);
-    const uint32_t nseg = v.n_anchor - 1;
-    int first = (int)ld_u32(e + v.L.o_aidx);
-    int next = (int)ld_u32(e + v.L.o_aidx + 4);
-    // software prefetch: every global load is issued two residues (or one segment) ahead of its use so the
-    // dependent chain of place_atom calls never waits on memory
-    const uint8_t* wp = words + 8 * (size_t)first;
-    uint64_t w_cur = ld_u64(wp);
-    uint64_t w_nxt = ld_u64(wp + 8 <= last_word ? wp + 8 : last_word);
-    for (uint32_t s = 0; s < nseg; s++) {
-        const int len = next - first + 1;
-        const int next2 = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)(s + 2 <= nseg ? s + 2 : nseg));
-        const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
-        const v3 A0 = ld_v3(anc), A1 = ld_v3(anc + 12), A2 = ld_v3(anc + 24);   // used after the residue loop
-        v3* Fs = F + 3 * (size_t)first + 3 * (size_t)s;
-        Fs[0] = p0; Fs[1] = p1; Fs[2] = p2;
-        for (int i = 0; i + 1 < len; i++) {
-            const uint8_t* pf = wp + 16;
-            const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
-            const bb_word w = decode_word(w_cur, P);
-            const v3 N = place_atom(p0, p1, p2, (float)1.3311, w.can, w.psi);
-            const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
-            const v3 CA = place_atom(p1, p2, N, l_nca, w.cna, w.omega);
-            const v3 C = place_atom(p2, N, CA, (float)1.5281, w.nca, w.phi);
-            Fs[3 * i + 3] = N; Fs[3 * i + 4] = CA; Fs[3 * i + 5] = C;
-            p0 = N; p1 = CA; p2 = C;
-            w_cur = w_nxt; w_nxt = w_pre; wp += 8;
-        }
-        // The next segment starts at word `next`; the loop consumed words first..next-1, so w_cur already
-        // holds word `next` (segments share their boundary residue).
-        // carry: blended last three atoms (indices T-3..T-1 of this segment)
-        const float T = (float)(3 * len);
-        const float j0 = (float)(3 * len - 3), j1 = (float)(3 * len - 2), j2 = (float)(3 * len - 1);
-        p0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / T, ((p0.y * 3.0f) + (A0.y * j0)) / T, ((p0.z * 3.0f) + (A0.z * j0)) / T};
-        p1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / T, ((p1.y * 2.0f) + (A1.y * j1)) / T, ((p1.z * 2.0f) + (A1.z * j1)) / T};
-        p2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / T, ((p2.y * 1.0f) + (A2.y * j2)) / T, ((p2.z * 1.0f) + (A2.z * j2)) / T};
-        first = next; next = next2;
-    }
-}
-
-// Reverse NeRF + blend, lane = segment. Reference: reconstructBackboneReverse (src/foldcomp.cpp:248-273),
-// Nerf::reconstructWithReversed (src/nerf.cpp:342-379), weightedAverage (src/atom_coordinate.cpp:145-163).
-// bb receives the final backbone (3 atoms per residue, chain-major).
-__global__ __launch_bounds__(BLOCK) void k_reverse_blend(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
-                                                         uint32_t n_entries, const uint32_t* __restrict__ res_off,
-                                                         const uint32_t* __restrict__ seg_off, const v3* __restrict__ fwd,
-                                                         v3* __restrict__ bb) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total_seg = seg_off[n_entries];
-    if (g >= total_seg) return;
-    // chain of this segment: largest c with seg_off[c] <= g
-    uint32_t lo = 0, hi = n_entries;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_off[mid] <= g) lo = mid; else hi = mid; }
-    const uint32_t c = lo, s = g - seg_off[c];
-    const uint8_t* e = blob + off[c];
-    const entry_view v = view_entry(e);
-    const bb_params P = load_params(e);
-    const uint8_t* words = e + v.L.o_words;
-    const int first = (int)ld_u32(e + v.L.o_aidx + 4 * s), next = (int)ld_u32(e + v.L.o_aidx + 4 * (s + 1));
-    const int len = next - first + 1, T = 3 * len;
-    const bool last_seg = (s + 2 == v.n_anchor);
-    const v3* Fs = fwd + 3 * (size_t)res_off[c] + 3 * (size_t)seg_off[c] + 3 * (size_t)first + 3 * (size_t)s;
-    v3* B = bb + 3 * (size_t)res_off[c] + 3 * (size_t)first;
-    const float Tf = (float)T;
-    const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
-    // reverse atoms f+3, f+2, f+1 (start: the anchor) and forward atoms f+2, f+1 for the bond angle at f+1
-    v3 r3 = ld_v3(anc + 24), r2 = ld_v3(anc + 12), r1 = ld_v3(anc);  // R[T-1], R[T-2], R[T-3]
-    if (last_seg) {  // only the last segment keeps its final three atoms (src/foldcomp.cpp:847-851)
-        for (int j = T - 3; j < T; j++) {
-            const v3 F = Fs[j];
-            const v3 R = (j == T - 3) ? r1 : (j == T - 2) ? r2 : r3;
-            const float wf = (float)(T - j), wr = (float)j;
-            B[j] = v3{((F.x * wf) + (R.x * wr)) / Tf, ((F.y * wf) + (R.y * wr)) / Tf, ((F.z * wf) + (R.z * wr)) / Tf};
-        }
-    }
-    if (T < 4) {
-        return;
-    }
-    // Walk the segment backwards one residue (= one packed word = three atoms) per iteration; the word and
-    // the three forward atoms of the NEXT iteration are loaded before the current one is computed.
-    v3 f2 = Fs[T - 2], f1 = Fs[T - 3];  // forward atoms f+2, f+1 for f = T-4
-    int wi = len - 2;                   // word index of atoms f = 3wi+2, 3wi+1, 3wi
-    uint64_t w_raw = ld_u64(words + 8 * (size_t)(first + wi));
-    v3 fa = Fs[3 * wi + 2], fb = Fs[3 * wi + 1], fc = Fs[3 * wi];
-    for (; wi >= 0; wi--) {
-        const int wn = wi > 0 ? wi - 1 : 0;
-        const uint64_t w_pre = ld_u64(words + 8 * (size_t)(first + wn));
-        const v3 na = Fs[3 * wn + 2], nb = Fs[3 * wn + 1], nc = Fs[3 * wn];
-        const bb_word w = decode_word(w_raw, P);
-#pragma unroll
-        for (int q = 2; q >= 0; q--) {
-            const int f = 3 * wi + q;
-            const v3 f0 = (q == 2) ? fa : (q == 1) ? fb : fc;
-            const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
-            const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
-            const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
-            const v3 R = place_atom(r3, r2, r1, Lb, ba, tor);   // a = R[f+3], b = R[f+2], c = R[f+1]
-            const float wf = (float)(T - f), wr = (float)f;
-            B[f] = v3{((f0.x * wf) + (R.x * wr)) / Tf, ((f0.y * wf) + (R.y * wr)) / Tf, ((f0.z * wf) + (R.z * wr)) / Tf};
-            r3 = r2; r2 = r1; r1 = R;
-            f2 = f1; f1 = f0;
-        }
-        w_raw = w_pre; fa = na; fb = nb; fc = nc;
-    }
 }
 
 #ifndef FCZ_BACKBONE_MIN_WAVES

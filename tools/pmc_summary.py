@@ -17,3 +17,30 @@ for k, v in sorted(d.items()):
     print("  per residue: valu wave-insts %.2f (thread util %.0f%%) vmem_rd %.3f vmem_wr %.3f lds %.3f salu %.2f | fetch %.1f B (x2 corrected) write %.1f B" % (
         g("SQ_INSTS_VALU") / R, 100 * g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_ACTIVE_INST_VALU") * 64, 1), g("SQ_INSTS_VMEM_RD") / R, g("SQ_INSTS_VMEM_WR") / R,
         g("SQ_INSTS_LDS") / R, g("SQ_INSTS_SALU") / R, 2 * g("FETCH_SIZE") * 1024 / R, g("WRITE_SIZE") * 1024 / R))
+
+# calibration (tools/pmc_calibrate.hip: every kernel reads 2^30 and writes 2^30 bytes, last two slightly less)
+cal = {}
+known = {"fczcal_copy16": 1 << 30, "fczcal_copy4": 1 << 30, "fczcal_lane_stream8": ((1 << 30) // 2800) * 2800, "fczcal_stride100": ((1 << 30) // 100) * 100}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = os.path.join("gpurun_out", "prof_" + tag, "cal_%s.csv" % ctr)
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            k = r["kernel"].replace("void ", "")
+            if k in known: cal[(k, ctr)] = float(r["per_dispatch"]) * 1024 / known[k]
+if cal:
+    print("calibration: counter KiB*1024 / known bytes")
+    for (k, c), v in sorted(cal.items()): print("  %-22s %-10s %.3f" % (k, c, v))
+# traffic.json for bench.py. Counter scale from the calibration: every fully-reused pattern (16 B and 4 B coalesced,
+# 100-byte lane stride) reads back FETCH_SIZE = 0.50 x bytes and WRITE_SIZE = 1.00 x bytes, so FETCH is doubled and
+# WRITE taken as is. The lane-streaming pattern (k_backbone) shows 1.73x / 1.61x on top of that: real sector
+# over-fetch / partial-line writes of that pattern, which must stay visible in the traffic figure.
+import json
+out = {"source": "profiles/%s_pmc_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, %d residues per launch; "
+                 "FETCH x2, WRITE x1 per profiles/%s_pmc_summary.txt calibration)" % (tag, int(R), tag),
+       "residues_per_chain": 350, "calibration": {"%s %s" % k: round(v, 3) for k, v in sorted(cal.items())}, "kernels": {}}
+for k, v in d.items():
+    if not k.startswith("fcz::k_") or "FETCH_SIZE" not in v: continue
+    out["kernels"][k.split("::")[1]] = {"fetch_bytes_per_residue": round(2 * v["FETCH_SIZE"] * 1024 / R, 2),
+                                        "write_bytes_per_residue": round(v.get("WRITE_SIZE", 0.0) * 1024 / R, 2)}
+if out["kernels"]:
+    json.dump(out, open(os.path.join("gpurun_out", "prof_" + tag, "traffic.json"), "w"), indent=1)

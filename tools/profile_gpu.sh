@@ -44,4 +44,22 @@ run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_C
 run pmc_sq2 --kernel-include-regex "fcz" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
 if [ -z "${NO_MEM:-}" ]; then run pmc_fetch --kernel-include-regex "fcz" --pmc FETCH_SIZE
 run pmc_write --kernel-include-regex "fcz" --pmc WRITE_SIZE; fi
+# FETCH_SIZE / WRITE_SIZE calibration on known byte counts in the kernels' own access patterns
+if [ -z "${NO_MEM:-}" ]; then
+  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/pmc_calibrate $REPO/tools/pmc_calibrate.hip
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/rp_cal
+    rocprofv3 --kernel-include-regex "fczcal" --pmc $ctr --output-format csv -d /tmp/rp_cal -o cal -- /tmp/pmc_calibrate > $OUT/cal_$ctr.out 2>&1
+    python3 - /tmp/rp_cal $OUT/cal_$ctr.csv <<'PY'
+import csv, glob, os, sys, collections
+agg = collections.defaultdict(float); cnt = collections.defaultdict(set)
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*_counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]; agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
+with open(sys.argv[2], "w") as o:
+    w = csv.writer(o); w.writerow(["kernel", "counter", "per_dispatch"])
+    for (k, c), v in sorted(agg.items()): w.writerow([k, c, v / max(len(cnt[k]), 1)])
+PY
+  done
+fi
 ls -la $OUT

@@ -255,7 +255,7 @@ def main():
 
     # per-kernel device time (HIP events on the codec's own stream)
     ktime = {}
-    for name in ("compress_sizes", "compress", "decompress_sizes", "decompress_backbone", "decompress_sidechain"):
+    for name in ("compress_sizes", "compress", "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain"):
         ms, n = codec.kernel_time(name)
         ktime[name] = (ms / n) if n else 0.0
     codec.enable_timing(False)
@@ -267,15 +267,17 @@ def main():
         # algorithmic bytes: compress reads 13A+9, writes fcz; decompress reads fcz, writes 12A+4
         bytes_compress = (13 * A + 9 + fcz_per_res) * R
         bytes_decompress = (fcz_per_res + 12 * A + 4) * R
-        dec_ms = ktime["decompress_backbone"] + ktime["decompress_sidechain"]
+        dec_ms = ktime["decompress_backbone"] + ktime["decompress_index"] + ktime["decompress_sidechain"]
         # The dominant kernel = the single longest launch. Decompress is two launches (k_backbone -> bb scratch ->
         # k_sidechain); SURVEY's decompress bytes belong to the pair, each kernel is charged its own share:
-        # k_backbone reads the header/anchors/words (fcz minus side-chain and B-factor bytes), k_sidechain reads
-        # those bytes and writes the atoms. The 36 B/residue bb hand-over is not algorithmic traffic.
+        # k_backbone reads the header/anchors/words (fcz minus side-chain and B-factor bytes), k_res_index reads the
+        # side-chain and B-factor bytes and writes the B-factors, k_sidechain writes the atoms. The hand-over arrays
+        # between the three (bb, per-residue index) are not algorithmic traffic.
         sc_bytes = (A - 3.0) + 1.0
         kern = {"k_compress_tiled": (bytes_compress, ktime["compress"]),
                 "k_backbone": ((fcz_per_res - sc_bytes) * R, ktime["decompress_backbone"]),
-                "k_sidechain": ((sc_bytes + 12 * A + 4) * R, ktime["decompress_sidechain"])}
+                "k_res_index": ((sc_bytes + 4) * R, ktime["decompress_index"]),
+                "k_sidechain": (12 * A * R, ktime["decompress_sidechain"])}
         dom = max(kern, key=lambda k: kern[k][1])
         by, ms = kern[dom]
         ach = by / (ms * 1e-3) / 1e9 if ms else 0.0

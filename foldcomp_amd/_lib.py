@@ -12,7 +12,8 @@ import os
 from .structure import CAtomsOut, CChainBatch, CEntryInfo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcz_hip.so")
+# FCZ_HIP_LIB selects another build of the same library (A/B timing of kernel variants); it is still a HIP build
+LIB_PATH = os.environ.get("FCZ_HIP_LIB") or os.path.join(_HERE, "libfcz_hip.so")
 
 FCZ_OK = 0
 STATUS = {0: "FCZ_OK", -1: "FCZ_E_INVALID_ARG", -2: "FCZ_E_NO_DEVICE", -3: "FCZ_E_HIP", -4: "FCZ_E_BAD_MAGIC",

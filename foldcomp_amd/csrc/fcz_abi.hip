@@ -13,6 +13,7 @@
 
 #include "fcz_kernels.h"
 #include "fcz_compress.h"
+#include "fcz_sidechain.h"
 
 // second, host-side instance of the generated tables (integer metadata for sizes/validation)
 namespace host_tab {
@@ -73,9 +74,13 @@ struct fcz_ctx {
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
     dev_buf wring;      // decompress: per-group ring of the segment's packed words
     dev_buf bb;         // decompress: blended backbone
+    dev_buf res_aoff;   // decompress: residue -> first output atom
+    dev_buf res_rc;     // decompress: residue -> residue code
+    dev_buf res_sc;     // decompress: residue -> its side-chain torsion bytes, 3 x R dwords
     // staging for the host-pointer entry points
     dev_buf stage[20];
     uint32_t* pinned = nullptr;  // 4 words
+    int n_cu = 256;
     bool timing = false;
     bool keep_first_angle = false;
     std::vector<timed_span> spans;
@@ -171,6 +176,8 @@ int fcz_ctx_create(int device, fcz_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return FCZ_E_NO_DEVICE;
     fcz_ctx* c = new fcz_ctx();
     c->device = device;
+    hipDeviceProp_t prop;
+    c->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FCZ_E_HIP; }
     if (hipHostMalloc((void**)&c->pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FCZ_E_HIP; }
     *out = c;
@@ -182,7 +189,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release();
+    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->res_rc.release(); c->res_sc.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -474,10 +481,21 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
         hipLaunchKernelGGL(k_backbone, dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
                            ctx->fwd.as<v3>(), ctx->wring.as<uint64_t>(), ring_rows, ctx->bb.as<v3>());
     }
+    rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
+    rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;
+    rc = ctx->res_sc.ensure(sizeof(uint32_t) * 3 * (size_t)R); if (rc) return rc;
+    {
+        span_guard g(ctx, "decompress_index");
+        hipLaunchKernelGGL(k_res_index, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
+                           res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
+                           ctx->res_sc.as<uint32_t>(), *out_dev);
+    }
     {
         span_guard g(ctx, "decompress_sidechain");
-        hipLaunchKernelGGL(k_sidechain, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
-                           res_off_dev, atom_off_dev, ctx->bb.as<v3>(), alt_order, *out_dev);
+        const uint32_t n_tiles = grid_for(R, SC_TILE);
+        const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_SIDECHAIN_MIN_BLOCKS * 4u);
+        hipLaunchKernelGGL(k_sidechain, dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, ctx->res_aoff.as<uint32_t>(),
+                           ctx->res_rc.as<uint8_t>(), ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
     }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;

@@ -479,115 +479,4 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
     if (__any(win >= 0)) flush();
 }
 
-// Side chains + final output, one wavefront per chain, lane = residue.
-// Reference: Nerf::reconstructAminoAcid (src/nerf.cpp:106-155), side-chain torsion de-quantisation
-// (src/foldcomp.cpp:338-369), B-factors and OXT (:884-898), `-a` order _reorderAtoms (:1563-1577).
-__global__ __launch_bounds__(BLOCK) void k_sidechain(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
-                                                     uint32_t n_entries, const uint32_t* __restrict__ res_off,
-                                                     const uint32_t* __restrict__ atom_off, const v3* __restrict__ bb,
-                                                     int alt_order, fcz_atoms_out out) {
-    __shared__ float s_tor_cos[256], s_tor_sin[256];
-    __shared__ float s_d2x[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];   // -1 * L * cos(ba)
-    __shared__ float s_sb[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];    // sin(ba)
-    __shared__ float s_slots[WAVES_PER_BLOCK][FCZ_MAX_RES_ATOMS * 3 * WAVE];
-    // per-lane table lookups (residue code varies per lane) come from LDS copies, not global memory
-    __shared__ uint16_t s_prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
-    __shared__ float s_blen[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
-    __shared__ uint8_t s_oslot[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];   // output position -> canonical slot
-    __shared__ uint8_t s_ratom[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
-    __shared__ uint8_t s_natoms[FCZ_N_RES_CODES];
-    // trig tables: the side-chain torsion takes one of 256 values (fixed-angle quantiser) and the bond
-    // angles are per-(residue, atom) constants, so every sinf/cosf of this kernel is precomputed here.
-    {
-        const int q = threadIdx.x;  // BLOCK == 256
-        const float cont = (180.0f - (-180.0f)) / 255.0f;
-        const float ta = deg2rad(dequant((uint32_t)q, -180.0f, cont));
-        s_tor_cos[q] = cosf_glibc(ta);
-        s_tor_sin[q] = sinf_glibc(ta);
-        for (int i = threadIdx.x; i < FCZ_N_RES_CODES * FCZ_MAX_RES_ATOMS; i += BLOCK) {
-            const int rc = i / FCZ_MAX_RES_ATOMS, j = i % FCZ_MAX_RES_ATOMS;
-            const float L = __uint_as_float(fcz_res_blen_bits[rc][j]);
-            const float ba = deg2rad(__uint_as_float(fcz_res_bang_bits[rc][j]));
-            s_d2x[rc][j] = -1.0f * L * cosf_glibc(ba);
-            s_sb[rc][j] = sinf_glibc(ba);
-            s_prev[rc][j] = fcz_res_prev[rc][j];
-            s_blen[rc][j] = L;
-            s_oslot[rc][j] = alt_order ? fcz_res_alt_slot[rc][j] : (uint8_t)j;
-            s_ratom[rc][j] = fcz_res_atom[rc][j];
-            if (j == 0) s_natoms[rc] = fcz_res_natoms[rc];
-        }
-    }
-    __syncthreads();
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (c >= n_entries) return;
-    const uint32_t r0 = res_off[c], n = res_off[c + 1] - r0;
-    if (n == 0) return;
-    const uint8_t* e = blob + off[c];
-    const entry_view v = view_entry(e);
-    const uint8_t* words = e + v.L.o_words;
-    const uint8_t* scb = e + v.L.o_sc;
-    const float tmin = ld_f32(e + v.L.o_tmp), tcf = ld_f32(e + v.L.o_tmp + 4);
-    const v3* B = bb + 3 * (size_t)r0;
-    const uint32_t abase = atom_off[c];
-    slot_store S{&s_slots[wave][0], lane};
-
-    uint32_t atom_run = 0, sc_run = 0;
-    for (uint32_t base = 0; base < n; base += WAVE) {
-        const uint32_t k = base + lane;
-        const bool act = k < n;
-        uint32_t rc = 23, na = 0, tq = 0;
-        v3 b0{0.f, 0.f, 0.f}, b1 = b0, b2 = b0;
-        if (act) {
-            // first batch of loads: residue code, B-factor byte, the three backbone atoms
-            rc = words[8 * (size_t)k] >> 3;
-            tq = e[v.L.o_tbytes + k];
-            b0 = B[3 * k]; b1 = B[3 * k + 1]; b2 = B[3 * k + 2];
-            if (k == 0) rc = (uint32_t)res_code_from_letter(e[20]);
-            if (rc >= 24) rc = 23;
-            na = s_natoms[rc];
-        }
-        uint32_t tot_a, tot_s;
-        const uint32_t a_off = atom_run + wave_excl_scan(na, lane, &tot_a);
-        const uint32_t s_off = sc_run + wave_excl_scan(act ? na - 3 : 0, lane, &tot_s);
-        atom_run += tot_a; sc_run += tot_s;
-        if (!act) continue;
-        // second batch: all (<= 11) side-chain torsion bytes of the residue as three unaligned dwords
-        // (reads at most 11 bytes past the last torsion byte: still inside the record, which continues
-        // with the 8-byte B-factor header and n B-factor bytes)
-        const uint8_t* sp = scb + s_off;
-        const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = (na > 11) ? ld_u32(sp + 8) : 0u;
-        S.put(0, b0); S.put(1, b1); S.put(2, b2);
-        for (uint32_t j = 3; j < na; j++) {
-            const uint32_t pk = s_prev[rc][j];
-            const uint32_t jj = j - 3;
-            const uint32_t qw = (jj < 4) ? q0 : (jj < 8 ? q1 : q2);
-            const uint32_t q = (qw >> (8 * (jj & 3))) & 0xffu;
-            const float L = s_blen[rc][j];
-            const float sb = s_sb[rc][j];
-            v3 d2;
-            d2.x = s_d2x[rc][j];
-            d2.y = L * s_tor_cos[q] * sb;
-            d2.z = L * s_tor_sin[q] * sb;
-            S.put((int)j, place_atom_d2(S.get(pk & 15), S.get((pk >> 4) & 15), S.get((pk >> 8) & 15), d2));
-        }
-        const uint32_t a = abase + a_off;
-        for (uint32_t j = 0; j < na; j++) {
-            const uint32_t slot = s_oslot[rc][j];
-            const v3 p = S.get((int)slot);
-            out.x[a + j] = p.x; out.y[a + j] = p.y; out.z[a + j] = p.z;
-            if (out.atom_code) out.atom_code[a + j] = s_ratom[rc][slot];
-        }
-        out.bfac_res[r0 + k] = dequant(tq, tmin, tcf);
-        if (out.res_code) out.res_code[r0 + k] = (uint8_t)rc;
-    }
-    if (lane == 0 && e[v.L.o_oxt]) {
-        const uint32_t a = abase + atom_run;
-        const v3 o = ld_v3(e + v.L.o_oxt + 1);
-        out.x[a] = o.x; out.y[a] = o.y; out.z[a] = o.z;
-        if (out.atom_code) out.atom_code[a] = FCZ_ATOM_OXT;
-    }
-}
-
 }  // namespace fcz

@@ -1,0 +1,313 @@
+// fcz_sidechain.h -- side-chain reconstruction of the decompress path (Nerf::reconstructAminoAcid, reference
+// src/nerf.cpp:106-155; the per-residue part of Foldcomp::decompress, src/foldcomp.cpp:860-900).
+//
+// Residues are independent once the blended backbone exists, so this stage ignores chain boundaries: the R
+// residues of the batch form one flat array, a block takes 256 consecutive residues (whatever chains they belong
+// to) and every atom that has to be placed is one work item.
+//
+//   k_res_index      one wavefront per chain: resolves everything that hangs off the chain's header into flat
+//                    per-residue arrays (first output atom, residue code, torsion bytes) and emits the outputs
+//                    that need no geometry (B-factors, residue codes, OXT).
+//   k_sidechain      persistent blocks over 256-residue tiles.
+//                    phase 0 (thread = residue): load the residue's index entry and backbone atoms (prefetched one
+//                      tile ahead); emit N, CA, C; place O (every residue's first item); publish the residue
+//                      in LDS; append its remaining atoms to per-depth work lists.
+//                    phase 1 (thread = work item): depth d = length of the predecessor chain of an atom inside
+//                      its residue (CB: 2 ... TRP CH2: 7). Lists are processed in depth order with a block barrier
+//                      in between, so every predecessor is in the LDS slot store when an item runs, and every
+//                      round has full wavefronts: 6.25 wave-rounds of place_atom per wavefront instead of the 11 a
+//                      residue-per-lane loop needs (the longest residue of 64 is almost always a TRP/ARG/TYR).
+//                    Atoms live in LDS in OUTPUT order (one buffer is both the predecessor store and the
+//                      write-back staging), so the tile leaves as fully coalesced stores: scattered 4-byte stores
+//                      (one L2 request per lane) cost 20 % of the kernel before.
+#pragma once
+#include "fcz_kernels.h"
+
+namespace fcz {
+
+// One wavefront per chain: everything of the record that is addressed through the chain's header is resolved
+// here, so k_sidechain sees plain per-residue arrays (one level of coalesced loads, nothing chain-dependent).
+//   res_aoff[r]   index of the residue's first output atom (n_res + 1 entries, the last = total atoms)
+//   res_rc[r]     residue code (first residue: header.firstResidue, src/foldcomp.cpp:863)
+//   res_sc[q][r]  the residue's (<= 11) side-chain torsion bytes as three dwords (bytes past the residue's own are
+//                 whatever follows in the record and are never used)
+// plus the per-residue outputs that need nothing else: B-factor (src/foldcomp.cpp:884-892), residue code, and the
+// chain's OXT atom (:893-900).
+__global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
+                                                     uint32_t n_entries, const uint32_t* __restrict__ res_off,
+                                                     const uint32_t* __restrict__ atom_off, uint32_t n_res,
+                                                     uint32_t* __restrict__ res_aoff, uint8_t* __restrict__ res_rc,
+                                                     uint32_t* __restrict__ res_sc, fcz_atoms_out out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (c >= n_entries) return;
+    const uint32_t r0 = res_off[c], n = res_off[c + 1] - r0;
+    if (n == 0) return;   // skipped entry
+    const uint8_t* e = blob + off[c];
+    const entry_view v = view_entry(e);
+    const uint32_t abase = atom_off[c];
+    const uint32_t first_rc = (uint32_t)res_code_from_letter(e[20]);
+    const float tmin = ld_f32(e + v.L.o_tmp), tcf = ld_f32(e + v.L.o_tmp + 4);
+    const uint8_t* words = e + v.L.o_words;
+    const uint8_t* scb = e + v.L.o_sc;
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t k = base + lane;
+        const bool act = k < n;
+        uint32_t na = 0, rc = 23, tq = 0;
+        if (act) {
+            rc = (k == 0) ? first_rc : (uint32_t)(words[8 * (size_t)k] >> 3);
+            tq = e[v.L.o_tbytes + k];
+            if (rc >= 24) rc = 23;
+            na = fcz_res_natoms[rc];
+        }
+        uint32_t tot;
+        const uint32_t ex = run + wave_excl_scan(na, lane, &tot);
+        run += tot;
+        if (!act) continue;
+        // atoms before this residue minus 3 per residue = torsion bytes before it. The three dwords read at most 11
+        // bytes past the residue's last torsion byte: still inside the record (8-byte B-factor header + n bytes follow)
+        const uint8_t* sp = scb + (ex - 3 * k);
+        const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = (na > 11) ? ld_u32(sp + 8) : 0u;
+        const size_t r = (size_t)r0 + k;
+        res_aoff[r] = abase + ex;
+        res_rc[r] = (uint8_t)rc;
+        res_sc[r] = q0; res_sc[(size_t)n_res + r] = q1; res_sc[2 * (size_t)n_res + r] = q2;
+        out.bfac_res[r] = dequant(tq, tmin, tcf);
+        if (out.res_code) out.res_code[r] = (uint8_t)rc;
+    }
+    if (lane == 0) {
+        const bool oxt = e[v.L.o_oxt] != 0;
+        if (oxt) {
+            const uint32_t a = abase + run;
+            const v3 o = ld_v3(e + v.L.o_oxt + 1);
+            out.x[a] = o.x; out.y[a] = o.y; out.z[a] = o.z;
+            if (out.atom_code) out.atom_code[a] = FCZ_ATOM_OXT;
+        }
+        if (r0 + n == n_res) res_aoff[n_res] = abase + run + (oxt ? 1u : 0u);   // closes the array: total atoms
+    }
+}
+
+constexpr int SC_TILE = BLOCK;             // residues per tile
+constexpr int SC_CAP = 3072;               // staged output atoms per pass (a typical tile holds 256 * 8.4 = 2140)
+constexpr int SC_DEPTHS = 6;               // list depths 2..7 (depth 1 = O, placed by the owning thread)
+constexpr int SC_FIELD = 10;               // bits per depth in the packed per-depth counters (<= 3 * 256 items)
+constexpr int SC_MAX_ITEMS = 10;           // listed atoms per residue (TRP: 14 - 3 backbone - O)
+constexpr int SC_GEOM_CODES = 20;          // residue codes that own side-chain geometry (the 20 standard residues)
+
+// ideal geometry of atom `slot` of a residue type, with every trig value precomputed, plus where its predecessors
+// and the atom itself sit in the residue's output order
+struct alignas(16) sc_geom {
+    float d2x;        // -1 * L * cos(bond angle)
+    float blen;       // L
+    float sb;         // sin(bond angle)
+    uint32_t meta;    // out pos of prev0 | prev1 << 4 | prev2 << 8 | own << 12 | atom code << 16
+};
+
+struct sidechain_lds {
+    float stage[3][SC_CAP];                            // x, y, z of the pass's atoms in OUTPUT order: predecessor store
+                                                       // and write-back buffer in one
+    uint32_t sc[3][SC_TILE];                           // torsion bytes of each residue (three dwords)
+    uint16_t apos[SC_TILE];                            // pass-local position of each residue's first atom
+    uint16_t list[SC_TILE * SC_MAX_ITEMS];             // work items: residue in tile | slot << 8, grouped by depth
+    uint8_t rc[SC_TILE];
+    unsigned long long wave_tot[WAVES_PER_BLOCK];
+    uint32_t dstart[SC_DEPTHS + 2];                    // list range of each depth in the current pass
+    // tables (the residue code differs per lane, so these are LDS lookups rather than scalar loads)
+    float tor_cos[256], tor_sin[256];                  // every sinf/cosf of a torsion byte
+    sc_geom geom[SC_GEOM_CODES][FCZ_MAX_RES_ATOMS];
+    uint8_t opos[FCZ_N_RES_CODES][4];                  // output position of N, CA, C, O
+    uint8_t items[FCZ_N_RES_CODES][SC_DEPTHS * 4];     // [depth-2][q]: slots (>= 4) of the residue's atoms at that depth, 0 = none
+    uint8_t natoms[FCZ_N_RES_CODES];
+    unsigned long long dcnt[FCZ_N_RES_CODES];          // items per depth, SC_FIELD bits each
+};
+
+#ifndef FCZ_SIDECHAIN_MIN_BLOCKS
+#define FCZ_SIDECHAIN_MIN_BLOCKS 3
+#endif
+
+// res_aoff has n_res + 1 entries (the last one = total atoms).
+__global__ __launch_bounds__(BLOCK, FCZ_SIDECHAIN_MIN_BLOCKS)
+void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ res_aoff, const uint8_t* __restrict__ res_rc,
+                 const uint32_t* __restrict__ res_sc, const v3* __restrict__ bb, int alt_order, fcz_atoms_out out) {
+    __shared__ sidechain_lds S;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    // ---- tables, once per (persistent) block ----
+    {
+        const float cont = (180.0f - (-180.0f)) / 255.0f;   // FixedAngleDiscretizer(255), src/discretizer.h:89-106
+        const float ta = deg2rad(dequant((uint32_t)t, -180.0f, cont));
+        S.tor_cos[t] = cosf_glibc(ta);
+        S.tor_sin[t] = sinf_glibc(ta);
+        if (t < FCZ_N_RES_CODES) {
+            const int rc = t, na = fcz_res_natoms[rc];
+            S.natoms[rc] = (uint8_t)na;
+            // canonical slot -> output position (the `-a` order permutes atoms inside a residue)
+            uint32_t opos[FCZ_MAX_RES_ATOMS];
+            for (int j = 0; j < FCZ_MAX_RES_ATOMS; j++) opos[j] = (uint32_t)j;
+            if (alt_order) for (int j = 0; j < na; j++) opos[fcz_res_alt_slot[rc][j]] = (uint32_t)j;
+            for (int j = 0; j < 4; j++) S.opos[rc][j] = (uint8_t)opos[j];
+            int depth[FCZ_MAX_RES_ATOMS];
+            for (int j = 0; j < FCZ_MAX_RES_ATOMS; j++) depth[j] = 0;
+            for (int j = 3; j < na; j++) {
+                const uint32_t pk = fcz_res_prev[rc][j];
+                int d = depth[pk & 15]; const int d1 = depth[(pk >> 4) & 15], d2 = depth[(pk >> 8) & 15];
+                d = d1 > d ? d1 : d; d = d2 > d ? d2 : d;
+                depth[j] = d + 1;
+                if (rc < SC_GEOM_CODES) {
+                    const float L = __uint_as_float(fcz_res_blen_bits[rc][j]);
+                    const float ba = deg2rad(__uint_as_float(fcz_res_bang_bits[rc][j]));
+                    sc_geom g;
+                    g.d2x = -1.0f * L * cosf_glibc(ba);
+                    g.blen = L;
+                    g.sb = sinf_glibc(ba);
+                    g.meta = opos[pk & 15] | (opos[(pk >> 4) & 15] << 4) | (opos[(pk >> 8) & 15] << 8) | (opos[j] << 12) |
+                             ((uint32_t)fcz_res_atom[rc][j] << 16);
+                    S.geom[rc][j] = g;
+                }
+            }
+            unsigned long long cnt = 0;
+            for (int d = 2; d < 2 + SC_DEPTHS; d++) {
+                int w = 0;
+                for (int q = 0; q < 4; q++) S.items[rc][4 * (d - 2) + q] = 0;
+                for (int j = 4; j < na; j++)
+                    if (depth[j] == d) { S.items[rc][4 * (d - 2) + w++] = (uint8_t)j; cnt += 1ull << (SC_FIELD * (d - 2)); }
+            }
+            S.dcnt[rc] = cnt;
+        }
+    }
+    __syncthreads();
+
+    // one tile of per-residue inputs, loaded a whole tile ahead of its use. Unconditional loads from clamped
+    // indices: a conditional merge would make the compiler wait for the data right here instead of a tile later.
+    struct res_in { uint32_t a, a_next, rc, q0, q1, q2, a_first, a_mid, a_end; v3 b0, b1, b2; };
+    auto load_res = [&](uint32_t tile) -> res_in {
+        const size_t r_lo = (size_t)tile * SC_TILE;
+        size_t r = r_lo + (size_t)t;
+        r = r < (size_t)n_res ? r : (size_t)n_res - 1;
+        const size_t rf = r_lo < (size_t)n_res ? r_lo : (size_t)n_res;
+        const size_t rm = r_lo + SC_TILE / 2 < (size_t)n_res ? r_lo + SC_TILE / 2 : (size_t)n_res;
+        const size_t re = r_lo + SC_TILE < (size_t)n_res ? r_lo + SC_TILE : (size_t)n_res;
+        res_in in;
+        in.a = res_aoff[r]; in.a_next = res_aoff[r + 1]; in.rc = res_rc[r];
+        in.q0 = res_sc[r]; in.q1 = res_sc[(size_t)n_res + r]; in.q2 = res_sc[2 * (size_t)n_res + r];
+        in.a_first = res_aoff[rf]; in.a_mid = res_aoff[rm]; in.a_end = res_aoff[re];
+        in.b0 = bb[3 * r]; in.b1 = bb[3 * r + 1]; in.b2 = bb[3 * r + 2];
+        return in;
+    };
+    res_in nxt = load_res(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t r = tile * SC_TILE + (uint32_t)t;
+        const res_in cur = nxt;
+        nxt = load_res(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
+        // a tile whose atoms do not fit the staging buffer (only possible when nearly every residue is a TRP/ARG/TYR)
+        // runs as two passes of 128 residues
+        const bool split = cur.a_end - cur.a_first > (uint32_t)SC_CAP;
+        for (int pass = 0; pass < (split ? 2 : 1); pass++) {
+            const int lo = (split && pass == 1) ? SC_TILE / 2 : 0, hi = (split && pass == 0) ? SC_TILE / 2 : SC_TILE;
+            const uint32_t A0 = (split && pass == 1) ? cur.a_mid : cur.a_first;
+            const uint32_t A1 = (split && pass == 0) ? cur.a_mid : cur.a_end;
+            const bool act = r < n_res && t >= lo && t < hi;
+            uint32_t rc = 23, na = 0;
+            if (act) {
+                const uint32_t ap = cur.a - A0;
+                const v3 b0 = cur.b0, b1 = cur.b1, b2 = cur.b2;
+                rc = cur.rc;
+                na = S.natoms[rc];
+                S.sc[0][t] = cur.q0; S.sc[1][t] = cur.q1; S.sc[2][t] = cur.q2;
+                S.apos[t] = (uint16_t)ap;
+                S.rc[t] = (uint8_t)rc;
+                const uint32_t op4 = *reinterpret_cast<const uint32_t*>(&S.opos[rc][0]);
+                const uint32_t p0 = ap + (op4 & 0xffu), p1 = ap + ((op4 >> 8) & 0xffu), p2 = ap + ((op4 >> 16) & 0xffu);
+                S.stage[0][p0] = b0.x; S.stage[1][p0] = b0.y; S.stage[2][p0] = b0.z;
+                S.stage[0][p1] = b1.x; S.stage[1][p1] = b1.y; S.stage[2][p1] = b1.z;
+                S.stage[0][p2] = b2.x; S.stage[1][p2] = b2.y; S.stage[2][p2] = b2.z;
+                if (out.atom_code) {
+                    out.atom_code[A0 + p0] = fcz_res_atom[rc][0]; out.atom_code[A0 + p1] = fcz_res_atom[rc][1];
+                    out.atom_code[A0 + p2] = fcz_res_atom[rc][2];
+                }
+                if (na > 3) {
+                    // O: slot 3 of every residue type, predecessors N, CA, C (src/amino_acid.h; fcz_res_prev[*][3] == 0x210)
+                    const sc_geom G = S.geom[rc][3];
+                    const uint32_t q = cur.q0 & 0xffu;
+                    v3 d2;
+                    d2.x = G.d2x;
+                    d2.y = G.blen * S.tor_cos[q] * G.sb;
+                    d2.z = G.blen * S.tor_sin[q] * G.sb;
+                    const v3 p = place_atom_d2(b0, b1, b2, d2);
+                    const uint32_t po = ap + (op4 >> 24);
+                    S.stage[0][po] = p.x; S.stage[1][po] = p.y; S.stage[2][po] = p.z;
+                    if (out.atom_code) out.atom_code[A0 + po] = (uint8_t)(G.meta >> 16);
+                }
+                if (cur.a_next - cur.a - na == 1) {
+                    // the chain's OXT (already written by k_res_index) lies inside this pass's output range: stage it so
+                    // that the write-back stores it again unchanged
+                    const uint32_t g = cur.a + na, po = ap + na;
+                    S.stage[0][po] = out.x[g]; S.stage[1][po] = out.y[g]; S.stage[2][po] = out.z[g];
+                }
+            }
+            // ---- per-depth work lists: block-wide exclusive scan of the packed per-depth counts ----
+            const unsigned long long mine = act ? S.dcnt[rc] : 0ull;
+            unsigned long long inc = mine;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) { const unsigned long long u = __shfl_up(inc, d, WAVE); if (lane >= d) inc += u; }
+            if (lane == WAVE - 1) S.wave_tot[wave] = inc;
+            __syncthreads();
+            unsigned long long pre = inc - mine, total = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES_PER_BLOCK; w++) { const unsigned long long v = S.wave_tot[w]; if (w < wave) pre += v; total += v; }
+            // list ranges per depth (uniform) and this thread's insert position per depth; all shifts are static
+            uint32_t ds = 0;
+            const uint32_t* my_items = reinterpret_cast<const uint32_t*>(&S.items[rc][0]);
+#pragma unroll
+            for (int d = 0; d < SC_DEPTHS; d++) {
+                if (t == 0) S.dstart[d] = ds;
+                const uint32_t base = ds + (uint32_t)((pre >> (SC_FIELD * d)) & ((1u << SC_FIELD) - 1u));
+                ds += (uint32_t)((total >> (SC_FIELD * d)) & ((1u << SC_FIELD) - 1u));
+                if (na > 4) {
+                    const uint32_t pack = my_items[d];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const uint32_t slot = (pack >> (8 * q)) & 0xffu;
+                        if (slot) S.list[base + q] = (uint16_t)((uint32_t)t | (slot << 8));
+                    }
+                }
+            }
+            if (t == 0) S.dstart[SC_DEPTHS] = ds;
+            __syncthreads();
+            // ---- items, depth by depth ----
+#pragma unroll 1
+            for (int d = 0; d < SC_DEPTHS; d++) {
+                const uint32_t dlo = S.dstart[d], dhi = S.dstart[d + 1];
+                for (uint32_t i = dlo + (uint32_t)t; i < dhi; i += BLOCK) {
+                    const uint32_t ent = S.list[i];
+                    const uint32_t rl = ent & 255u, j = ent >> 8;
+                    const sc_geom G = S.geom[S.rc[rl]][j];
+                    const uint32_t ap = S.apos[rl];
+                    const uint32_t jj = j - 3;
+                    const uint32_t q = (S.sc[jj >> 2][rl] >> (8 * (jj & 3u))) & 0xffu;
+                    v3 d2;
+                    d2.x = G.d2x;
+                    d2.y = G.blen * S.tor_cos[q] * G.sb;
+                    d2.z = G.blen * S.tor_sin[q] * G.sb;
+                    const uint32_t ia = ap + (G.meta & 15u), ib = ap + ((G.meta >> 4) & 15u), ic = ap + ((G.meta >> 8) & 15u);
+                    const v3 pa{S.stage[0][ia], S.stage[1][ia], S.stage[2][ia]};
+                    const v3 pb{S.stage[0][ib], S.stage[1][ib], S.stage[2][ib]};
+                    const v3 pc{S.stage[0][ic], S.stage[1][ic], S.stage[2][ic]};
+                    const v3 p = place_atom_d2(pa, pb, pc, d2);
+                    const uint32_t po = ap + ((G.meta >> 12) & 15u);
+                    S.stage[0][po] = p.x; S.stage[1][po] = p.y; S.stage[2][po] = p.z;
+                    if (out.atom_code) out.atom_code[A0 + po] = (uint8_t)(G.meta >> 16);
+                }
+                __syncthreads();
+            }
+            // ---- write-back: the pass's atoms are one contiguous range of the output arrays ----
+            const uint32_t n_at = A1 - A0;
+            for (uint32_t i = (uint32_t)t; i < n_at; i += BLOCK) {
+                out.x[A0 + i] = S.stage[0][i]; out.y[A0 + i] = S.stage[1][i]; out.z[A0 + i] = S.stage[2][i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace fcz

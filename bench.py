@@ -255,7 +255,7 @@ def main():
 
     # per-kernel device time (HIP events on the codec's own stream)
     ktime = {}
-    for name in ("compress_sizes", "compress", "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain"):
+    for name in ("compress_sizes", "compress_index", "compress_angles", "compress_pack", "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain"):
         ms, n = codec.kernel_time(name)
         ktime[name] = (ms / n) if n else 0.0
     codec.enable_timing(False)
@@ -274,7 +274,12 @@ def main():
         # side-chain and B-factor bytes and writes the B-factors, k_sidechain writes the atoms. The hand-over arrays
         # between the three (bb, per-residue index) are not algorithmic traffic.
         sc_bytes = (A - 3.0) + 1.0
-        kern = {"k_compress_tiled": (bytes_compress, ktime["compress"]),
+        ktime["compress"] = ktime["compress_index"] + ktime["compress_angles"] + ktime["compress_pack"]
+        # compress is three launches; the angle kernel reads the atoms and writes the side-chain bytes, the pack kernel
+        # reads codes/B-factors/offsets and writes the rest of the record ([6][R] angle scratch = hand-over, not counted)
+        kern = {"k_compress_angles": ((13 * A + (A - 3.0)) * R, ktime["compress_angles"]),
+                "k_compress_index": (1 * R, ktime["compress_index"]),
+                "k_compress_pack": ((9 + fcz_per_res - (A - 3.0)) * R, ktime["compress_pack"]),
                 "k_backbone": ((fcz_per_res - sc_bytes) * R, ktime["decompress_backbone"]),
                 "k_res_index": ((sc_bytes + 4) * R, ktime["decompress_index"]),
                 "k_sidechain": (12 * A * R, ktime["decompress_sidechain"])}

@@ -64,6 +64,7 @@ struct fcz_ctx {
     dev_buf ang;        // compress: 6 x R floats
     dev_buf sizes;      // compress: C x u64
     dev_buf scan_tmp;   // block partials of the device scans
+    dev_buf res_sc_addr; // compress: residue -> output byte offset of its side-chain torsion bytes
     // decompress: the segment/residue prefixes computed by fcz_decompress_sizes_dev are reused by the
     // fcz_decompress_batch_dev call that follows on the same entries
     const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_S = 0, sized_maxseg = 0;
@@ -189,7 +190,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->res_rc.release(); c->res_sc.release();
+    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->res_rc.release(); c->res_sc.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -252,9 +253,25 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
     if (in->n_chains == 0) return FCZ_OK;
     int rc = ctx->ang.ensure(sizeof(float) * 6 * (size_t)std::max<uint32_t>(in->n_residues, 1));
     if (rc) return rc;
-    span_guard g(ctx, "compress");
-    hipLaunchKernelGGL(k_compress_tiled, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in,
-                       out_off_dev, out_dev, status_dev, ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
+    rc = ctx->res_sc_addr.ensure(sizeof(uint64_t) * (size_t)std::max<uint32_t>(in->n_residues, 1));
+    if (rc) return rc;
+    const dim3 per_chain(grid_for(in->n_chains, WAVES_PER_BLOCK));
+    {
+        span_guard g(ctx, "compress_index");
+        hipLaunchKernelGGL(k_compress_index, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, ctx->res_sc_addr.as<uint64_t>());
+    }
+    if (in->n_residues) {
+        span_guard g(ctx, "compress_angles");
+        const uint32_t n_tiles = grid_for(in->n_residues, CK_TILE);
+        const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_COMPRESS_MIN_BLOCKS * 4u);
+        hipLaunchKernelGGL(k_compress_angles, dim3(blocks), dim3(BLOCK), 0, ctx->stream, *in, n_tiles,
+                           ctx->res_sc_addr.as<uint64_t>(), out_dev, ctx->ang.as<float>());
+    }
+    {
+        span_guard g(ctx, "compress_pack");
+        hipLaunchKernelGGL(k_compress_pack, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
+                           ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
+    }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
 }
@@ -599,12 +616,3 @@ extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, ui
     return FCZ_OK;
 }
 
-#ifdef FCZ_PROFILE_PHASES
-extern "C" int fcz_debug_phase_cycles(fcz_ctx* ctx, unsigned long long* out16, int reset) {
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(fcz::g_phase_cycles), sizeof(unsigned long long) * 16));
-    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_phase_cycles), z, sizeof z)); }
-    return FCZ_OK;
-}
-#endif

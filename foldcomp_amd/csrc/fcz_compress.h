@@ -1,67 +1,36 @@
-// fcz_compress.h -- k_compress_tiled: the compress kernel (Foldcomp::preprocess/compress/writeStream,
-// reference src/foldcomp.cpp:450-606, 1038-1109).
+// fcz_compress.h -- the compress path (Foldcomp::preprocess/compress/writeStream, reference
+// src/foldcomp.cpp:450-606, 1038-1109) as three kernels.
 //
-// One wavefront per chain. The chain is walked in tiles of up to 64 residues:
-//   1. the tile's atoms (a contiguous range of the SoA arrays, plus the next residue for the backbone
-//      windows that straddle the tile edge) arrive with coalesced 16-byte loads that were issued one tile
-//      earlier (register prefetch) and are parked in LDS as {x, y, z, code} records;
-//   2. every residue lane reads its atoms' codes from LDS (all reads in flight at once) and records, per
-//      canonical slot, the index of the first atom with that name (findFirstAtomCoords semantics,
-//      reference src/sidechain.cpp:140-147); absent names point at an all-zero record, which is what the
-//      reference reads for a missing atom;
-//   3. all angle evaluations of the tile form ONE flat work list -- 3 backbone dihedrals + 3 backbone bond
-//      angles per residue window, then one dihedral per side-chain atom -- and lanes take items
-//      round-robin: every iteration has 64 busy lanes running the same code. Side-chain items are
-//      numbered exactly like the FCZ side-chain byte stream, so their byte stores are consecutive.
-// Backbone angles go to per-chain scratch (coalesced per angle type); after the tile loop the wave reduces
-// min/max per type and quantises + packs the 8-byte words from registers.
+// Every angle of a chain is a function of one residue (side-chain torsions) or of one residue and its successor
+// (the six backbone values of a residue window), so the heavy part ignores chain boundaries:
+//
+//   k_compress_index   one wavefront per chain. res_sc_addr[r] = byte offset, inside the output blob, of residue r's
+//                      first side-chain torsion byte; bit 63 marks the last residue of a chain (no window).
+//   k_compress_angles  persistent blocks over flat tiles of 256 consecutive residues of the batch (any chains).
+//                      The tile's atoms (one contiguous range of the SoA arrays, plus the successor of the last
+//                      residue) are parked in LDS as {x, y, z, code} records; one thread per residue records the first
+//                      atom of every canonical name (findFirstAtomCoords, reference src/sidechain.cpp:140-147; a missing
+//                      name points at an all-zero record, which is what the reference reads for it); then every angle
+//                      evaluation of the tile is one work item -- 3 dihedrals + 3 bond angles per residue window, one
+//                      dihedral per side-chain atom -- and threads take items round-robin, so every round is a full
+//                      wavefront. Backbone angles go to the [6][R] scratch `ang` (coalesced per type), side-chain
+//                      torsions are quantised (FixedAngleDiscretizer(255), src/foldcomp.cpp:532-538) and stored
+//                      straight into the FCZ record (consecutive items = consecutive bytes).
+//   k_compress_pack    one wavefront per chain: validation, per-chain quantiser parameters (min/max with
+//                      std::min_element semantics, src/discretizer.cpp:22-33), the packed 8-byte words
+//                      (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52), B-factor bytes, anchors
+//                      (_setAnchor :745-761), OXT (:474-482), title and header (:1038-1109).
 #pragma once
 #include "fcz_kernels.h"
 
 namespace fcz {
-
-// Optional phase timer (build with -DFCZ_PROFILE_PHASES): per-wave s_memtime deltas summed into g_phase_cycles.
-#ifdef FCZ_PROFILE_PHASES
-__device__ unsigned long long g_phase_cycles[16];
-#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(); unsigned long long ph_acc[10] = {0,0,0,0,0,0,0,0,0,0};
-#define PH_MARK(i) { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; }
-#define PH_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 10; i_++) atomicAdd(&g_phase_cycles[i_], ph_acc[i_]); }
-#else
-#define PH_DECL
-#define PH_MARK(i)
-#define PH_FLUSH
-#endif
-
-#ifndef FCZ_COMPRESS_MIN_WAVES
-#define FCZ_COMPRESS_MIN_WAVES 2
-#endif
-constexpr int CT_CAP = 768;          // staged atom records per tile (typical tile: 65 residues * 8.4 atoms = 545)
-constexpr int CT_ZERO = CT_CAP;      // index of the all-zero record (missing atoms)
-constexpr int CT_NV = CT_CAP / (4 * WAVE);   // float4 staging rounds per array
-constexpr int CT_SB = 8;             // tiles per metadata super-block (512 residues)
-
-struct alignas(16) compress_tile_lds {
-    float4 atom[CT_CAP + 1];                       // {x, y, z, code bits}
-    uint16_t idx[66][16];                          // [residue in tile][canonical slot] -> atom record index
-    uint16_t scpre[66];                            // tile-local exclusive prefix of side-chain torsion counts
-    uint8_t rc[68];
-    uint8_t item_res[64 * 11];                     // side-chain item -> residue in tile
-    float out_bb[6][WAVE];                         // backbone angles of the tile, flushed with coalesced stores
-    alignas(4) uint8_t out_sc[64 * 11 + 4];        // side-chain bytes of the tile
-};
-
-__device__ __forceinline__ v3 tile_atom(const compress_tile_lds& L, uint32_t res, uint32_t slot) {
-    const float4 a = L.atom[L.idx[res][slot]];
-    return v3{a.x, a.y, a.z};
-}
 
 // ---- wave reductions on the DPP cross-lane network (no LDS traffic) -------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
-// four DPP steps leave every lane with the extremum of its row of 16; the four rows are combined through
-// scalar reads
+// four DPP steps leave every lane with the extremum of its row of 16; the four rows are combined through scalar reads
 __device__ __forceinline__ float wave_min_f32(float v) {
     v = __builtin_fminf(v, dpp_f32<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
     v = __builtin_fminf(v, dpp_f32<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
@@ -94,11 +63,60 @@ __device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint3
     return lo_hi{wave_ext_min(mn), wave_ext_max(mx)};
 }
 
-// tile geometry shared by the prefetch and the consumer
-struct tile_ext { uint32_t T, nres, A0, cnt; bool look; };
+constexpr uint64_t CK_LAST = 1ull << 63;   // res_sc_addr flag: last residue of its chain
+constexpr int CK_TILE = BLOCK;              // residues per tile
+constexpr int CK_CAP = 2304;                // staged atom records per pass (a typical tile: 257 * 8.35 = 2146)
+constexpr int CK_ZERO = CK_CAP;             // index of the all-zero record (missing atoms)
 
-// last few atoms of the whole batch: element-wise loads that never run past the end of the arrays.
-// Returned by value: taking the address of the prefetch registers would demote them to scratch memory.
+// =====================================================================================================================
+// k_compress_index
+// =====================================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_compress_index(fcz_chain_batch in, const uint64_t* __restrict__ out_off,
+                                                          uint64_t* __restrict__ res_sc_addr) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (c >= in.n_chains) return;
+    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
+    if (n == 0) return;
+    const uint32_t thr = in.anchor_threshold > 0 ? (uint32_t)in.anchor_threshold : 1u;
+    const rec_layout RL = make_layout(n, n / thr + 2, in.title_off[c + 1] - in.title_off[c], 0);   // o_sc does not depend on n_sc
+    const uint64_t base = out_off[c] + RL.o_sc;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < n; b += WAVE) {
+        const uint32_t k = b + lane;
+        uint32_t cnt = 0;
+        if (k < n) { const uint32_t rc = in.res_code[r0 + k]; cnt = fcz_res_natoms[rc < 24 ? rc : 23] - 3; }
+        uint32_t tot;
+        const uint32_t ex = run + wave_excl_scan(cnt, lane, &tot);
+        run += tot;
+        if (k < n) res_sc_addr[r0 + k] = (base + ex) | (k == n - 1 ? CK_LAST : 0ull);
+    }
+}
+
+// =====================================================================================================================
+// k_compress_angles
+// =====================================================================================================================
+struct alignas(16) compress_lds {
+    float4 atom[CK_CAP + 1];                    // {x, y, z, code bits}; [CK_ZERO] = zeros
+    uint16_t idx[16][CK_TILE + 8];              // [canonical slot][residue in tile] -> atom record (row CK_TILE.. = successor)
+    unsigned long long sc_addr[CK_TILE];        // res_sc_addr of the tile's residues
+    uint32_t olo[CK_TILE + 2];                  // atom_off of residues 0..CK_TILE+1 of the tile (clamped)
+    uint16_t scpre[CK_TILE];                    // pass-local exclusive prefix of side-chain torsion counts
+    uint8_t rc[CK_TILE + 8];
+    uint8_t item_res[CK_TILE * 11];             // side-chain item -> residue in tile
+    uint32_t wave_tot[WAVES_PER_BLOCK];
+    uint32_t first_bad;
+    uint8_t slot_of[FCZ_N_RES_CODES][40];       // atom code -> canonical slot, 255 = not in residue
+    uint16_t prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
+    uint8_t natoms[32];
+};
+
+__device__ __forceinline__ v3 tile_atom(const compress_lds& L, uint32_t res, uint32_t slot) {
+    const float4 a = L.atom[L.idx[slot][res]];
+    return v3{a.x, a.y, a.z};
+}
+
+// last few atoms of the whole batch: element-wise loads that never run past the end of the arrays
 struct atom_quad { float4 x, y, z; uint32_t c; };
 __device__ __noinline__ atom_quad load_atoms_tail(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                   const uint8_t* __restrict__ code, uint32_t a, uint32_t left) {
@@ -112,54 +130,332 @@ __device__ __noinline__ atom_quad load_atoms_tail(const float* __restrict__ x, c
     return q;
 }
 
-__global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_WAVES)
-void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                      int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle) {
-    __shared__ compress_tile_lds s_tile[WAVES_PER_BLOCK];
-    __shared__ uint8_t s_slot_of[FCZ_N_RES_CODES][40];  // atom code -> canonical slot, 255 = not in residue
-    __shared__ uint16_t s_prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
-    __shared__ uint8_t s_natoms[32];
+#ifndef FCZ_COMPRESS_MIN_BLOCKS
+#define FCZ_COMPRESS_MIN_BLOCKS 3
+#endif
 
-    for (int i = threadIdx.x; i < FCZ_N_RES_CODES * 40; i += BLOCK) (&s_slot_of[0][0])[i] = 255;
-    if (threadIdx.x < 32) s_natoms[threadIdx.x] = fcz_res_natoms[threadIdx.x < 24 ? threadIdx.x : 23];
+__global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_BLOCKS)
+void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out,
+                       float* __restrict__ ang) {
+    __shared__ compress_lds L;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int i = t; i < FCZ_N_RES_CODES * 40; i += BLOCK) (&L.slot_of[0][0])[i] = 255;
+    if (t < 32) L.natoms[t] = fcz_res_natoms[t < 24 ? t : 23];
+    if (t == 0) L.atom[CK_ZERO] = float4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    for (int i = threadIdx.x; i < FCZ_N_RES_CODES * FCZ_MAX_RES_ATOMS; i += BLOCK) {
-        int rc = i / FCZ_MAX_RES_ATOMS, j = i % FCZ_MAX_RES_ATOMS;
-        if (j < fcz_res_natoms[rc]) s_slot_of[rc][fcz_res_atom[rc][j]] = (uint8_t)j;
-        s_prev[rc][j] = fcz_res_prev[rc][j];
+    for (int i = t; i < FCZ_N_RES_CODES * FCZ_MAX_RES_ATOMS; i += BLOCK) {
+        const int rc = i / FCZ_MAX_RES_ATOMS, j = i % FCZ_MAX_RES_ATOMS;
+        if (j < fcz_res_natoms[rc]) L.slot_of[rc][fcz_res_atom[rc][j]] = (uint8_t)j;
+        L.prev[rc][j] = fcz_res_prev[rc][j];
     }
     __syncthreads();
 
+    const uint32_t R = in.n_residues;
+    const size_t Rz = R;
+    const float sc_min = -180.0f, sc_disc = 255.0f / (180.0f - (-180.0f));   // FixedAngleDiscretizer(255)
+    constexpr int NV = CK_CAP / (4 * BLOCK);   // full float4 rounds; the rest of the staging buffer is one atom per thread
+    static_assert(CK_CAP - NV * 4 * BLOCK <= BLOCK, "tail round covers one atom per thread");
+
+    // ---- software pipeline: while tile T computes, the per-residue metadata and the atoms of tile T+1 are in flight.
+    //      All loads are unconditional (clamped indices): a conditional merge would make the compiler wait for the data
+    //      at the load instead of a tile later. No global store is issued between these loads and the end of the tile's
+    //      items (results stay in registers), so nothing forces the memory queue to drain early. ----
+    struct meta { uint32_t olo, ox, rc, rc_succ, a0_next, e_next; unsigned long long sa; };
+    auto load_meta = [&](uint32_t tile) -> meta {
+        const size_t r_lo = (size_t)tile * CK_TILE;
+        const size_t r = r_lo + (size_t)t;
+        auto cl = [&](size_t x) -> size_t { return x < Rz ? x : Rz; };
+        meta m;
+        m.olo = in.atom_off[cl(r)];
+        m.ox = in.atom_off[cl(r_lo + CK_TILE + (size_t)(t & 1))];            // olo[256], olo[257]
+        m.rc = in.res_code[r < Rz ? r : Rz - 1];
+        m.rc_succ = in.res_code[r_lo + CK_TILE < Rz ? r_lo + CK_TILE : Rz - 1];
+        m.sa = res_sc_addr[r < Rz ? r : Rz - 1];
+        const size_t r_n = r_lo + (size_t)gridDim.x * CK_TILE;               // this block's next tile
+        m.a0_next = in.atom_off[cl(r_n)];
+        m.e_next = in.atom_off[cl(r_n + CK_TILE + 1)];
+        return m;
+    };
+    // rounds 0..NV-1: four atoms per thread (16-byte loads); the remaining CK_CAP - NV*4*BLOCK atoms: one atom per thread
+    float4 px[NV], py[NV], pz[NV];
+    uint32_t pc[NV];
+    float tx = 0.f, ty = 0.f, tz = 0.f; uint32_t tc = 0;
+    auto issue_atoms = [&](uint32_t A0, uint32_t cnt) {
+        // clamp instead of predicating: every load is issued, out-of-range groups re-read the last in-range one
+        const uint32_t last4 = cnt > 4 ? ((cnt - 1) & ~3u) : 0u;
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            uint32_t i4 = 4 * ((uint32_t)u * BLOCK + (uint32_t)t);
+            i4 = i4 < cnt ? i4 : last4;
+            const size_t g = (size_t)A0 + i4;                                // simple_tile(): reads stay inside the arrays
+            px[u] = ld_f4(in.x + g); py[u] = ld_f4(in.y + g); pz[u] = ld_f4(in.z + g); pc[u] = ld_u32(in.atom_code + g);
+        }
+        uint32_t i1 = NV * 4 * BLOCK + (uint32_t)t;
+        i1 = i1 < cnt ? i1 : cnt - 1;
+        const size_t g = (size_t)A0 + i1;
+        tx = in.x[g]; ty = in.y[g]; tz = in.z[g]; tc = in.atom_code[g];
+    };
+    // the prefetch covers residues 0..256 of a tile (the successor row always included); it is used when that fits
+    // (and the 16-byte reads of its last group stay inside the arrays: the last tile of the batch takes the other path)
+    auto simple_tile = [&](uint32_t a0, uint32_t e) -> bool { return e - a0 <= (uint32_t)CK_CAP && (size_t)e + 4 <= (size_t)in.n_atoms; };
+
+    meta mcur = load_meta(blockIdx.x);
+    uint32_t a0_cur, e_cur;
+    {
+        const size_t r_lo = (size_t)blockIdx.x * CK_TILE;
+        a0_cur = in.atom_off[r_lo < Rz ? r_lo : Rz];
+        e_cur = in.atom_off[r_lo + CK_TILE + 1 < Rz ? r_lo + CK_TILE + 1 : Rz];
+    }
+    bool pre_cur = simple_tile(a0_cur, e_cur);
+    if (pre_cur) issue_atoms(a0_cur, e_cur - a0_cur);
+
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t r_lo = tile * CK_TILE;
+        const uint32_t nres = (R - r_lo < (uint32_t)CK_TILE) ? R - r_lo : (uint32_t)CK_TILE;
+        // ---- park the prefetched metadata (and atoms) in LDS ----
+        {
+            L.olo[t] = mcur.olo;
+            if (t < 2) L.olo[CK_TILE + t] = mcur.ox;
+            const bool in_r = r_lo + (uint32_t)t < R;
+            L.rc[t] = (uint8_t)(in_r && mcur.rc < 24 ? mcur.rc : 23);
+            L.sc_addr[t] = in_r ? mcur.sa : CK_LAST;
+            if (t == 0) L.rc[CK_TILE] = (uint8_t)(mcur.rc_succ < 24 ? mcur.rc_succ : 23);
+        }
+        const uint32_t A0s = a0_cur, cnts = e_cur - a0_cur;
+        const bool simple = pre_cur;
+        if (simple) {
+#pragma unroll
+            for (int u = 0; u < NV; u++) {
+                const uint32_t i4 = 4 * ((uint32_t)u * BLOCK + (uint32_t)t);
+                if (i4 < cnts) {
+                    const float4 x = px[u], y = py[u], z = pz[u]; const uint32_t c = pc[u];
+                    L.atom[i4 + 0] = float4{x.x, y.x, z.x, __uint_as_float(c & 0xffu)};
+                    L.atom[i4 + 1] = float4{x.y, y.y, z.y, __uint_as_float((c >> 8) & 0xffu)};
+                    L.atom[i4 + 2] = float4{x.z, y.z, z.z, __uint_as_float((c >> 16) & 0xffu)};
+                    L.atom[i4 + 3] = float4{x.w, y.w, z.w, __uint_as_float(c >> 24)};
+                }
+            }
+            const uint32_t i1 = NV * 4 * BLOCK + (uint32_t)t;
+            if (i1 < cnts) L.atom[i1] = float4{tx, ty, tz, __uint_as_float(tc)};
+        }
+        // ---- prefetch of this block's next tile ----
+        const uint32_t tile_n = tile + gridDim.x;
+        const uint32_t a0_n = mcur.a0_next, e_n = mcur.e_next;
+        const bool pre_n = tile_n < n_tiles && simple_tile(a0_n, e_n);
+        const meta mnext = load_meta(tile_n < n_tiles ? tile_n : tile);
+        if (pre_n) issue_atoms(a0_n, e_n - a0_n);
+        __syncthreads();
+
+        // ---- passes: residues [s, e) whose atoms (plus the successor of e-1) are parked; one pass for a normal tile ----
+        uint32_t s = 0;
+        while (s < nres) {
+            uint32_t e = nres, A0 = A0s;
+            bool tail_succ = true;
+            if (!simple) {
+                A0 = L.olo[s];
+                // atoms needed when the pass ends before residue x (x > s); the successor only if it is in the same chain
+                auto need_end = [&](uint32_t x) -> uint32_t {
+                    const bool last = (L.sc_addr[x - 1] & CK_LAST) != 0;
+                    return last ? L.olo[x] : L.olo[x + 1];
+                };
+                if (need_end(nres) - A0 > (uint32_t)CK_CAP) {
+                    // unusually atom-rich stretch (explicit hydrogens, ...): shorten the pass. need_end is monotone.
+                    if (t == 0) L.first_bad = nres + 1;
+                    __syncthreads();
+                    const uint32_t x = s + 1 + (uint32_t)t;   // candidate ends s+1 .. s+256
+                    if (x <= nres && need_end(x) - A0 > (uint32_t)CK_CAP) atomicMin(&L.first_bad, x);
+                    __syncthreads();
+                    e = L.first_bad - 1;
+                    __syncthreads();
+                    if (e <= s) { s++; continue; }   // residue s (+ successor) alone exceeds the capacity: k_compress_pack rejects its chain
+                }
+                tail_succ = (L.sc_addr[e - 1] & CK_LAST) == 0;   // successor row needed (it exists then)
+                const uint32_t cnt = (tail_succ ? L.olo[e + 1] : L.olo[e]) - A0;
+                for (uint32_t i4 = 4 * (uint32_t)t; i4 < cnt; i4 += 4 * BLOCK) {
+                    float4 qx, qy, qz; uint32_t qc;
+                    if ((size_t)A0 + i4 + 4 <= (size_t)in.n_atoms) {
+                        qx = ld_f4(in.x + A0 + i4); qy = ld_f4(in.y + A0 + i4); qz = ld_f4(in.z + A0 + i4);
+                        qc = ld_u32(in.atom_code + A0 + i4);
+                    } else {
+                        const atom_quad q = load_atoms_tail(in.x, in.y, in.z, in.atom_code, A0 + i4, cnt - i4);
+                        qx = q.x; qy = q.y; qz = q.z; qc = q.c;
+                    }
+                    L.atom[i4 + 0] = float4{qx.x, qy.x, qz.x, __uint_as_float(qc & 0xffu)};
+                    L.atom[i4 + 1] = float4{qx.y, qy.y, qz.y, __uint_as_float((qc >> 8) & 0xffu)};
+                    L.atom[i4 + 2] = float4{qx.z, qy.z, qz.z, __uint_as_float((qc >> 16) & 0xffu)};
+                    L.atom[i4 + 3] = float4{qx.w, qy.w, qz.w, __uint_as_float(qc >> 24)};
+                }
+                __syncthreads();
+            } else {
+                tail_succ = r_lo + nres < R;   // row nres exists in the batch
+            }
+
+            // ---- slot index table: first atom of each canonical name; one thread per residue row ----
+            const uint32_t last_row = tail_succ ? e : e - 1;
+            for (uint32_t rr = s + (uint32_t)t; rr <= last_row; rr += BLOCK) {
+                const uint32_t rc = L.rc[rr];
+                const uint32_t lo = L.olo[rr] - A0, hi = L.olo[rr + 1] - A0;
+                uint32_t codes[16], slots[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) codes[j] = (lo + j < hi) ? __float_as_uint(L.atom[lo + j].w) : 255u;
+#pragma unroll
+                for (int j = 0; j < 16; j++) slots[j] = (codes[j] < 40u) ? L.slot_of[rc][codes[j]] : 255u;
+                // every slot starts at the zero record; then descending j, so that the first occurrence of a name is
+                // the write that lands last (LDS operations of one wave execute in issue order)
+#pragma unroll
+                for (int sl = 0; sl < 16; sl++) L.idx[sl][rr] = (uint16_t)CK_ZERO;
+                uint32_t filled = 0;
+#pragma unroll
+                for (int j = 15; j >= 0; j--) {
+                    const uint32_t sl = slots[j];
+                    if (sl != 255u) { filled |= 1u << sl; L.idx[sl][rr] = (uint16_t)(lo + j); }
+                }
+                for (uint32_t i = lo + 16; i < hi; i++) {   // residues with more than 16 atoms (explicit hydrogens)
+                    const uint32_t code = __float_as_uint(L.atom[i].w);
+                    const uint32_t sl = code < 40u ? L.slot_of[rc][code] : 255u;
+                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; L.idx[sl][rr] = (uint16_t)i; }
+                }
+            }
+
+            // ---- side-chain item numbering of the pass: block scan of the per-residue torsion counts ----
+            const bool mine = (uint32_t)t >= s && (uint32_t)t < e;
+            const bool my_win = mine && (L.sc_addr[t] & CK_LAST) == 0;
+            const uint32_t my_cnt = mine ? (uint32_t)L.natoms[L.rc[t]] - 3u : 0u;
+            uint32_t inc = my_cnt;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) { const uint32_t u = __shfl_up(inc, d, WAVE); if (lane >= d) inc += u; }
+            if (lane == WAVE - 1) L.wave_tot[wave] = inc;
+            __syncthreads();
+            uint32_t my_pre = inc - my_cnt, n_sc = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES_PER_BLOCK; w++) { const uint32_t v = L.wave_tot[w]; if (w < wave) my_pre += v; n_sc += v; }
+            if (mine) {
+                L.scpre[t] = (uint16_t)my_pre;
+                for (uint32_t j = 0; j < my_cnt; j++) L.item_res[my_pre + j] = (uint8_t)t;
+            }
+            __syncthreads();
+
+            // ---- items. Every item is "angle between two vectors": for a dihedral the two plane normals
+            //      (getTorsionFromXYZ, reference src/torsion_angle.cpp:50-94), for a bond angle the two bond vectors
+            //      (angle(), src/float3d.h:55-65; getBondAngles src/nerf.cpp:495-508). Results stay in registers. ----
+            // backbone: thread = residue window (k, k+1). psi = (N0,CA0,C0,N1), omega = (CA0,C0,N1,CA1),
+            // phi = (C0,N1,CA1,C1) -> arrays 1, 2, 0 (split src/foldcomp.cpp:488-492); ca_c_n = (CA0,C0,N1),
+            // c_n_ca = (C0,N1,CA1), n_ca_c = (N1,CA1,C1) -> arrays 4, 5, 3 (split :497-505)
+            float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, bb4 = 0.f, bb5 = 0.f;
+#pragma unroll 1
+            for (uint32_t q = 0; q < 6; q++) {   // q uniform: one copy of the dihedral and of the bond-angle code
+                if (!my_win) continue;
+                const bool dih = q < 3;
+                const uint32_t g0 = dih ? q : q - 2;     // first backbone atom of the item in the window N0 CA0 C0 N1 CA1 C1
+                const v3 a = tile_atom(L, (uint32_t)t + (g0 >= 3 ? 1u : 0u), g0 >= 3 ? g0 - 3 : g0);
+                const v3 b = tile_atom(L, (uint32_t)t + (g0 + 1 >= 3 ? 1u : 0u), g0 + 1 >= 3 ? g0 - 2 : g0 + 1);
+                const v3 cc = tile_atom(L, (uint32_t)t + (g0 + 2 >= 3 ? 1u : 0u), g0 + 2 >= 3 ? g0 - 1 : g0 + 2);
+                float v;
+                if (dih) v = dihedral_deg(a, b, cc, tile_atom(L, (uint32_t)t + 1u, g0));
+                else v = bond_angle_deg(a, b, cc);
+                // psi, omega, phi -> arrays 1, 2, 0; ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3
+                bb1 = q == 0 ? v : bb1; bb2 = q == 1 ? v : bb2; bb0 = q == 2 ? v : bb0;
+                bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
+            }
+            // side-chain torsions (calculateTorsionAnglesInResidue, reference src/sidechain.cpp:149-168): flat list
+            uint32_t scb[3] = {0u, 0u, 0u};
+#pragma unroll 1
+            for (uint32_t i = 0; i < 11; i++) {
+                const uint32_t ts = (uint32_t)t + i * BLOCK;
+                if (i * BLOCK >= n_sc) break;
+                uint32_t q = 0;
+                if (ts < n_sc) {
+                    const uint32_t res = L.item_res[ts];
+                    const uint32_t j = 3 + ts - L.scpre[res];
+                    const uint32_t pk = L.prev[L.rc[res]][j];
+                    const v3 a = tile_atom(L, res, pk & 15u), b = tile_atom(L, res, (pk >> 4) & 15u), cc = tile_atom(L, res, (pk >> 8) & 15u);
+                    const v3 d = tile_atom(L, res, j);
+                    q = quant_trunc(dihedral_deg(a, b, cc, d), sc_min, sc_disc) & 0xffu;   // src/foldcomp.cpp:532-538
+                }
+                const uint32_t sh = q << (8 * (i & 3u));
+                scb[0] |= (i < 4) ? sh : 0u; scb[1] |= (i >= 4 && i < 8) ? sh : 0u; scb[2] |= (i >= 8) ? sh : 0u;
+            }
+            // ---- results out: 6 coalesced float stores per window, consecutive bytes for consecutive side-chain items ----
+            if (my_win) {
+                float* ap = ang + r_lo + (uint32_t)t;
+                ap[0] = bb0; ap[Rz] = bb1; ap[2 * Rz] = bb2; ap[3 * Rz] = bb3; ap[4 * Rz] = bb4; ap[5 * Rz] = bb5;
+            }
+#pragma unroll 1
+            for (uint32_t i = 0; i < 11; i++) {
+                const uint32_t ts = (uint32_t)t + i * BLOCK;
+                if (i * BLOCK >= n_sc) break;
+                if (ts < n_sc) {
+                    const uint32_t res = L.item_res[ts];
+                    const uint32_t jj = ts - L.scpre[res];
+                    const uint32_t w = (i < 4) ? scb[0] : (i < 8 ? scb[1] : scb[2]);
+                    out[(L.sc_addr[res] & ~CK_LAST) + jj] = (uint8_t)(w >> (8 * (i & 3u)));
+                }
+            }
+            __syncthreads();
+            s = e;
+        }
+        mcur = mnext; a0_cur = a0_n; e_cur = e_n; pre_cur = pre_n;
+    }
+}
+
+// =====================================================================================================================
+// k_compress_pack
+// =====================================================================================================================
+__global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                         int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= in.n_chains) return;
-    compress_tile_lds& L = s_tile[wave];
-    PH_DECL
-
     const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
     const uint32_t title_len = in.title_off[c + 1] - in.title_off[c];
     const uint32_t thr = (uint32_t)in.anchor_threshold;
     uint8_t* rec = out + out_off[c];
     const uint32_t rec_size = (uint32_t)(out_off[c + 1] - out_off[c]);
-    // header scalars: issued now, consumed at the very end
     const int32_t h_first_res = in.first_res_index[c], h_first_atom = in.first_atom_index[c];
     const char h_chain = in.chain_id[c];
     const uint32_t a_first = in.atom_off[r0], a_end = in.atom_off[r0 + n];
-    const uint32_t h_rc_first = in.res_code[r0], h_rc_last = in.res_code[r0 + (n ? n - 1 : 0)];
+    const uint32_t h_rc_first = n ? in.res_code[r0] : 23u, h_rc_last = n ? in.res_code[r0 + n - 1] : 23u;
+
+    // ---- every load of a normal chain (<= 384 residues) is issued here, unconditionally and from clamped indices, so
+    //      that validation, anchors and quantisation do not each pay a memory round trip ----
+    constexpr int U = 6;
+    const bool small = n >= 2 && n <= (uint32_t)(U * WAVE);
+    const size_t R = in.n_residues;
+    const uint32_t m = n ? n - 1 : 0;
+    float* a_arr = ang + (r0 < R ? r0 : (R ? R - 1 : 0));   // array q of this chain = a_arr + q*R : phi psi omega n_ca_c ca_c_n c_n_ca
+    float va[7][U];
+    uint32_t rcs[U], o0[U], o2[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { rcs[u] = 0; o0[u] = o2[u] = 0; for (int q = 0; q < 7; q++) va[q][u] = 0.f; }
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = u * WAVE + lane;
+            const uint32_t kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
+#pragma unroll
+            for (int q = 0; q < 6; q++) va[q][u] = a_arr[(size_t)q * R + kw];
+            va[6][u] = in.bfac_ca[r0 + kr];
+            rcs[u] = in.res_code[r0 + kr];
+            o0[u] = in.atom_off[r0 + kr];
+            o2[u] = in.atom_off[r0 + (k + 2 < n ? k + 2 : n)];
+        }
+    }
 
     // ---- validation (the reference aborts on these inputs) + total side-chain torsion count ----
     int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
     uint32_t nsc = 0;
-    for (uint32_t k0 = 0; k0 < n; k0 += 8 * WAVE) {   // 8 independent loads in flight per round trip
-        uint32_t rcs[8];
+    auto check = [&](uint32_t rc, uint32_t span) {
+        if (!res_code_ok(rc)) bad = bad ? bad : FCZ_E_RESIDUE;
+        // a residue and its successor must fit the staging buffer of k_compress_angles (not a protein otherwise)
+        if (span > (uint32_t)CK_CAP) bad = bad ? bad : FCZ_E_INVALID_ARG;
+        nsc += fcz_res_natoms[rc < 24 ? rc : 23] - 3;
+    };
+    if (small) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * WAVE + lane; rcs[u] = (k < n) ? in.res_code[r0 + k] : 0xffu; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (rcs[u] == 0xffu) continue;
-            if (!res_code_ok(rcs[u])) bad = bad ? bad : FCZ_E_RESIDUE;
-            nsc += s_natoms[rcs[u] & 31u] - 3;
-        }
+        for (int u = 0; u < U; u++) if ((uint32_t)(u * WAVE + lane) < n) check(rcs[u], o2[u] - o0[u]);
+    } else {
+        for (uint32_t k = lane; k < n; k += WAVE)
+            check(in.res_code[r0 + k], in.atom_off[r0 + (k + 2 < n ? k + 2 : n)] - in.atom_off[r0 + k]);
     }
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) { int o = __shfl_xor(bad, d, WAVE); bad = o < bad ? o : bad; }
@@ -169,293 +465,51 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         return;
     }
     nsc = wave_sum(nsc);
-    PH_MARK(0)
 
-    const uint32_t m = n - 1;
     const uint32_t n_anchor = n / thr + 2;
     const uint32_t interval = n / (n_anchor - 1);
     const rec_layout RL = make_layout(n, n_anchor, title_len, nsc);
-    const size_t R = in.n_residues;
-    float* a_arr = ang + r0;   // array q of this chain = a_arr + q*R : phi psi omega n_ca_c ca_c_n c_n_ca
-    const float sc_min = -180.0f, sc_disc = 255.0f / (180.0f - (-180.0f));  // FixedAngleDiscretizer(255)
 
-    if (lane == 0) L.atom[CT_ZERO] = float4{0.f, 0.f, 0.f, 0.f};
-
-    // Metadata registers of the current super-block, rotated so that index 0 is always the current tile:
-    // mo[u] = atom_off of residue (tile base + u*64 + lane), mr[u] = its residue code.
-    uint32_t mo[CT_SB + 1], mr[CT_SB + 1];
-    auto load_meta = [&](uint32_t sb_base) {
+    // ---- anchors (Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1045-1059): one lane per anchor; N, CA, C are
+    //      the first atoms of those names in the residue ----
+    for (uint32_t sl = lane; sl < n_anchor; sl += WAVE) {
+        const uint32_t k = (sl + 1 < n_anchor) ? sl * interval : n - 1;
+        const uint32_t lo = in.atom_off[r0 + k], hi = in.atom_off[r0 + k + 1];
+        // the first 8 atom codes in one batch of loads (N, CA, C lead every residue of a normal file); a serial scan
+        // with one dependent load per atom only when a name is still missing after those
+        uint32_t at[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint32_t codes[8];
 #pragma unroll
-        for (int u = 0; u <= CT_SB; u++) { const uint32_t k = sb_base + u * WAVE + lane; mo[u] = in.atom_off[r0 + (k <= n ? k : n)]; }
+        for (int j = 0; j < 8; j++) codes[j] = (lo + j < hi) ? (uint32_t)in.atom_code[lo + j] : 255u;
 #pragma unroll
-        for (int u = 0; u <= CT_SB; u++) { const uint32_t k = sb_base + u * WAVE + lane; mr[u] = (k < n) ? in.res_code[r0 + k] : 23u; }
-    };
-    // extent of the tile that starts at residue `base` (metadata in o_lane = mo[0], o_next = mo[1])
-    auto tile_extent = [&](uint32_t base, uint32_t o_lane, uint32_t o_next) -> tile_ext {
-        tile_ext e;
-        e.T = (n - base < (uint32_t)WAVE) ? (n - base) : (uint32_t)WAVE;
-        e.A0 = __shfl(o_lane, 0, WAVE);
-        const uint32_t o64 = __shfl(o_next, 0, WAVE), o65 = __shfl(o_next, 1, WAVE);
-        e.look = base + e.T < n;
-        const uint32_t last = e.T + (e.look ? 1u : 0u);
-        uint32_t A1 = (last == 65) ? o65 : (last == 64 ? o64 : __shfl(o_lane, (int)(last & 63u), WAVE));
-        if (A1 - e.A0 > (uint32_t)CT_CAP) {
-            // unusually atom-rich residues (e.g. explicit hydrogens): shrink the tile. Residues [0,t) plus the
-            // look-ahead residue t fit iff the ends of residues 0..t all lie within the staging capacity.
-            uint32_t my_end = __shfl_down(o_lane, 1, WAVE);
-            if (lane == 63) my_end = o64;
-            const bool fits = (base + lane < n) && (my_end - e.A0 <= (uint32_t)CT_CAP);
-            const unsigned long long fm = __ballot(fits);
-            const uint32_t lead = (fm == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~fm);
-            if (lead < 2) { e.T = 0; e.nres = 0; e.cnt = 0; return e; }   // not a protein chain
-            e.T = lead - 1; e.look = true;
-            A1 = (e.T + 1 == 64) ? o64 : __shfl(o_lane, (int)(e.T + 1), WAVE);
+        for (int j = 7; j >= 0; j--) {
+            at[0] = codes[j] == 0u ? lo + j : at[0];
+            at[1] = codes[j] == 1u ? lo + j : at[1];
+            at[2] = codes[j] == 2u ? lo + j : at[2];
         }
-        e.nres = e.T + (e.look ? 1u : 0u);
-        e.cnt = A1 - e.A0;
-        return e;
-    };
-    // coalesced 16-byte loads of a tile's atoms into registers
-    float4 px[CT_NV], py[CT_NV], pz[CT_NV];
-    uint32_t pc[CT_NV];
-    auto issue_atoms = [&](const tile_ext& e) {
-        const bool whole = (size_t)e.A0 + CT_CAP + 4 <= (size_t)in.n_atoms;   // 16-byte reads stay inside the arrays
-#pragma unroll
-        for (int u = 0; u < CT_NV; u++) {
-            const uint32_t i4 = 4 * (u * WAVE + lane);
-            px[u] = py[u] = pz[u] = float4{0.f, 0.f, 0.f, 0.f}; pc[u] = 0;
-            if (i4 < e.cnt) {
-                if (whole || (size_t)e.A0 + i4 + 4 <= (size_t)in.n_atoms) {
-                    px[u] = ld_f4(in.x + e.A0 + i4);
-                    py[u] = ld_f4(in.y + e.A0 + i4);
-                    pz[u] = ld_f4(in.z + e.A0 + i4);
-                    pc[u] = ld_u32(in.atom_code + e.A0 + i4);
-                } else {
-                    const atom_quad q = load_atoms_tail(in.x, in.y, in.z, in.atom_code, e.A0 + i4, e.cnt - i4);
-                    px[u] = q.x; py[u] = q.y; pz[u] = q.z; pc[u] = q.c;
-                }
+        if (__builtin_expect((at[0] & at[1] & at[2]) == 0xffffffffu || at[0] == 0xffffffffu || at[1] == 0xffffffffu || at[2] == 0xffffffffu, 0)) {
+            for (uint32_t i = lo + 8; i < hi; i++) {
+                const uint32_t code = in.atom_code[i];
+                if (code == 0u && at[0] == 0xffffffffu) at[0] = i;
+                if (code == 1u && at[1] == 0xffffffffu) at[1] = i;
+                if (code == 2u && at[2] == 0xffffffffu) at[2] = i;
             }
         }
-    };
-
-    uint32_t sc_base = 0;       // side-chain bytes emitted so far
-    uint32_t base = 0;
-    uint32_t slot_in_sb = 0;    // tiles consumed from the current super-block
-    uint32_t last_cnt = 1;      // staged atoms of the final tile (for the OXT test)
-    tile_ext cur; cur.T = 0; cur.nres = 0; cur.cnt = 0; cur.A0 = 0; cur.look = false;
-    // Software pipeline with a single copy of every stage: pass -1 only prefetches tile 0; pass t >= 0 parks
-    // tile t in LDS, prefetches tile t+1 and then computes tile t.
-    for (int pass = -1;; pass++) {
-        const bool live = pass >= 0;
-        if (live && cur.T == 0) {  // one residue plus its successor exceed the staging capacity
-            for (uint32_t i = lane; i < rec_size; i += WAVE) rec[i] = 0;
-            if (lane == 0 && status) status[c] = FCZ_E_INVALID_ARG;
-            return;
-        }
-        const uint32_t T = cur.T, cnt = cur.cnt, A0 = cur.A0;
-        const bool look = cur.look;
-        const uint32_t o_lane = mo[0], rc_lane = mr[0];
-        uint32_t o64r = 0, o65r = 0, rc64 = 23;
-        if (live) {
-            o64r = __shfl(mo[1], 0, WAVE) - A0; o65r = __shfl(mo[1], 1, WAVE) - A0;
-            rc64 = __shfl(mr[1], 0, WAVE);          // code of residue base+64
-            // ---- park the prefetched atoms in LDS as {x,y,z,code} records ----
+        v3 p[3];
 #pragma unroll
-            for (int u = 0; u < CT_NV; u++) {
-                const uint32_t i4 = 4 * (u * WAVE + lane);
-                if (i4 < cnt) {
-                    L.atom[i4 + 0] = float4{px[u].x, py[u].x, pz[u].x, __uint_as_float(pc[u] & 0xffu)};
-                    L.atom[i4 + 1] = float4{px[u].y, py[u].y, pz[u].y, __uint_as_float((pc[u] >> 8) & 0xffu)};
-                    L.atom[i4 + 2] = float4{px[u].z, py[u].z, pz[u].z, __uint_as_float((pc[u] >> 16) & 0xffu)};
-                    L.atom[i4 + 3] = float4{px[u].w, py[u].w, pz[u].w, __uint_as_float(pc[u] >> 24)};
-                }
-            }
-            L.rc[lane] = (uint8_t)rc_lane;
+        for (int q = 0; q < 3; q++) {
+            const bool have = at[q] != 0xffffffffu;
+            const uint32_t i = have ? at[q] : lo;   // any valid index; masked below
+            const bool ok = have && lo < hi;
+            p[q] = ok ? v3{in.x[i], in.y[i], in.z[i]} : v3{0.f, 0.f, 0.f};
         }
-        // ---- metadata rotation + prefetch of the next tile (loads land while this tile computes) ----
-        const uint32_t base_next = live ? base + T : 0u;
-        const bool have_next = base_next < n;
-        tile_ext nxt; nxt.T = 0; nxt.nres = 0; nxt.cnt = 0; nxt.A0 = 0; nxt.look = false;
-        if (have_next) {
-            if (live && T == (uint32_t)WAVE && slot_in_sb + 1 < CT_SB) {
-#pragma unroll
-                for (int u = 0; u < CT_SB; u++) { mo[u] = mo[u + 1]; mr[u] = mr[u + 1]; }
-                slot_in_sb++;
-            } else {
-                // first tile, super-block exhausted, or a shrunken tile shifted the grid: (re)load metadata
-                slot_in_sb = 0;
-                load_meta(base_next);
-            }
-            nxt = tile_extent(base_next, mo[0], mo[1]);
-            if (nxt.T) issue_atoms(nxt);
-        }
-        PH_MARK(2)
-        if (!live) { cur = nxt; continue; }
-        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in issue order: no memory fence needed
-
-        // ---- slot index table: first atom of each canonical name ----
-        {
-            const uint32_t a_lo = o_lane - A0;
-            uint32_t a_hi = __shfl_down(o_lane, 1, WAVE) - A0;
-            if (lane == 63) a_hi = o64r;
-            const uint32_t nres_t = T + (look ? 1u : 0u);
-            // lanes 0..T-1 own the tile's residues; the look-ahead residue T is built by lane T when the tile is
-            // short, by lane 0 (second trip, offsets from the next metadata column) when T == 64
-            for (uint32_t rr = lane; rr < nres_t; rr += WAVE) {
-                const bool second = rr >= (uint32_t)WAVE;
-                const uint32_t rc = second ? rc64 : rc_lane;
-                const uint32_t lo = second ? o64r : a_lo, hi = second ? o65r : a_hi;
-                // all code reads of the residue in flight together, then all slot lookups
-                uint32_t codes[16], slots[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) codes[j] = (lo + j < hi) ? __float_as_uint(L.atom[lo + j].w) : 255u;
-#pragma unroll
-                for (int j = 0; j < 16; j++) slots[j] = (codes[j] < 40u) ? s_slot_of[rc][codes[j]] : 255u;
-                const uint32_t zz = (uint32_t)CT_ZERO | ((uint32_t)CT_ZERO << 16);
-                uint4* row = reinterpret_cast<uint4*>(&L.idx[rr][0]);
-                row[0] = uint4{zz, zz, zz, zz};
-                row[1] = uint4{zz, zz, zz, zz};
-                uint32_t filled = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const uint32_t sl = slots[j];
-                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; L.idx[rr][sl] = (uint16_t)(lo + j); }
-                }
-                for (uint32_t i = lo + 16; i < hi; i++) {   // residues with more than 16 atoms (explicit hydrogens)
-                    const uint32_t code = __float_as_uint(L.atom[i].w);
-                    const uint32_t sl = code < 40u ? s_slot_of[rc][code] : 255u;
-                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; L.idx[rr][sl] = (uint16_t)i; }
-                }
-            }
-        }
-        // side-chain item numbering of this tile
-        uint32_t my_cnt = 0;
-        if ((uint32_t)lane < T) my_cnt = s_natoms[rc_lane & 31u] - 3;
-        uint32_t tile_sc;
-        const uint32_t my_pre = wave_excl_scan(my_cnt, lane, &tile_sc);
-        if ((uint32_t)lane < T) {
-            L.scpre[lane] = (uint16_t)my_pre;
-            for (uint32_t j = 0; j < my_cnt; j++) L.item_res[my_pre + j] = (uint8_t)lane;
-        }
-        __builtin_amdgcn_wave_barrier();
-        PH_MARK(3)
-
-        // ---- anchors (reference Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1045-1059) ----
-        if ((uint32_t)lane < T) {
-            const uint32_t k = base + lane;
-            const uint32_t ia = k / interval;
-            const bool is_a = (k % interval == 0) && (ia < n_anchor - 1);
-            const bool is_last = (k == n - 1);
-            if (is_a || is_last) {
-                const v3 N0 = tile_atom(L, lane, 0), CA0 = tile_atom(L, lane, 1), C0 = tile_atom(L, lane, 2);
-                for (int rep = 0; rep < 2; rep++) {
-                    if (rep == 0 ? !is_a : !is_last) continue;
-                    const uint32_t slot = rep == 0 ? ia : n_anchor - 1;
-                    uint8_t* p = rec + RL.o_anchor + 36 * slot;
-                    st_f32(p, N0.x); st_f32(p + 4, N0.y); st_f32(p + 8, N0.z);
-                    st_f32(p + 12, CA0.x); st_f32(p + 16, CA0.y); st_f32(p + 20, CA0.z);
-                    st_f32(p + 24, C0.x); st_f32(p + 28, C0.y); st_f32(p + 32, C0.z);
-                    st_u32(rec + RL.o_aidx + 4 * slot, k);
-                }
-            }
-            if (keep_first_angle && k == 0)
-                a_arr[3 * R + (n - 1)] = bond_angle_deg(tile_atom(L, 0, 0), tile_atom(L, 0, 1), tile_atom(L, 0, 2));
-        }
-        PH_MARK(4)
-
-        // ---- the flat work list of the tile ----
-        // items [0,3W): backbone dihedrals (q = item / W: psi, omega, phi), [3W,6W): backbone bond angles
-        // (ca_c_n, c_n_ca, n_ca_c), then the side-chain dihedrals. W = residue windows of the tile (k < n-1).
-        // Every item is "angle between two vectors": for a dihedral the two plane normals (getTorsionFromXYZ,
-        // reference src/torsion_angle.cpp:50-94), for a bond angle the two bond vectors (angle(),
-        // src/float3d.h:55-65; getBondAngles src/nerf.cpp:495-508); getCosineTheta + acos is one shared path.
-        const uint32_t W = (base + T <= m) ? T : (m > base ? m - base : 0);
-        const uint32_t n_items = 6 * W + tile_sc;
-        for (uint32_t t0 = 0; t0 < n_items; t0 += WAVE) {
-            const uint32_t t = t0 + lane;
-            if (t >= n_items) continue;
-            uint32_t rA, sA, rB, sB, rC, sC, rD, sD;   // (residue in tile, slot) of the 4 (3) points
-            bool is_dih;
-            uint32_t dest;       // backbone: arr * 64 + residue in tile; side chain: byte index in the tile
-            const bool is_bb = t < 6 * W;
-            if (is_bb) {
-                is_dih = t < 3 * W;
-                const uint32_t tt = is_dih ? t : t - 3 * W;
-                const uint32_t q = (tt >= 2 * W) ? 2u : (tt >= W ? 1u : 0u);
-                const uint32_t res = tt - q * W;
-                const uint32_t g0 = is_dih ? q : q + 1;           // first backbone atom of the window (0=N0 .. 5=C1)
-                rA = res + (g0 >= 3 ? 1u : 0u);     sA = g0 >= 3 ? g0 - 3 : g0;
-                rB = res + (g0 + 1 >= 3 ? 1u : 0u); sB = g0 + 1 >= 3 ? g0 - 2 : g0 + 1;
-                rC = res + (g0 + 2 >= 3 ? 1u : 0u); sC = g0 + 2 >= 3 ? g0 - 1 : g0 + 2;
-                rD = res + 1u;                       sD = g0;         // atom g0+3 (dihedrals only)
-                // psi, omega, phi -> arrays 1, 2, 0 (split src/foldcomp.cpp:488-492);
-                // ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3 (split :497-505)
-                const uint32_t arr = is_dih ? ((q == 0) ? 1u : (q == 1 ? 2u : 0u)) : ((q == 0) ? 4u : (q == 1 ? 5u : 3u));
-                dest = arr * WAVE + res;
-            } else {
-                // calculateTorsionAnglesInResidue, reference src/sidechain.cpp:149-168
-                is_dih = true;
-                const uint32_t ts = t - 6 * W;
-                const uint32_t res = L.item_res[ts];
-                const uint32_t j = 3 + ts - L.scpre[res];
-                const uint32_t pk = s_prev[L.rc[res]][j];
-                rA = rB = rC = rD = res;
-                sA = pk & 15u; sB = (pk >> 4) & 15u; sC = (pk >> 8) & 15u; sD = j;
-                dest = ts;
-            }
-            const v3 a = tile_atom(L, rA, sA), b = tile_atom(L, rB, sB), cc = tile_atom(L, rC, sC);
-            v3 va, vb, d2;
-            v3 u1{0.f, 0.f, 0.f}, u2 = u1;
-            if (is_dih) {
-                const v3 d = tile_atom(L, rD, sD);
-                const v3 d1 = vsub(b, a);
-                d2 = vsub(cc, b);
-                const v3 d3 = vsub(d, cc);
-                u1 = vcross(d1, d2); u2 = vcross(d2, d3);
-                va = u1; vb = u2;
-            } else {
-                va = vsub(a, b); vb = vsub(cc, b);
-                d2 = va;
-            }
-            const float ct = vcos_theta(va, vb);
-            float v = acos_deg(ct);
-            if (is_dih) {
-                if (v != v) v = (ct < 0.0f) ? 180.0f : 0.0f;   // isnan(acos) guard, src/torsion_angle.cpp:77-84
-                const v3 w = vcross(u2, d2);
-                if ((u1.x * w.x) + (u1.y * w.y) + (u1.z * w.z) < 0.0f) v = -1.0f * v;
-            }
-            if (is_bb) (&L.out_bb[0][0])[dest] = v;
-            else L.out_sc[dest] = (uint8_t)quant_trunc(v, sc_min, sc_disc);   // src/foldcomp.cpp:532-538
-        }
-        // ---- flush the tile's results: 6 coalesced float stores + the side-chain bytes as (unaligned) dwords.
-        //      No global store inside the item loop keeps the wave's VMEM queue short, so the wait for the
-        //      prefetched next tile never has to drain stores.
-        __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < W) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) a_arr[(size_t)q * R + base + lane] = L.out_bb[q][lane];
-        }
-        {
-            uint8_t* dstp = rec + RL.o_sc + sc_base;
-            const uint32_t nd = tile_sc >> 2;
-#pragma unroll
-            for (int u = 0; u < 3; u++) {
-                const uint32_t d = u * WAVE + lane;
-                if (d < nd) st_u32(dstp + 4 * d, *reinterpret_cast<const uint32_t*>(&L.out_sc[4 * d]));
-            }
-            const uint32_t tail = tile_sc & 3u;
-            if ((uint32_t)lane < tail) dstp[4 * nd + lane] = L.out_sc[4 * nd + lane];
-        }
-        sc_base += tile_sc;
-        last_cnt = cnt;
-        base = base_next;
-        cur = nxt;
-        PH_MARK(5)
-        __builtin_amdgcn_wave_barrier();
-        PH_MARK(6)
-        if (!have_next) break;
+        uint8_t* q = rec + RL.o_anchor + 36 * sl;
+        st_f32(q, p[0].x); st_f32(q + 4, p[0].y); st_f32(q + 8, p[0].z);
+        st_f32(q + 12, p[1].x); st_f32(q + 16, p[1].y); st_f32(q + 20, p[1].z);
+        st_f32(q + 24, p[2].x); st_f32(q + 28, p[2].y); st_f32(q + 32, p[2].z);
+        st_u32(rec + RL.o_aidx + 4 * sl, k);
+        if (keep_first_angle && sl == 0) a_arr[3 * R + (n - 1)] = bond_angle_deg(p[0], p[1], p[2]);
     }
-    __threadfence_block();
 
     // ---- per-chain quantiser parameters (Discretizer::Discretizer src/discretizer.cpp:22-33), then the
     //      packed words (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52) + B-factor bytes ----
@@ -483,19 +537,8 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane); lo = e.lo; hi = e.hi; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
     };
-    constexpr int U = 8;
-    if (n <= (uint32_t)(U * WAVE)) {
-        // everything of the chain in registers: one batch of loads, no reload for the quantisation pass
-        float va[7][U];
-        uint32_t rcs[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t k = u * WAVE + lane;
-#pragma unroll
-            for (int q = 0; q < 6; q++) va[q][u] = (k < m) ? a_arr[(size_t)q * R + k] : 0.0f;
-            va[6][u] = (k < n) ? in.bfac_ca[r0 + k] : 0.0f;
-            rcs[u] = (k < n) ? in.res_code[r0 + k] : 0u;
-        }
+    if (small) {
+        // everything of the chain is in registers already: no reload for the quantisation pass
 #pragma unroll
         for (int q = 0; q < 7; q++) {
             float lo = kInf, hi = -kInf;
@@ -512,6 +555,7 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         for (int u = 0; u < U; u++) {
             const uint32_t k = u * WAVE + lane;
             if (k < n) pack_store(k, rcs[u], va[0][u], va[1][u], va[2][u], va[3][u], va[4][u], va[5][u], va[6][u]);
+            __builtin_amdgcn_sched_barrier(0);   // one word at a time: interleaving all of them only inflates the live set
         }
     } else {
         for (int q = 0; q < 7; q++) {
@@ -519,18 +563,16 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
             const float* src = (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0);
             const uint32_t cntq = (q < 6) ? m : n;
             for (uint32_t k0 = 0; k0 < cntq; k0 += U * WAVE) {
-                float t[U];
+                float tv[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) { const uint32_t k = k0 + u * WAVE + lane; t[u] = (k < cntq) ? src[k] : 0.0f; }
+                for (int u = 0; u < U; u++) { const uint32_t k = k0 + u * WAVE + lane; tv[u] = (k < cntq) ? src[k] : 0.0f; }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const bool on = k0 + u * WAVE + lane < cntq;
-                    lo = __builtin_fminf(lo, on ? t[u] : kInf); hi = __builtin_fmaxf(hi, on ? t[u] : -kInf);
+                    lo = __builtin_fminf(lo, on ? tv[u] : kInf); hi = __builtin_fmaxf(hi, on ? tv[u] : -kInf);
                 }
             }
-            float lo_w = wave_min_f32(lo), hi_w = wave_max_f32(hi);
-            if (__builtin_expect(lo_w == 0.0f || hi_w == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane); lo_w = e.lo; hi_w = e.hi; }
-            qmin[q] = lo_w; qdisc[q] = nbins[q] / (hi_w - lo_w); qcont[q] = (hi_w - lo_w) / nbins[q];
+            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), src, cntq);
         }
         for (uint32_t k = lane; k < n; k += WAVE) {
             const bool w = k < m;
@@ -539,7 +581,6 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         }
     }
 
-    PH_MARK(7)
     for (uint32_t i = lane; i < title_len; i += WAVE) rec[RL.o_title + i] = (uint8_t)in.titles[in.title_off[c] + i];
 
     // ---- header (CompressedFileHeader src/foldcomp.h:118-136; get_header src/foldcomp.cpp:1340) ----
@@ -560,20 +601,18 @@ void k_compress_tiled(fcz_chain_batch in, const uint64_t* __restrict__ out_off, 
         st_u32(h + 20, title_len);
 #pragma unroll
         for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, qmin[q]); st_f32(h + 48 + 4 * q, qcont[q]); }
-        // OXT (src/foldcomp.cpp:474-482): the last atom of the span, still parked in LDS from the final tile
-        const float4 la = L.atom[last_cnt - 1];
-        const bool has_oxt = __float_as_uint(la.w) == FCZ_ATOM_OXT;
+        // OXT (src/foldcomp.cpp:474-482): the last atom of the span
+        const uint32_t la = a_end - 1;
+        const bool has_oxt = a_end > a_first && in.atom_code[la] == FCZ_ATOM_OXT;
         uint8_t* o = rec + RL.o_oxt;
         o[0] = has_oxt ? 1 : 0;
-        st_f32(o + 1, has_oxt ? la.x : 0.0f);
-        st_f32(o + 5, has_oxt ? la.y : 0.0f);
-        st_f32(o + 9, has_oxt ? la.z : 0.0f);
+        st_f32(o + 1, has_oxt ? in.x[la] : 0.0f);
+        st_f32(o + 5, has_oxt ? in.y[la] : 0.0f);
+        st_f32(o + 9, has_oxt ? in.z[la] : 0.0f);
         st_f32(rec + RL.o_tmp, qmin[6]);
         st_f32(rec + RL.o_tmp + 4, qcont[6]);
         if (status) status[c] = FCZ_OK;
     }
-    PH_MARK(8)
-    PH_FLUSH
 }
 
 }  // namespace fcz

@@ -38,7 +38,11 @@ for f in glob.glob(os.path.join(src, "**", "*.csv"), recursive=True):
 PY
   rm -rf /tmp/rp_$name
 }
-if [ -z "${PMC_ONLY:-}" ]; then run stats --kernel-trace --stats; fi
+if [ -z "${PMC_ONLY:-}" ]; then
+  run stats --kernel-trace --stats
+  # the same trace for the default bench command (1 M chains), the line the driver records
+  if [ -n "${FULL_STATS:-}" ]; then SAVE_ARGS=$ARGS; ARGS="--cpu-sample 0"; run stats_full --kernel-trace --stats; ARGS=$SAVE_ARGS; fi
+fi
 # PMC passes: counters only (no trace domains besides kernel dispatch), one group per pass
 run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --kernel-include-regex "fcz" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU

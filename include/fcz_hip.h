@@ -135,8 +135,7 @@ int fcz_compress_batch(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* 
                        uint8_t* out, int32_t* status);
 
 /* Device-resident variant: every pointer inside `in`, plus out_off/out/status, is a device pointer
- * (titles included). Work is enqueued on the ctx stream; no host synchronisation. `max_chain_res`
- * is an upper bound of residues per chain (sizing of per-lane work), 0 = unknown (library scans). */
+ * (titles included). Work is enqueued on the ctx stream; no host synchronisation. */
 int fcz_compress_sizes_dev(fcz_ctx* ctx, const fcz_chain_batch* in, uint64_t* out_off_dev);
 int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off_dev,
                            uint8_t* out_dev, int32_t* status_dev);
@@ -176,7 +175,8 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
- * group since the last reset: "compress", "decompress_backbone", "decompress_sidechain", ... */
+ * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
+ * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

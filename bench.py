@@ -48,16 +48,22 @@ def parse_args():
     ap.add_argument("--gen-chunk", type=int, default=32768)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="chains timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4] stand-in: log-normal chain lengths (mu = ln 250, sigma = 0.6, clipped to [16, 2700]) "
+                         "instead of the fixed --residues; not the headline workload")
     return ap.parse_args()
 
 
-def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base):
+def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base, mixed=False):
     """build the rank's batch on the GPU chunk by chunk -> dict of device tensors (fcz_chain_batch layout)"""
     parts = []
     done = 0
+    if mixed:
+        chunk = min(chunk, 2048)   # the generator is dense in [chains, longest chain]
     while done < n_chains:
         c = min(chunk, n_chains - done)
-        parts.append(synthetic.generate(c, n_res, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
+        lens = synthetic.mixed_lengths(c, seed=seed_base + done + 7) if mixed else n_res
+        parts.append(synthetic.generate(c, lens, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
                                         first_chain_id=seed_base + done))
         done += c
     if len(parts) == 1:
@@ -190,7 +196,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     C, n_res = args.chains, args.residues
-    d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C)
+    d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C, mixed=args.mixed)
     R, M = int(d["res_off"][-1]) & 0xFFFFFFFF, int(d["atom_off"][-1]) & 0xFFFFFFFF
     codec = Codec(local)
     lib = codec.lib
@@ -286,7 +292,7 @@ def main():
         dom = max(kern, key=lambda k: kern[k][1])
         by, ms = kern[dom]
         ach = by / (ms * 1e-3) / 1e9 if ms else 0.0
-        traffic, traffic_src = measured_traffic(dom, R, n_res)
+        traffic, traffic_src = measured_traffic(dom, R, -1 if args.mixed else n_res)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
@@ -311,8 +317,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 + u8 bitpack",
             "data": "synthetic",
-            "config": {"workload": f"{C} synthetic {n_res}-residue chains per GPU, compress+decompress, anchor -b {args.anchor}",
-                       "chains_per_gpu": C, "residues_per_chain": n_res, "atoms_per_residue": round(A, 3),
+            "config": {"workload": (f"{C} synthetic mixed-length chains per GPU (log-normal, mean {R / C:.0f} residues), "
+                                    if args.mixed else f"{C} synthetic {n_res}-residue chains per GPU, ")
+                                   + f"compress+decompress, anchor -b {args.anchor}",
+                       "chains_per_gpu": C, "residues_per_chain": round(R / C, 1) if args.mixed else n_res, "atoms_per_residue": round(A, 3),
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,

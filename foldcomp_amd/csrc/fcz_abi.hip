@@ -75,6 +75,7 @@ struct fcz_ctx {
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
     dev_buf wring;      // decompress: per-group ring of the segment's packed words
     dev_buf bb;         // decompress: blended backbone
+    dev_buf len_perm;   // decompress: entries ordered by residue count (n u32) + bucket counters (2 x LEN_BUCKETS + 1)
     dev_buf res_aoff;   // decompress: residue -> first output atom
     dev_buf res_rc;     // decompress: residue -> residue code
     dev_buf res_sc;     // decompress: residue -> its side-chain torsion bytes, 3 x R dwords
@@ -190,7 +191,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->res_rc.release(); c->res_sc.release();
+    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->len_perm.release(); c->res_rc.release(); c->res_sc.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -418,6 +419,18 @@ int fcz_check(const uint8_t* e, uint64_t len) {
     return 0;
 }
 
+// entries ordered by residue count for k_backbone (counting sort: histogram, scan, scatter); cnt_res = per-entry counts
+static int build_len_perm(fcz_ctx* ctx, const uint32_t* cnt_res, uint32_t n) {
+    int rc = ctx->len_perm.ensure(sizeof(uint32_t) * ((size_t)n + 2 * LEN_BUCKETS + 2)); if (rc) return rc;
+    if (!n) return FCZ_OK;
+    uint32_t* perm = ctx->len_perm.as<uint32_t>(); uint32_t* hist = perm + n; uint32_t* cursor = hist + LEN_BUCKETS;
+    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(uint32_t) * LEN_BUCKETS, ctx->stream));
+    hipLaunchKernelGGL(k_len_sort, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, cnt_res, n, hist, perm, 0);
+    if ((rc = device_scan<uint32_t>(ctx, hist, cursor, LEN_BUCKETS))) return rc;
+    hipLaunchKernelGGL(k_len_sort, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, cnt_res, n, cursor, perm, 1);
+    return FCZ_OK;
+}
+
 int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
                              uint32_t* res_off_dev, uint32_t* atom_off_dev, uint32_t* total_res, uint32_t* total_atoms) {
     if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev) return FCZ_E_INVALID_ARG;
@@ -434,6 +447,7 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
         if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
         if ((rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
         if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
+        if ((rc = build_len_perm(ctx, cr, n))) return rc;
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -468,6 +482,7 @@ static int ensure_segments(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t
     rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     if ((rc = device_scan<uint32_t>(ctx, cr, ctx->stage[16].as<uint32_t>(), n))) return rc;
     if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
+    if ((rc = build_len_perm(ctx, cr, n))) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], ctx->stage[16].as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -496,7 +511,7 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     {
         span_guard g(ctx, "decompress_backbone");
         hipLaunchKernelGGL(k_backbone, dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
-                           ctx->fwd.as<v3>(), ctx->wring.as<uint64_t>(), ring_rows, ctx->bb.as<v3>());
+                           ctx->len_perm.as<uint32_t>(), ctx->fwd.as<v3>(), ctx->wring.as<uint64_t>(), ring_rows, ctx->bb.as<v3>());
     }
     rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
     rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;

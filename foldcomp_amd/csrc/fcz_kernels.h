@@ -311,6 +311,39 @@ __device__ __forceinline__ bb_word decode_word(uint64_t raw, const bb_params& P)
     return r;
 }
 
+// ---- chains ordered by length (longest first) for the lane = chain kernel ---------------------------------------
+// k_backbone walks 64 chains per wavefront in lock step, so a wavefront lasts as long as its longest chain. A counting
+// sort on the residue count (16-residue buckets, descending) puts chains of similar length into the same wavefront and
+// dispatches the long ones first; with a uniform batch it degenerates to blocks of 64 consecutive chains. One atomic
+// per distinct bucket per wavefront (a contended atomic per chain would serialise at ~88 per microsecond).
+constexpr int LEN_BUCKETS = 4096;
+__device__ __forceinline__ uint32_t len_bucket(uint32_t n_res) {
+    const uint32_t b = n_res >> 4;
+    return (uint32_t)LEN_BUCKETS - 1u - (b < (uint32_t)LEN_BUCKETS ? b : (uint32_t)LEN_BUCKETS - 1u);
+}
+// mode 0: hist[bucket] += 1 per chain; mode 1: perm[cursor[bucket]++] = chain
+__global__ __launch_bounds__(BLOCK) void k_len_sort(const uint32_t* __restrict__ cnt_res, uint32_t n, uint32_t* __restrict__ counter,
+                                                    uint32_t* __restrict__ perm, int mode) {
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool act = c < n;
+    const uint32_t b = act ? len_bucket(cnt_res[c]) : 0xffffffffu;
+    unsigned long long todo = __ballot(act);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t b0 = __shfl(b, leader, WAVE);
+        const unsigned long long same = __ballot(act && b == b0) & todo;
+        if (act && b == b0 && ((todo >> lane) & 1ull)) {
+            const uint32_t rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&counter[b0], (uint32_t)__builtin_popcountll(same));
+            base = __shfl(base, leader, WAVE);
+            if (mode) perm[base + rank] = c;
+        }
+        todo &= ~same;
+    }
+}
+
 #ifndef FCZ_BACKBONE_MIN_WAVES
 #define FCZ_BACKBONE_MIN_WAVES 2
 #endif
@@ -333,11 +366,12 @@ struct backbone_lds {
 
 __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries,
-        const uint32_t* __restrict__ res_off, v3* __restrict__ ring, uint64_t* __restrict__ wring, uint32_t ring_rows,
-        v3* __restrict__ bb) {
+        const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ perm, v3* __restrict__ ring,
+        uint64_t* __restrict__ wring, uint32_t ring_rows, v3* __restrict__ bb) {
     __shared__ backbone_lds S;
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * WAVE + lane;
+    const uint32_t slot = blockIdx.x * WAVE + lane;
+    const uint32_t c = slot < n_entries ? perm[slot] : n_entries;   // chains grouped by length, longest first
     const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
     v3* Rg = ring + (size_t)blockIdx.x * ring_rows * WAVE + lane;            // atom row j at Rg[j * WAVE]
     uint64_t* Wg = wring + (size_t)blockIdx.x * (ring_rows / 3) * WAVE + lane;   // word row i at Wg[i * WAVE]

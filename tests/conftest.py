@@ -25,6 +25,11 @@ def golden():
 @pytest.fixture(scope="session")
 def codec():
     """The HIP codec on cuda:0. Fails (not skips) when the extension is missing on a GPU box."""
+    # torch first: its wheel bundles its own HIP runtime, which only finds the GPU if it initialises before the
+    # system runtime that libfcz_hip.so links (tests that build inputs on the device need both in one process)
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     from foldcomp_amd.codec import Codec
     c = Codec(0)
     yield c

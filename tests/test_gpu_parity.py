@@ -108,3 +108,51 @@ def test_invalid_chain_reports_status(codec, golden):
     blob, off, st = codec.compress_batch(b, strict=False)
     assert st[0] == -6
     assert not blob.any()
+
+
+def test_device_resident_entry_points_vs_oracle(codec):
+    """the *_dev entry points on device buffers (the calls bench.py times): sizes -> compress -> sizes -> decompress,
+    mixed lengths incl. chains longer than the register path of the pack kernel; results against the oracle"""
+    import ctypes
+    import torch
+    from foldcomp_amd import _lib, synthetic
+    from foldcomp_amd.structure import CAtomsOut
+    import bench
+    lens = [350] * 70 + [2, 5, 64, 65, 383, 384, 385, 700, 1100, 40, 41, 16] + list(synthetic.mixed_lengths(60, seed=3))
+    d = synthetic.generate(len(lens), lens, seed=777, device="cuda:0")
+    C = len(lens)
+    R, M = int(d["res_off"][-1]), int(d["atom_off"][-1])
+    lib = codec.lib
+    cb = bench.c_batch(d)
+    off_dev = torch.zeros(C + 1, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    _lib.check(lib.fcz_compress_sizes_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr()), "sizes")
+    codec.synchronize()
+    blob_dev = torch.zeros(int(off_dev[-1]), dtype=torch.uint8, device="cuda:0")
+    st_dev = torch.full((C,), -99, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    _lib.check(lib.fcz_compress_batch_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr(), blob_dev.data_ptr(), st_dev.data_ptr()), "compress")
+    codec.synchronize()
+    hb = synthetic.to_chain_batch(d)
+    oblob, ooff, ost = H.oracle_compress(hb, n_threads=8)
+    assert (st_dev.cpu().numpy() == 0).all() and (ost == 0).all()
+    assert np.array_equal(off_dev.cpu().numpy().astype(np.uint64), ooff)
+    assert blob_dev.cpu().numpy().tobytes() == oblob.tobytes()
+    for rep in range(2):   # second pass: sizes cache of the ctx is reused / refreshed
+        res_off = torch.zeros(C + 1, dtype=torch.int32, device="cuda:0"); atom_off = torch.zeros(C + 1, dtype=torch.int32, device="cuda:0")
+        out = {k: torch.zeros(M + 1, dtype=torch.float32, device="cuda:0") for k in ("x", "y", "z")}
+        bf = torch.zeros(R, dtype=torch.float32, device="cuda:0"); rcod = torch.zeros(R, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        tr = ctypes.c_uint32(); ta = ctypes.c_uint32()
+        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off.data_ptr(), atom_off.data_ptr(),
+                                                ctypes.byref(tr), ctypes.byref(ta)), "dsizes")
+        assert tr.value == R and ta.value == M
+        cout = CAtomsOut(out["x"].data_ptr(), out["y"].data_ptr(), out["z"].data_ptr(), bf.data_ptr(), rcod.data_ptr(), None)
+        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off.data_ptr(), atom_off.data_ptr(),
+                                                0, ctypes.byref(cout)), "decompress")
+        codec.synchronize()
+        o = H.oracle_decompress(oblob, ooff, n_threads=8)
+        for k in ("x", "y", "z"):
+            assert np.array_equal(_bits(out[k][:M].cpu().numpy()), _bits(o[k])), (rep, k)
+        assert np.array_equal(_bits(bf.cpu().numpy()), _bits(o["bfac_res"]))
+        assert np.array_equal(rcod.cpu().numpy(), o["res_code"])

@@ -115,15 +115,15 @@ def decompress_many(entries: Sequence[bytes], *, alt_order: bool = False, codec:
     off = np.zeros(len(entries) + 1, np.uint64)
     off[1:] = np.cumsum([len(e) for e in entries])
     blob = np.frombuffer(b"".join(entries), np.uint8) if entries else np.zeros(0, np.uint8)
-    d = c.decompress_batch(blob, off, alt_order=alt_order)
+    texts, status = c.decompress_pdb(blob, off, alt_order=alt_order)   # reconstruction and PDB text both on the device
     out = []
     for i, e in enumerate(entries):
-        if d["info"][i].status != 0:
+        if status[i] != 0:
             if skip_bad:
                 out.append(None); continue
             raise error("Error decompressing.")
         rec = fczfile.parse(e)
-        out.append((rec.title, _pdb_from_result(rec, d, i, alt_order)))
+        out.append((rec.title, texts[i].decode("latin-1")))
     return out
 
 

@@ -102,6 +102,20 @@ class Codec:
                        "fcz_decompress_batch")
         return dict(x=x, y=y, z=z, bfac_res=bf, res_code=rc, atom_code=ac, res_off=res_off, atom_off=atom_off, info=info)
 
+    def decompress_pdb(self, blob: np.ndarray, off: np.ndarray, alt_order: bool = False):
+        """FCZ entries -> (list of PDB texts as bytes, per-entry status); decoding and text formatting both on the GPU"""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        text_off = np.zeros(n + 1, np.uint64)
+        status = np.zeros(max(n, 1), np.int32)
+        _lib.check(self.lib.fcz_decompress_pdb_begin(self.ctx, blob.ctypes.data, off.ctypes.data, n, int(alt_order),
+                                                     text_off.ctypes.data, status.ctypes.data), "fcz_decompress_pdb_begin")
+        text = np.zeros(int(text_off[-1]), np.uint8)
+        _lib.check(self.lib.fcz_decompress_pdb_fetch(self.ctx, text.ctypes.data if len(text) else None), "fcz_decompress_pdb_fetch")
+        raw = text.tobytes()
+        return [raw[int(text_off[i]):int(text_off[i + 1])] for i in range(n)], status[:n]
+
     # ---- timing ---------------------------------------------------------------------------------
     def enable_timing(self, on: bool = True):
         self.lib.fcz_ctx_enable_timing(self.ctx, int(on))

@@ -14,6 +14,7 @@
 #include "fcz_kernels.h"
 #include "fcz_compress.h"
 #include "fcz_sidechain.h"
+#include "fcz_pdb.h"
 
 // second, host-side instance of the generated tables (integer metadata for sizes/validation)
 namespace host_tab {
@@ -81,6 +82,8 @@ struct fcz_ctx {
     dev_buf res_sc;     // decompress: residue -> its side-chain torsion bytes, 3 x R dwords
     // staging for the host-pointer entry points
     dev_buf stage[20];
+    dev_buf pdb_size, pdb_off, pdb_text;   // PDB text: per-entry sizes, offsets (n+1 u64), the text of the last begin() call
+    uint64_t pdb_bytes = 0;
     uint32_t* pinned = nullptr;  // 4 words
     int n_cu = 256;
     bool timing = false;
@@ -191,7 +194,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->len_perm.release(); c->res_rc.release(); c->res_sc.release();
+    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -204,6 +207,93 @@ int fcz_ctx_synchronize(fcz_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FCZ_OK;
 }
+// ------------------------------------------------------------------------------------------------
+// PDB text of decompressed chains (writeAtomCoordinatesToPDB, reference src/atom_coordinate.cpp:220-291)
+// ------------------------------------------------------------------------------------------------
+int fcz_pdb_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, const uint32_t* res_off_dev,
+                      const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev, uint64_t* text_off_dev) {
+    if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev || !atoms_dev || !text_off_dev) return FCZ_E_INVALID_ARG;
+    if (!atoms_dev->x || !atoms_dev->y || !atoms_dev->z || !atoms_dev->bfac_res || !atoms_dev->res_code) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->pdb_size.ensure(sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    span_guard g(ctx, "pdb_sizes");
+    if (n) hipLaunchKernelGGL(k_pdb_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
+                              res_off_dev, atom_off_dev, *atoms_dev, ctx->pdb_size.as<uint64_t>());
+    if ((rc = device_scan<uint64_t>(ctx, ctx->pdb_size.as<uint64_t>(), text_off_dev, n))) return rc;
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+int fcz_pdb_format_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, const uint32_t* res_off_dev,
+                       const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev, int alt_order, const uint64_t* text_off_dev,
+                       uint8_t* text_dev) {
+    if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev || !atoms_dev || !text_off_dev || !text_dev) return FCZ_E_INVALID_ARG;
+    if (!atoms_dev->x || !atoms_dev->y || !atoms_dev->z || !atoms_dev->bfac_res || !atoms_dev->res_code) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return FCZ_OK;
+    span_guard g(ctx, "pdb_format");
+    hipLaunchKernelGGL(k_pdb_format, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
+                       atom_off_dev, *atoms_dev, alt_order, text_off_dev, text_dev);
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+// Host-pointer convenience: FCZ entries in, PDB text out, everything in between on the device. begin() leaves the text in
+// the ctx and reports the per-entry text offsets; fetch() copies it out.
+int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order, uint64_t* text_off,
+                             int32_t* status) {
+    if (!ctx || !blob || !off || !text_off) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->pdb_bytes = 0;
+    ctx->sizes_fresh = false;   // the staging buffers the cache is keyed on are about to be rewritten
+    if (n == 0) { text_off[0] = 0; return FCZ_OK; }
+    const uint64_t blob_bytes = off[n];
+    int rc;
+    if ((rc = ctx->stage[0].ensure(std::max<uint64_t>(blob_bytes, 16)))) return rc;
+    if ((rc = ctx->stage[1].ensure(sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ctx->stage[2].ensure(sizeof(uint32_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ctx->stage[3].ensure(sizeof(uint32_t) * ((size_t)n + 1)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->stage[0].p, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[1].p, off, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t R = 0, M = 0;
+    rc = fcz_decompress_sizes_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
+                                  ctx->stage[3].as<uint32_t>(), &R, &M);
+    if (rc) return rc;
+    if (status) {   // per-entry status of the sizes pass (cnt layout: 3 x n counts, then n status words)
+        HIP_TRY(hipMemcpyAsync(status, ctx->cnt.as<uint32_t>() + 3 * (size_t)n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (int i = 4; i < 7; i++) if ((rc = ctx->stage[i].ensure(std::max<size_t>(sizeof(float) * (size_t)M, 16)))) return rc;
+    if ((rc = ctx->stage[7].ensure(std::max<size_t>(sizeof(float) * (size_t)R, 16)))) return rc;
+    if ((rc = ctx->stage[8].ensure(std::max<size_t>((size_t)R, 16)))) return rc;
+    fcz_atoms_out dv;
+    dv.x = ctx->stage[4].as<float>(); dv.y = ctx->stage[5].as<float>(); dv.z = ctx->stage[6].as<float>();
+    dv.bfac_res = ctx->stage[7].as<float>(); dv.res_code = ctx->stage[8].as<uint8_t>(); dv.atom_code = nullptr;
+    if ((rc = ctx->pdb_off.ensure(sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if (R) {
+        rc = fcz_decompress_batch_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
+                                      ctx->stage[3].as<uint32_t>(), alt_order, &dv);
+        if (rc) return rc;
+    }
+    ctx->sizes_fresh = false;
+    rc = fcz_pdb_sizes_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
+                           ctx->stage[3].as<uint32_t>(), &dv, ctx->pdb_off.as<uint64_t>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(text_off, ctx->pdb_off.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->pdb_bytes = text_off[n];
+    if ((rc = ctx->pdb_text.ensure(std::max<uint64_t>(ctx->pdb_bytes, 16)))) return rc;
+    return fcz_pdb_format_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
+                              ctx->stage[3].as<uint32_t>(), &dv, alt_order, ctx->pdb_off.as<uint64_t>(), ctx->pdb_text.as<uint8_t>());
+}
+
+int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out) {
+    if (!ctx || (!text_out && ctx->pdb_bytes)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->pdb_bytes) HIP_TRY(hipMemcpyAsync(text_out, ctx->pdb_text.p, ctx->pdb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}
+
 int fcz_ctx_enable_timing(fcz_ctx* c, int enable) { if (!c) return FCZ_E_INVALID_ARG; drain_spans(c); c->timing = enable != 0; return FCZ_OK; }
 void fcz_ctx_reset_timing(fcz_ctx* c) { if (!c) return; drain_spans(c); c->acc.clear(); }
 int fcz_ctx_kernel_time(fcz_ctx* c, const char* name, double* ms, uint64_t* launches) {
@@ -537,6 +627,7 @@ int fcz_decompress_batch(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off,
                          const uint32_t* atom_off, int alt_order, const fcz_atoms_out* out) {
     if (!ctx || !blob || !off || !res_off || !atom_off || !out) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    ctx->sizes_fresh = false;   // the staging buffers the cache is keyed on are about to be rewritten
     if (n == 0) return FCZ_OK;
     const uint64_t blob_bytes = off[n];
     const uint32_t R = res_off[n], M = atom_off[n];

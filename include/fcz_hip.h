@@ -168,6 +168,25 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
                              const uint32_t* res_off_dev, const uint32_t* atom_off_dev, int alt_order,
                              const fcz_atoms_out* out_dev);
 
+/* ---- PDB text -------------------------------------------------------------------------------- */
+/* The text `foldcomp decompress` writes for every entry (writeAtomCoordinatesToPDB, src/atom_coordinate.cpp:220-291,
+ * called from src/main.cpp:625-637 and foldcomp/foldcomp.cxx:224-250): TITLE records wrapped at 70 columns, one
+ * 81-byte ATOM record per atom (numbers by fast_ftoa<1000,3> / <100,2>, :185-218; printf widens a column that
+ * overflows), one TER record. Inputs: the same FCZ entries plus the arrays fcz_decompress_batch_dev filled
+ * (x, y, z, bfac_res, res_code required); everything else comes from the entry headers.
+ * fcz_pdb_sizes_dev: exclusive prefix of the exact text sizes in text_off_dev[n+1] (bytes; skipped entries: 0). */
+int fcz_pdb_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                      const uint32_t* res_off_dev, const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev,
+                      uint64_t* text_off_dev);
+int fcz_pdb_format_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                       const uint32_t* res_off_dev, const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev,
+                       int alt_order, const uint64_t* text_off_dev, uint8_t* text_dev);
+/* Host-pointer convenience: FCZ entries -> PDB text with every stage on the device. begin() fills text_off[n+1]
+ * (host) and status[n] (may be NULL) and keeps the text in the ctx; fetch() copies text_off[n] bytes out. */
+int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order,
+                             uint64_t* text_off, int32_t* status);
+int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
+
 /* ---- check -------------------------------------------------------------------------------- */
 /* Foldcomp::checkValidity (src/foldcomp.cpp:1492-1532) on one entry; returns the reference's
  * ValidityError value (0 = SUCCESS .. 6) or a negative fcz_status if the entry cannot be read. */
@@ -176,7 +195,7 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
  * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
- * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain". */
+ * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

@@ -1,0 +1,74 @@
+"""GPU: PDB text produced on the device (k_pdb_sizes / k_pdb_format) against the reference's own text (goldens) and, for
+column overflows the goldens do not contain, against the host restatement in foldcomp_amd/pdbio.py (itself pinned to the
+goldens in test_host_formats.py)."""
+import numpy as np
+import pytest
+
+from foldcomp_amd import fczfile
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(entries):
+    off = np.zeros(len(entries) + 1, np.uint64)
+    off[1:] = np.cumsum([len(e) for e in entries])
+    return np.frombuffer(b"".join(entries), np.uint8), off
+
+
+def test_pdb_text_equals_reference_for_every_golden(codec, golden):
+    z, index = golden
+    names = [n for n in index if f"{n}/pdb0" in z.files and f"{n}/fcz" in z.files]
+    assert len(names) >= 20
+    entries = [z[f"{n}/fcz"].tobytes() for n in names]
+    blob, off = _blob(entries)
+    texts, status = codec.decompress_pdb(blob, off)
+    assert (status == 0).all()
+    for n, t in zip(names, texts):
+        exp = z[f"{n}/pdb0"].tobytes()
+        assert t == exp, (n, len(t), len(exp), next((i for i in range(min(len(t), len(exp))) if t[i] != exp[i]), None))
+
+
+def _host_text(codec, entries, alt_order=False):
+    from foldcomp_amd.api import _pdb_from_result
+    blob, off = _blob(entries)
+    d = codec.decompress_batch(blob, off, alt_order=alt_order)
+    return [_pdb_from_result(fczfile.parse(e), d, i, alt_order).encode("latin-1") for i, e in enumerate(entries)]
+
+
+def test_pdb_text_column_overflows_and_long_titles(codec):
+    from foldcomp_amd import synthetic
+    from foldcomp_amd.structure import ChainBatch  # noqa: F401
+    lens = [40, 5200, 33, 64, 65, 2]
+    d = synthetic.generate(len(lens), lens, seed=99)
+    b = synthetic.to_chain_batch(d)
+    # chain 0: residue numbers run past 9999; chain 1: atom serials run past 99999; chain 2: coordinates and B-factors
+    # wider than their columns; chain 3: very long title (continuation numbers > 99); chain 4: no title
+    b.first_res_index[0] = 9985
+    b.first_atom_index[1] = 65000
+    a0, a1 = int(b.atom_off[b.res_off[2]]), int(b.atom_off[b.res_off[3]])
+    b.x[a0:a1] += np.float32(20000.0); b.y[a0:a1] -= np.float32(3000.0); b.z[a0:a1] += np.float32(123456.0)
+    b.bfac_ca[b.res_off[2]:b.res_off[3]] = np.linspace(900.0, 1800.0, int(b.res_off[3] - b.res_off[2])).astype(np.float32)
+    titles = [b"t0", b"chain with many atoms", b"far away", bytes((65 + i % 26) for i in range(7300)), b"", b"x" * 70]
+    b.titles = np.frombuffer(b"".join(titles), np.uint8).copy()
+    b.title_off = np.concatenate([[0], np.cumsum([len(t) for t in titles])]).astype(np.uint32)
+    blob, off, st = codec.compress_batch(b)
+    assert (st == 0).all()
+    entries = [blob[off[i]:off[i + 1]].tobytes() for i in range(len(lens))]
+    for alt in (False, True):
+        texts, status = codec.decompress_pdb(blob, off, alt_order=alt)
+        assert (status == 0).all()
+        exp = _host_text(codec, entries, alt_order=alt)
+        for i, (t, e) in enumerate(zip(texts, exp)):
+            assert t == e, (alt, i, len(t), len(e), next((k for k in range(min(len(t), len(e))) if t[k] != e[k]), None))
+    # the overflow cases really are in the data
+    t = texts[0].decode("latin-1")
+    assert any(len(line) > 80 for line in t.split("\n"))
+
+
+def test_pdb_text_skips_bad_entries(codec, golden):
+    z, index = golden
+    good = z["pdb:test_af/fcz"].tobytes()
+    blob, off = _blob([good, b"NOPE" + good[4:], good[:100], good])
+    texts, status = codec.decompress_pdb(blob, off)
+    assert status[0] == 0 and status[3] == 0 and status[1] != 0 and status[2] != 0
+    assert texts[1] == b"" and texts[2] == b"" and texts[0] == texts[3] == z["pdb:test_af/pdb0"].tobytes()

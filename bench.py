@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--gen-chunk", type=int, default=32768)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="chains timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--pdb-sample", type=int, default=65536,
+                    help="chains rendered to PDB text on the device after the timed region (SURVEY §8 f2 leg; 0 = skip)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4] stand-in: log-normal chain lengths (mu = ln 250, sigma = 0.6, clipped to [16, 2700]) "
                          "instead of the fixed --residues; not the headline workload")
@@ -264,6 +266,46 @@ def main():
     for name in ("compress_sizes", "compress_index", "compress_angles", "compress_pack", "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain"):
         ms, n = codec.kernel_time(name)
         ktime[name] = (ms / n) if n else 0.0
+    # ---- §8 f2 leg, outside the timed region: PDB text of the first chains, formatted on the device ----
+    pdb = None
+    if args.pdb_sample and rank == 0:
+        npdb = min(C, args.pdb_sample)
+        text_off = torch.zeros(npdb + 1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.fcz_pdb_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), npdb, res_off_dev.data_ptr(),
+                                         atom_off_dev.data_ptr(), ctypes.byref(cout), text_off.data_ptr()), "pdb sizes")
+        codec.synchronize()
+        tbytes = int(text_off[-1])
+        text_dev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        codec.reset_timing()
+        for _ in range(3):
+            _lib.check(lib.fcz_pdb_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), npdb, res_off_dev.data_ptr(),
+                                             atom_off_dev.data_ptr(), ctypes.byref(cout), text_off.data_ptr()), "pdb sizes")
+            _lib.check(lib.fcz_pdb_format_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), npdb, res_off_dev.data_ptr(),
+                                              atom_off_dev.data_ptr(), ctypes.byref(cout), 0, text_off.data_ptr(), text_dev.data_ptr()), "pdb format")
+        codec.synchronize()
+        ms_s, n_s = codec.kernel_time("pdb_sizes"); ms_f, n_f = codec.kernel_time("pdb_format")
+        ms_s /= max(n_s, 1); ms_f /= max(n_f, 1)
+        n_at = int(atom_off_dev[npdb]) & 0xFFFFFFFF
+        # parity of the first chain against the host restatement of the reference writer (foldcomp_amd/pdbio.py)
+        from foldcomp_amd import fczfile
+        from foldcomp_amd.api import _pdb_from_result
+        e0 = blob_dev[:int(off_dev[1])].cpu().numpy().tobytes()
+        a1, r1 = int(atom_off_dev[1]), int(res_off_dev[1])
+        d0 = {"atom_off": np.asarray([0, a1]), "res_off": np.asarray([0, r1]), "res_code": out_t["res_code"][:r1].cpu().numpy(),
+              "bfac_res": out_t["bfac_res"][:r1].cpu().numpy(), "x": out_t["x"][:a1].cpu().numpy(), "y": out_t["y"][:a1].cpu().numpy(),
+              "z": out_t["z"][:a1].cpu().numpy()}
+        rec = fczfile.parse(e0)
+        from foldcomp_amd._aa_tables import RES_ALT_SLOT, RES_ATOMS, RES_NATOMS
+        ac = np.concatenate([[RES_ATOMS[c][j] for j in range(RES_NATOMS[c])] for c in d0["res_code"]] + [[36]] * (a1 - int(sum(RES_NATOMS[c] for c in d0["res_code"]))))
+        d0["atom_code"] = np.asarray(ac, np.uint8)
+        ok_pdb = text_dev[:int(text_off[1])].cpu().numpy().tobytes() == _pdb_from_result(rec, d0, 0, False).encode("latin-1")
+        pdb = {"chains": npdb, "atoms": n_at, "text_bytes": tbytes, "ms_sizes": round(ms_s, 4), "ms_format": round(ms_f, 4),
+               "write_GBs": round(tbytes / (ms_f * 1e-3) / 1e9, 1) if ms_f else None,
+               "frac_of_hbm_peak": round(tbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_f else None,
+               "atoms_per_s": round(n_at / ((ms_s + ms_f) * 1e-3)) if ms_f else None, "first_chain_equals_host_writer": bool(ok_pdb)}
+        del text_dev
     codec.enable_timing(False)
     bad_status = int((status_dev != 0).sum())
 
@@ -324,7 +366,7 @@ def main():
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pdb_text": pdb,
         }
         print(json.dumps(line))
     if world > 1:

@@ -74,7 +74,7 @@ struct fcz_ctx {
     dev_buf seg_off;    // decompress: (n+1) u32
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
-    dev_buf wring;      // decompress: per-group ring of the segment's packed words
+    dev_buf wring;      // decompress: per-group ring of cos/sin of the segment's torsions
     dev_buf bb;         // decompress: blended backbone
     dev_buf len_perm;   // decompress: entries ordered by residue count (n u32) + bucket counters (2 x LEN_BUCKETS + 1)
     dev_buf res_aoff;   // decompress: residue -> first output atom
@@ -596,12 +596,12 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     const uint32_t groups = grid_for(n, WAVE);
     const uint32_t ring_rows = 3 * (max_seg ? max_seg : 1);
     rc = ctx->fwd.ensure(sizeof(v3) * (size_t)groups * ring_rows * WAVE); if (rc) return rc;
-    rc = ctx->wring.ensure(sizeof(uint64_t) * (size_t)groups * (ring_rows / 3) * WAVE); if (rc) return rc;
+    rc = ctx->wring.ensure(sizeof(float) * 6 * (size_t)groups * (ring_rows / 3) * WAVE); if (rc) return rc;
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     {
         span_guard g(ctx, "decompress_backbone");
         hipLaunchKernelGGL(k_backbone, dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
-                           ctx->len_perm.as<uint32_t>(), ctx->fwd.as<v3>(), ctx->wring.as<uint64_t>(), ring_rows, ctx->bb.as<v3>());
+                           ctx->len_perm.as<uint32_t>(), ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, ctx->bb.as<v3>());
     }
     rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
     rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;

@@ -354,7 +354,8 @@ __global__ __launch_bounds__(BLOCK) void k_len_sort(const uint32_t* __restrict__
 // src/atom_coordinate.cpp:145-163); the next segment starts from the blended last three atoms (:855-857).
 // The forward atoms of the current segment live in a per-group ring [atom][lane] (every lane only ever
 // re-reads its own column, the transposed layout is purely for coalescing: one 768-byte row per step), so the
-// intermediate never makes a strided trip through HBM. bb receives the final backbone (3 atoms per residue,
+// intermediate never makes a strided trip through HBM. A second ring carries cos/sin of the three torsions of every
+// word: the reverse pass places its atoms with the same torsions, so it neither decodes the word nor repeats the trig. bb receives the final backbone (3 atoms per residue,
 // chain-major).
 // window of blended backbone atoms per lane, flushed with wave-cooperative contiguous stores
 constexpr int BW = 16;                      // atoms per lane and window
@@ -367,14 +368,15 @@ struct backbone_lds {
 __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries,
         const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ perm, v3* __restrict__ ring,
-        uint64_t* __restrict__ wring, uint32_t ring_rows, v3* __restrict__ bb) {
+        float* __restrict__ tring, uint32_t ring_rows, v3* __restrict__ bb) {
     __shared__ backbone_lds S;
     const int lane = threadIdx.x;
     const uint32_t slot = blockIdx.x * WAVE + lane;
     const uint32_t c = slot < n_entries ? perm[slot] : n_entries;   // chains grouped by length, longest first
     const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
     v3* Rg = ring + (size_t)blockIdx.x * ring_rows * WAVE + lane;            // atom row j at Rg[j * WAVE]
-    uint64_t* Wg = wring + (size_t)blockIdx.x * (ring_rows / 3) * WAVE + lane;   // word row i at Wg[i * WAVE]
+    // cos/sin of the three torsions of word i at rows 6i .. 6i+5: the reverse pass needs nothing else of the word
+    float* Tg = tring + (size_t)blockIdx.x * (ring_rows / 3) * 6 * WAVE + lane;
     const uint8_t* e = blob + (valid ? off[c] : off[0]);
     entry_view v; v.n = 0; v.n_anchor = 1; v.e = e; v.L = make_layout(0, 0, 0, 0);
     bb_params P{};
@@ -442,12 +444,17 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             if (i + 1 >= len) continue;
             const uint8_t* pf = wp + 16;
             const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
-            Wg[(size_t)i * WAVE] = w_cur;                 // the reverse pass re-reads the word from the ring (coalesced)
             const bb_word w = decode_word(w_cur, P);
-            const v3 N = place_atom(p0, p1, p2, (float)1.3311, w.can, w.psi);
+            float s_psi, c_psi, s_om, c_om, s_phi, c_phi;
+            sincosf_pair(deg2rad(w.psi), &s_psi, &c_psi);
+            sincosf_pair(deg2rad(w.omega), &s_om, &c_om);
+            sincosf_pair(deg2rad(w.phi), &s_phi, &c_phi);
+            float* Tw = Tg + (size_t)(6 * i) * WAVE;
+            Tw[0] = c_psi; Tw[WAVE] = s_psi; Tw[2 * WAVE] = c_om; Tw[3 * WAVE] = s_om; Tw[4 * WAVE] = c_phi; Tw[5 * WAVE] = s_phi;
+            const v3 N = place_atom_d2(p0, p1, p2, nerf_d2_trig((float)1.3311, w.can, c_psi, s_psi));
             const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
-            const v3 CA = place_atom(p1, p2, N, l_nca, w.cna, w.omega);
-            const v3 C = place_atom(p2, N, CA, (float)1.5281, w.nca, w.phi);
+            const v3 CA = place_atom_d2(p1, p2, N, nerf_d2_trig(l_nca, w.cna, c_om, s_om));
+            const v3 C = place_atom_d2(p2, N, CA, nerf_d2_trig((float)1.5281, w.nca, c_phi, s_phi));
             Rg[(size_t)(3 * i + 3) * WAVE] = N; Rg[(size_t)(3 * i + 4) * WAVE] = CA; Rg[(size_t)(3 * i + 5) * WAVE] = C;
             p0 = N; p1 = CA; p2 = C;
             w_cur = w_nxt; w_nxt = w_pre; wp += 8;
@@ -469,22 +476,25 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         // forward atoms f+2, f+1 for f = T-4 are the last-but-one and last-but-two forward atoms = p1, p0
         v3 f2 = p1, f1 = p0;
         int wi0 = len - 2;
-        uint64_t w_raw = 0;
+        float tq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // cos, sin of psi, omega, phi of the current word
         v3 fa{0.f, 0.f, 0.f}, fb = fa, fc = fa;
         if (wi0 >= 0) {
-            w_raw = Wg[(size_t)wi0 * WAVE];
+#pragma unroll
+            for (int u = 0; u < 6; u++) tq[u] = Tg[(size_t)(6 * wi0 + u) * WAVE];
             fa = Rg[(size_t)(3 * wi0 + 2) * WAVE]; fb = Rg[(size_t)(3 * wi0 + 1) * WAVE]; fc = Rg[(size_t)(3 * wi0) * WAVE];
         }
         for (int wi = maxlen - 2; wi >= 0; wi--) {       // wave-uniform trip count; lanes join when wi <= len-2
             const bool on = wi <= wi0;
-            uint64_t w_pre = w_raw;
+            float tn[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) tn[u] = tq[u];
             v3 na = fa, nb = fb, nc = fc;
             if (on) {
                 const int wn = wi > 0 ? wi - 1 : 0;
-                w_pre = Wg[(size_t)wn * WAVE];
+#pragma unroll
+                for (int u = 0; u < 6; u++) tn[u] = Tg[(size_t)(6 * wn + u) * WAVE];
                 na = Rg[(size_t)(3 * wn + 2) * WAVE]; nb = Rg[(size_t)(3 * wn + 1) * WAVE]; nc = Rg[(size_t)(3 * wn) * WAVE];
             }
-            const bb_word w = decode_word(w_raw, P);
 #pragma unroll
             for (int q = 2; q >= 0; q--) {
                 const int f = 3 * wi + q;
@@ -493,8 +503,8 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
                 if (on) {
                     const float ba = bond_angle_deg(f0, f1, f2);  // angle at forward atom f+1 (getBondAngles on forward atoms)
                     const float Lb = (q == 0) ? 1.4581f : (q == 1) ? 1.5281f : 1.3311f;  // src/nerf.h:40-41
-                    const float tor = (q == 0) ? w.psi : (q == 1) ? w.omega : w.phi;
-                    const v3 Rv = place_atom(r3, r2, r1, Lb, ba, tor);   // a = R[f+3], b = R[f+2], c = R[f+1]
+                    // torsion of the step: psi, omega, phi for q = 0, 1, 2 (cos at tq[2q], sin at tq[2q+1])
+                    const v3 Rv = place_atom_d2(r3, r2, r1, nerf_d2_trig(Lb, ba, tq[2 * q], tq[2 * q + 1]));   // a = R[f+3], b = R[f+2], c = R[f+1]
                     const float wf = (float)(T - f), wr = (float)f;
                     Bv = v3{((f0.x * wf) + (Rv.x * wr)) / Tf, ((f0.y * wf) + (Rv.y * wr)) / Tf, ((f0.z * wf) + (Rv.z * wr)) / Tf};
                     r3 = r2; r2 = r1; r1 = Rv;
@@ -502,7 +512,11 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
                 }
                 emit(on, b0 + f, Bv);
             }
-            if (on) { w_raw = w_pre; fa = na; fb = nb; fc = nc; }
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < 6; u++) tq[u] = tn[u];
+                fa = na; fb = nb; fc = nc;
+            }
         }
         if (act) {
             // carry into the next segment: blended last three atoms (indices T-3..T-1)

@@ -386,6 +386,19 @@ __device__ __forceinline__ v3 nerf_d2(float L, float bond_angle_deg_, float tors
     return d2;
 }
 
+// the same with the torsion's cosine and sine already known (they depend on the torsion alone, so the reverse pass of
+// the backbone reuses the forward pass's values)
+__device__ __forceinline__ v3 nerf_d2_trig(float L, float bond_angle_deg_, float ct, float st) {
+    const float ba = deg2rad(bond_angle_deg_);
+    float sb, cb;
+    sincosf_pair(ba, &sb, &cb);
+    v3 d2;
+    d2.x = -1.0f * L * cb;
+    d2.y = L * ct * sb;
+    d2.z = L * st * sb;
+    return d2;
+}
+
 __device__ __forceinline__ v3 place_atom(v3 a, v3 b, v3 c, float L, float ba_deg, float ta_deg) {
     return place_atom_d2(a, b, c, nerf_d2(L, ba_deg, ta_deg));
 }

@@ -244,6 +244,10 @@ def main():
     for _ in range(args.warmup):
         step()
     codec.synchronize(); torch.cuda.synchronize()
+    warm_csum = None
+    if rank == 0 and args.warmup and not args.no_parity:
+        nb8 = (fcz_bytes // 8) * 8
+        warm_csum = int(blob_dev[:nb8].view(torch.int64).sum()) if nb8 else 0
     codec.enable_timing(True); codec.reset_timing()
     if world > 1:
         dist.barrier()
@@ -266,6 +270,38 @@ def main():
     for name in ("compress_sizes", "compress_index", "compress_angles", "compress_pack", "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain"):
         ms, n = codec.kernel_time(name)
         ktime[name] = (ms / n) if n else 0.0
+    # ---- size-independent properties of the FULL batch (outside the timed region) ----
+    props = None
+    if rank == 0 and not args.no_parity:
+        # (1) determinism: the blob after the timed steps has the checksum it had after the warm-up steps
+        nb8 = (fcz_bytes // 8) * 8
+        csum = int(blob_dev[:nb8].view(torch.int64).sum()) if nb8 else 0
+        # (2) decode(encode(x)) ~ x: decompress once more in the input's atom order (`-a`) and compare every atom
+        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
+                                                atom_off_dev.data_ptr(), ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())), "dsizes")
+        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
+                                                atom_off_dev.data_ptr(), 1, ctypes.byref(cout)), "decompress -a")
+        codec.synchronize()
+        sq = 0.0; mx = 0.0; step_n = 1 << 28
+        for a in range(0, M, step_n):
+            b_ = min(M, a + step_n)
+            dsq = (out_t["x"][a:b_] - d["x"][a:b_]) ** 2
+            dsq += (out_t["y"][a:b_] - d["y"][a:b_]) ** 2
+            dsq += (out_t["z"][a:b_] - d["z"][a:b_]) ** 2
+            sq += float(dsq.sum(dtype=torch.float64)); mx = max(mx, float(dsq.max()))
+            del dsq
+        # (3) sizes: decompress counts == input counts, every chain compressed with status OK
+        same_counts = bool(torch.equal(res_off_dev, d["res_off"].to(torch.int32)))
+        props = {"all_atom_rmsd_A": round((sq / M) ** 0.5, 4), "max_atom_deviation_A": round(mx ** 0.5, 3),
+                 "residue_counts_round_trip": same_counts, "blob_checksum": csum,
+                 "deterministic": csum == warm_csum if warm_csum is not None else None}
+        # restore the default-order outputs the PDB leg below formats
+        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
+                                                atom_off_dev.data_ptr(), ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())), "dsizes")
+        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
+                                                atom_off_dev.data_ptr(), 0, ctypes.byref(cout)), "decompress")
+        codec.synchronize()
+
     # ---- §8 f2 leg, outside the timed region: PDB text of the first chains, formatted on the device ----
     pdb = None
     if args.pdb_sample and rank == 0:
@@ -366,7 +402,7 @@ def main():
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pdb_text": pdb,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props, "pdb_text": pdb,
         }
         print(json.dumps(line))
     if world > 1:

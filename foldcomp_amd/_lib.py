@@ -83,7 +83,7 @@ EXPORTS = ["fcz_ctx_create", "fcz_ctx_destroy", "fcz_ctx_stream", "fcz_ctx_synch
            "fcz_compress_angles", "fcz_compress_sizes_dev", "fcz_compress_batch_dev", "fcz_decompress_sizes", "fcz_decompress_batch",
            "fcz_decompress_sizes_dev", "fcz_decompress_batch_dev", "fcz_pdb_sizes_dev", "fcz_pdb_format_dev",
            "fcz_decompress_pdb_begin", "fcz_decompress_pdb_fetch", "fcz_check", "fcz_ctx_enable_timing",
-           "fcz_ctx_kernel_time", "fcz_ctx_reset_timing"]
+           "fcz_ctx_kernel_time", "fcz_ctx_reset_timing", "fcz_selftest_math"]
 
 
 def status_name(code: int) -> str:

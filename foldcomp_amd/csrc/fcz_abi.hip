@@ -68,10 +68,9 @@ struct fcz_ctx {
     dev_buf res_sc_addr; // compress: residue -> output byte offset of its side-chain torsion bytes
     // decompress: the segment/residue prefixes computed by fcz_decompress_sizes_dev are reused by the
     // fcz_decompress_batch_dev call that follows on the same entries
-    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_S = 0, sized_maxseg = 0;
+    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_maxseg = 0;
     bool sizes_fresh = false;
-    dev_buf cnt;        // decompress: 3 x n u32 counts + n i32 status
-    dev_buf seg_off;    // decompress: (n+1) u32
+    dev_buf cnt;        // decompress: 2 x n u32 counts (residues, atoms) + n i32 status
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
     dev_buf wring;      // decompress: per-group ring of cos/sin of the segment's torsions
@@ -194,7 +193,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->seg_off.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release();
+    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
@@ -259,8 +258,8 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
     rc = fcz_decompress_sizes_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
                                   ctx->stage[3].as<uint32_t>(), &R, &M);
     if (rc) return rc;
-    if (status) {   // per-entry status of the sizes pass (cnt layout: 3 x n counts, then n status words)
-        HIP_TRY(hipMemcpyAsync(status, ctx->cnt.as<uint32_t>() + 3 * (size_t)n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) {   // per-entry status of the sizes pass (cnt layout: 2 x n counts, then n status words)
+        HIP_TRY(hipMemcpyAsync(status, ctx->cnt.as<uint32_t>() + 2 * (size_t)n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     }
     for (int i = 4; i < 7; i++) if ((rc = ctx->stage[i].ensure(std::max<size_t>(sizeof(float) * (size_t)M, 16)))) return rc;
     if ((rc = ctx->stage[7].ensure(std::max<size_t>(sizeof(float) * (size_t)R, 16)))) return rc;
@@ -521,64 +520,56 @@ static int build_len_perm(fcz_ctx* ctx, const uint32_t* cnt_res, uint32_t n) {
     return FCZ_OK;
 }
 
+// The sizes pass of the decompress path: per-entry validation and counts (k_entry_sizes), their exclusive prefixes, the
+// longest anchor segment of the batch (sizes the ring of k_backbone) and the length order of the entries. The totals come
+// back through pinned host words after one stream synchronisation. atom_off_dev may be null (prefix not needed).
+static int run_entry_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* res_off_dev,
+                           uint32_t* atom_off_dev) {
+    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 3 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; int32_t* st = (int32_t*)(ca + n);
+    if ((rc = ctx->maxseg.ensure(16))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, st,
+                              ctx->maxseg.as<uint32_t>());
+    if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
+    if (atom_off_dev && (rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
+    if ((rc = build_len_perm(ctx, cr, n))) return rc;
+    HIP_TRY(hipGetLastError());
+    ctx->pinned[1] = 0;
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (atom_off_dev) HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}
+
 int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
                              uint32_t* res_off_dev, uint32_t* atom_off_dev, uint32_t* total_res, uint32_t* total_atoms) {
     if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
-    rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
-    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
-    if ((rc = ctx->maxseg.ensure(16))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
     {
         span_guard g(ctx, "decompress_sizes");
-        if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st,
-                                  ctx->maxseg.as<uint32_t>());
-        if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
-        if ((rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
-        if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
-        if ((rc = build_len_perm(ctx, cr, n))) return rc;
-        HIP_TRY(hipGetLastError());
+        int rc = run_entry_sizes(ctx, blob_dev, off_dev, n, res_off_dev, atom_off_dev);
+        if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (total_res) *total_res = ctx->pinned[0];
     if (total_atoms) *total_atoms = ctx->pinned[1];
+    // the fcz_decompress_batch_dev call that follows on the same entries reuses the totals and the length order
     ctx->sized_blob = blob_dev; ctx->sized_off = off_dev; ctx->sized_n = n;
-    ctx->sized_R = ctx->pinned[0]; ctx->sized_S = ctx->pinned[2]; ctx->sized_maxseg = ctx->pinned[3]; ctx->sizes_fresh = true;
+    ctx->sized_R = ctx->pinned[0]; ctx->sized_maxseg = ctx->pinned[3]; ctx->sizes_fresh = true;
     return FCZ_OK;
 }
 
-// The segment prefix (seg_off) lives in the ctx: fcz_decompress_sizes_dev computes it; the batch call
-// recomputes it when it is called without a preceding sizes call on the same entries.
-static int ensure_segments(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res,
-                           uint32_t* total_seg, uint32_t* max_seg_len) {
+// Totals and length order for a batch call: taken from the preceding sizes call on the same entries, else recomputed.
+static int ensure_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res, uint32_t* max_seg_len) {
     if (ctx->sizes_fresh && ctx->sized_blob == blob_dev && ctx->sized_off == off_dev && ctx->sized_n == n) {
         ctx->sizes_fresh = false;   // single use: the records may be rewritten before the next call
-        *total_res = ctx->sized_R; *total_seg = ctx->sized_S; *max_seg_len = ctx->sized_maxseg;
+        *total_res = ctx->sized_R; *max_seg_len = ctx->sized_maxseg;
         return FCZ_OK;
     }
-    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
-    rc = ctx->seg_off.ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
-    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; uint32_t* cs = ca + n; int32_t* st = (int32_t*)(cs + n);
-    if ((rc = ctx->maxseg.ensure(16))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
-    if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, cs, st,
-                              ctx->maxseg.as<uint32_t>());
-    // scans of residues (scratch, reusing cr in place is not possible: use stage[16]) and segments
-    rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
-    if ((rc = device_scan<uint32_t>(ctx, cr, ctx->stage[16].as<uint32_t>(), n))) return rc;
-    if ((rc = device_scan<uint32_t>(ctx, cs, ctx->seg_off.as<uint32_t>(), n))) return rc;
-    if ((rc = build_len_perm(ctx, cr, n))) return rc;
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], ctx->stage[16].as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[2], ctx->seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *total_res = ctx->pinned[0]; *total_seg = ctx->pinned[2]; *max_seg_len = ctx->pinned[3];
+    int rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
+    if ((rc = run_entry_sizes(ctx, blob_dev, off_dev, n, ctx->stage[16].as<uint32_t>(), nullptr))) return rc;
+    *total_res = ctx->pinned[0]; *max_seg_len = ctx->pinned[3];
     return FCZ_OK;
 }
 
@@ -589,8 +580,8 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     if (!out_dev->x || !out_dev->y || !out_dev->z || !out_dev->bfac_res) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) return FCZ_OK;
-    uint32_t R = 0, S = 0, max_seg = 0;
-    int rc = ensure_segments(ctx, blob_dev, off_dev, n, &R, &S, &max_seg);
+    uint32_t R = 0, max_seg = 0;
+    int rc = ensure_sizes(ctx, blob_dev, off_dev, n, &R, &max_seg);
     if (rc) return rc;
     if (R == 0) return FCZ_OK;
     const uint32_t groups = grid_for(n, WAVE);

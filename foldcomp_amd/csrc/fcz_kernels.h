@@ -205,11 +205,11 @@ __device__ __forceinline__ int res_code_from_letter(uint8_t ch) {
     return 23;
 }
 
-// One wavefront per entry: validate + count. counts[i] = {n_res, n_atoms_out, n_segments, status}
+// One wavefront per entry: validate + count (residues, output atoms, status) and the longest anchor segment of the batch
 __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                        uint32_t n_entries, uint32_t* __restrict__ cnt_res,
-                                                       uint32_t* __restrict__ cnt_atoms, uint32_t* __restrict__ cnt_seg,
-                                                       int32_t* __restrict__ status, uint32_t* __restrict__ max_seg_len) {
+                                                       uint32_t* __restrict__ cnt_atoms, int32_t* __restrict__ status,
+                                                       uint32_t* __restrict__ max_seg_len) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (i >= n_entries) return;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
     const uint8_t* e = blob + off[i];
     const uint64_t len = off[i + 1] - off[i];
     int st = FCZ_OK;
-    uint32_t n = 0, na_total = 0, nseg = 0;
+    uint32_t n = 0, na_total = 0;
     if (len < 76) st = FCZ_E_TRUNCATED;
     else if (!(e[0] == 'F' && e[1] == 'C' && e[2] == 'M' && e[3] == 'P')) st = FCZ_E_BAD_MAGIC;
     else {
@@ -245,14 +245,14 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
             na = wave_sum(na); nsc = wave_sum(nsc);
             if (__any(bad == 1)) st = FCZ_E_RESIDUE;
             else if (__any(bad == 2) || nsc != v.n_sc) st = FCZ_E_TRUNCATED;
-            else { na_total = na + (e[v.L.o_oxt] ? 1 : 0); nseg = v.n_anchor - 1; }
+            else na_total = na + (e[v.L.o_oxt] ? 1 : 0);
         }
     }
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(seg_max, d, WAVE); seg_max = o > seg_max ? o : seg_max; }
     if (lane == 0) {
         const bool ok = st == FCZ_OK;
-        cnt_res[i] = ok ? n : 0; cnt_atoms[i] = ok ? na_total : 0; cnt_seg[i] = ok ? nseg : 0;
+        cnt_res[i] = ok ? n : 0; cnt_atoms[i] = ok ? na_total : 0;
         status[i] = st;
         // one contended atomic per entry would serialise (~88 atomics/us on one address): only the rare raisers go through
         if (ok && max_seg_len && seg_max > __builtin_nontemporal_load(max_seg_len)) atomicMax(max_seg_len, seg_max);

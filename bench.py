@@ -342,6 +342,29 @@ def main():
                "frac_of_hbm_peak": round(tbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_f else None,
                "atoms_per_s": round(n_at / ((ms_s + ms_f) * 1e-3)) if ms_f else None, "first_chain_equals_host_writer": bool(ok_pdb)}
         del text_dev
+    # ---- §8 f4 leg: `extract --plddt -p 2` of every record straight from the FCZ bytes ----
+    ext = None
+    if rank == 0 and not args.no_parity:
+        data_off = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.fcz_extract_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, 0, 2, data_off.data_ptr()), "extract sizes")
+        codec.synchronize()
+        dbytes = int(data_off[-1])
+        data_dev = torch.empty(max(dbytes, 1), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        codec.reset_timing()
+        for _ in range(3):
+            _lib.check(lib.fcz_extract_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, 0, 2, data_off.data_ptr(), data_dev.data_ptr()), "extract")
+        codec.synchronize()
+        ms_e, n_e = codec.kernel_time("extract"); ms_e /= max(n_e, 1)
+        from foldcomp_amd import fczfile as _ff
+        e0 = blob_dev[:int(off_dev[1])].cpu().numpy().tobytes()
+        ok_e = data_dev[:int(data_off[1])].cpu().numpy().tobytes() == _ff.extract_plddt(_ff.parse(e0), 2).encode()
+        ext = {"mode": "plddt -p 2", "records": C, "data_bytes": dbytes, "ms": round(ms_e, 4),
+               "residues_per_s": round(R / (ms_e * 1e-3)) if ms_e else None,
+               "GBs_read_plus_written": round((fcz_bytes + dbytes) / (ms_e * 1e-3) / 1e9, 1) if ms_e else None,
+               "first_record_equals_host": bool(ok_e)}
+        del data_dev
     codec.enable_timing(False)
     bad_status = int((status_dev != 0).sum())
 
@@ -402,7 +425,7 @@ def main():
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props, "pdb_text": pdb,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props, "pdb_text": pdb, "extract": ext,
         }
         print(json.dumps(line))
     if world > 1:

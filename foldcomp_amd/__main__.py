@@ -306,28 +306,51 @@ def run_decompress(a, inputs, output, kind, single):
 
 
 def run_extract(a, inputs, output, kind, single):
+    """pLDDT / sequence strings come from the device (k_extract); the FASTA-like / TSV wrapping is host text"""
     merged = [] if (a.merge and not single) else None
     out_dir_made = False
+    pend: List[Tuple[str, bytes, fczfile.FczRecord]] = []
+
+    def emit(name, rec, s):
+        nonlocal out_dir_made
+        title = rec.title if a.use_title else os.path.basename(name)
+        if a.ext_mode == 0:
+            text = fczfile.fasta_like(title, s) if a.plddt_digits == 1 else fczfile.tsv_line(title, rec.n_residues, s)
+        else:
+            text = fczfile.fasta_like(title, s)
+        if single:
+            open(output, "w").write(text)
+        elif merged is not None:
+            merged.append(text)
+        else:
+            if not out_dir_made:
+                os.makedirs(output, exist_ok=True); out_dir_made = True
+            open(os.path.join(output, file_parts(os.path.basename(name))[0] + "." + a.suffix), "w").write(text)
+
+    def flush():
+        if not pend:
+            return
+        off = np.zeros(len(pend) + 1, np.uint64)
+        off[1:] = np.cumsum([len(d) for _, d, _ in pend])
+        blob = np.frombuffer(b"".join(d for _, d, _ in pend), np.uint8)
+        digits = min(max(int(a.plddt_digits), 1), 4)
+        outs = default_codec().extract(blob, off, mode=0 if a.ext_mode == 0 else 1, digits=digits)
+        for (name, _, rec), s in zip(pend, outs):
+            if not s and rec.n_residues:
+                print(f"[Error] reading {name}", file=sys.stderr); continue
+            emit(name, rec, s.decode("latin-1"))
+        pend.clear()
+
     for inp in inputs:
         for name, data in iter_entries(inp, a.recursive, a.id_list, a.id_mode):
             try:
                 rec = fczfile.parse(data)
             except fczfile.FczFormatError:
                 print(f"[Error] reading {name}", file=sys.stderr); continue
-            title = rec.title if a.use_title else os.path.basename(name)
-            if a.ext_mode == 0:
-                s = fczfile.extract_plddt(rec, a.plddt_digits)
-                text = fczfile.fasta_like(title, s) if a.plddt_digits == 1 else fczfile.tsv_line(title, rec.n_residues, s)
-            else:
-                text = fczfile.fasta_like(title, fczfile.sequence(rec))
-            if single:
-                open(output, "w").write(text)
-            elif merged is not None:
-                merged.append(text)
-            else:
-                if not out_dir_made:
-                    os.makedirs(output, exist_ok=True); out_dir_made = True
-                open(os.path.join(output, file_parts(os.path.basename(name))[0] + "." + a.suffix), "w").write(text)
+            pend.append((name, data, rec))
+            if len(pend) >= BATCH_CHAINS:
+                flush()
+    flush()
     if merged is not None:
         open(output.rstrip("/") if not output.endswith("/") else output.rstrip("/") + "." + a.suffix, "w").write("".join(merged))
 

@@ -116,6 +116,20 @@ class Codec:
         raw = text.tobytes()
         return [raw[int(text_off[i]):int(text_off[i + 1])] for i in range(n)], status[:n]
 
+    def extract(self, blob: np.ndarray, off: np.ndarray, mode: int = 0, digits: int = 2):
+        """FCZ entries -> list of data strings (bytes): pLDDT digits (mode 0) or the amino-acid sequence (mode 1); entries
+        that cannot be read give b''"""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        data_off = np.zeros(n + 1, np.uint64)
+        _lib.check(self.lib.fcz_extract_sizes(blob.ctypes.data, off.ctypes.data, n, int(mode), int(digits), data_off.ctypes.data), "fcz_extract_sizes")
+        data = np.zeros(int(data_off[-1]), np.uint8)
+        _lib.check(self.lib.fcz_extract(self.ctx, blob.ctypes.data, off.ctypes.data, n, int(mode), int(digits), data_off.ctypes.data,
+                                        data.ctypes.data if len(data) else None), "fcz_extract")
+        raw = data.tobytes()
+        return [raw[int(data_off[i]):int(data_off[i + 1])] for i in range(n)]
+
     # ---- timing ---------------------------------------------------------------------------------
     def enable_timing(self, on: bool = True):
         self.lib.fcz_ctx_enable_timing(self.ctx, int(on))

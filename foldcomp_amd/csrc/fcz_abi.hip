@@ -15,6 +15,7 @@
 #include "fcz_compress.h"
 #include "fcz_sidechain.h"
 #include "fcz_pdb.h"
+#include "fcz_extract.h"
 
 // second, host-side instance of the generated tables (integer metadata for sizes/validation)
 namespace host_tab {
@@ -289,6 +290,68 @@ int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out) {
     if (!ctx || (!text_out && ctx->pdb_bytes)) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->pdb_bytes) HIP_TRY(hipMemcpyAsync(text_out, ctx->pdb_text.p, ctx->pdb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extract (Foldcomp::extract, reference src/foldcomp.cpp:1260-1336)
+// ------------------------------------------------------------------------------------------------
+static inline int extract_args_ok(int mode, int digits) { return (mode == 0 && digits >= 1 && digits <= 4) || mode == 1; }
+
+int fcz_extract_sizes(const uint8_t* blob, const uint64_t* off, uint32_t n, int mode, int digits, uint64_t* data_off) {
+    if (!blob || !off || !data_off || !extract_args_ok(mode, digits)) return FCZ_E_INVALID_ARG;
+    data_off[0] = 0;
+    for (uint32_t i = 0; i < n; i++)
+        data_off[i + 1] = data_off[i] + extract_bytes(extract_entry_residues(blob + off[i], off[i + 1] - off[i]), mode, digits);
+    return FCZ_OK;
+}
+
+int fcz_extract_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, int mode, int digits,
+                          uint64_t* data_off_dev) {
+    if (!ctx || !blob_dev || !off_dev || !data_off_dev || !extract_args_ok(mode, digits)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->pdb_size.ensure(sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    span_guard g(ctx, "extract_sizes");
+    if (n) hipLaunchKernelGGL(k_extract_sizes, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, mode, digits,
+                              ctx->pdb_size.as<uint64_t>());
+    if ((rc = device_scan<uint64_t>(ctx, ctx->pdb_size.as<uint64_t>(), data_off_dev, n))) return rc;
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+int fcz_extract_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, int mode, int digits,
+                    const uint64_t* data_off_dev, uint8_t* data_dev) {
+    if (!ctx || !blob_dev || !off_dev || !data_off_dev || !data_dev || !extract_args_ok(mode, digits)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return FCZ_OK;
+    span_guard g(ctx, "extract");
+    hipLaunchKernelGGL(k_extract, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, mode, digits,
+                       data_off_dev, data_dev);
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+int fcz_extract(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int mode, int digits, const uint64_t* data_off,
+                uint8_t* data_out) {
+    if (!ctx || !blob || !off || !data_off || !extract_args_ok(mode, digits)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0 || data_off[n] == 0) return FCZ_OK;
+    if (!data_out) return FCZ_E_INVALID_ARG;
+    ctx->sizes_fresh = false;   // staging buffers are rewritten
+    const uint64_t blob_bytes = off[n], data_bytes = data_off[n];
+    int rc;
+    if ((rc = ctx->stage[0].ensure(std::max<uint64_t>(blob_bytes, 16)))) return rc;
+    if ((rc = ctx->stage[1].ensure(sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ctx->pdb_off.ensure(sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ctx->pdb_text.ensure(std::max<uint64_t>(data_bytes, 16)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->stage[0].p, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[1].p, off, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->pdb_off.p, data_off, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    rc = fcz_extract_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, mode, digits, ctx->pdb_off.as<uint64_t>(),
+                         ctx->pdb_text.as<uint8_t>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(data_out, ctx->pdb_text.p, data_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FCZ_OK;
 }

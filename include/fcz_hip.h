@@ -187,6 +187,20 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
                              uint64_t* text_off, int32_t* status);
 int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
 
+/* ---- extract ---------------------------------------------------------------------------------- */
+/* Foldcomp::extract (src/foldcomp.cpp:1260-1336) straight from the FCZ bytes, no reconstruction.
+ *   mode 0: pLDDT (B-factor) of every residue with `digits` in 1..4 characters ("d", "dd", "dd.d", "dd.dd"; digit rules
+ *           :1286-1325), joined by ',' when digits > 1;   mode 1: one-letter amino-acid sequence (digits ignored).
+ * data_off[n+1] = exclusive prefix of the data sizes (entries that fail Foldcomp::read's checks: 0 bytes); the caller wraps
+ * each string into the FASTA-like / TSV line (writeFASTALike / writeTSV, :1223-1237). */
+int fcz_extract_sizes(const uint8_t* blob, const uint64_t* off, uint32_t n, int mode, int digits, uint64_t* data_off);
+int fcz_extract(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int mode, int digits,
+                const uint64_t* data_off, uint8_t* data_out);
+int fcz_extract_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, int mode, int digits,
+                          uint64_t* data_off_dev);
+int fcz_extract_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, int mode, int digits,
+                    const uint64_t* data_off_dev, uint8_t* data_dev);
+
 /* ---- check -------------------------------------------------------------------------------- */
 /* Foldcomp::checkValidity (src/foldcomp.cpp:1492-1532) on one entry; returns the reference's
  * ValidityError value (0 = SUCCESS .. 6) or a negative fcz_status if the entry cannot be read. */
@@ -195,7 +209,7 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
  * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
- * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format". */
+ * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format", "extract_sizes", "extract". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

@@ -72,3 +72,23 @@ def test_pdb_text_skips_bad_entries(codec, golden):
     texts, status = codec.decompress_pdb(blob, off)
     assert status[0] == 0 and status[3] == 0 and status[1] != 0 and status[2] != 0
     assert texts[1] == b"" and texts[2] == b"" and texts[0] == texts[3] == z["pdb:test_af/pdb0"].tobytes()
+
+
+def test_extract_equals_reference_for_every_golden(codec, golden):
+    """k_extract (pLDDT digits 1..4, sequence) against the reference's `foldcomp extract` strings"""
+    z, index = golden
+    names = [n for n in index if f"{n}/plddt2" in z.files and f"{n}/fcz" in z.files]
+    assert len(names) >= 20
+    entries = [z[f"{n}/fcz"].tobytes() for n in names]
+    blob, off = _blob(entries)
+
+    for digits in (1, 2, 3, 4):
+        got = codec.extract(blob, off, mode=0, digits=digits)
+        for n, g in zip(names, got):
+            assert g == z[f"{n}/plddt{digits}"].tobytes(), (n, digits)
+    got = codec.extract(blob, off, mode=1)
+    for n, g in zip(names, got):
+        assert g == z[f"{n}/fasta"].tobytes(), n
+    # unreadable entries give empty strings
+    bad = codec.extract(*_blob([entries[0], b"FCMPxx", entries[0][:90]]), mode=0, digits=2)
+    assert bad[1] == b"" and bad[2] == b"" and bad[0] == z[f"{names[0]}/plddt2"].tobytes()

@@ -82,14 +82,30 @@ __global__ __launch_bounds__(BLOCK) void k_compress_index(fcz_chain_batch in, co
     const rec_layout RL = make_layout(n, n / thr + 2, in.title_off[c + 1] - in.title_off[c], 0);   // o_sc does not depend on n_sc
     const uint64_t base = out_off[c] + RL.o_sc;
     uint32_t run = 0;
-    for (uint32_t b = 0; b < n; b += WAVE) {
-        const uint32_t k = b + lane;
-        uint32_t cnt = 0;
-        if (k < n) { const uint32_t rc = in.res_code[r0 + k]; cnt = fcz_res_natoms[rc < 24 ? rc : 23] - 3; }
-        uint32_t tot;
-        const uint32_t ex = run + wave_excl_scan(cnt, lane, &tot);
-        run += tot;
-        if (k < n) res_sc_addr[r0 + k] = (base + ex) | (k == n - 1 ? CK_LAST : 0ull);
+    constexpr int U = 6;
+    if (n <= (uint32_t)(U * WAVE)) {   // a normal chain: one memory round trip for all residue codes
+        uint32_t cnt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const uint32_t k = u * WAVE + lane; cnt[u] = in.res_code[r0 + (k < n ? k : n - 1)]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = u * WAVE + lane;
+            const uint32_t c3 = k < n ? (uint32_t)fcz_res_natoms[cnt[u] < 24 ? cnt[u] : 23] - 3u : 0u;
+            uint32_t tot;
+            const uint32_t ex = run + wave_excl_scan(c3, lane, &tot);
+            run += tot;
+            if (k < n) res_sc_addr[r0 + k] = (base + ex) | (k == n - 1 ? CK_LAST : 0ull);
+        }
+    } else {
+        for (uint32_t b = 0; b < n; b += WAVE) {
+            const uint32_t k = b + lane;
+            uint32_t cnt = 0;
+            if (k < n) { const uint32_t rc = in.res_code[r0 + k]; cnt = fcz_res_natoms[rc < 24 ? rc : 23] - 3; }
+            uint32_t tot;
+            const uint32_t ex = run + wave_excl_scan(cnt, lane, &tot);
+            run += tot;
+            if (k < n) res_sc_addr[r0 + k] = (base + ex) | (k == n - 1 ? CK_LAST : 0ull);
+        }
     }
 }
 

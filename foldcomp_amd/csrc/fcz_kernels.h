@@ -114,9 +114,12 @@ __global__ __launch_bounds__(BLOCK) void k_compress_sizes(fcz_chain_batch in, ui
     if (c >= in.n_chains) return;
     const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
     uint32_t nsc = 0;
-    for (uint32_t k = lane; k < n; k += WAVE) {
-        const uint32_t rc = in.res_code[r0 + k];
-        nsc += fcz_res_natoms[rc < 24 ? rc : 23] - 3;
+    for (uint32_t k0 = 0; k0 < n; k0 += 8 * WAVE) {   // eight independent loads in flight per memory round trip
+        uint32_t rcs[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * WAVE + lane; rcs[u] = in.res_code[r0 + (k < n ? k : n - 1)]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (k0 + u * WAVE + lane < n) nsc += fcz_res_natoms[rcs[u] < 24 ? rcs[u] : 23] - 3;
     }
     nsc = wave_sum(nsc);
     if (lane == 0) {
@@ -227,12 +230,20 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
         else if (n < 2 || v.n_anchor < 2) st = FCZ_E_TOO_SHORT;
         else {
             uint32_t na = 0, nsc = 0; int bad = 0;
-            for (uint32_t k = lane; k < n; k += WAVE) {
-                uint32_t rc = e[v.L.o_words + 8 * k] >> 3;
-                if (k == 0) rc = (uint32_t)res_code_from_letter(e[20]);  // header.firstResidue, src/foldcomp.cpp:863
-                if (rc >= 24) rc = 23;
-                if (!res_code_ok(rc)) bad = 1;
-                na += fcz_res_natoms[rc]; nsc += fcz_res_natoms[rc] - 3;
+            const uint32_t rc_first = (uint32_t)res_code_from_letter(e[20]);  // header.firstResidue, src/foldcomp.cpp:863
+            for (uint32_t k0 = 0; k0 < n; k0 += 8 * WAVE) {   // eight independent loads in flight per memory round trip
+                uint32_t wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * WAVE + lane; wb[u] = e[v.L.o_words + 8 * (size_t)(k < n ? k : n - 1)]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + u * WAVE + lane;
+                    if (k >= n) continue;
+                    uint32_t rc = k == 0 ? rc_first : (wb[u] >> 3);
+                    if (rc >= 24) rc = 23;
+                    if (!res_code_ok(rc)) bad = 1;
+                    na += fcz_res_natoms[rc]; nsc += fcz_res_natoms[rc] - 3;
+                }
             }
             // anchor indices must be usable as segment bounds
             for (uint32_t s = lane; s + 1 < v.n_anchor; s += WAVE) {

@@ -51,30 +51,73 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
     const uint8_t* words = e + v.L.o_words;
     const uint8_t* scb = e + v.L.o_sc;
     uint32_t run = 0;
-    for (uint32_t base = 0; base < n; base += WAVE) {
-        const uint32_t k = base + lane;
-        const bool act = k < n;
-        uint32_t na = 0, rc = 23, tq = 0;
-        if (act) {
-            rc = (k == 0) ? first_rc : (uint32_t)(words[8 * (size_t)k] >> 3);
-            tq = e[v.L.o_tbytes + k];
-            if (rc >= 24) rc = 23;
-            na = fcz_res_natoms[rc];
-        }
-        uint32_t tot;
-        const uint32_t ex = run + wave_excl_scan(na, lane, &tot);
-        run += tot;
-        if (!act) continue;
-        // atoms before this residue minus 3 per residue = torsion bytes before it. The three dwords read at most 11
-        // bytes past the residue's last torsion byte: still inside the record (8-byte B-factor header + n bytes follow)
-        const uint8_t* sp = scb + (ex - 3 * k);
-        const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = (na > 11) ? ld_u32(sp + 8) : 0u;
+    auto emit = [&](uint32_t k, uint32_t rc, uint32_t tq, uint32_t ex, uint32_t q0, uint32_t q1, uint32_t q2) {
         const size_t r = (size_t)r0 + k;
         res_aoff[r] = abase + ex;
         res_rc[r] = (uint8_t)rc;
         res_sc[r] = q0; res_sc[(size_t)n_res + r] = q1; res_sc[2 * (size_t)n_res + r] = q2;
         out.bfac_res[r] = dequant(tq, tmin, tcf);
         if (out.res_code) out.res_code[r] = (uint8_t)rc;
+    };
+    // Torsion bytes of a residue: atoms before it minus 3 per residue = torsion bytes before it. The dwords read at most 11
+    // bytes past the residue's last torsion byte: still inside the record (8-byte B-factor header + n bytes follow).
+    constexpr int U = 6;
+    if (n <= (uint32_t)(U * WAVE)) {
+        // a normal chain: every load of a dependency level is in flight at once (two memory round trips per chain
+        // instead of two per 64 residues)
+        uint32_t wb[U], tq[U], rc[U], na[U], ex[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = u * WAVE + lane, kc = k < n ? k : n - 1;
+            wb[u] = words[8 * (size_t)kc];
+            tq[u] = e[v.L.o_tbytes + kc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = u * WAVE + lane;
+            uint32_t r = (k == 0) ? first_rc : (wb[u] >> 3);
+            if (r >= 24) r = 23;
+            rc[u] = r;
+            na[u] = k < n ? (uint32_t)fcz_res_natoms[r] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t tot;
+            ex[u] = run + wave_excl_scan(na[u], lane, &tot);
+            run += tot;
+        }
+        uint32_t q0[U], q1[U], q2[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = u * WAVE + lane;
+            const bool act = k < n;
+            const uint8_t* sp = scb + (act ? ex[u] - 3 * k : 0u);
+            q0[u] = ld_u32(sp); q1[u] = ld_u32(sp + 4);
+            q2[u] = ld_u32((act && na[u] > 11) ? sp + 8 : sp);   // only TRP / TYR own a third dword
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = u * WAVE + lane;
+            if (k < n) emit(k, rc[u], tq[u], ex[u], q0[u], q1[u], na[u] > 11 ? q2[u] : 0u);
+        }
+    } else {
+        for (uint32_t base = 0; base < n; base += WAVE) {
+            const uint32_t k = base + lane;
+            const bool act = k < n;
+            uint32_t na = 0, rc = 23, tq = 0;
+            if (act) {
+                rc = (k == 0) ? first_rc : (uint32_t)(words[8 * (size_t)k] >> 3);
+                tq = e[v.L.o_tbytes + k];
+                if (rc >= 24) rc = 23;
+                na = fcz_res_natoms[rc];
+            }
+            uint32_t tot;
+            const uint32_t ex = run + wave_excl_scan(na, lane, &tot);
+            run += tot;
+            if (!act) continue;
+            const uint8_t* sp = scb + (ex - 3 * k);
+            emit(k, rc, tq, ex, ld_u32(sp), ld_u32(sp + 4), (na > 11) ? ld_u32(sp + 8) : 0u);
+        }
     }
     if (lane == 0) {
         const bool oxt = e[v.L.o_oxt] != 0;

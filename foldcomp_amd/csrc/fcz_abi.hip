@@ -69,12 +69,13 @@ struct fcz_ctx {
     dev_buf res_sc_addr; // compress: residue -> output byte offset of its side-chain torsion bytes
     // decompress: the segment/residue prefixes computed by fcz_decompress_sizes_dev are reused by the
     // fcz_decompress_batch_dev call that follows on the same entries
-    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_maxseg = 0;
+    const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_maxseg = 0, sized_maxnseg = 0, sized_nlong = 0;
     bool sizes_fresh = false;
     dev_buf cnt;        // decompress: 2 x n u32 counts (residues, atoms) + n i32 status
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
     dev_buf wring;      // decompress: per-group ring of cos/sin of the segment's torsions
+    dev_buf fwd_long, wring_long;   // decompress: the same per (group, segment) for the long chains' split form
     dev_buf bb;         // decompress: blended backbone
     dev_buf len_perm;   // decompress: entries ordered by residue count (n u32) + bucket counters (2 x LEN_BUCKETS + 1)
     dev_buf res_aoff;   // decompress: residue -> first output atom
@@ -84,7 +85,9 @@ struct fcz_ctx {
     dev_buf stage[20];
     dev_buf pdb_size, pdb_off, pdb_text;   // PDB text: per-entry sizes, offsets (n+1 u64), the text of the last begin() call
     uint64_t pdb_bytes = 0;
-    uint32_t* pinned = nullptr;  // 4 words
+    uint32_t* pinned = nullptr;  // 16 words
+    hipStream_t stream2 = nullptr;   // long chains of a decompress batch run beside the rest
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_cu = 256;
     bool timing = false;
     bool keep_first_angle = false;
@@ -173,6 +176,7 @@ int fcz_res_code_atom(int rc, int j, int alt) {
     return host_tab::h_res_atom[rc][slot];
 }
 
+void fcz_ctx_destroy(fcz_ctx* c);
 int fcz_ctx_create(int device, fcz_ctx** out) {
     if (!out) return FCZ_E_INVALID_ARG;
     *out = nullptr;
@@ -185,6 +189,9 @@ int fcz_ctx_create(int device, fcz_ctx** out) {
     c->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FCZ_E_HIP; }
     if (hipHostMalloc((void**)&c->pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FCZ_E_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { fcz_ctx_destroy(c); return FCZ_E_HIP; }
     *out = c;
     return FCZ_OK;
 }
@@ -194,9 +201,12 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release();
+    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -601,7 +611,12 @@ static int run_entry_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t
     ctx->pinned[1] = 0;
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (atom_off_dev) HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 8, hipMemcpyDeviceToHost, ctx->stream));   // [3] longest segment, [4] most segments
+    ctx->pinned[5] = 0;
+    if (n) {   // chains of FCZ_LONG_CHAIN residues or more lead the length order: the end of their last bucket is their count
+        const uint32_t* cursor = ctx->len_perm.as<uint32_t>() + n + LEN_BUCKETS;
+        HIP_TRY(hipMemcpyAsync(&ctx->pinned[5], cursor + len_bucket(FCZ_LONG_CHAIN), 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FCZ_OK;
 }
@@ -619,20 +634,22 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     if (total_atoms) *total_atoms = ctx->pinned[1];
     // the fcz_decompress_batch_dev call that follows on the same entries reuses the totals and the length order
     ctx->sized_blob = blob_dev; ctx->sized_off = off_dev; ctx->sized_n = n;
-    ctx->sized_R = ctx->pinned[0]; ctx->sized_maxseg = ctx->pinned[3]; ctx->sizes_fresh = true;
+    ctx->sized_R = ctx->pinned[0]; ctx->sized_maxseg = ctx->pinned[3]; ctx->sized_maxnseg = ctx->pinned[4]; ctx->sized_nlong = ctx->pinned[5];
+    ctx->sizes_fresh = true;
     return FCZ_OK;
 }
 
 // Totals and length order for a batch call: taken from the preceding sizes call on the same entries, else recomputed.
-static int ensure_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res, uint32_t* max_seg_len) {
+static int ensure_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* total_res, uint32_t* max_seg_len,
+                        uint32_t* max_nseg, uint32_t* n_long) {
     if (ctx->sizes_fresh && ctx->sized_blob == blob_dev && ctx->sized_off == off_dev && ctx->sized_n == n) {
         ctx->sizes_fresh = false;   // single use: the records may be rewritten before the next call
-        *total_res = ctx->sized_R; *max_seg_len = ctx->sized_maxseg;
+        *total_res = ctx->sized_R; *max_seg_len = ctx->sized_maxseg; *max_nseg = ctx->sized_maxnseg; *n_long = ctx->sized_nlong;
         return FCZ_OK;
     }
     int rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     if ((rc = run_entry_sizes(ctx, blob_dev, off_dev, n, ctx->stage[16].as<uint32_t>(), nullptr))) return rc;
-    *total_res = ctx->pinned[0]; *max_seg_len = ctx->pinned[3];
+    *total_res = ctx->pinned[0]; *max_seg_len = ctx->pinned[3]; *max_nseg = ctx->pinned[4]; *n_long = ctx->pinned[5];
     return FCZ_OK;
 }
 
@@ -643,19 +660,47 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     if (!out_dev->x || !out_dev->y || !out_dev->z || !out_dev->bfac_res) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) return FCZ_OK;
-    uint32_t R = 0, max_seg = 0;
-    int rc = ensure_sizes(ctx, blob_dev, off_dev, n, &R, &max_seg);
+    uint32_t R = 0, max_seg = 0, max_nseg = 0, n_long = 0;
+    int rc = ensure_sizes(ctx, blob_dev, off_dev, n, &R, &max_seg, &max_nseg, &n_long);
     if (rc) return rc;
     if (R == 0) return FCZ_OK;
-    const uint32_t groups = grid_for(n, WAVE);
     const uint32_t ring_rows = 3 * (max_seg ? max_seg : 1);
-    rc = ctx->fwd.ensure(sizeof(v3) * (size_t)groups * ring_rows * WAVE); if (rc) return rc;
-    rc = ctx->wring.ensure(sizeof(float) * 6 * (size_t)groups * (ring_rows / 3) * WAVE); if (rc) return rc;
+    const size_t slot_atoms = (size_t)ring_rows * WAVE, slot_trig = (size_t)(ring_rows / 3) * 6 * WAVE;
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
+    const uint32_t* perm = ctx->len_perm.as<uint32_t>();
+    // Long chains (>= FCZ_LONG_CHAIN residues, the head of the length order): when there are too few of them to fill the
+    // GPU their serial forward pass would hold the launch for ~8 us per residue, so they take the split form (forward
+    // pass, then one block per segment for the reverse pass) on a second stream beside the fused kernel of the rest.
+    const uint32_t groups_long_all = grid_for(n_long, WAVE);
+    const bool split_long = n_long > 0 && max_nseg > 0 && groups_long_all < 2u * 4u * (uint32_t)ctx->n_cu;
+    const uint32_t n_split = split_long ? n_long : 0;
+    if (split_long) {
+        const size_t per_group = (size_t)max_nseg * (slot_atoms * sizeof(v3) + slot_trig * sizeof(float));
+        const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(groups_long_all, ((size_t)6 << 30) / per_group));
+        rc = ctx->fwd_long.ensure(sizeof(v3) * slot_atoms * max_nseg * chunk); if (rc) return rc;
+        rc = ctx->wring_long.ensure(sizeof(float) * slot_trig * max_nseg * chunk); if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        for (uint32_t g0 = 0; g0 < groups_long_all; g0 += chunk) {
+            const uint32_t g = std::min(chunk, groups_long_all - g0);
+            const uint32_t slots = std::min<uint32_t>(n_long - g0 * WAVE, g * WAVE);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<1>), dim3(g), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
+                               perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<2>), dim3(g * max_nseg), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
+                               perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
+    const uint32_t n_fused = n - n_split;
+    const uint32_t groups = grid_for(n_fused, WAVE);
+    rc = ctx->fwd.ensure(sizeof(v3) * (size_t)std::max<uint32_t>(groups, 1) * slot_atoms); if (rc) return rc;
+    rc = ctx->wring.ensure(sizeof(float) * (size_t)std::max<uint32_t>(groups, 1) * slot_trig); if (rc) return rc;
     {
         span_guard g(ctx, "decompress_backbone");
-        hipLaunchKernelGGL(k_backbone, dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, res_off_dev,
-                           ctx->len_perm.as<uint32_t>(), ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, ctx->bb.as<v3>());
+        if (groups)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<0>), dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, n_fused, res_off_dev,
+                               perm + n_split, ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, 1u, ctx->bb.as<v3>());
+        if (split_long) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
     rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;

@@ -208,7 +208,7 @@ __device__ __forceinline__ int res_code_from_letter(uint8_t ch) {
     return 23;
 }
 
-// One wavefront per entry: validate + count (residues, output atoms, status) and the longest anchor segment of the batch
+// One wavefront per entry: validate + count (residues, output atoms, status) the longest anchor segment of the batch (max_seg_len[0]) and the most segments of a chain (max_seg_len[1])
 __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                        uint32_t n_entries, uint32_t* __restrict__ cnt_res,
                                                        uint32_t* __restrict__ cnt_atoms, int32_t* __restrict__ status,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
     const uint8_t* e = blob + off[i];
     const uint64_t len = off[i + 1] - off[i];
     int st = FCZ_OK;
-    uint32_t n = 0, na_total = 0;
+    uint32_t n = 0, na_total = 0, n_seg = 0;
     if (len < 76) st = FCZ_E_TRUNCATED;
     else if (!(e[0] == 'F' && e[1] == 'C' && e[2] == 'M' && e[3] == 'P')) st = FCZ_E_BAD_MAGIC;
     else {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
             na = wave_sum(na); nsc = wave_sum(nsc);
             if (__any(bad == 1)) st = FCZ_E_RESIDUE;
             else if (__any(bad == 2) || nsc != v.n_sc) st = FCZ_E_TRUNCATED;
-            else na_total = na + (e[v.L.o_oxt] ? 1 : 0);
+            else { na_total = na + (e[v.L.o_oxt] ? 1 : 0); n_seg = v.n_anchor - 1; }
         }
     }
 #pragma unroll
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
         status[i] = st;
         // one contended atomic per entry would serialise (~88 atomics/us on one address): only the rare raisers go through
         if (ok && max_seg_len && seg_max > __builtin_nontemporal_load(max_seg_len)) atomicMax(max_seg_len, seg_max);
+        if (ok && max_seg_len && n_seg > __builtin_nontemporal_load(max_seg_len + 1)) atomicMax(max_seg_len + 1, n_seg);
     }
 }
 
@@ -328,7 +329,8 @@ __device__ __forceinline__ bb_word decode_word(uint64_t raw, const bb_params& P)
 // dispatches the long ones first; with a uniform batch it degenerates to blocks of 64 consecutive chains. One atomic
 // per distinct bucket per wavefront (a contended atomic per chain would serialise at ~88 per microsecond).
 constexpr int LEN_BUCKETS = 4096;
-__device__ __forceinline__ uint32_t len_bucket(uint32_t n_res) {
+constexpr uint32_t FCZ_LONG_CHAIN = 1024;   // residues; a multiple of the 16-residue bucket width (see k_backbone MODE 1/2)
+__host__ __device__ __forceinline__ uint32_t len_bucket(uint32_t n_res) {
     const uint32_t b = n_res >> 4;
     return (uint32_t)LEN_BUCKETS - 1u - (b < (uint32_t)LEN_BUCKETS ? b : (uint32_t)LEN_BUCKETS - 1u);
 }
@@ -340,7 +342,9 @@ __global__ __launch_bounds__(BLOCK) void k_len_sort(const uint32_t* __restrict__
     const bool act = c < n;
     const uint32_t b = act ? len_bucket(cnt_res[c]) : 0xffffffffu;
     unsigned long long todo = __ballot(act);
-    while (todo) {
+    // a few aggregated rounds take care of buckets shared by many lanes (a uniform batch: one atomic per wavefront); lanes
+    // whose bucket is rare in the wavefront then go one by one -- their addresses hardly collide
+    for (int round = 0; round < 4 && todo; round++) {
         const int leader = __builtin_ctzll(todo);
         const uint32_t b0 = __shfl(b, leader, WAVE);
         const unsigned long long same = __ballot(act && b == b0) & todo;
@@ -352,6 +356,10 @@ __global__ __launch_bounds__(BLOCK) void k_len_sort(const uint32_t* __restrict__
             if (mode) perm[base + rank] = c;
         }
         todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) {
+        const uint32_t base = atomicAdd(&counter[b], 1u);
+        if (mode) perm[base] = c;
     }
 }
 
@@ -376,39 +384,59 @@ struct backbone_lds {
     int lo[WAVE], hi[WAVE];                 // filled slots [lo, hi)
 };
 
+// MODE 0 (the default): forward and reverse pass of every segment fused as described above; one ring slot per group.
+// A lone wavefront needs ~8 us per residue in that form, so a 2 700-residue chain would hold the whole launch for 22 ms.
+// Chains beyond FCZ_LONG_CHAIN residues therefore take two launches instead:
+// MODE 1: forward pass only (the serial part: every segment starts from the carry of the previous one), forward atoms and
+//         torsion trig of segment s parked in ring slot (group, s);
+// MODE 2: one block per (group, segment): reverse pass + blend of that segment from its slot -- the segments of a chain
+//         run side by side.
+template <int MODE>
 __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
-        const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries,
+        const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries, uint32_t n_slots,
         const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ perm, v3* __restrict__ ring,
-        float* __restrict__ tring, uint32_t ring_rows, v3* __restrict__ bb) {
+        float* __restrict__ tring, uint32_t ring_rows, uint32_t seg_slots, v3* __restrict__ bb) {
     __shared__ backbone_lds S;
     const int lane = threadIdx.x;
-    const uint32_t slot = blockIdx.x * WAVE + lane;
-    const uint32_t c = slot < n_entries ? perm[slot] : n_entries;   // chains grouped by length, longest first
+    const uint32_t grp = (MODE == 2) ? blockIdx.x / seg_slots : blockIdx.x;
+    const uint32_t seg_only = (MODE == 2) ? blockIdx.x - grp * seg_slots : 0u;
+    const uint32_t slot = grp * WAVE + lane;
+    const uint32_t c = slot < n_slots ? perm[slot] : n_entries;   // chains grouped by length, longest first
     const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
-    v3* Rg = ring + (size_t)blockIdx.x * ring_rows * WAVE + lane;            // atom row j at Rg[j * WAVE]
-    // cos/sin of the three torsions of word i at rows 6i .. 6i+5: the reverse pass needs nothing else of the word
-    float* Tg = tring + (size_t)blockIdx.x * (ring_rows / 3) * 6 * WAVE + lane;
+    // ring slot of segment sg: atom row j at Rg[j * WAVE]; cos/sin of the three torsions of word i at Tg rows 6i .. 6i+5
+    // (the reverse pass needs nothing else of the word)
+    auto ring_slot = [&](uint32_t sg) -> size_t { return (MODE == 0) ? (size_t)grp : (size_t)grp * seg_slots + sg; };
+    v3* Rg = ring + ring_slot(seg_only) * ring_rows * WAVE + lane;
+    float* Tg = tring + ring_slot(seg_only) * (ring_rows / 3) * 6 * WAVE + lane;
     const uint8_t* e = blob + (valid ? off[c] : off[0]);
     entry_view v; v.n = 0; v.n_anchor = 1; v.e = e; v.L = make_layout(0, 0, 0, 0);
     bb_params P{};
-    if (valid) { v = view_entry(e); P = load_params(e); }
+    if (valid) { v = view_entry(e); if (MODE != 2) P = load_params(e); }
     const uint8_t* words = e + v.L.o_words;
     const uint8_t* last_word = words + 8 * (size_t)(v.n ? v.n - 1 : 0);
     const uint32_t nseg = valid ? v.n_anchor - 1 : 0;
     uint32_t maxseg = nseg;
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(maxseg, d, WAVE); maxseg = o > maxseg ? o : maxseg; }
+    if (MODE == 2 && seg_only >= maxseg) return;     // no chain of the group has this segment (uniform)
     v3* Bc = bb + 3 * (size_t)(valid ? res_off[c] : 0);
     v3 p0{0.f, 0.f, 0.f}, p1 = p0, p2 = p0;
     int first = 0, next = 0;
     const uint8_t* wp = words;
     uint64_t w_cur = 0, w_nxt = 0;
-    if (valid) {
-        p0 = ld_v3(e + v.L.o_anchor); p1 = ld_v3(e + v.L.o_anchor + 12); p2 = ld_v3(e + v.L.o_anchor + 24);
-        first = (int)ld_u32(e + v.L.o_aidx); next = (int)ld_u32(e + v.L.o_aidx + 4);
-        wp = words + 8 * (size_t)first;
-        w_cur = ld_u64(wp);
-        w_nxt = ld_u64(wp + 8 <= last_word ? wp + 8 : last_word);
+    if (MODE != 2) {
+        if (valid) {
+            p0 = ld_v3(e + v.L.o_anchor); p1 = ld_v3(e + v.L.o_anchor + 12); p2 = ld_v3(e + v.L.o_anchor + 24);
+            first = (int)ld_u32(e + v.L.o_aidx); next = (int)ld_u32(e + v.L.o_aidx + 4);
+            wp = words + 8 * (size_t)first;
+            w_cur = ld_u64(wp);
+            w_nxt = ld_u64(wp + 8 <= last_word ? wp + 8 : last_word);
+        }
+    } else if (valid && seg_only < nseg) {
+        // the segment's bounds come straight from the anchor index list; its forward atoms wait in the ring slot
+        first = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)seg_only); next = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)(seg_only + 1));
+        const int len0 = next - first + 1;
+        p0 = Rg[(size_t)(3 * len0 - 3) * WAVE]; p1 = Rg[(size_t)(3 * len0 - 2) * WAVE]; p2 = Rg[(size_t)(3 * len0 - 1) * WAVE];
     }
     // ---- output window: blended atoms are parked in LDS and leave as contiguous runs per chain ----
     long long win = -1;           // window index (chain-major atom index / BW) this lane is filling, -1 = none
@@ -436,9 +464,14 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             S.atom[lane][3 * slot] = a.x; S.atom[lane][3 * slot + 1] = a.y; S.atom[lane][3 * slot + 2] = a.z;
         }
     };
-    for (uint32_t s = 0; s < maxseg; s++) {
+    const uint32_t s_begin = (MODE == 2) ? seg_only : 0u, s_end = (MODE == 2) ? seg_only + 1 : maxseg;
+    for (uint32_t s = s_begin; s < s_end; s++) {
         const bool act = s < nseg;
         const int len = act ? next - first + 1 : 0;
+        if (MODE == 1) {
+            Rg = ring + ring_slot(s) * ring_rows * WAVE + lane;
+            Tg = tring + ring_slot(s) * (ring_rows / 3) * 6 * WAVE + lane;
+        }
         int maxlen = len;
 #pragma unroll
         for (int d = WAVE / 2; d > 0; d >>= 1) { const int o = __shfl_xor(maxlen, d, WAVE); maxlen = o > maxlen ? o : maxlen; }
@@ -448,10 +481,10 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             next2 = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)(s + 2 <= nseg ? s + 2 : nseg));
             const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
             A0 = ld_v3(anc); A1 = ld_v3(anc + 12); A2 = ld_v3(anc + 24);   // next anchor: carry + reverse start
-            Rg[0] = p0; Rg[WAVE] = p1; Rg[2 * WAVE] = p2;
+            if (MODE != 2) { Rg[0] = p0; Rg[WAVE] = p1; Rg[2 * WAVE] = p2; }
         }
         // ---- forward NeRF of the segment ----
-        for (int i = 0; i + 1 < maxlen; i++) {
+        for (int i = 0; MODE != 2 && i + 1 < maxlen; i++) {
             if (i + 1 >= len) continue;
             const uint8_t* pf = wp + 16;
             const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
@@ -479,7 +512,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         const v3 c0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
         const v3 c1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
         const v3 c2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
-        {
+        if (MODE != 1) {
             // only the last segment keeps its final three atoms (src/foldcomp.cpp:847-851)
             const bool fin = act && (s + 1 == nseg);
             emit(fin, b0 + T - 1, c2); emit(fin, b0 + T - 2, c1); emit(fin, b0 + T - 3, c0);
@@ -489,12 +522,12 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         int wi0 = len - 2;
         float tq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // cos, sin of psi, omega, phi of the current word
         v3 fa{0.f, 0.f, 0.f}, fb = fa, fc = fa;
-        if (wi0 >= 0) {
+        if (MODE != 1 && wi0 >= 0) {
 #pragma unroll
             for (int u = 0; u < 6; u++) tq[u] = Tg[(size_t)(6 * wi0 + u) * WAVE];
             fa = Rg[(size_t)(3 * wi0 + 2) * WAVE]; fb = Rg[(size_t)(3 * wi0 + 1) * WAVE]; fc = Rg[(size_t)(3 * wi0) * WAVE];
         }
-        for (int wi = maxlen - 2; wi >= 0; wi--) {       // wave-uniform trip count; lanes join when wi <= len-2
+        for (int wi = maxlen - 2; MODE != 1 && wi >= 0; wi--) {       // wave-uniform trip count; lanes join when wi <= len-2
             const bool on = wi <= wi0;
             float tn[6];
 #pragma unroll
@@ -535,7 +568,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             first = next; next = next2;
         }
     }
-    if (__any(win >= 0)) flush();
+    if (MODE != 1 && __any(win >= 0)) flush();
 }
 
 }  // namespace fcz

@@ -94,3 +94,27 @@ def test_no_cpu_fallback_without_gpu():
     from foldcomp_amd.codec import Codec
     with pytest.raises(_lib.FczLibraryError):
         Codec(0)
+
+
+def test_host_extract_sizes_match_reference_strings(golden):
+    """fcz_extract_sizes is pure host code: the data sizes must equal the lengths of the reference's extract strings"""
+    z, index = golden
+    lib = _lib.load()
+    names = [n for n in index if f"{n}/plddt2" in z.files and f"{n}/fcz" in z.files]
+    entries = [z[f"{n}/fcz"].tobytes() for n in names]
+    off = np.zeros(len(entries) + 1, np.uint64)
+    off[1:] = np.cumsum([len(e) for e in entries])
+    blob = np.frombuffer(b"".join(entries), np.uint8)
+    for mode, digits, key in [(0, 1, "plddt1"), (0, 2, "plddt2"), (0, 3, "plddt3"), (0, 4, "plddt4"), (1, 0, "fasta")]:
+        data_off = np.zeros(len(entries) + 1, np.uint64)
+        assert lib.fcz_extract_sizes(blob.ctypes.data, off.ctypes.data, len(entries), mode, digits, data_off.ctypes.data) == 0
+        got = np.diff(data_off).astype(np.int64)
+        exp = np.asarray([len(z[f"{n}/{key}"].tobytes()) for n in names], np.int64)
+        assert np.array_equal(got, exp), (key, got[:5], exp[:5])
+    # unreadable entries: zero bytes; bad arguments: status, not a crash
+    bad = [b"NOPE" + entries[0][4:], entries[0][:80]]
+    off2 = np.asarray([0, len(bad[0]), len(bad[0]) + len(bad[1])], np.uint64)
+    d2 = np.zeros(3, np.uint64)
+    assert lib.fcz_extract_sizes(np.frombuffer(b"".join(bad), np.uint8).ctypes.data, off2.ctypes.data, 2, 0, 2, d2.ctypes.data) == 0
+    assert d2[2] == 0
+    assert lib.fcz_extract_sizes(blob.ctypes.data, off.ctypes.data, 1, 0, 7, d2.ctypes.data) == -1   # FCZ_E_INVALID_ARG

@@ -71,7 +71,7 @@ struct fcz_ctx {
     // fcz_decompress_batch_dev call that follows on the same entries
     const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_maxseg = 0, sized_maxnseg = 0, sized_nlong = 0;
     bool sizes_fresh = false;
-    dev_buf cnt;        // decompress: 2 x n u32 counts (residues, atoms) + n i32 status
+    dev_buf cnt;        // decompress: 2 x n u32 counts (residues, atoms) + n i32 status + n u32 segment info
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
     dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
     dev_buf wring;      // decompress: per-group ring of cos/sin of the segment's torsions
@@ -598,12 +598,14 @@ static int build_len_perm(fcz_ctx* ctx, const uint32_t* cnt_res, uint32_t n) {
 // back through pinned host words after one stream synchronisation. atom_off_dev may be null (prefix not needed).
 static int run_entry_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* res_off_dev,
                            uint32_t* atom_off_dev) {
-    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 3 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
-    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; int32_t* st = (int32_t*)(ca + n);
+    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; int32_t* st = (int32_t*)(ca + n); uint32_t* seg = (uint32_t*)(st + n);
     if ((rc = ctx->maxseg.ensure(16))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
-    if (n) hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, st,
-                              ctx->maxseg.as<uint32_t>());
+    if (n) {
+        hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, st, seg);
+        hipLaunchKernelGGL(k_seg_max, dim3(std::min<uint32_t>(grid_for(n, 1024), 256)), dim3(1024), 0, ctx->stream, seg, n, ctx->maxseg.as<uint32_t>());
+    }
     if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
     if (atom_off_dev && (rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
     if ((rc = build_len_perm(ctx, cr, n))) return rc;

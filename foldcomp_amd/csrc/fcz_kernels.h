@@ -1,13 +1,13 @@
-// fcz_kernels.h -- HIP kernels of the FCZ codec for gfx950 (wave64): shared primitives + the decompress side.
+// fcz_kernels.h -- HIP kernels of the FCZ codec for gfx950 (wave64): shared primitives, the size passes and the
+// backbone stage of the decompress side. The other stages: fcz_compress.h (compress), fcz_sidechain.h (side chains),
+// fcz_pdb.h (PDB text), fcz_extract.h (extract).
 //
-// compress  (Foldcomp::preprocess/compress/writeStream, reference src/foldcomp.cpp:450-606,1038-1109)
-//   k_compress_sizes:     one wavefront per chain: exact record size (Foldcomp::getSize)
-//   k_compress_tiled:     fcz_compress.h
-// decompress (Foldcomp::read/decompress, reference src/foldcomp.cpp:779-1036)
-//   k_entry_sizes:        one wavefront per entry: header validation, residue/atom/segment counts
-//   k_backbone:           one wavefront per 64 entries, lane = chain: forward NeRF, reverse NeRF, blend
-//   k_sidechain:          one wavefront per chain, lane = residue; emits the final SoA atoms
-//   k_scan_reduce / k_scan_u64 / k_scan_apply: exclusive scans (offsets)
+//   k_compress_sizes   one wavefront per chain: exact record size (Foldcomp::getSize, reference src/foldcomp.cpp:1190-1214)
+//   k_entry_sizes      one wavefront per entry: what Foldcomp::read checks (:904-1036) + residue / atom counts, longest
+//                      anchor segment and segment count;  k_seg_max reduces the last two over the batch
+//   k_len_sort         counting sort of the entries by residue count (longest first) for the lane = chain kernel
+//   k_backbone<MODE>   one wavefront per 64 entries, lane = chain: forward NeRF, reverse NeRF, blend (:779-858, 167-273)
+//   k_scan_reduce / k_scan_u64 / k_scan_apply   exclusive scans (offsets)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -67,13 +67,13 @@ struct fcz_ctx {
     dev_buf sizes;      // compress: C x u64
     dev_buf scan_tmp;   // block partials of the device scans
     dev_buf res_sc_addr; // compress: residue -> output byte offset of its side-chain torsion bytes
-    // decompress: the segment/residue prefixes computed by fcz_decompress_sizes_dev are reused by the
+    // decompress: the totals and the length order computed by fcz_decompress_sizes_dev are reused by the
     // fcz_decompress_batch_dev call that follows on the same entries
     const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_maxseg = 0, sized_maxnseg = 0, sized_nlong = 0;
     bool sizes_fresh = false;
     dev_buf cnt;        // decompress: 2 x n u32 counts (residues, atoms) + n i32 status + n u32 segment info
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
-    dev_buf maxseg;     // decompress: one word, longest anchor segment of the batch
+    dev_buf maxseg;     // decompress: two words: longest anchor segment of the batch, most segments of a chain
     dev_buf wring;      // decompress: per-group ring of cos/sin of the segment's torsions
     dev_buf fwd_long, wring_long;   // decompress: the same per (group, segment) for the long chains' split form
     dev_buf bb;         // decompress: blended backbone

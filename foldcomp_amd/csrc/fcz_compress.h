@@ -574,26 +574,48 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
             __builtin_amdgcn_sched_barrier(0);   // one word at a time: interleaving all of them only inflates the live set
         }
     } else {
-        for (int q = 0; q < 7; q++) {
-            float lo = kInf, hi = -kInf;
-            const float* src = (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0);
-            const uint32_t cntq = (q < 6) ? m : n;
-            for (uint32_t k0 = 0; k0 < cntq; k0 += U * WAVE) {
-                float tv[U];
+        // longer chains: all seven arrays advance together, 128 residues per memory round trip (clamped, unconditional
+        // loads), first for the extrema, then again (from the L2) for the words
+        float lo[7], hi[7];
 #pragma unroll
-                for (int u = 0; u < U; u++) { const uint32_t k = k0 + u * WAVE + lane; tv[u] = (k < cntq) ? src[k] : 0.0f; }
+        for (int q = 0; q < 7; q++) { lo[q] = kInf; hi[q] = -kInf; }
+        for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
+            float tv[7][2];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const bool on = k0 + u * WAVE + lane < cntq;
-                    lo = __builtin_fminf(lo, on ? tv[u] : kInf); hi = __builtin_fmaxf(hi, on ? tv[u] : -kInf);
+            for (int u = 0; u < 2; u++) {
+                const uint32_t k = k0 + u * WAVE + lane, kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
+#pragma unroll
+                for (int q = 0; q < 6; q++) tv[q][u] = a_arr[(size_t)q * R + kw];
+                tv[6][u] = in.bfac_ca[r0 + kr];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t k = k0 + u * WAVE + lane;
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const bool on = k < ((q < 6) ? m : n);
+                    lo[q] = __builtin_fminf(lo[q], on ? tv[q][u] : kInf); hi[q] = __builtin_fmaxf(hi[q], on ? tv[q][u] : -kInf);
                 }
             }
-            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), src, cntq);
         }
-        for (uint32_t k = lane; k < n; k += WAVE) {
-            const bool w = k < m;
-            pack_store(k, in.res_code[r0 + k], w ? a_arr[k] : 0.f, w ? a_arr[R + k] : 0.f, w ? a_arr[2 * R + k] : 0.f,
-                       w ? a_arr[3 * R + k] : 0.f, w ? a_arr[4 * R + k] : 0.f, w ? a_arr[5 * R + k] : 0.f, in.bfac_ca[r0 + k]);
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+            finish_q(q, wave_min_f32(lo[q]), wave_max_f32(hi[q]), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), (q < 6) ? m : n);
+        for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
+            float tv[7][2]; uint32_t rc2[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t k = k0 + u * WAVE + lane, kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
+#pragma unroll
+                for (int q = 0; q < 6; q++) tv[q][u] = a_arr[(size_t)q * R + kw];
+                tv[6][u] = in.bfac_ca[r0 + kr];
+                rc2[u] = in.res_code[r0 + kr];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t k = k0 + u * WAVE + lane;
+                if (k < n) pack_store(k, rc2[u], tv[0][u], tv[1][u], tv[2][u], tv[3][u], tv[4][u], tv[5][u], tv[6][u]);
+            }
         }
     }
 

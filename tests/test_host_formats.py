@@ -124,3 +124,36 @@ def test_fragmenting_rules():
     assert list(split_residues(t.take(chains[0]))) == [0, 4, 8, 12]
     with pytest.raises(Exception):
         parse_pdb(txt, single_chain=True)
+
+
+def test_pdb_writer_restatement_equals_reference_on_column_overflows():
+    """The goldens hold no line whose numbers overflow their columns (serial > 99999, residue number > 9999, coordinates
+    beyond 8 characters, B-factor beyond 6, titles with continuation numbers > 99). The device writer is tested against
+    pdbio.py on such lines (tests/test_gpu_pdb.py), so pdbio.py itself is pinned to the real reference on them here."""
+    import pytest
+    import _harness as H
+    if not H.have_ref():
+        pytest.skip("oracle/_ref (the reference built from its own sources) is not available")
+    from foldcomp_amd import fczfile, synthetic
+    from foldcomp_amd.api import _pdb_from_result
+    lens = [40, 5200, 33, 64]
+    b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=99))
+    b.first_res_index[0] = 9985
+    b.first_atom_index[1] = 65000
+    a0, a1 = int(b.atom_off[b.res_off[2]]), int(b.atom_off[b.res_off[3]])
+    b.x[a0:a1] += np.float32(20000.0); b.y[a0:a1] -= np.float32(3000.0); b.z[a0:a1] += np.float32(123456.0)
+    b.bfac_ca[b.res_off[2]:b.res_off[3]] = np.linspace(900.0, 1800.0, int(b.res_off[3] - b.res_off[2])).astype(np.float32)
+    titles = [b"t0", b"chain with many atoms", b"far away", bytes((65 + i % 26) for i in range(7300))]
+    b.titles = np.frombuffer(b"".join(titles), np.uint8).copy()
+    b.title_off = np.concatenate([[0], np.cumsum([len(t) for t in titles])]).astype(np.uint32)
+    blob, off, st = H.oracle_compress(b, n_threads=4)
+    assert (st == 0).all()
+    for alt in (False, True):
+        o = H.oracle_decompress(blob, off, alt_order=alt, n_threads=4)
+        for i in range(len(lens)):
+            e = blob[off[i]:off[i + 1]].tobytes()
+            ref = H.ref_decompress_pdb(e, alt_order=alt)
+            mine = _pdb_from_result(fczfile.parse(e), o, i, alt)
+            assert mine == ref, (alt, i)
+            if i < 3:
+                assert any(len(line) > 80 for line in ref.split("\n")), "the case must really overflow a column"

@@ -324,9 +324,10 @@ def main():
         ms_s, n_s = codec.kernel_time("pdb_sizes"); ms_f, n_f = codec.kernel_time("pdb_format")
         ms_s /= max(n_s, 1); ms_f /= max(n_f, 1)
         n_at = int(atom_off_dev[npdb]) & 0xFFFFFFFF
-        # parity of the first chain against the host restatement of the reference writer (foldcomp_amd/pdbio.py)
+        # parity of the first chain against the host restatement of the reference writer (oracle/host_text.py, a checker)
         from foldcomp_amd import fczfile
-        from foldcomp_amd.api import _pdb_from_result
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from host_text import pdb_from_result as _pdb_from_result
         e0 = blob_dev[:int(off_dev[1])].cpu().numpy().tobytes()
         a1, r1 = int(atom_off_dev[1]), int(res_off_dev[1])
         d0 = {"atom_off": np.asarray([0, a1]), "res_off": np.asarray([0, r1]), "res_code": out_t["res_code"][:r1].cpu().numpy(),
@@ -358,8 +359,10 @@ def main():
         codec.synchronize()
         ms_e, n_e = codec.kernel_time("extract"); ms_e /= max(n_e, 1)
         from foldcomp_amd import fczfile as _ff
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from host_text import extract_plddt as _extract_plddt
         e0 = blob_dev[:int(off_dev[1])].cpu().numpy().tobytes()
-        ok_e = data_dev[:int(data_off[1])].cpu().numpy().tobytes() == _ff.extract_plddt(_ff.parse(e0), 2).encode()
+        ok_e = data_dev[:int(data_off[1])].cpu().numpy().tobytes() == _extract_plddt(_ff.parse(e0), 2).encode()
         ext = {"mode": "plddt -p 2", "records": C, "data_bytes": dbytes, "ms": round(ms_e, 4),
                "residues_per_s": round(R / (ms_e * 1e-3)) if ms_e else None,
                # algorithmic bytes: header (84 B) + one B-factor byte per residue in, the characters out

@@ -17,7 +17,7 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import fczfile, pdbio
+from . import fczfile
 from ._aa_tables import RES1, RES3
 from .codec import Codec
 from .database import DatabaseReader
@@ -81,33 +81,6 @@ def compress(name: str, pdb_content: str, *, anchor_residue_threshold: int = DEF
 
 
 # ---- decompress ----------------------------------------------------------------------------------
-def _pdb_from_result(rec: fczfile.FczRecord, d, i: int, alt_order: bool) -> str:
-    a0, a1 = int(d["atom_off"][i]), int(d["atom_off"][i + 1])
-    r0, r1 = int(d["res_off"][i]), int(d["res_off"][i + 1])
-    n_at = a1 - a0
-    rc = d["res_code"][r0:r1]
-    ac = d["atom_code"][a0:a1]
-    natoms = np.asarray([len_ for len_ in map(lambda c: _NATOMS[c], rc)], np.int64)
-    res_of_atom = np.repeat(np.arange(r1 - r0), natoms)
-    has_oxt = n_at == int(natoms.sum()) + 1
-    bf = d["bfac_res"][r0:r1][res_of_atom]
-    resnum = rec.first_res_index + res_of_atom
-    rcode_atom = rc[res_of_atom]
-    names = None
-    if has_oxt:
-        # the OXT record carries header.nResidue as residue number and header.lastResidue as name
-        # (Foldcomp::read, src/foldcomp.cpp:960-963)
-        bf = np.concatenate([bf, d["bfac_res"][r1 - 1:r1]])
-        resnum = np.concatenate([resnum, [rec.n_residues]])
-        rcode_atom = np.concatenate([rcode_atom, rc[-1:]])
-        names = [RES3[c] for c in rcode_atom[:-1]] + [pdbio.three_letter_from_one(rec.last_residue)]
-    return pdbio.format_pdb(rec.title, ac, rcode_atom, resnum, rec.chain, rec.first_atom_index,
-                            d["x"][a0:a1], d["y"][a0:a1], d["z"][a0:a1], bf, res_name_override=names)
-
-
-from ._aa_tables import RES_NATOMS as _NATOMS  # noqa: E402
-
-
 def decompress_many(entries: Sequence[bytes], *, alt_order: bool = False, codec: Optional[Codec] = None,
                     skip_bad: bool = False) -> List[Optional[Tuple[str, str]]]:
     """[fcz, ...] -> [(name, pdb_text), ...] in one GPU batch"""

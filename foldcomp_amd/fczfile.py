@@ -109,37 +109,6 @@ def sequence(rec: FczRecord) -> str:
     return "".join(RES1[c] if c < 24 else "X" for c in rec.res_codes)
 
 
-def extract_plddt(rec: FczRecord, digits: int) -> str:
-    """Foldcomp::extract type 0 (src/foldcomp.cpp:1262-1325), float32 arithmetic and C truncation"""
-    digits = min(max(int(digits), 1), 4)
-    tf = temp_factors(rec)
-    mn, cf = struct.unpack_from("<ff", rec.raw, rec.o_tmp)
-    maxval = np.float32(np.float32(cf) * np.float32(255.0)) + np.float32(mn)
-    zero_one = bool(maxval <= np.float32(1.0)) and digits <= 2
-    f32 = np.float32
-    if zero_one:
-        cl = np.clip(tf, f32(0), f32(1))
-        d1 = (cl * f32(10)).astype(np.int32) % 10
-        d2 = (cl * f32(100)).astype(np.int32) % 10
-    else:
-        cl = np.clip(tf, f32(0), f32(100))
-        d1 = (cl / f32(10)).astype(np.int32)       # (char)(clamped / 10.0f): 100 -> 10 -> ':'
-        d2 = cl.astype(np.int32) % 10
-    d3 = (cl * f32(10)).astype(np.int32) % 10
-    d4 = (cl * f32(100)).astype(np.int32) % 10
-    parts = []
-    for i in range(len(tf)):
-        s = chr(48 + int(d1[i]))
-        if digits > 1:
-            s += chr(48 + int(d2[i]))
-        if digits >= 3:
-            s += "." + chr(48 + int(d3[i]))
-        if digits == 4:
-            s += chr(48 + int(d4[i]))
-        parts.append(s)
-    return ("," if digits > 1 else "").join(parts)
-
-
 def fasta_like(title: str, data: str) -> str:
     return f">{title}\n{data}\n"          # writeFASTALike, src/foldcomp.cpp:1223-1231
 

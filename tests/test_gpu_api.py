@@ -5,7 +5,7 @@ import pytest
 
 import foldcomp_amd as foldcomp
 from _cases import db_cases, golden_batch
-from foldcomp_amd import pdbio
+import host_text as pdbio   # oracle/host_text.py: host restatement of the reference writer
 from foldcomp_amd._aa_tables import RES3
 from foldcomp_amd.database import DatabaseWriter
 

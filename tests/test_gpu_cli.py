@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from _cases import golden_batch
-from foldcomp_amd import pdbio
+import host_text as pdbio   # oracle/host_text.py: host restatement of the reference writer
 from foldcomp_amd.__main__ import file_parts, main
 from foldcomp_amd.database import DatabaseReader
 

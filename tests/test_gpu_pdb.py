@@ -1,5 +1,5 @@
 """GPU: PDB text produced on the device (k_pdb_sizes / k_pdb_format) against the reference's own text (goldens) and, for
-column overflows the goldens do not contain, against the host restatement in foldcomp_amd/pdbio.py (itself pinned to the
+column overflows the goldens do not contain, against the host restatement in oracle/host_text.py (itself pinned to the
 goldens in test_host_formats.py)."""
 import numpy as np
 import pytest
@@ -29,7 +29,7 @@ def test_pdb_text_equals_reference_for_every_golden(codec, golden):
 
 
 def _host_text(codec, entries, alt_order=False):
-    from foldcomp_amd.api import _pdb_from_result
+    from host_text import pdb_from_result as _pdb_from_result
     blob, off = _blob(entries)
     d = codec.decompress_batch(blob, off, alt_order=alt_order)
     return [_pdb_from_result(fczfile.parse(e), d, i, alt_order).encode("latin-1") for i, e in enumerate(entries)]

@@ -8,14 +8,15 @@ import pytest
 
 import _harness as H
 from _cases import compress_cases, db_cases, entries_blob
-from foldcomp_amd import fczfile, pdbio
+import host_text as pdbio   # oracle/host_text.py
+from foldcomp_amd import fczfile
 from foldcomp_amd._aa_tables import RES3, RES_NATOMS
 from foldcomp_amd.database import DatabaseReader, DatabaseWriter
 
 
 def _pdb_text_from_oracle(z, name):
     """coordinates from the oracle (checker), text from the product's formatter"""
-    from foldcomp_amd.api import _pdb_from_result
+    from host_text import pdb_from_result as _pdb_from_result
     e = z[f"{name}/fcz"].tobytes()
     blob, off = entries_blob([e])
     d = H.oracle_decompress(blob, off)
@@ -56,7 +57,7 @@ def test_extract_strings_match_reference(golden):
     for name in compress_cases(index) + db_cases(index):
         rec = fczfile.parse(z[f"{name}/fcz"].tobytes())
         for d in (1, 2, 3, 4):
-            assert fczfile.extract_plddt(rec, d) == z[f"{name}/plddt{d}"].tobytes().decode("latin-1"), (name, d)
+            assert pdbio.extract_plddt(rec, d) == z[f"{name}/plddt{d}"].tobytes().decode("latin-1"), (name, d)
         assert fczfile.sequence(rec) == z[f"{name}/fasta"].tobytes().decode("latin-1"), name
 
 
@@ -66,8 +67,8 @@ def test_committed_plddt_fixtures(golden):
     rec = fczfile.parse(z["fixture:test_af.fcz"].tobytes())
     fa = z["fixture:test_af.plddt"].tobytes().decode()
     tsv = z["fixture:test_af.plddt.tsv"].tobytes().decode()
-    assert fczfile.fasta_like("test/test_af.fcz", fczfile.extract_plddt(rec, 1)) == fa
-    assert fczfile.tsv_line("test/test_af.fcz", rec.n_residues, fczfile.extract_plddt(rec, 4)) == tsv
+    assert fczfile.fasta_like("test/test_af.fcz", pdbio.extract_plddt(rec, 1)) == fa
+    assert fczfile.tsv_line("test/test_af.fcz", rec.n_residues, pdbio.extract_plddt(rec, 4)) == tsv
 
 
 def test_get_data_fcz_lists_match_reference_angles(golden):
@@ -129,13 +130,13 @@ def test_fragmenting_rules():
 def test_pdb_writer_restatement_equals_reference_on_column_overflows():
     """The goldens hold no line whose numbers overflow their columns (serial > 99999, residue number > 9999, coordinates
     beyond 8 characters, B-factor beyond 6, titles with continuation numbers > 99). The device writer is tested against
-    pdbio.py on such lines (tests/test_gpu_pdb.py), so pdbio.py itself is pinned to the real reference on them here."""
+    oracle/host_text.py on such lines (tests/test_gpu_pdb.py), so that restatement itself is pinned to the real reference on them here."""
     import pytest
     import _harness as H
     if not H.have_ref():
         pytest.skip("oracle/_ref (the reference built from its own sources) is not available")
     from foldcomp_amd import fczfile, synthetic
-    from foldcomp_amd.api import _pdb_from_result
+    from host_text import pdb_from_result as _pdb_from_result
     lens = [40, 5200, 33, 64]
     b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=99))
     b.first_res_index[0] = 9985

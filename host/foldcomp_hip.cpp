@@ -1,0 +1,576 @@
+// foldcomp_hip.cpp -- the C++ host of the MI355X codec: a `foldcomp`-style command line over the C-ABI of include/fcz_hip.h.
+//
+//   foldcomp-hip compress   [-b N] [-y] [-r] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir>]
+//   foldcomp-hip decompress [-a] [-y] [-r] <fcz file|dir> [<pdb file|dir>]
+//   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir> [<out file>]
+//   foldcomp-hip check      [-r] <fcz file|dir>
+//   foldcomp-hip dump-batch [-b N] <pdb file>          (host-side batch of a file as text: no GPU needed; used by the tests)
+//
+// It mirrors the reference's own driver (src/main.cpp:438-536 compress, :612-689 decompress, :780-795 extract, :912-926
+// check) for PDB text files and directories: structures are parsed on the host threads, fragments (one chain without gaps
+// = one FCZ record, src/main.cpp:465-508) are batched, and every batch makes ONE trip through the GPU
+// (fcz_compress_batch / fcz_decompress_pdb_* / fcz_extract). Host logic restated here, each with its reference:
+//   fixed-column ATOM parser            foldcomp/foldcomp.cxx:259-278, gemmi number parsing = strtod -> float
+//   removeAlternativePosition           src/atom_coordinate.cpp:362-370
+//   identifyChains                      src/atom_coordinate.cpp:469-497
+//   identifyDiscontinousResInd          src/atom_coordinate.cpp:506-530
+//   splitAtomByResidue                  src/atom_coordinate.cpp:304-328
+//   getFileParts / isCompressible       src/utility.cpp:118-140
+// mmCIF, .gz, tar and database containers are handled by the Python host (python -m foldcomp_amd).
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "../include/fcz_hip.h"
+}
+
+namespace {
+
+constexpr size_t BATCH_CHAINS = 16384;
+
+// ---- atoms of one input file (the reference's std::vector<AtomCoordinate>, as parallel arrays) ----
+struct AtomTable {
+    std::vector<std::string> atom, residue;
+    std::vector<char> chain;
+    std::vector<int> atom_index, res_index;
+    std::vector<float> x, y, z, bfac;
+    size_t size() const { return atom.size(); }
+    AtomTable slice(size_t a, size_t b) const {
+        AtomTable t;
+        t.atom.assign(atom.begin() + a, atom.begin() + b); t.residue.assign(residue.begin() + a, residue.begin() + b);
+        t.chain.assign(chain.begin() + a, chain.begin() + b);
+        t.atom_index.assign(atom_index.begin() + a, atom_index.begin() + b); t.res_index.assign(res_index.begin() + a, res_index.begin() + b);
+        t.x.assign(x.begin() + a, x.begin() + b); t.y.assign(y.begin() + a, y.begin() + b); t.z.assign(z.begin() + a, z.begin() + b);
+        t.bfac.assign(bfac.begin() + a, bfac.begin() + b);
+        return t;
+    }
+    void push_from(const AtomTable& o, size_t i) {
+        atom.push_back(o.atom[i]); residue.push_back(o.residue[i]); chain.push_back(o.chain[i]);
+        atom_index.push_back(o.atom_index[i]); res_index.push_back(o.res_index[i]);
+        x.push_back(o.x[i]); y.push_back(o.y[i]); z.push_back(o.z[i]); bfac.push_back(o.bfac[i]);
+    }
+};
+
+std::string strip(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) a++;
+    while (b > a && isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+std::string field(const std::string& line, size_t a, size_t b) { return a < line.size() ? line.substr(a, std::min(b, line.size()) - a) : std::string(); }
+bool starts_with(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
+bool ends_with(const std::string& s, const std::string& p) { return s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0; }
+
+int parse_int(const std::string& f) {
+    const std::string s = strip(f);
+    char* end = nullptr;
+    const long v = strtol(s.c_str(), &end, 10);
+    if (s.empty() || *end) throw std::runtime_error("invalid integer field '" + f + "'");
+    return (int)v;
+}
+float parse_float(const std::string& f) {   // text -> double -> float, as gemmi / the Python binding do
+    const std::string s = strip(f);
+    char* end = nullptr;
+    const double v = strtod(s.c_str(), &end);
+    if (s.empty() || *end) throw std::runtime_error("invalid number field '" + f + "'");
+    return (float)v;
+}
+
+std::vector<std::string> split_lines(const std::string& text) {
+    std::vector<std::string> lines;
+    size_t a = 0;
+    while (a <= text.size()) {
+        size_t b = text.find('\n', a);
+        if (b == std::string::npos) b = text.size();
+        std::string l = text.substr(a, b - a);
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        if (b > a || b < text.size()) lines.push_back(l);
+        a = b + 1;
+    }
+    return lines;
+}
+
+AtomTable parse_pdb(const std::vector<std::string>& lines, bool hetatm) {
+    AtomTable t;
+    for (const std::string& line : lines) {
+        if (!(starts_with(line, "ATOM") || (hetatm && starts_with(line, "HETATM")))) continue;
+        t.atom.push_back(strip(field(line, 12, 16)));
+        t.residue.push_back(strip(field(line, 17, 20)));
+        const std::string ch = field(line, 21, 22);
+        t.chain.push_back(ch.empty() ? ' ' : ch[0]);
+        t.atom_index.push_back(parse_int(field(line, 6, 11)));
+        t.res_index.push_back(parse_int(field(line, 22, 26)));
+        t.x.push_back(parse_float(field(line, 30, 38))); t.y.push_back(parse_float(field(line, 38, 46))); t.z.push_back(parse_float(field(line, 46, 54)));
+        const std::string b = strip(field(line, 60, 66));
+        t.bfac.push_back(b.empty() ? 0.0f : parse_float(b));
+    }
+    return t;
+}
+
+// gemmi: _entry.id = HEADER id code (cols 63-66), else the TITLE records
+std::string pdb_title(const std::vector<std::string>& lines) {
+    std::vector<std::string> parts;
+    for (const std::string& line : lines) {
+        if (starts_with(line, "HEADER") && line.size() >= 66 && !strip(field(line, 62, 66)).empty()) return strip(field(line, 62, 66));
+        if (starts_with(line, "TITLE")) parts.push_back(strip(field(line, 10, 80)));
+        if (starts_with(line, "ATOM")) break;
+    }
+    std::string out;
+    for (size_t i = 0; i < parts.size(); i++) out += (i ? " " : "") + parts[i];
+    return strip(out);
+}
+
+AtomTable remove_alternative_position(const AtomTable& t) {
+    AtomTable o;
+    const std::string* prev = nullptr;
+    for (size_t i = 0; i < t.size(); i++) {
+        if (prev && t.atom[i] == *prev) continue;
+        o.push_from(t, i);
+        prev = &t.atom[i];
+    }
+    return o;
+}
+
+struct Range { size_t a, b; };
+
+std::vector<Range> identify_chains(const AtomTable& t) {
+    std::vector<Range> out;
+    const size_t n = t.size();
+    size_t start = 0, i = 1;
+    while (i < n) {
+        if (t.chain[i] != t.chain[i - 1]) {
+            if (t.atom[i] == "N") { out.push_back({start, i}); start = i; }
+            else {
+                size_t j = i;
+                while (j < n && t.atom[j] != "N") j++;
+                if (j == n) break;
+                out.push_back({start, i});
+                start = j; i = start;
+            }
+        }
+        i++;
+    }
+    out.push_back({start, n});
+    return out;
+}
+
+std::vector<Range> identify_discontinuous(const AtomTable& t, Range r) {
+    std::vector<size_t> n_idx;
+    for (size_t i = r.a; i < r.b; i++) if (t.atom[i] == "N") n_idx.push_back(i);
+    std::vector<Range> out;
+    if (n_idx.empty()) return out;
+    size_t start = n_idx[0];
+    for (size_t q = 0; q + 1 < n_idx.size(); q++)
+        if (t.res_index[n_idx[q + 1]] - t.res_index[n_idx[q]] > 1) { out.push_back({start, n_idx[q + 1]}); start = n_idx[q + 1]; }
+    out.push_back({start, r.b});
+    return out;
+}
+
+// residue boundaries as atom offsets (a new residue starts where residue_index changes; the last atom always joins the
+// open residue)
+std::vector<uint32_t> split_residues(const AtomTable& t) {
+    std::vector<uint32_t> ro{0};
+    const size_t n = t.size();
+    for (size_t i = 1; i < n; i++) if (t.res_index[i] != t.res_index[i - 1] && i != n - 1) ro.push_back((uint32_t)i);
+    ro.push_back((uint32_t)n);
+    return ro;
+}
+
+// ---- SoA batch = fcz_chain_batch ----
+struct Batch {
+    std::vector<uint32_t> res_off{0}, atom_off, title_off{0};
+    std::vector<float> x, y, z, bfac_ca;
+    std::vector<uint8_t> atom_code, res_code;
+    std::vector<int32_t> first_res, first_atom;
+    std::string chain_id, titles;
+    size_t n_chains() const { return res_off.size() - 1; }
+
+    // appends one fragment; throws std::runtime_error with what the reference would abort on
+    void add(const AtomTable& t, const std::string& title) {
+        if (t.size() == 0) throw std::runtime_error("empty chain");
+        const std::vector<uint32_t> ro = split_residues(t);
+        const size_t nres = ro.size() - 1, abase = x.size();
+        std::vector<uint8_t> ac(t.size()), rc(nres);
+        std::vector<float> bf(nres, 0.0f);
+        for (size_t i = 0; i < t.size(); i++) ac[i] = (uint8_t)fcz_atom_code_from_name(t.atom[i].c_str());
+        for (size_t r = 0; r < nres; r++) {
+            const int code = fcz_res_code_from_name(t.residue[ro[r]].c_str());
+            if (code < 0) throw std::runtime_error("residue name '" + t.residue[ro[r]] + "' is not supported by the codec");
+            rc[r] = (uint8_t)code;
+            long pos[3] = {-1, -1, -1};
+            for (uint32_t i = ro[r]; i < ro[r + 1]; i++) if (ac[i] < 3 && pos[ac[i]] < 0) pos[ac[i]] = i;
+            if (pos[0] < 0 || pos[1] < 0 || pos[2] < 0 || !(pos[0] < pos[1] && pos[1] < pos[2]))
+                throw std::runtime_error("residue without N, CA, C backbone atoms in order");
+            bf[r] = t.bfac[pos[1]];
+        }
+        for (size_t r = 0; r < nres; r++) atom_off.push_back((uint32_t)(abase + ro[r]));
+        x.insert(x.end(), t.x.begin(), t.x.end()); y.insert(y.end(), t.y.begin(), t.y.end()); z.insert(z.end(), t.z.begin(), t.z.end());
+        atom_code.insert(atom_code.end(), ac.begin(), ac.end());
+        res_code.insert(res_code.end(), rc.begin(), rc.end());
+        bfac_ca.insert(bfac_ca.end(), bf.begin(), bf.end());
+        res_off.push_back(res_off.back() + (uint32_t)nres);
+        first_res.push_back(t.res_index[0]); first_atom.push_back(t.atom_index[0]);
+        chain_id.push_back(t.chain[0]);
+        titles += title; title_off.push_back((uint32_t)titles.size());
+    }
+    fcz_chain_batch view(int anchor_threshold) {
+        if (atom_off.size() == res_code.size()) atom_off.push_back((uint32_t)x.size());
+        fcz_chain_batch b{};
+        b.n_chains = (uint32_t)n_chains(); b.n_residues = (uint32_t)res_code.size(); b.n_atoms = (uint32_t)x.size();
+        b.anchor_threshold = anchor_threshold;
+        b.res_off = res_off.data(); b.atom_off = atom_off.data(); b.x = x.data(); b.y = y.data(); b.z = z.data();
+        b.atom_code = atom_code.data(); b.res_code = res_code.data(); b.bfac_ca = bfac_ca.data();
+        b.first_res_index = first_res.data(); b.first_atom_index = first_atom.data(); b.chain_id = chain_id.data();
+        b.titles = titles.data(); b.title_off = title_off.data();
+        return b;
+    }
+};
+
+// ---- files ----
+std::string read_file(const std::string& p) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + p);
+    std::ostringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+bool is_dir(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+std::string base_name(const std::string& p) { const size_t i = p.find_last_of('/'); return i == std::string::npos ? p : p.substr(i + 1); }
+void list_files(const std::string& dir, bool recursive, std::vector<std::string>& out) {
+    std::vector<std::string> files, dirs;
+    if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* e = readdir(d)) {
+            const std::string n = e->d_name;
+            if (n == "." || n == "..") continue;
+            const std::string p = dir + "/" + n;
+            (is_dir(p) ? dirs : files).push_back(p);
+        }
+        closedir(d);
+    }
+    std::sort(files.begin(), files.end()); std::sort(dirs.begin(), dirs.end());
+    out.insert(out.end(), files.begin(), files.end());
+    if (recursive) for (const std::string& s : dirs) list_files(s, true, out);
+}
+// getFileParts: split at the last '.', a trailing .gz stays with the extension
+void file_parts(const std::string& base, std::string& stem, std::string& ext) {
+    stem = base; ext.clear();
+    std::string gz;
+    if (ends_with(base, ".gz")) { stem = base.substr(0, base.size() - 3); gz = ".gz"; }
+    const size_t i = stem.rfind('.');
+    if (i != std::string::npos) { ext = stem.substr(i + 1) + gz; stem = stem.substr(0, i); }
+    else ext = gz.empty() ? "" : gz.substr(1);
+}
+bool is_compressible(const std::string& ext) { return ext == "pdb" || ext == "cif" || ext == "pdb.gz" || ext == "cif.gz"; }
+
+bool write_out(const std::string& path, const char* data, size_t n, bool overwrite) {
+    if (exists(path) && !overwrite) { fprintf(stderr, "[Error] Output file already exists: %s\n", base_name(path).c_str()); return false; }
+    std::ofstream f(path, std::ios::binary);
+    if (!f) { fprintf(stderr, "[Error] cannot write %s\n", path.c_str()); return false; }
+    f.write(data, (std::streamsize)n);
+    return true;
+}
+void make_dir(const std::string& p) { if (!exists(p)) mkdir(p.c_str(), 0777); }
+
+struct Options {
+    std::string mode, input, output;
+    int brk = 25, digits = 1, ext_mode = 0;
+    bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false;
+};
+
+struct Fragment { std::string out_name; AtomTable atoms; std::string title; };
+
+// one structure file -> its fragments (src/main.cpp:455-508)
+void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
+                  std::vector<Fragment>& out) {
+    const std::vector<std::string> lines = split_lines(read_file(path));
+    AtomTable t = parse_pdb(lines, true);
+    const std::string base = base_name(path);
+    if (t.size() == 0) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base.c_str()); return; }
+    std::string title = pdb_title(lines);
+    if (title.empty() || title == base) title = out_stem;            // src/main.cpp:465
+    t = remove_alternative_position(t);
+    const std::vector<Range> chains = identify_chains(t);
+    for (const Range& cs : chains) {
+        const std::vector<Range> frags = identify_discontinuous(t, cs);
+        if (o.skip_discontinuous && frags.size() > 1) { fprintf(stderr, "Skipping discontinuous chain: %s\n", base.c_str()); continue; }
+        for (size_t j = 0; j < frags.size(); j++) {
+            std::string fname = out_stem;
+            if (chains.size() > 1) fname += t.chain[cs.a];
+            if (frags.size() > 1) fname += "_" + std::to_string(j);
+            if (to_dir_or_file) fname += is_compressible(ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
+            out.push_back({fname, t.slice(frags[j].a, frags[j].b), title});
+        }
+    }
+}
+
+int need_ctx(fcz_ctx** ctx) {
+    const int rc = fcz_ctx_create(0, ctx);
+    if (rc != FCZ_OK) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
+    return rc;
+}
+
+// ---- compress ----
+int run_compress(const Options& o) {
+    const bool single = !is_dir(o.input);
+    std::string output = o.output;
+    if (output.empty()) {
+        if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + ".fcz"; }
+        else output = o.input + "_fcz";
+    }
+    std::vector<std::string> files;
+    if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
+    if (!single) make_dir(output);
+    fcz_ctx* ctx = nullptr;
+    if (need_ctx(&ctx)) return 1;
+    std::vector<Fragment> pending;
+    auto flush = [&]() {
+        if (pending.empty()) return;
+        Batch b;
+        std::vector<size_t> kept;
+        for (size_t i = 0; i < pending.size(); i++) {
+            Batch probe = b;                                    // a fragment the codec cannot take is reported and left out
+            try { b.add(pending[i].atoms, pending[i].title); kept.push_back(i); }
+            catch (const std::exception& e) { b = probe; fprintf(stderr, "[Error] compressing %s: %s\n", pending[i].out_name.c_str(), e.what()); }
+        }
+        if (!kept.empty()) {
+            fcz_chain_batch v = b.view(o.brk);
+            std::vector<uint64_t> off(v.n_chains + 1);
+            fcz_compress_sizes(&v, off.data());
+            std::vector<uint8_t> blob(off.back());
+            std::vector<int32_t> status(v.n_chains);
+            const int rc = fcz_compress_batch(ctx, &v, off.data(), blob.data(), status.data());
+            if (rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
+            for (size_t q = 0; q < kept.size(); q++) {
+                const Fragment& f = pending[kept[q]];
+                if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
+                const std::string path = single ? output : output + "/" + f.out_name;
+                write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
+            }
+        }
+        pending.clear();
+    };
+    for (const std::string& path : files) {
+        std::string stem, ext;
+        file_parts(base_name(path), stem, ext);
+        std::string out_stem = stem;
+        if (single) { std::string os_, oe; file_parts(base_name(output), os_, oe); out_stem = os_; }
+        try { fragments_of(path, out_stem, ext, true, o, pending); }
+        catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(path).c_str(), e.what()); }
+        if (pending.size() >= BATCH_CHAINS) flush();
+    }
+    flush();
+    fcz_ctx_destroy(ctx);
+    return 0;
+}
+
+// ---- FCZ inputs ----
+struct Entries {
+    std::vector<std::string> names;
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> off{0};
+    void add(const std::string& name, const std::string& data) {
+        names.push_back(name); blob.insert(blob.end(), data.begin(), data.end()); off.push_back(blob.size());
+    }
+    uint32_t n() const { return (uint32_t)names.size(); }
+    void clear() { names.clear(); blob.clear(); off.assign(1, 0); }
+};
+
+int run_decompress(const Options& o) {
+    const bool single = !is_dir(o.input);
+    std::string output = o.output;
+    if (output.empty()) {
+        if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + ".pdb"; }
+        else output = o.input + "_pdb";
+    }
+    std::vector<std::string> files;
+    if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
+    if (!single) make_dir(output);
+    fcz_ctx* ctx = nullptr;
+    if (need_ctx(&ctx)) return 1;
+    Entries ents;
+    auto flush = [&]() {
+        if (!ents.n()) return;
+        std::vector<uint64_t> text_off(ents.n() + 1);
+        std::vector<int32_t> status(ents.n());
+        int rc = fcz_decompress_pdb_begin(ctx, ents.blob.data(), ents.off.data(), ents.n(), o.alt ? 1 : 0, text_off.data(), status.data());
+        std::string text(rc == FCZ_OK ? text_off.back() : 0, '\0');
+        if (rc == FCZ_OK) rc = fcz_decompress_pdb_fetch(ctx, (uint8_t*)text.data());
+        if (rc != FCZ_OK) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
+        for (uint32_t i = 0; i < ents.n() && rc == FCZ_OK; i++) {
+            if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", ents.names[i].c_str()); continue; }
+            std::string stem, ext;
+            file_parts(base_name(ents.names[i]), stem, ext);
+            const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
+            write_out(single ? output : output + "/" + fname, text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
+        }
+        ents.clear();
+    };
+    for (const std::string& path : files) {
+        try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+        if (ents.n() >= BATCH_CHAINS) flush();
+    }
+    flush();
+    fcz_ctx_destroy(ctx);
+    return 0;
+}
+
+// title and residue count straight from the FCZ header (src/foldcomp.h:118-136)
+bool fcz_header(const uint8_t* e, uint64_t len, std::string& title, uint32_t& n_res) {
+    if (len < 76 || memcmp(e, "FCMP", 4) != 0) return false;
+    n_res = (uint32_t)e[4] | ((uint32_t)e[5] << 8);
+    uint32_t tl; memcpy(&tl, e + 24, 4);
+    const uint64_t o_title = 76 + 4ull * e[12];
+    if (o_title + tl > len) return false;
+    title.assign((const char*)e + o_title, tl);
+    return true;
+}
+
+int run_extract(const Options& o) {
+    const bool single = !is_dir(o.input);
+    const int digits = std::min(std::max(o.digits, 1), 4);
+    const std::string suffix = o.ext_mode == 1 ? "fasta" : (digits == 1 ? "plddt" : "plddt.tsv");
+    std::string output = o.output;
+    if (output.empty()) {
+        if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + "." + suffix; }
+        else output = o.input + "." + suffix;                    // merged output, like the reference's default
+    }
+    std::vector<std::string> files;
+    if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
+    fcz_ctx* ctx = nullptr;
+    if (need_ctx(&ctx)) return 1;
+    std::string merged;
+    Entries ents;
+    auto flush = [&]() {
+        if (!ents.n()) return;
+        std::vector<uint64_t> data_off(ents.n() + 1);
+        fcz_extract_sizes(ents.blob.data(), ents.off.data(), ents.n(), o.ext_mode == 1 ? 1 : 0, digits, data_off.data());
+        std::string data(data_off.back(), '\0');
+        const int rc = fcz_extract(ctx, ents.blob.data(), ents.off.data(), ents.n(), o.ext_mode == 1 ? 1 : 0, digits, data_off.data(), (uint8_t*)data.data());
+        if (rc != FCZ_OK) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
+        for (uint32_t i = 0; i < ents.n() && rc == FCZ_OK; i++) {
+            std::string title; uint32_t n_res = 0;
+            const uint64_t len = ents.off[i + 1] - ents.off[i];
+            if (!fcz_header(ents.blob.data() + ents.off[i], len, title, n_res) || (data_off[i + 1] == data_off[i] && n_res)) {
+                fprintf(stderr, "[Error] reading %s\n", ents.names[i].c_str()); continue;
+            }
+            if (!o.use_title) title = base_name(ents.names[i]);
+            const std::string s = data.substr(data_off[i], data_off[i + 1] - data_off[i]);
+            if (o.ext_mode == 0 && digits > 1) merged += title + "\t" + std::to_string(n_res) + "\t" + s + "\n";   // writeTSV
+            else merged += ">" + title + "\n" + s + "\n";                                                       // writeFASTALike
+        }
+        ents.clear();
+    };
+    for (const std::string& path : files) {
+        try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+        if (ents.n() >= BATCH_CHAINS) flush();
+    }
+    flush();
+    fcz_ctx_destroy(ctx);
+    write_out(output, merged.data(), merged.size(), true);
+    return 0;
+}
+
+int run_check(const Options& o) {
+    std::vector<std::string> files;
+    if (is_dir(o.input)) list_files(o.input, o.recursive, files); else files.push_back(o.input);
+    static const char* msgs[] = {"", "backbone count mismatch", "side chain count mismatch", "temperature factor count mismatch",
+                                 "empty backbone angles", "empty side chain angles", "empty temperature factors"};
+    for (const std::string& path : files) {
+        std::string data;
+        try { data = read_file(path); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); continue; }
+        const int rc = data.empty() ? -5 : fcz_check((const uint8_t*)data.data(), data.size());
+        if (rc == 0) printf("[Info] %s is valid.\n", path.c_str());
+        else fprintf(stderr, "[Error] %s: %s\n", path.c_str(), (rc >= 1 && rc <= 6) ? msgs[rc] : "not a valid FCZ entry");
+    }
+    return 0;
+}
+
+// the host-side batch of one file as text (no GPU): what fcz_compress_batch would be handed
+int run_dump_batch(const Options& o) {
+    std::string stem, ext;
+    file_parts(base_name(o.input), stem, ext);
+    std::vector<Fragment> frags;
+    try { fragments_of(o.input, stem, ext, true, o, frags); }
+    catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(o.input).c_str(), e.what()); return 1; }
+    Batch b;
+    for (const Fragment& f : frags) {
+        try { b.add(f.atoms, f.title); printf("fragment %s\n", f.out_name.c_str()); }
+        catch (const std::exception& e) { printf("rejected %s: %s\n", f.out_name.c_str(), e.what()); }
+    }
+    fcz_chain_batch v = b.view(o.brk);
+    printf("n_chains %u n_residues %u n_atoms %u anchor %d\n", v.n_chains, v.n_residues, v.n_atoms, v.anchor_threshold);
+    auto dump_u32 = [](const char* name, const uint32_t* p, size_t n) { printf("%s", name); for (size_t i = 0; i < n; i++) printf(" %u", p[i]); printf("\n"); };
+    dump_u32("res_off", v.res_off, v.n_chains + 1);
+    dump_u32("atom_off", v.atom_off, v.n_residues + 1);
+    dump_u32("title_off", v.title_off, v.n_chains + 1);
+    printf("res_code"); for (uint32_t i = 0; i < v.n_residues; i++) printf(" %u", v.res_code[i]); printf("\n");
+    printf("atom_code"); for (uint32_t i = 0; i < v.n_atoms; i++) printf(" %u", v.atom_code[i]); printf("\n");
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    printf("x"); for (uint32_t i = 0; i < v.n_atoms; i++) printf(" %08x", bits(v.x[i])); printf("\n");
+    printf("y"); for (uint32_t i = 0; i < v.n_atoms; i++) printf(" %08x", bits(v.y[i])); printf("\n");
+    printf("z"); for (uint32_t i = 0; i < v.n_atoms; i++) printf(" %08x", bits(v.z[i])); printf("\n");
+    printf("bfac_ca"); for (uint32_t i = 0; i < v.n_residues; i++) printf(" %08x", bits(v.bfac_ca[i])); printf("\n");
+    printf("first_res"); for (uint32_t i = 0; i < v.n_chains; i++) printf(" %d", v.first_res_index[i]); printf("\n");
+    printf("first_atom"); for (uint32_t i = 0; i < v.n_chains; i++) printf(" %d", v.first_atom_index[i]); printf("\n");
+    printf("chain_id %s\n", std::string(v.chain_id, v.n_chains).c_str());
+    printf("titles %s\n", std::string(v.titles, v.title_off[v.n_chains]).c_str());
+    std::vector<uint64_t> off(v.n_chains + 1);
+    fcz_compress_sizes(&v, off.data());
+    printf("fcz_size"); for (uint32_t i = 0; i < v.n_chains; i++) printf(" %llu", (unsigned long long)(off[i + 1] - off[i])); printf("\n");
+    return 0;
+}
+
+void usage() {
+    fprintf(stderr,
+            "usage: foldcomp-hip compress   [-b N] [-y] [-r] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir>]\n"
+            "       foldcomp-hip decompress [-a] [-y] [-r] <fcz file|dir> [<pdb file|dir>]\n"
+            "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir> [<out>]\n"
+            "       foldcomp-hip check      [-r] <fcz file|dir>\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next_int = [&](int& dst) { if (i + 1 < argc) dst = atoi(argv[++i]); };
+        if (a == "-a" || a == "--alt") o.alt = true;
+        else if (a == "-y" || a == "--overwrite") o.overwrite = true;
+        else if (a == "-r" || a == "--recursive") o.recursive = true;
+        else if (a == "-b" || a == "--break") next_int(o.brk);
+        else if (a == "-p" || a == "--plddt-digits") next_int(o.digits);
+        else if (a == "-t" || a == "--threads") { int unused; next_int(unused); }
+        else if (a == "--plddt") o.ext_mode = 0;
+        else if (a == "--fasta" || a == "--amino-acid") o.ext_mode = 1;
+        else if (a == "--use-title") o.use_title = true;
+        else if (a == "--skip-discontinuous") o.skip_discontinuous = true;
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else pos.push_back(a);
+    }
+    if (pos.size() < 2) { usage(); return 0; }
+    o.mode = pos[0]; o.input = pos[1];
+    while (o.input.size() > 1 && o.input.back() == '/') o.input.pop_back();
+    if (pos.size() > 2) { o.output = pos[2]; while (o.output.size() > 1 && o.output.back() == '/') o.output.pop_back(); }
+    if (!exists(o.input)) { fprintf(stderr, "[Error] %s does not exist.\n", o.input.c_str()); return 1; }
+    if (o.brk <= 0) { fprintf(stderr, "[Error] -b needs a positive value.\n"); return 1; }
+    if (o.mode == "compress") return run_compress(o);
+    if (o.mode == "decompress") return run_decompress(o);
+    if (o.mode == "extract") return run_extract(o);
+    if (o.mode == "check") return run_check(o);
+    if (o.mode == "dump-batch") return run_dump_batch(o);
+    usage();
+    return 1;
+}

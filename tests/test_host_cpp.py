@@ -1,0 +1,141 @@
+"""The C++ host (host/foldcomp-hip) over the C-ABI.
+CPU: `dump-batch` -- the SoA batch it hands to fcz_compress_batch -- equals what the Python host builds from the same PDB
+text (parser, alternative positions, chain and gap splitting, residue splitting, codes, CA B-factors, titles, names).
+GPU: compress / decompress / extract / check of files and directories against the reference-minted goldens."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _cases import golden_batch
+import host_text as pdbio   # oracle/host_text.py
+from foldcomp_amd.structure import Chain, build_batch, identify_chains, identify_discontinuous, parse_pdb, remove_alternative_position
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "host", "foldcomp-hip")
+
+
+def _pdb_text(z, name, chain=None, first_res=None):
+    b = golden_batch(z, name)
+    res_of_atom = np.repeat(np.arange(b.n_residues), np.diff(b.atom_off.astype(np.int64)))
+    fr = int(b.first_res_index[0]) if first_res is None else first_res
+    return pdbio.format_pdb("", b.atom_code, b.res_code[res_of_atom], fr + res_of_atom,
+                            chain or chr(b.chain_id[0]), int(b.first_atom_index[0]), b.x, b.y, b.z, b.bfac_ca[res_of_atom])
+
+
+def _run(*args):
+    assert os.path.exists(BIN), "host/foldcomp-hip missing: run __graft_entry__.build()"
+    return subprocess.run([BIN, *args], capture_output=True, text=True, timeout=120)
+
+
+def _dump(path, brk=25):
+    r = _run("dump-batch", "-b", str(brk), str(path))
+    assert r.returncode == 0, r.stderr
+    d = {"fragment": [], "rejected": []}
+    for line in r.stdout.splitlines():
+        k, _, v = line.partition(" ")
+        if k in ("fragment", "rejected"):
+            d[k].append(v)
+        else:
+            d[k] = v
+    return d
+
+
+def _python_batch(text, stem, brk=25):
+    t = remove_alternative_position(parse_pdb(text, hetatm=True))
+    chains = identify_chains(t)
+    names, cs_list = [], []
+    for cs in chains:
+        frags = identify_discontinuous(t, cs)
+        for j, sl in enumerate(frags):
+            nm = stem + (t.chain[cs.start] if len(chains) > 1 else "") + (f"_{j}" if len(frags) > 1 else "") + ".fcz"
+            names.append(nm); cs_list.append(Chain(stem, t.take(sl)))
+    return names, build_batch(cs_list, brk)
+
+
+def _same(d, names, b):
+    assert d["fragment"] == names
+    ints = lambda k: np.asarray(d[k].split(), np.int64) if d[k] else np.zeros(0, np.int64)
+    hexf = lambda k: np.asarray([int(v, 16) for v in d[k].split()], np.uint32)
+    assert np.array_equal(ints("res_off"), b.res_off) and np.array_equal(ints("atom_off"), b.atom_off)
+    assert np.array_equal(ints("title_off"), b.title_off)
+    assert np.array_equal(ints("res_code"), b.res_code) and np.array_equal(ints("atom_code"), b.atom_code)
+    for k, a in (("x", b.x), ("y", b.y), ("z", b.z), ("bfac_ca", b.bfac_ca)):
+        assert np.array_equal(hexf(k), a.view(np.uint32)), k
+    assert np.array_equal(ints("first_res"), b.first_res_index) and np.array_equal(ints("first_atom"), b.first_atom_index)
+    assert d["chain_id"] == bytes(b.chain_id).decode() and d["titles"] == bytes(b.titles).decode()
+
+
+@pytest.mark.parametrize("name", ["pdb:test_af", "pdb:test", "syn:len350", "syn:len26"])
+def test_cpp_host_batch_equals_python_host(tmp_path, golden, name):
+    z, _ = golden
+    text = _pdb_text(z, name)
+    p = tmp_path / "in.pdb"
+    p.write_text(text)
+    names, b = _python_batch(text, "in")
+    _same(_dump(p), names, b)
+
+
+def test_cpp_host_multichain_gaps_altloc_hetatm(tmp_path, golden):
+    z, _ = golden
+    a = _pdb_text(z, "pdb:multichainA")
+    b0, b1 = _pdb_text(z, "pdb:multichainB_0"), _pdb_text(z, "pdb:multichainB_1")
+    # duplicate every 7th ATOM line (an alternative position), add HETATM-free noise lines and a HEADER without id
+    la = a.splitlines()
+    dup = []
+    for i, l in enumerate(la):
+        dup.append(l)
+        if l.startswith("ATOM") and i % 7 == 3:
+            dup.append(l[:30] + "   9.999   9.999   9.999" + l[54:])
+    text = "REMARK test\n" + "\n".join(dup) + "\n" + b0 + b1 + "END\n"
+    p = tmp_path / "multi.pdb"
+    p.write_text(text)
+    names, bb = _python_batch(text, "multi")
+    assert len(names) == 3 and names[0].startswith("multi") and names[1].endswith("_0.fcz")
+    _same(_dump(p, brk=10), names, _python_batch(text, "multi", 10)[1])
+    # a residue the codec cannot take is reported, not compressed
+    bad = a.replace(" ALA ", " MSE ", 3)
+    q = tmp_path / "bad.pdb"
+    q.write_text(bad)
+    d = _dump(q)
+    if " MSE " in bad:
+        assert d["rejected"] and "MSE" in d["rejected"][0] and d["n_chains"].startswith("0")
+
+
+@pytest.mark.gpu
+def test_cpp_cli_files_and_directories(tmp_path, golden):
+    z, _ = golden
+    d = tmp_path / "in"
+    d.mkdir()
+    names = ["pdb:test_af", "pdb:test", "syn:len350", "syn:len26"]
+    for n in names:
+        (d / (n.split(":")[1] + ".pdb")).write_text(_pdb_text(z, n))
+    r = _run("compress", str(d), str(tmp_path / "fcz"))
+    assert r.returncode == 0, r.stderr
+
+    def no_title(f):   # everything except lenTitle and the title bytes (CLI title = file stem)
+        na, tl = f[12], int.from_bytes(f[24:28], "little")
+        return f[:24] + f[28:76 + 4 * na] + f[76 + 4 * na + tl:]
+    for n in names:
+        stem = n.split(":")[1]
+        got = (tmp_path / "fcz" / f"{stem}.fcz").read_bytes()
+        assert no_title(got) == no_title(z[f"{n}/fcz"].tobytes()), n
+    r = _run("decompress", str(tmp_path / "fcz"), str(tmp_path / "pdb"))
+    assert r.returncode == 0, r.stderr
+    for n in names:
+        stem = n.split(":")[1]
+        back = (tmp_path / "pdb" / f"{stem}.pdb").read_text()
+        ref = z[f"{n}/pdb0"].tobytes().decode("latin-1")
+        assert [l for l in back.splitlines() if l.startswith(("ATOM", "TER"))] == [l for l in ref.splitlines() if l.startswith(("ATOM", "TER"))], n
+    r = _run("extract", "--plddt", "-p", "2", str(tmp_path / "fcz"), str(tmp_path / "out.tsv"))
+    assert r.returncode == 0, r.stderr
+    rows = {l.split("\t")[0]: l.split("\t") for l in (tmp_path / "out.tsv").read_text().splitlines()}
+    assert rows["test_af.fcz"][2] == z["pdb:test_af/plddt2"].tobytes().decode()
+    r = _run("extract", "--fasta", str(tmp_path / "fcz" / "test.fcz"), str(tmp_path / "seq.fasta"))
+    assert (tmp_path / "seq.fasta").read_text().splitlines()[1] == z["pdb:test/fasta"].tobytes().decode()
+    r = _run("check", str(tmp_path / "fcz"))
+    assert r.stdout.count("is valid") == 4
+    # single file, alternative atom order
+    r = _run("decompress", "-a", str(tmp_path / "fcz" / "test_af.fcz"), str(tmp_path / "alt.pdb"))
+    assert r.returncode == 0 and (tmp_path / "alt.pdb").read_text().count("ATOM") == z["pdb:test_af/pdb0"].tobytes().count(b"ATOM")

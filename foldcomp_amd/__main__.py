@@ -154,7 +154,9 @@ def iter_entries(inp: str, recursive: bool, id_list: Optional[str], id_mode: int
             ids = [r.id_of_key(int(w)) if id_mode == 0 else r.id_of_name(w) for w in want]
             ids = [i for i in ids if i >= 0]
         for i in ids:
-            yield r.name(i), r.data(i).rstrip(b"\0")
+            # the stored bytes, MMseqs NUL terminator included: the codec takes the record length from the header (a record may
+            # itself end in zero bytes, so nothing is stripped here)
+            yield r.name(i), r.data(i)
         r.close()
     elif inp.endswith((".tar", ".tar.gz", ".tgz")):
         with tarfile.open(inp) as tf:

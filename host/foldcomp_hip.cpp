@@ -1,10 +1,12 @@
 // foldcomp_hip.cpp -- the C++ host of the MI355X codec: a `foldcomp`-style command line over the C-ABI of include/fcz_hip.h.
 //
-//   foldcomp-hip compress   [-b N] [-y] [-r] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir>]
-//   foldcomp-hip decompress [-a] [-y] [-r] <fcz file|dir> [<pdb file|dir>]
-//   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir> [<out file>]
-//   foldcomp-hip check      [-r] <fcz file|dir>
-//   foldcomp-hip dump-batch [-b N] <pdb file>          (host-side batch of a file as text: no GPU needed; used by the tests)
+//   foldcomp-hip compress   [-b N] [-y] [-r] [-d] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir|db>]
+//   foldcomp-hip decompress [-a] [-y] [-r] [-d] <fcz file|dir|db> [<pdb file|dir|db>]
+//   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir|db> [<out file>]
+//   foldcomp-hip check      [-r] <fcz file|dir|db>
+//   no GPU needed (used by the tests):
+//   foldcomp-hip dump-batch [-b N] <pdb file>          the host-side batch of a file as text
+//   foldcomp-hip db-pack <dir> <db> / db-unpack <db> <dir>   files <-> database container
 //
 // It mirrors the reference's own driver (src/main.cpp:438-536 compress, :612-689 decompress, :780-795 extract, :912-926
 // check) for PDB text files and directories: structures are parsed on the host threads, fragments (one chain without gaps
@@ -16,9 +18,13 @@
 //   identifyDiscontinousResInd          src/atom_coordinate.cpp:506-530
 //   splitAtomByResidue                  src/atom_coordinate.cpp:304-328
 //   getFileParts / isCompressible       src/utility.cpp:118-140
-// mmCIF, .gz, tar and database containers are handled by the Python host (python -m foldcomp_amd).
+//   database container (-d)            src/database_reader.cpp, src/database_writer.cpp
+// mmCIF, .gz and tar inputs are handled by the Python host (python -m foldcomp_amd).
 #include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -26,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -282,13 +289,80 @@ bool write_out(const std::string& path, const char* data, size_t n, bool overwri
 }
 void make_dir(const std::string& p) { if (!exists(p)) mkdir(p.c_str(), 0777); }
 
+
+// ---- Foldcomp / MMseqs2-style database container (reference src/database_reader.cpp, src/database_writer.cpp):
+//      `<db>` concatenated entries, `<db>.index` lines "key\toffset\tlength", `<db>.lookup` lines "key\tname\t0",
+//      `<db>.dbtype` = int32 12 ----
+struct DbReader {
+    struct Row { long long key, off, len; };
+    std::vector<Row> rows;                 // sorted by key (stable), as the reference reader does
+    std::vector<std::pair<long long, std::string>> lookup;   // sorted by key
+    const char* data = nullptr; size_t size = 0; int fd = -1;
+    explicit DbReader(const std::string& path) {
+        std::ifstream fi(path + ".index");
+        if (!fi) throw std::runtime_error("cannot open " + path + ".index");
+        Row r;
+        while (fi >> r.key >> r.off >> r.len) rows.push_back(r);
+        std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.key < b.key; });
+        std::ifstream fl(path + ".lookup");
+        std::string line;
+        while (fl && std::getline(fl, line)) {
+            const size_t t1 = line.find('\t');
+            if (t1 == std::string::npos) continue;
+            const size_t t2 = line.find('\t', t1 + 1);
+            lookup.push_back({atoll(line.substr(0, t1).c_str()), line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1)});
+        }
+        std::stable_sort(lookup.begin(), lookup.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st; fstat(fd, &st); size = (size_t)st.st_size;
+        if (size) { void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0); if (p == MAP_FAILED) throw std::runtime_error("mmap failed"); data = (const char*)p; }
+    }
+    ~DbReader() { if (data) munmap((void*)data, size); if (fd >= 0) close(fd); }
+    size_t n() const { return rows.size(); }
+    std::string name(size_t i) const {
+        auto it = std::lower_bound(lookup.begin(), lookup.end(), rows[i].key, [](const auto& a, long long k) { return a.first < k; });
+        return (it != lookup.end() && it->first == rows[i].key) ? it->second : std::to_string(rows[i].key);
+    }
+    // the stored bytes. MMseqs-made databases end every entry with a NUL: it stays -- the codec, like Foldcomp::read, takes
+    // the record length from the header and ignores what follows (a record may legitimately end in zero bytes itself)
+    std::string entry(size_t i) const {
+        const long long o = rows[i].off, l = rows[i].len;
+        if (o < 0 || l < 0 || (size_t)(o + l) > size) throw std::runtime_error("database entry out of range");
+        return std::string(data + o, (size_t)l);
+    }
+};
+
+struct DbWriter {
+    struct Row { long long key, off, len; std::string name; };
+    std::string path; std::ofstream out; std::vector<Row> rows; long long pos = 0;
+    explicit DbWriter(const std::string& p) : path(p), out(p, std::ios::binary) {
+        if (!out) throw std::runtime_error("cannot write " + p);
+        std::ofstream t(p + ".dbtype", std::ios::binary);
+        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+    }
+    void append(const char* d, size_t n, long long key, const std::string& name, bool nul) {
+        out.write(d, (std::streamsize)n);
+        if (nul) out.put('\0');
+        const long long len = (long long)n + (nul ? 1 : 0);
+        rows.push_back({key, pos, len, name}); pos += len;
+    }
+    void close() {   // free_writer: index and lookup sorted by key (src/database_writer.cpp:59-73)
+        std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.key < b.key; });
+        std::ofstream fi(path + ".index"), fl(path + ".lookup");
+        for (const Row& r : rows) { fi << r.key << "\t" << r.off << "\t" << r.len << "\n"; fl << r.key << "\t" << r.name << "\t0\n"; }
+        out.close();
+    }
+};
+bool is_db(const std::string& p) { return exists(p + ".dbtype"); }
+
 struct Options {
     std::string mode, input, output;
     int brk = 25, digits = 1, ext_mode = 0;
-    bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false;
+    bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
 };
 
-struct Fragment { std::string out_name; AtomTable atoms; std::string title; };
+struct Fragment { std::string out_name, db_name; AtomTable atoms; std::string title; };   // db_name: lookup name = the input file's stem
 
 // one structure file -> its fragments (src/main.cpp:455-508)
 void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
@@ -309,7 +383,7 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
             if (chains.size() > 1) fname += t.chain[cs.a];
             if (frags.size() > 1) fname += "_" + std::to_string(j);
             if (to_dir_or_file) fname += is_compressible(ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
-            out.push_back({fname, t.slice(frags[j].a, frags[j].b), title});
+            out.push_back({fname, out_stem, t.slice(frags[j].a, frags[j].b), title});
         }
     }
 }
@@ -330,7 +404,10 @@ int run_compress(const Options& o) {
     }
     std::vector<std::string> files;
     if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
-    if (!single) make_dir(output);
+    if (o.db && o.output.empty()) output = o.input + "_db";
+    std::unique_ptr<DbWriter> dbw;
+    long long db_key = 0;
+    if (o.db) dbw.reset(new DbWriter(output)); else if (!single) make_dir(output);
     fcz_ctx* ctx = nullptr;
     if (need_ctx(&ctx)) return 1;
     std::vector<Fragment> pending;
@@ -354,6 +431,7 @@ int run_compress(const Options& o) {
             for (size_t q = 0; q < kept.size(); q++) {
                 const Fragment& f = pending[kept[q]];
                 if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
+                if (dbw) { dbw->append((const char*)blob.data() + off[q], off[q + 1] - off[q], db_key++, f.db_name, false); continue; }
                 const std::string path = single ? output : output + "/" + f.out_name;
                 write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
             }
@@ -365,11 +443,12 @@ int run_compress(const Options& o) {
         file_parts(base_name(path), stem, ext);
         std::string out_stem = stem;
         if (single) { std::string os_, oe; file_parts(base_name(output), os_, oe); out_stem = os_; }
-        try { fragments_of(path, out_stem, ext, true, o, pending); }
+        try { fragments_of(path, out_stem, ext, !o.db, o, pending); }
         catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(path).c_str(), e.what()); }
         if (pending.size() >= BATCH_CHAINS) flush();
     }
     flush();
+    if (dbw) dbw->close();
     fcz_ctx_destroy(ctx);
     return 0;
 }
@@ -386,16 +465,36 @@ struct Entries {
     void clear() { names.clear(); blob.clear(); off.assign(1, 0); }
 };
 
+// every FCZ entry of a file, a directory or a database, in batches
+template <class F>
+void for_each_entry(const Options& o, Entries& ents, F&& flush) {
+    if (is_db(o.input)) {
+        DbReader r(o.input);
+        for (size_t i = 0; i < r.n(); i++) {
+            try { ents.add(r.name(i), r.entry(i)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+            if (ents.n() >= BATCH_CHAINS) flush();
+        }
+    } else {
+        std::vector<std::string> files;
+        if (is_dir(o.input)) list_files(o.input, o.recursive, files); else files.push_back(o.input);
+        for (const std::string& path : files) {
+            try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+            if (ents.n() >= BATCH_CHAINS) flush();
+        }
+    }
+    flush();
+}
+
 int run_decompress(const Options& o) {
-    const bool single = !is_dir(o.input);
+    const bool single = !is_dir(o.input) && !is_db(o.input);
     std::string output = o.output;
     if (output.empty()) {
         if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + ".pdb"; }
-        else output = o.input + "_pdb";
+        else output = o.input + (o.db ? "_pdb_db" : "_pdb");
     }
-    std::vector<std::string> files;
-    if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
-    if (!single) make_dir(output);
+    std::unique_ptr<DbWriter> dbw;
+    long long db_key = 0;
+    if (o.db) dbw.reset(new DbWriter(output)); else if (!single) make_dir(output);
     fcz_ctx* ctx = nullptr;
     if (need_ctx(&ctx)) return 1;
     Entries ents;
@@ -412,15 +511,14 @@ int run_decompress(const Options& o) {
             std::string stem, ext;
             file_parts(base_name(ents.names[i]), stem, ext);
             const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
+            // PDB text in a database carries the MMseqs terminator (src/main.cpp:659)
+            if (dbw) { dbw->append(text.data() + text_off[i], text_off[i + 1] - text_off[i], db_key++, stem, true); continue; }
             write_out(single ? output : output + "/" + fname, text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
         }
         ents.clear();
     };
-    for (const std::string& path : files) {
-        try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
-        if (ents.n() >= BATCH_CHAINS) flush();
-    }
-    flush();
+    for_each_entry(o, ents, flush);
+    if (dbw) dbw->close();
     fcz_ctx_destroy(ctx);
     return 0;
 }
@@ -437,7 +535,7 @@ bool fcz_header(const uint8_t* e, uint64_t len, std::string& title, uint32_t& n_
 }
 
 int run_extract(const Options& o) {
-    const bool single = !is_dir(o.input);
+    const bool single = !is_dir(o.input) && !is_db(o.input);
     const int digits = std::min(std::max(o.digits, 1), 4);
     const std::string suffix = o.ext_mode == 1 ? "fasta" : (digits == 1 ? "plddt" : "plddt.tsv");
     std::string output = o.output;
@@ -445,8 +543,6 @@ int run_extract(const Options& o) {
         if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + "." + suffix; }
         else output = o.input + "." + suffix;                    // merged output, like the reference's default
     }
-    std::vector<std::string> files;
-    if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
     fcz_ctx* ctx = nullptr;
     if (need_ctx(&ctx)) return 1;
     std::string merged;
@@ -471,27 +567,52 @@ int run_extract(const Options& o) {
         }
         ents.clear();
     };
-    for (const std::string& path : files) {
-        try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
-        if (ents.n() >= BATCH_CHAINS) flush();
-    }
-    flush();
+    for_each_entry(o, ents, flush);
     fcz_ctx_destroy(ctx);
     write_out(output, merged.data(), merged.size(), true);
     return 0;
 }
 
 int run_check(const Options& o) {
-    std::vector<std::string> files;
-    if (is_dir(o.input)) list_files(o.input, o.recursive, files); else files.push_back(o.input);
     static const char* msgs[] = {"", "backbone count mismatch", "side chain count mismatch", "temperature factor count mismatch",
                                  "empty backbone angles", "empty side chain angles", "empty temperature factors"};
+    Entries ents;
+    auto flush = [&]() {
+        for (uint32_t i = 0; i < ents.n(); i++) {
+            const uint64_t len = ents.off[i + 1] - ents.off[i];
+            const int rc = len ? fcz_check(ents.blob.data() + ents.off[i], len) : -5;
+            if (rc == 0) printf("[Info] %s is valid.\n", ents.names[i].c_str());
+            else fprintf(stderr, "[Error] %s: %s\n", ents.names[i].c_str(), (rc >= 1 && rc <= 6) ? msgs[rc] : "not a valid FCZ entry");
+        }
+        ents.clear();
+    };
+    for_each_entry(o, ents, flush);
+    return 0;
+}
+
+// pure host: files of a directory -> database / database -> files (no GPU)
+int run_db_pack(const Options& o) {
+    if (o.output.empty()) { fprintf(stderr, "[Error] db-pack needs an output database.\n"); return 1; }
+    std::vector<std::string> files;
+    list_files(o.input, o.recursive, files);
+    DbWriter w(o.output);
+    long long key = 0;
     for (const std::string& path : files) {
-        std::string data;
-        try { data = read_file(path); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); continue; }
-        const int rc = data.empty() ? -5 : fcz_check((const uint8_t*)data.data(), data.size());
-        if (rc == 0) printf("[Info] %s is valid.\n", path.c_str());
-        else fprintf(stderr, "[Error] %s: %s\n", path.c_str(), (rc >= 1 && rc <= 6) ? msgs[rc] : "not a valid FCZ entry");
+        std::string stem, ext;
+        file_parts(base_name(path), stem, ext);
+        const std::string d = read_file(path);
+        w.append(d.data(), d.size(), key++, stem, false);
+    }
+    w.close();
+    return 0;
+}
+int run_db_unpack(const Options& o) {
+    if (o.output.empty()) { fprintf(stderr, "[Error] db-unpack needs an output directory.\n"); return 1; }
+    DbReader r(o.input);
+    make_dir(o.output);
+    for (size_t i = 0; i < r.n(); i++) {
+        const std::string d = r.entry(i);
+        write_out(o.output + "/" + r.name(i), d.data(), d.size(), true);
     }
     return 0;
 }
@@ -557,6 +678,7 @@ int main(int argc, char** argv) {
         else if (a == "--fasta" || a == "--amino-acid") o.ext_mode = 1;
         else if (a == "--use-title") o.use_title = true;
         else if (a == "--skip-discontinuous") o.skip_discontinuous = true;
+        else if (a == "-d" || a == "--db") o.db = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else pos.push_back(a);
     }
@@ -571,6 +693,8 @@ int main(int argc, char** argv) {
     if (o.mode == "extract") return run_extract(o);
     if (o.mode == "check") return run_check(o);
     if (o.mode == "dump-batch") return run_dump_batch(o);
+    if (o.mode == "db-pack") return run_db_pack(o);
+    if (o.mode == "db-unpack") return run_db_unpack(o);
     usage();
     return 1;
 }

@@ -139,3 +139,37 @@ def test_cpp_cli_files_and_directories(tmp_path, golden):
     # single file, alternative atom order
     r = _run("decompress", "-a", str(tmp_path / "fcz" / "test_af.fcz"), str(tmp_path / "alt.pdb"))
     assert r.returncode == 0 and (tmp_path / "alt.pdb").read_text().count("ATOM") == z["pdb:test_af/pdb0"].tobytes().count(b"ATOM")
+
+
+def test_cpp_host_database_container(tmp_path, golden):
+    """db-pack / db-unpack (no GPU): the C++ reader and writer interoperate with the Python ones (same .index / .lookup /
+    .dbtype text, NUL-terminated entries stripped on read)"""
+    from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+    z, index = golden
+    names = [n for n in index if n.startswith("db:")][:6]
+    src = tmp_path / "files"
+    src.mkdir()
+    for n in names:
+        (src / (n.replace(":", "_") + ".fcz")).write_bytes(z[f"{n}/fcz"].tobytes())
+    r = _run("db-pack", str(src), str(tmp_path / "cdb"))
+    assert r.returncode == 0, r.stderr
+    rd = DatabaseReader(str(tmp_path / "cdb"))
+    assert len(rd) == len(names)
+    got = {rd.name(i): rd.data(i) for i in range(len(rd))}
+    rd.close()
+    for n in names:
+        assert got[n.replace(":", "_")] == z[f"{n}/fcz"].tobytes()
+    assert (tmp_path / "cdb.dbtype").read_bytes() == (12).to_bytes(4, "little")
+    # Python writer (entries with the MMseqs NUL terminator, keys out of order) -> C++ reader
+    w = DatabaseWriter(str(tmp_path / "pdb"))
+    for k, n in reversed(list(enumerate(names))):
+        w.append(z[f"{n}/fcz"].tobytes() + b"\0", k, n.replace(":", "_") + ".fcz")
+    w.close()
+    r = _run("db-unpack", str(tmp_path / "pdb"), str(tmp_path / "out"))
+    assert r.returncode == 0, r.stderr
+    for n in names:   # stored bytes, terminator included (a record may itself end in zero bytes: nothing is stripped)
+        assert (tmp_path / "out" / (n.replace(":", "_") + ".fcz")).read_bytes() == z[f"{n}/fcz"].tobytes() + b"\0"
+    # check runs on the host only: a database input is walked entry by entry; trailing terminators do not matter
+    for db in ("cdb", "pdb"):
+        r = _run("check", str(tmp_path / db))
+        assert r.stdout.count("is valid") == len(names), (db, r.stderr)

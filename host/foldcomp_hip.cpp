@@ -19,12 +19,14 @@
 //   splitAtomByResidue                  src/atom_coordinate.cpp:304-328
 //   getFileParts / isCompressible       src/utility.cpp:118-140
 //   database container (-d)            src/database_reader.cpp, src/database_writer.cpp
-// mmCIF, .gz and tar inputs are handled by the Python host (python -m foldcomp_amd).
+//   mmCIF _atom_site loop, .gz         src/structure_reader.cpp:31-61 (gemmi), zlib
+// tar inputs are handled by the Python host (python -m foldcomp_amd).
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -147,6 +149,91 @@ AtomTable remove_alternative_position(const AtomTable& t) {
         prev = &t.atom[i];
     }
     return o;
+}
+
+// ---- .gz inputs (zlib) ----
+std::string gunzip(const std::string& z) {
+    z_stream st{};
+    if (inflateInit2(&st, 16 + MAX_WBITS) != Z_OK) throw std::runtime_error("zlib init failed");
+    st.next_in = (Bytef*)z.data(); st.avail_in = (uInt)z.size();
+    std::string out; char buf[1 << 16];
+    int rc;
+    do {
+        st.next_out = (Bytef*)buf; st.avail_out = sizeof buf;
+        rc = inflate(&st, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&st); throw std::runtime_error("not a valid gzip stream"); }
+        out.append(buf, sizeof buf - st.avail_out);
+    } while (rc != Z_STREAM_END);
+    inflateEnd(&st);
+    return out;
+}
+
+// ---- minimal mmCIF reader: the _atom_site loop (what gemmi hands to StructureReader::updateStructure, reference
+//      src/structure_reader.cpp:31-61) and _entry.id ----
+std::vector<std::string> cif_split(const std::string& s) {
+    std::vector<std::string> out;
+    size_t i = 0, n = s.size();
+    while (i < n) {
+        if (isspace((unsigned char)s[i])) { i++; continue; }
+        if (s[i] == '\'' || s[i] == '"') {
+            const char q = s[i]; size_t j = i + 1;
+            while (j < n && !(s[j] == q && (j + 1 == n || isspace((unsigned char)s[j + 1])))) j++;
+            out.push_back(s.substr(i + 1, j - i - 1)); i = j + 1;
+        } else {
+            size_t j = i;
+            while (j < n && !isspace((unsigned char)s[j])) j++;
+            out.push_back(s.substr(i, j - i)); i = j;
+        }
+    }
+    return out;
+}
+AtomTable parse_cif(const std::vector<std::string>& lines, std::string& title) {
+    std::vector<std::string> cols;
+    std::vector<std::vector<std::string>> rows;
+    bool in_loop = false, in_site = false;
+    for (const std::string& line : lines) {
+        const std::string s = strip(line);
+        if (starts_with(s, "_entry.id")) {
+            const size_t sp = s.find_first_of(" \t");
+            std::string v = sp == std::string::npos ? "" : strip(s.substr(sp));
+            while (!v.empty() && (v.front() == '\'' || v.front() == '"')) v.erase(v.begin());
+            while (!v.empty() && (v.back() == '\'' || v.back() == '"')) v.pop_back();
+            title = v;
+        }
+        if (s == "loop_") { in_loop = true; in_site = false; cols.clear(); continue; }
+        if (in_loop && starts_with(s, "_atom_site.")) {
+            std::string c = s.substr(11);
+            const size_t sp = c.find_first_of(" \t");
+            if (sp != std::string::npos) c = c.substr(0, sp);
+            cols.push_back(c); in_site = true; continue;
+        }
+        if (in_loop && starts_with(s, "_")) { in_site = false; continue; }
+        if (in_site && !cols.empty()) {
+            if (s.empty() || s[0] == '#') { in_loop = in_site = false; continue; }
+            rows.push_back(cif_split(s));
+        }
+    }
+    auto col = [&](std::initializer_list<const char*> names) -> int {
+        for (const char* nm : names) for (size_t i = 0; i < cols.size(); i++) if (cols[i] == nm) return (int)i;
+        return -1;
+    };
+    const int c_atom = col({"label_atom_id", "auth_atom_id"}), c_res = col({"label_comp_id", "auth_comp_id"});
+    const int c_chain = col({"auth_asym_id", "label_asym_id"}), c_seq = col({"auth_seq_id", "label_seq_id"});
+    const int c_id = col({"id"}), c_b = col({"B_iso_or_equiv"}), cx = col({"Cartn_x"}), cy = col({"Cartn_y"}), cz = col({"Cartn_z"});
+    AtomTable t;
+    if (c_atom < 0 || c_res < 0 || c_chain < 0 || c_seq < 0 || cx < 0 || cy < 0 || cz < 0) return t;
+    for (const auto& r : rows) {
+        if (r.size() < cols.size()) continue;
+        std::string an = r[c_atom];
+        while (!an.empty() && an.front() == '"') an.erase(an.begin());
+        while (!an.empty() && an.back() == '"') an.pop_back();
+        t.atom.push_back(an); t.residue.push_back(r[c_res]); t.chain.push_back(r[c_chain].empty() ? ' ' : r[c_chain][0]);
+        t.atom_index.push_back(c_id >= 0 ? parse_int(r[c_id]) : (int)t.atom.size());
+        t.res_index.push_back((r[c_seq] == "." || r[c_seq] == "?") ? 0 : parse_int(r[c_seq]));
+        t.x.push_back(parse_float(r[cx])); t.y.push_back(parse_float(r[cy])); t.z.push_back(parse_float(r[cz]));
+        t.bfac.push_back((c_b >= 0 && r[c_b] != "." && r[c_b] != "?") ? parse_float(r[c_b]) : 0.0f);
+    }
+    return t;
 }
 
 struct Range { size_t a, b; };
@@ -367,11 +454,16 @@ struct Fragment { std::string out_name, db_name; AtomTable atoms; std::string ti
 // one structure file -> its fragments (src/main.cpp:455-508)
 void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
                   std::vector<Fragment>& out) {
-    const std::vector<std::string> lines = split_lines(read_file(path));
-    AtomTable t = parse_pdb(lines, true);
     const std::string base = base_name(path);
+    std::string raw = read_file(path);
+    std::string plain = base;
+    if (ends_with(base, ".gz")) { raw = gunzip(raw); plain = base.substr(0, base.size() - 3); }
+    const std::vector<std::string> lines = split_lines(raw);
+    std::string title;
+    AtomTable t;
+    if (ends_with(plain, ".cif")) t = parse_cif(lines, title);
+    else { t = parse_pdb(lines, true); title = pdb_title(lines); }
     if (t.size() == 0) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base.c_str()); return; }
-    std::string title = pdb_title(lines);
     if (title.empty() || title == base) title = out_stem;            // src/main.cpp:465
     t = remove_alternative_position(t);
     const std::vector<Range> chains = identify_chains(t);

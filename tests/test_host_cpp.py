@@ -173,3 +173,44 @@ def test_cpp_host_database_container(tmp_path, golden):
     for db in ("cdb", "pdb"):
         r = _run("check", str(tmp_path / db))
         assert r.stdout.count("is valid") == len(names), (db, r.stderr)
+
+
+def _cif_text(z, name, entry_id="1ABC"):
+    from foldcomp_amd._aa_tables import ATOM_NAMES, RES3
+    b = golden_batch(z, name)
+    res_of_atom = np.repeat(np.arange(b.n_residues), np.diff(b.atom_off.astype(np.int64)))
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_comp_id", "auth_asym_id", "auth_seq_id",
+            "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv"]
+    out = ["data_" + entry_id, "_entry.id " + entry_id, "#", "loop_"] + ["_atom_site." + c for c in cols]
+    for i in range(b.n_atoms):
+        an = ATOM_NAMES[b.atom_code[i]]
+        r = int(res_of_atom[i])
+        out.append("ATOM %d %s %s %s %s %d %.3f %.3f %.3f 1.00 %.2f" % (
+            int(b.first_atom_index[0]) + i, an[0], ('"%s"' % an) if "'" in an else an, RES3[b.res_code[r]], chr(b.chain_id[0]),
+            int(b.first_res_index[0]) + r, b.x[i], b.y[i], b.z[i], b.bfac_ca[r]))
+    out.append("#")
+    return "\n".join(out) + "\n"
+
+
+def test_cpp_host_reads_mmcif_and_gzip_like_the_python_host(tmp_path, golden):
+    import gzip
+    from foldcomp_amd.__main__ import load_structure
+    z, _ = golden
+    cif = _cif_text(z, "pdb:test_af")
+    pdb = _pdb_text(z, "pdb:test")
+    (tmp_path / "a.cif").write_text(cif)
+    (tmp_path / "b.cif.gz").write_bytes(gzip.compress(cif.encode()))
+    (tmp_path / "c.pdb.gz").write_bytes(gzip.compress(pdb.encode()))
+    for fname, stem in (("a.cif", "a"), ("b.cif.gz", "b"), ("c.pdb.gz", "c")):
+        path = tmp_path / fname
+        t, title = load_structure(str(path), path.read_bytes())
+        if title == fname:
+            title = stem
+        t = remove_alternative_position(t)
+        chains = identify_chains(t)
+        assert len(chains) == 1
+        frags = identify_discontinuous(t, chains[0])
+        b = build_batch([Chain(title, t.take(sl)) for sl in frags], 25)
+        names = [stem + (f"_{j}" if len(frags) > 1 else "") + ".fcz" for j in range(len(frags))]
+        _same(_dump(path), names, b)
+    assert _dump(tmp_path / "a.cif")["titles"] == "1ABC"

@@ -25,6 +25,8 @@ def _pdb_text(z, name, chain=None, first_res=None):
 
 
 def _run(*args):
+    if not os.path.exists(BIN):   # normally built by __graft_entry__.build(); g++ and the library are enough to build it here
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host")], capture_output=True, timeout=300)
     assert os.path.exists(BIN), "host/foldcomp-hip missing: run __graft_entry__.build()"
     return subprocess.run([BIN, *args], capture_output=True, text=True, timeout=120)
 

@@ -480,6 +480,27 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
     }
 }
 
+// fragments of many structure files, parsed on all host threads (the reference: `omp parallel for` over entries,
+// src/input_processor.h:85-101), kept in file order; messages are printed in file order too
+void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t b, bool single, const std::string& output, bool to_dir_or_file,
+                        const Options& o, std::vector<Fragment>& out) {
+    std::vector<std::vector<Fragment>> per(b - a);
+    std::vector<std::string> err(b - a);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long long i = (long long)a; i < (long long)b; i++) {
+        std::string stem, ext;
+        file_parts(base_name(files[i]), stem, ext);
+        std::string out_stem = stem;
+        if (single) { std::string os_, oe; file_parts(base_name(output), os_, oe); out_stem = os_; }
+        try { fragments_of(files[i], out_stem, ext, to_dir_or_file, o, per[i - a]); }
+        catch (const std::exception& e) { err[i - a] = "[Error] " + base_name(files[i]) + ": " + e.what() + "\n"; }
+    }
+    for (size_t i = 0; i < b - a; i++) {
+        if (!err[i].empty()) fputs(err[i].c_str(), stderr);
+        for (Fragment& f : per[i]) out.push_back(std::move(f));
+    }
+}
+
 int need_ctx(fcz_ctx** ctx) {
     const int rc = fcz_ctx_create(0, ctx);
     if (rc != FCZ_OK) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
@@ -530,13 +551,9 @@ int run_compress(const Options& o) {
         }
         pending.clear();
     };
-    for (const std::string& path : files) {
-        std::string stem, ext;
-        file_parts(base_name(path), stem, ext);
-        std::string out_stem = stem;
-        if (single) { std::string os_, oe; file_parts(base_name(output), os_, oe); out_stem = os_; }
-        try { fragments_of(path, out_stem, ext, !o.db, o, pending); }
-        catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(path).c_str(), e.what()); }
+    constexpr size_t FILE_CHUNK = 2048;   // files parsed side by side before the next GPU batch is considered
+    for (size_t f0 = 0; f0 < files.size(); f0 += FILE_CHUNK) {
+        fragments_of_files(files, f0, std::min(files.size(), f0 + FILE_CHUNK), single, output, !o.db, o, pending);
         if (pending.size() >= BATCH_CHAINS) flush();
     }
     flush();
@@ -711,11 +728,10 @@ int run_db_unpack(const Options& o) {
 
 // the host-side batch of one file as text (no GPU): what fcz_compress_batch would be handed
 int run_dump_batch(const Options& o) {
-    std::string stem, ext;
-    file_parts(base_name(o.input), stem, ext);
+    std::vector<std::string> files;
+    if (is_dir(o.input)) list_files(o.input, o.recursive, files); else files.push_back(o.input);
     std::vector<Fragment> frags;
-    try { fragments_of(o.input, stem, ext, true, o, frags); }
-    catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(o.input).c_str(), e.what()); return 1; }
+    fragments_of_files(files, 0, files.size(), false, "", true, o, frags);
     Batch b;
     for (const Fragment& f : frags) {
         try { b.add(f.atoms, f.title); printf("fragment %s\n", f.out_name.c_str()); }

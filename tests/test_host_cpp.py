@@ -216,3 +216,29 @@ def test_cpp_host_reads_mmcif_and_gzip_like_the_python_host(tmp_path, golden):
         names = [stem + (f"_{j}" if len(frags) > 1 else "") + ".fcz" for j in range(len(frags))]
         _same(_dump(path), names, b)
     assert _dump(tmp_path / "a.cif")["titles"] == "1ABC"
+
+
+def test_cpp_host_directory_is_parsed_in_file_order(tmp_path, golden):
+    """a directory goes through the multi-threaded parse: fragments and arrays must come out in sorted file order"""
+    z, _ = golden
+    d = tmp_path / "many"
+    d.mkdir()
+    cases = ["pdb:test_af", "pdb:test", "syn:len350", "syn:len26", "pdb:multichainA"]
+    texts = {}
+    for rep in range(6):
+        for n in cases:
+            stem = f"{n.split(':')[1]}_{rep:02d}"
+            texts[stem] = _pdb_text(z, n)
+            (d / (stem + ".pdb")).write_text(texts[stem])
+    names, chains = [], []
+    for stem in sorted(texts):                      # list_files sorts by path
+        nm, b1 = _python_batch(texts[stem], stem)
+        names += nm
+    # one Python batch over everything, in the same order
+    all_chains = []
+    for stem in sorted(texts):
+        t = remove_alternative_position(parse_pdb(texts[stem], hetatm=True))
+        for cs in identify_chains(t):
+            for sl in identify_discontinuous(t, cs):
+                all_chains.append(Chain(stem, t.take(sl)))
+    _same(_dump(d), names, build_batch(all_chains, 25))

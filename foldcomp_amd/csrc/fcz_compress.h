@@ -10,12 +10,14 @@
 //                      The tile's atoms (one contiguous range of the SoA arrays, plus the successor of the last
 //                      residue) are parked in LDS as {x, y, z, code} records; one thread per residue records the first
 //                      atom of every canonical name (findFirstAtomCoords, reference src/sidechain.cpp:140-147; a missing
-//                      name points at an all-zero record, which is what the reference reads for it); then every angle
-//                      evaluation of the tile is one work item -- 3 dihedrals + 3 bond angles per residue window, one
-//                      dihedral per side-chain atom -- and threads take items round-robin, so every round is a full
-//                      wavefront. Backbone angles go to the [6][R] scratch `ang` (coalesced per type), side-chain
-//                      torsions are quantised (FixedAngleDiscretizer(255), src/foldcomp.cpp:532-538) and stored
-//                      straight into the FCZ record (consecutive items = consecutive bytes).
+//                      name points at an all-zero record, which is what the reference reads for it). Then the angles:
+//                      thread = residue window for the 3 dihedrals + 3 bond angles of the backbone, thread = work item
+//                      (one dihedral per side-chain atom, taken round-robin from a flat list) for the side chains, so
+//                      every round is a full wavefront. The next tile's atoms are prefetched into registers meanwhile and
+//                      results stay in registers until the tile is done (no store drains the prefetch). Backbone angles
+//                      go to the [6][R] scratch `ang` (coalesced per type), side-chain torsions are quantised
+//                      (FixedAngleDiscretizer(255), src/foldcomp.cpp:532-538) and stored straight into the FCZ record
+//                      (consecutive items = consecutive bytes).
 //   k_compress_pack    one wavefront per chain: validation, per-chain quantiser parameters (min/max with
 //                      std::min_element semantics, src/discretizer.cpp:22-33), the packed 8-byte words
 //                      (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52), B-factor bytes, anchors

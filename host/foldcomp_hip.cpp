@@ -4,6 +4,7 @@
 //   foldcomp-hip decompress [-a] [-y] [-r] [-d] <fcz file|dir|db> [<pdb file|dir|db>]
 //   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir|db> [<out file>]
 //   foldcomp-hip check      [-r] <fcz file|dir|db>
+//   foldcomp-hip rmsd       <pdb|cif> <pdb|cif>
 //   no GPU needed (used by the tests):
 //   foldcomp-hip dump-batch [-b N] <pdb file>          the host-side batch of a file as text
 //   foldcomp-hip db-pack <dir> <db> / db-unpack <db> <dir>   files <-> database container
@@ -32,6 +33,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -760,12 +762,40 @@ int run_dump_batch(const Options& o) {
     return 0;
 }
 
+// `foldcomp rmsd a.pdb b.pdb` (reference src/main.cpp:1016-1060, RMSD at src/atom_coordinate.cpp:424-434: float accumulation,
+// no superposition): prints "file1 file2 n_residues n_atoms backbone_rmsd all_atom_rmsd"
+AtomTable load_table(const std::string& path) {
+    const std::string base = base_name(path);
+    std::string raw = read_file(path), plain = base, title;
+    if (ends_with(base, ".gz")) { raw = gunzip(raw); plain = base.substr(0, base.size() - 3); }
+    const std::vector<std::string> lines = split_lines(raw);
+    return ends_with(plain, ".cif") ? parse_cif(lines, title) : parse_pdb(lines, true);
+}
+int run_rmsd(const Options& o) {
+    if (o.output.empty()) { fprintf(stderr, "[Error] rmsd needs two structure files.\n"); return 1; }
+    const AtomTable a = load_table(o.input), b = load_table(o.output);
+    if (a.size() != b.size()) { fprintf(stderr, "[Error] The number of atoms in the two structures differ.\n"); return 1; }
+    float sum_bb = 0.0f, sum_all = 0.0f; size_t n_bb = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        const float dx = a.x[i] - b.x[i], dy = a.y[i] - b.y[i], dz = a.z[i] - b.z[i];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        sum_all += d2;
+        if (a.atom[i] == "N" || a.atom[i] == "CA" || a.atom[i] == "C") { sum_bb += d2; n_bb++; }
+    }
+    size_t n_res = 0;
+    for (size_t i = 0; i < a.size(); i++) if (i == 0 || a.res_index[i] != a.res_index[i - 1] || a.chain[i] != a.chain[i - 1]) n_res++;
+    const double bb = std::sqrt((double)(sum_bb / (float)std::max<size_t>(n_bb, 1))), all = std::sqrt((double)(sum_all / (float)std::max<size_t>(a.size(), 1)));
+    printf("%s\t%s\t%zu\t%zu\t%g\t%g\n", o.input.c_str(), o.output.c_str(), n_res, a.size(), bb, all);
+    return 0;
+}
+
 void usage() {
     fprintf(stderr,
             "usage: foldcomp-hip compress   [-b N] [-y] [-r] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir>]\n"
             "       foldcomp-hip decompress [-a] [-y] [-r] <fcz file|dir> [<pdb file|dir>]\n"
             "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir> [<out>]\n"
-            "       foldcomp-hip check      [-r] <fcz file|dir>\n");
+            "       foldcomp-hip check      [-r] <fcz file|dir|db>\n"
+            "       foldcomp-hip rmsd       <pdb|cif> <pdb|cif>\n");
 }
 
 }  // namespace
@@ -801,6 +831,7 @@ int main(int argc, char** argv) {
     if (o.mode == "extract") return run_extract(o);
     if (o.mode == "check") return run_check(o);
     if (o.mode == "dump-batch") return run_dump_batch(o);
+    if (o.mode == "rmsd") return run_rmsd(o);
     if (o.mode == "db-pack") return run_db_pack(o);
     if (o.mode == "db-unpack") return run_db_unpack(o);
     usage();

@@ -242,3 +242,19 @@ def test_cpp_host_directory_is_parsed_in_file_order(tmp_path, golden):
             for sl in identify_discontinuous(t, cs):
                 all_chains.append(Chain(stem, t.take(sl)))
     _same(_dump(d), names, build_batch(all_chains, 25))
+
+
+def test_cpp_host_rmsd_matches_python_host(tmp_path, golden, capsys):
+    from foldcomp_amd.__main__ import main as py_main
+    z, _ = golden
+    a = tmp_path / "a.pdb"; b = tmp_path / "b.pdb"
+    a.write_text(_pdb_text(z, "pdb:test_af"))
+    b.write_text(z["pdb:test_af/pdb0"].tobytes().decode("latin-1"))
+    r = _run("rmsd", str(a), str(b))
+    assert r.returncode == 0, r.stderr
+    py_main(["rmsd", str(a), str(b)])
+    py = capsys.readouterr().out.strip().split("\t")
+    cc = r.stdout.strip().split("\t")
+    assert cc[:4] == py[:4]                                  # files, residues, atoms
+    assert abs(float(cc[4]) - float(py[4])) < 1e-3 and abs(float(cc[5]) - float(py[5])) < 1e-3
+    assert _run("rmsd", str(a), str(a)).stdout.strip().split("\t")[4:] == ["0", "0"]

@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--pdb-sample", type=int, default=65536,
                     help="chains rendered to PDB text on the device after the timed region (SURVEY §8 f2 leg; 0 = skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch/rendezvous check only: ranks are started and meet in a process group (gloo when no GPU is "
+                         "present), no codec call is made and the JSON line carries value null; used by the CPU tests")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4] stand-in: log-normal chain lengths (mu = ln 250, sigma = 0.6, clipped to [16, 2700]) "
                          "instead of the fixed --residues; not the headline workload")
@@ -78,6 +81,9 @@ def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base, mixed=F
         for p in parts:
             v = p[k].to(torch.int64)
             acc.append(v[:-1] + base); base += int(v[-1])
+        if base >= 1 << 32:
+            # the ABI counts residues and atoms in uint32 (carried in torch int32 here): refuse instead of wrapping
+            raise SystemExit(f"bench.py: {k} total {base} does not fit the uint32 counts of fcz_chain_batch; use fewer --chains per GPU")
         acc.append(torch.tensor([base], dtype=torch.int64, device=device))
         out[k] = torch.cat(acc).to(torch.int32)
     return out
@@ -182,11 +188,56 @@ def parity_sample(hb, blob_dev, off_dev, out_t, atom_off_host, n):
     return ok_c, bool(ok_d)
 
 
+def self_launch_command(args_gpus, argv, env):
+    """--gpus N > 1 outside a torch.distributed launcher: the command that starts N ranks of this script on this node
+    (one per GPU, RCCL rendezvous on 127.0.0.1). None when no launch is needed. A launcher whose WORLD_SIZE disagrees with
+    --gpus is an error: a silent 1-GPU run labelled as N GPUs (or the reverse) must not happen."""
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != int(args_gpus):
+            raise SystemExit(f"bench.py: --gpus {args_gpus} but the launcher set WORLD_SIZE={ws}; refusing to run a mislabelled job")
+        return None
+    if args_gpus <= 1:
+        return None
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(args_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def dry_run(args, world, rank):
+    """rendezvous only (see --dry-run): proves that N ranks were started and see each other"""
+    import torch.distributed as dist
+    have_gpu = torch.cuda.is_available()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if have_gpu else "gloo")
+        t = torch.ones(1, device=f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}" if have_gpu else "cpu")
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs", "value": None,
+                          "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "dry_run": True}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    cmd = self_launch_command(args.gpus, sys.argv[1:], os.environ)
+    if cmd is not None:
+        import subprocess
+        if not args.dry_run and torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the FCZ hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -196,6 +247,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
+        world = dist.get_world_size()   # what RCCL actually formed; n_gpus below reports this, not the flag
+        assert world == args.gpus, (world, args.gpus)
 
     C, n_res = args.chains, args.residues
     d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C, mixed=args.mixed)
@@ -414,7 +467,9 @@ def main():
             hb256 = host_sample(d, n)
             ok_c, ok_d = parity_sample(hb256, blob_dev, off_dev, out_t, None, n)
             parity = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": bad_status}
-        cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if args.cpu_sample else None
+        # the CPU baseline is timed at N=1 only (a launcher pins every rank to one OpenMP thread, and the host cores would be
+        # shared with the other ranks' launch threads)
+        cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if (args.cpu_sample and world == 1) else None
         total_res = R * world * args.steps
         line = {
             "metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs",

@@ -32,3 +32,37 @@ def test_traffic_table_covers_the_reported_kernels():
     # other chain lengths have no measured profile: null, never a made-up number
     assert b.measured_traffic("k_compress_angles", 1000, 123) == (None, None)
     assert b.measured_traffic("no_such_kernel", 1000, 350) == (None, None)
+
+
+def test_gpus_flag_and_launcher_must_agree():
+    b = _bench()
+    import pytest
+    # inside a launcher with the matching world size: no re-launch
+    assert b.self_launch_command(2, ["--gpus", "2"], {"WORLD_SIZE": "2"}) is None
+    assert b.self_launch_command(1, [], {}) is None
+    # --gpus N without a launcher: N ranks of this script under torch.distributed.run on 127.0.0.1
+    cmd = b.self_launch_command(4, ["--gpus", "4", "--steps", "3"], {})
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    # a launcher whose world size disagrees with the flag: refuse (a mislabelled run is worse than none)
+    with pytest.raises(SystemExit):
+        b.self_launch_command(8, ["--gpus", "8"], {"WORLD_SIZE": "1"})
+    with pytest.raises(SystemExit):
+        b.self_launch_command(1, [], {"WORLD_SIZE": "2"})
+
+
+def test_plain_python_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must become a 2-rank job: the dry run meets in a process group (gloo here)
+    and reports the world size the group saw"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line)["n_gpus"] == 2
+    # and a real (non-dry) run on a box without GPUs fails loudly instead of printing a number
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

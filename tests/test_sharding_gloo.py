@@ -33,6 +33,36 @@ def _worker(rank, world, port, tmp, golden_path):
     dist.destroy_process_group()
 
 
+def test_pack_index_is_flat_arrays():
+    from foldcomp_amd.shard import pack_index
+    rec, blob = pack_index([10, 20, 30], [5, 6, 7], ["a", "bcd", ""])
+    assert rec.dtype == np.int64 and rec.tolist() == [5, 10, 0, 6, 20, 1, 7, 30, 4]
+    assert blob.dtype == np.uint8 and blob.tobytes() == b"abcd"
+    rec, blob = pack_index([], [], [])
+    assert rec.size == 0 and blob.size == 0
+
+
+def test_pwrite_all_loops(tmp_path, monkeypatch):
+    from foldcomp_amd import shard
+    calls = []
+    real = os.pwrite
+    def short(fd, data, off):   # a kernel that takes 3 bytes at a time
+        calls.append(off)
+        return real(fd, bytes(data[:3]), off)
+    monkeypatch.setattr(shard.os, "pwrite", short)
+    p = tmp_path / "f"
+    p.write_bytes(b"\0" * 12)
+    fd = os.open(str(p), os.O_WRONLY)
+    shard.pwrite_all(fd, b"0123456789", 2)
+    os.close(fd)
+    assert p.read_bytes() == b"\0\0" + b"0123456789" and calls == [2, 5, 8, 11]
+    monkeypatch.setattr(shard.os, "pwrite", lambda fd, data, off: 0)
+    fd = os.open(str(p), os.O_WRONLY)
+    with pytest.raises(OSError):
+        shard.pwrite_all(fd, b"xyz", 0)
+    os.close(fd)
+
+
 def test_shard_range_balances():
     from foldcomp_amd.shard import shard_range
     w = [10] * 100

@@ -175,7 +175,15 @@ class FoldcompDatabase:
         if index < 0 or index >= len(self):
             raise IndexError("index out of range")
         i = self._ids[index] if self._ids is not None else index
-        return self._reader.data(i, strip_nul=True)   # drops the trailing byte like the reference
+        # The reference drops the last byte of every entry (foldcomp.cxx:66,73), which is right for MMseqs2-made databases
+        # (entries end in a NUL) and one byte short for the ones `foldcomp compress --db` writes (no terminator,
+        # src/main.cpp:516). Here only a real terminator is dropped: the byte after the record's header-derived length, or
+        # the NUL that closes a non-FCZ (text) entry.
+        data = self._reader.data(i)
+        size = fczfile.record_size(data)
+        if size >= 0:
+            return data[:size] if len(data) > size else data
+        return data[:-1] if data.endswith(b"\0") else data
 
     def __getitem__(self, index):
         data = self._entry(int(index))

@@ -461,6 +461,9 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
 
     // ---- validation (the reference aborts on these inputs) + total side-chain torsion count ----
     int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
+    // nResidue is a uint16 and nAnchor a uint8 in the header (src/foldcomp.h:120-125): a chain beyond them would get a record
+    // whose layout uses the full values and whose header holds wrapped ones (the reference writes exactly that, unreadable)
+    if (!bad && (n > 65535u || n / thr + 2u > 255u)) bad = FCZ_E_INVALID_ARG;
     uint32_t nsc = 0;
     auto check = [&](uint32_t rc, uint32_t span) {
         if (!res_code_ok(rc)) bad = bad ? bad : FCZ_E_RESIDUE;

@@ -74,6 +74,17 @@ def parse(raw: bytes) -> FczRecord:
     return FczRecord(raw, n, na, ir, ia, n_anchor, chain, nsc, fr, lr, title, mins, cfs, o_words, o_sc, o_tmp)
 
 
+def record_size(raw) -> int:
+    """byte length of the FCZ record that starts at raw[0] according to its own header (Foldcomp::getSize,
+    src/foldcomp.cpp:1190-1214), -1 when raw does not start with an FCZ header"""
+    if len(raw) < 76 or bytes(raw[:4]) != MAGIC:
+        return -1
+    n, = struct.unpack_from("<H", raw, 4)
+    nsc, = struct.unpack_from("<I", raw, 16)
+    tl, = struct.unpack_from("<I", raw, 24)
+    return 76 + 4 * raw[12] + tl + 36 * raw[12] + 13 + 8 * n + nsc + 8 + n
+
+
 def unpack_fields(rec: FczRecord):
     """-> dict of uint32 arrays (convertBytesToBackboneChain, src/foldcomp.cpp:60-77)"""
     w = rec.words.astype(np.uint32)

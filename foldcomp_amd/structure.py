@@ -200,6 +200,9 @@ def build_batch(chains: Sequence[Chain], anchor_threshold: int = 25) -> ChainBat
             raise StructureError("empty chain")
         ro = split_residues(t)
         nres = len(ro) - 1
+        if nres > 65535 or (anchor_threshold > 0 and nres // anchor_threshold + 2 > 255):
+            # uint16 nResidue / uint8 nAnchor of the FCZ header (src/foldcomp.h:120-125) would wrap
+            raise StructureError(f"chain of {nres} residues does not fit the FCZ header (65535 residues, 255 anchors)")
         ac = np.fromiter((ATOM_CODE.get(a, ATOM_CODE_OTHER) for a in t.atom), np.uint8, len(t))
         rc = np.empty(nres, np.uint8)
         bf = np.zeros(nres, np.float32)

@@ -293,10 +293,14 @@ struct Batch {
     size_t n_chains() const { return res_off.size() - 1; }
 
     // appends one fragment; throws std::runtime_error with what the reference would abort on
-    void add(const AtomTable& t, const std::string& title) {
+    void add(const AtomTable& t, const std::string& title, int anchor_threshold = 25) {
         if (t.size() == 0) throw std::runtime_error("empty chain");
         const std::vector<uint32_t> ro = split_residues(t);
         const size_t nres = ro.size() - 1, abase = x.size();
+        // the FCZ header holds nResidue in 16 bits and nAnchor in 8 (src/foldcomp.h:120-125): the reference wraps silently
+        // and writes a record nobody can read; here the chain is refused
+        if (nres > 65535 || (anchor_threshold > 0 && nres / (size_t)anchor_threshold + 2 > 255))
+            throw std::runtime_error("chain of " + std::to_string(nres) + " residues does not fit the FCZ header (65535 residues, 255 anchors)");
         std::vector<uint8_t> ac(t.size()), rc(nres);
         std::vector<float> bf(nres, 0.0f);
         for (size_t i = 0; i < t.size(); i++) ac[i] = (uint8_t)fcz_atom_code_from_name(t.atom[i].c_str());
@@ -526,14 +530,15 @@ int run_compress(const Options& o) {
     fcz_ctx* ctx = nullptr;
     if (need_ctx(&ctx)) return 1;
     std::vector<Fragment> pending;
+    bool hard_fail = false;
     auto flush = [&]() {
         if (pending.empty()) return;
         Batch b;
         std::vector<size_t> kept;
         for (size_t i = 0; i < pending.size(); i++) {
-            Batch probe = b;                                    // a fragment the codec cannot take is reported and left out
-            try { b.add(pending[i].atoms, pending[i].title); kept.push_back(i); }
-            catch (const std::exception& e) { b = probe; fprintf(stderr, "[Error] compressing %s: %s\n", pending[i].out_name.c_str(), e.what()); }
+            // a fragment the codec cannot take is reported and left out (Batch::add throws before it changes the batch)
+            try { b.add(pending[i].atoms, pending[i].title, o.brk); kept.push_back(i); }
+            catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", pending[i].out_name.c_str(), e.what()); }
         }
         if (!kept.empty()) {
             fcz_chain_batch v = b.view(o.brk);
@@ -542,7 +547,11 @@ int run_compress(const Options& o) {
             std::vector<uint8_t> blob(off.back());
             std::vector<int32_t> status(v.n_chains);
             const int rc = fcz_compress_batch(ctx, &v, off.data(), blob.data(), status.data());
-            if (rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
+            if (rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG) {
+                // a failure of the call itself (device, memory): no per-chain status was written, nothing may be emitted
+                fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size());
+                hard_fail = true; pending.clear(); return;
+            }
             for (size_t q = 0; q < kept.size(); q++) {
                 const Fragment& f = pending[kept[q]];
                 if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
@@ -561,7 +570,7 @@ int run_compress(const Options& o) {
     flush();
     if (dbw) dbw->close();
     fcz_ctx_destroy(ctx);
-    return 0;
+    return hard_fail ? 1 : 0;
 }
 
 // ---- FCZ inputs ----
@@ -723,7 +732,8 @@ int run_db_unpack(const Options& o) {
     make_dir(o.output);
     for (size_t i = 0; i < r.n(); i++) {
         const std::string d = r.entry(i);
-        write_out(o.output + "/" + r.name(i), d.data(), d.size(), true);
+        // names come from the (untrusted) .lookup file: only their last path component is used
+        write_out(o.output + "/" + base_name(r.name(i)), d.data(), d.size(), true);
     }
     return 0;
 }

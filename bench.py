@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--pdb-sample", type=int, default=65536,
                     help="chains rendered to PDB text on the device after the timed region (SURVEY §8 f2 leg; 0 = skip)")
+    ap.add_argument("--mixed-chains", type=int, default=542_000,
+                    help="chains per GPU of the secondary legs (decompress_only = BASELINE configs[2] shape, mixed = configs[4] shape: "
+                         "log-normal lengths, anchor -b 25); 0 = skip")
+    ap.add_argument("--mixed-steps", type=int, default=3)
     ap.add_argument("--dry-run", action="store_true",
                     help="launch/rendezvous check only: ranks are started and meet in a process group (gloo when no GPU is "
                          "present), no codec call is made and the JSON line carries value null; used by the CPU tests")
@@ -64,11 +68,21 @@ def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base, mixed=F
     parts = []
     done = 0
     if mixed:
-        chunk = min(chunk, 2048)   # the generator is dense in [chains, longest chain]
+        # The generator is dense in [chains, longest chain of the chunk]: chains are drawn with log-normal lengths, dealt into
+        # chunks of similar length (so that a chunk costs its own residues, not 2 700 per chain) and the chunks are laid out in
+        # random order. Lengths vary freely across the batch and every 2 048-chain stretch is uniform within ~1 %.
+        chunk = min(chunk, 2048)
+        lens_all = np.sort(synthetic.mixed_lengths(n_chains, seed=seed_base + 7))
+        starts = np.arange(0, n_chains, chunk)
+        order = np.random.default_rng(seed_base + 11).permutation(len(starts))
+        for ci in order:
+            lens = lens_all[starts[ci]:starts[ci] + chunk]
+            parts.append(synthetic.generate(len(lens), lens, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
+                                            first_chain_id=seed_base + done))
+            done += len(lens)
     while done < n_chains:
         c = min(chunk, n_chains - done)
-        lens = synthetic.mixed_lengths(c, seed=seed_base + done + 7) if mixed else n_res
-        parts.append(synthetic.generate(c, lens, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
+        parts.append(synthetic.generate(c, n_res, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
                                         first_chain_id=seed_base + done))
         done += c
     if len(parts) == 1:
@@ -188,6 +202,155 @@ def parity_sample(hb, blob_dev, off_dev, out_t, atom_off_host, n):
     return ok_c, bool(ok_d)
 
 
+class Workload:
+    """one rank's resident batch plus every output buffer of the round trip; compress() / decompress() only enqueue on the
+    codec's stream (device pointers in, device pointers out)"""
+
+    def __init__(self, codec, d, dev):
+        self.codec, self.lib, self.d, self.dev = codec, codec.lib, d, dev
+        self.C = d["res_off"].numel() - 1
+        self.R, self.M = int(d["res_off"][-1]) & 0xFFFFFFFF, int(d["atom_off"][-1]) & 0xFFFFFFFF
+        self.cb = c_batch(d)
+        C, R, M = self.C, self.R, self.M
+        self.off_dev = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(self.lib.fcz_compress_sizes_dev(codec.ctx, ctypes.byref(self.cb), self.off_dev.data_ptr()), "sizes")
+        codec.synchronize()
+        self.fcz_bytes = int(self.off_dev[-1])          # exact: Foldcomp::getSize on the device
+        self.blob_dev = torch.zeros(self.fcz_bytes, dtype=torch.uint8, device=dev)
+        self.status_dev = torch.zeros(C, dtype=torch.int32, device=dev)
+        self.res_off_dev = torch.zeros(C + 1, dtype=torch.int32, device=dev)
+        self.atom_off_dev = torch.zeros(C + 1, dtype=torch.int32, device=dev)
+        self.out_t = {k: torch.zeros(M, dtype=torch.float32, device=dev) for k in ("x", "y", "z")}
+        self.out_t["bfac_res"] = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.out_t["res_code"] = torch.zeros(R, dtype=torch.uint8, device=dev)
+        o = self.out_t
+        self.cout = CAtomsOut(o["x"].data_ptr(), o["y"].data_ptr(), o["z"].data_ptr(), o["bfac_res"].data_ptr(), o["res_code"].data_ptr(), None)
+        torch.cuda.synchronize()
+
+    def compress(self):
+        """SoA atoms -> FCZ records"""
+        _lib.check(self.lib.fcz_compress_sizes_dev(self.codec.ctx, ctypes.byref(self.cb), self.off_dev.data_ptr()), "sizes")
+        _lib.check(self.lib.fcz_compress_batch_dev(self.codec.ctx, ctypes.byref(self.cb), self.off_dev.data_ptr(), self.blob_dev.data_ptr(),
+                                                   self.status_dev.data_ptr()), "compress")
+
+    def decompress(self, alt_order=0):
+        """FCZ records -> SoA atoms"""
+        tr = ctypes.c_uint32(); ta = ctypes.c_uint32()
+        _lib.check(self.lib.fcz_decompress_sizes_dev(self.codec.ctx, self.blob_dev.data_ptr(), self.off_dev.data_ptr(), self.C,
+                                                     self.res_off_dev.data_ptr(), self.atom_off_dev.data_ptr(), ctypes.byref(tr), ctypes.byref(ta)), "dsizes")
+        assert tr.value == self.R and ta.value == self.M, (tr.value, self.R, ta.value, self.M)
+        _lib.check(self.lib.fcz_decompress_batch_dev(self.codec.ctx, self.blob_dev.data_ptr(), self.off_dev.data_ptr(), self.C,
+                                                     self.res_off_dev.data_ptr(), self.atom_off_dev.data_ptr(), alt_order, ctypes.byref(self.cout)), "decompress")
+
+    def checksum(self):
+        nb8 = (self.fcz_bytes // 8) * 8
+        return int(self.blob_dev[:nb8].view(torch.int64).sum()) if nb8 else 0
+
+    def round_trip_deviation(self):
+        """decode(encode(x)) against x over the whole batch, atoms in the input's order (`-a`): (rmsd, max deviation) in A"""
+        self.decompress(alt_order=1)
+        self.codec.synchronize()
+        sq = 0.0; mx = 0.0; step_n = 1 << 28
+        for a in range(0, self.M, step_n):
+            b_ = min(self.M, a + step_n)
+            dsq = (self.out_t["x"][a:b_] - self.d["x"][a:b_]) ** 2
+            dsq += (self.out_t["y"][a:b_] - self.d["y"][a:b_]) ** 2
+            dsq += (self.out_t["z"][a:b_] - self.d["z"][a:b_]) ** 2
+            sq += float(dsq.sum(dtype=torch.float64)); mx = max(mx, float(dsq.max()))
+            del dsq
+        return (sq / self.M) ** 0.5, mx ** 0.5
+
+    def kernel_bytes(self):
+        """algorithmic bytes per launch of each kernel: the compress side reads
+        13 B per atom + 9 B per residue and writes the record, the decompress side reads the record and writes 12 B per atom + 4 B
+        per residue; hand-over arrays between kernels (angles, blended backbone, per-residue index) are not algorithmic traffic"""
+        A = self.M / self.R; f = self.fcz_bytes / self.R; R = self.R
+        sc = (A - 3.0) + 1.0                          # side-chain torsion bytes + the B-factor byte, per residue
+        return {"k_compress_angles": (13 * A + (A - 3.0)) * R, "k_compress_index": 1.0 * R, "k_compress_pack": (9 + f - (A - 3.0)) * R,
+                "k_backbone": (f - sc) * R, "k_res_index": (sc + 4) * R, "k_sidechain": 12 * A * R}
+
+
+KERNEL_SPANS = {"k_compress_angles": "compress_angles", "k_compress_index": "compress_index", "k_compress_pack": "compress_pack",
+                "k_backbone": "decompress_backbone", "k_res_index": "decompress_index", "k_sidechain": "decompress_sidechain"}
+ALL_SPANS = ("compress_sizes", "compress_index", "compress_angles", "compress_pack", "decompress_sizes", "decompress_backbone",
+             "decompress_index", "decompress_sidechain")
+
+
+def span_ms(codec):
+    out = {}
+    for name in ALL_SPANS:
+        ms, n = codec.kernel_time(name)
+        out[name] = (ms / n) if n else 0.0
+    return out
+
+
+def timed(fn, steps, world, dist, dev):
+    """`steps` calls of fn bracketed by barrier + synchronize on both sides; seconds, max over ranks"""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def secondary_legs(args, codec, dev, rank, world, dist):
+    """BASELINE configs[2] and configs[4] at their shape (the datasets themselves cannot be fetched): `--mixed-chains` chains
+    per GPU with log-normal lengths (AFDB Swiss-Prot has 542 k structures), anchor -b 25.
+      decompress_only  device-resident FCZ records -> SoA atoms (sizes pass + batch), the configs[2] operation
+      mixed            compress + decompress of the same ragged batch, the configs[4] operation
+    Each with its own time, residues/s (all ranks), per-kernel times, roofline fraction of its longest kernel, a 256-chain
+    oracle sample (bit-exact bar) and the full-batch round-trip deviation. Outside the headline `value`."""
+    Cm = args.mixed_chains
+    d = generate_resident(Cm, 0, args.anchor, args.gen_chunk, dev, seed_base=(1 << 30) + rank * Cm, mixed=True)
+    note(f"secondary legs: generated {Cm} mixed-length chains")
+    w = Workload(codec, d, dev)
+    w.compress(); w.decompress(); codec.synchronize()            # warm-up; leaves the FCZ records resident
+    steps = max(1, args.mixed_steps)
+    kb = w.kernel_bytes()
+
+    def leg(fn, names, nbytes):
+        codec.reset_timing()
+        dt = timed(lambda: (fn(), codec.synchronize()), steps, world, dist, dev)
+        km = span_ms(codec)
+        dom = max(names, key=lambda k: km[KERNEL_SPANS[k]])
+        ms = km[KERNEL_SPANS[dom]]
+        ach = kb[dom] / (ms * 1e-3) / 1e9 if ms else 0.0
+        return {"chains_per_gpu": Cm, "residues_per_gpu": w.R, "mean_residues_per_chain": round(w.R / Cm, 1), "longest_chain": int((d["res_off"][1:] - d["res_off"][:-1]).max()),
+                "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "residues_per_s": round(w.R * world * steps / dt),
+                "algorithmic_GBs": round(nbytes / (dt / steps) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4), "traffic": None},
+                "kernel_ms": {k: round(v, 4) for k, v in km.items() if v}}
+
+    A = w.M / w.R; f = w.fcz_bytes / w.R
+    dec = leg(w.decompress, ("k_backbone", "k_res_index", "k_sidechain"), (f + 12 * A + 4) * w.R)
+    mix = leg(lambda: (w.compress(), w.decompress()), tuple(KERNEL_SPANS), (13 * A + 9 + f + f + 12 * A + 4) * w.R)
+    if rank == 0 and not args.no_parity:
+        n = min(256, Cm)
+        hb = host_sample(d, n)
+        ok_c, ok_d = parity_sample(hb, w.blob_dev, w.off_dev, w.out_t, None, n)
+        rmsd, mx = w.round_trip_deviation()
+        par = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": int((w.status_dev != 0).sum()),
+               "all_atom_rmsd_A": round(rmsd, 4), "max_atom_deviation_A": round(mx, 3),
+               "residue_counts_round_trip": bool(torch.equal(w.res_off_dev, d["res_off"].to(torch.int32)))}
+        dec["parity"] = par; mix["parity"] = par
+    del w, d
+    torch.cuda.empty_cache()
+    return dec, mix
+
+
 def self_launch_command(args_gpus, argv, env):
     """--gpus N > 1 outside a torch.distributed launcher: the command that starts N ranks of this script on this node
     (one per GPU, RCCL rendezvous on 127.0.0.1). None when no launch is needed. A launcher whose WORLD_SIZE disagrees with
@@ -225,6 +388,15 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress + wall time to stderr (stdout carries exactly one JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse_args()
     cmd = self_launch_command(args.gpus, sys.argv[1:], os.environ)
@@ -252,56 +424,32 @@ def main():
 
     C, n_res = args.chains, args.residues
     d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C, mixed=args.mixed)
-    R, M = int(d["res_off"][-1]) & 0xFFFFFFFF, int(d["atom_off"][-1]) & 0xFFFFFFFF
+    note(f"generated {C} chains")
     codec = Codec(local)
     lib = codec.lib
-    cb = c_batch(d)
-
-    # output buffers (sizes are exact: Foldcomp::getSize on the device)
-    off_dev = torch.zeros(C + 1, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    _lib.check(lib.fcz_compress_sizes_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr()), "sizes")
-    codec.synchronize()
-    fcz_bytes = int(off_dev[-1])
-    blob_dev = torch.zeros(fcz_bytes, dtype=torch.uint8, device=dev)
-    status_dev = torch.zeros(C, dtype=torch.int32, device=dev)
-    res_off_dev = torch.zeros(C + 1, dtype=torch.int32, device=dev)
-    atom_off_dev = torch.zeros(C + 1, dtype=torch.int32, device=dev)
-    out_t = {k: torch.zeros(M, dtype=torch.float32, device=dev) for k in ("x", "y", "z")}
-    out_t["bfac_res"] = torch.zeros(R, dtype=torch.float32, device=dev)
-    out_t["res_code"] = torch.zeros(R, dtype=torch.uint8, device=dev)
-    cout = CAtomsOut(out_t["x"].data_ptr(), out_t["y"].data_ptr(), out_t["z"].data_ptr(), out_t["bfac_res"].data_ptr(),
-                     out_t["res_code"].data_ptr(), None)
+    w = Workload(codec, d, dev)
+    R, M, fcz_bytes = w.R, w.M, w.fcz_bytes
+    off_dev, blob_dev, status_dev, res_off_dev, atom_off_dev, out_t, cout = (w.off_dev, w.blob_dev, w.status_dev, w.res_off_dev,
+                                                                             w.atom_off_dev, w.out_t, w.cout)
     lengths_dev = torch.zeros(C, dtype=torch.int64, device=dev)
     gathered = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
     def step():
-        # compress: SoA atoms -> FCZ records
-        _lib.check(lib.fcz_compress_sizes_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr()), "sizes")
-        _lib.check(lib.fcz_compress_batch_dev(codec.ctx, ctypes.byref(cb), off_dev.data_ptr(), blob_dev.data_ptr(),
-                                              status_dev.data_ptr()), "compress")
+        w.compress()
         if world > 1:
             # the only exchange of the sharded job: per-record lengths -> rank 0 builds the global index
             codec.synchronize()
             torch.sub(off_dev[1:], off_dev[:-1], out=lengths_dev)
             dist.gather(lengths_dev, gathered, dst=0)
-        # decompress: FCZ records -> SoA atoms
-        tr = ctypes.c_uint32(); ta = ctypes.c_uint32()
-        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
-                                                atom_off_dev.data_ptr(), ctypes.byref(tr), ctypes.byref(ta)), "dsizes")
-        assert tr.value == R and ta.value == M, (tr.value, R, ta.value, M)
-        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
-                                                atom_off_dev.data_ptr(), 0, ctypes.byref(cout)), "decompress")
+        w.decompress()
 
     for _ in range(args.warmup):
         step()
     codec.synchronize(); torch.cuda.synchronize()
-    warm_csum = None
-    if rank == 0 and args.warmup and not args.no_parity:
-        nb8 = (fcz_bytes // 8) * 8
-        warm_csum = int(blob_dev[:nb8].view(torch.int64).sum()) if nb8 else 0
+    warm_csum = w.checksum() if (rank == 0 and args.warmup and not args.no_parity) else None
     codec.enable_timing(True); codec.reset_timing()
+    # the timed region: exactly --steps steps between barrier + synchronize pairs, max over ranks
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -319,42 +467,28 @@ def main():
         dt = float(t.item())
 
     # per-kernel device time (HIP events on the codec's own stream)
-    ktime = {}
-    for name in ("compress_sizes", "compress_index", "compress_angles", "compress_pack", "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain"):
-        ms, n = codec.kernel_time(name)
-        ktime[name] = (ms / n) if n else 0.0
+    ktime = span_ms(codec)
+    note(f"headline timed: {dt / args.steps * 1e3:.2f} ms/step")
+    # ---- BASELINE configs[2] / configs[4] at their shape: every rank runs them (their clocks are max-over-ranks too) ----
+    legs = secondary_legs(args, codec, dev, rank, world, dist) if (args.mixed_chains and not args.mixed) else None
+    note("secondary legs done")
     # ---- size-independent properties of the FULL batch (outside the timed region) ----
     props = None
     if rank == 0 and not args.no_parity:
         # (1) determinism: the blob after the timed steps has the checksum it had after the warm-up steps
-        nb8 = (fcz_bytes // 8) * 8
-        csum = int(blob_dev[:nb8].view(torch.int64).sum()) if nb8 else 0
+        csum = w.checksum()
         # (2) decode(encode(x)) ~ x: decompress once more in the input's atom order (`-a`) and compare every atom
-        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
-                                                atom_off_dev.data_ptr(), ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())), "dsizes")
-        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
-                                                atom_off_dev.data_ptr(), 1, ctypes.byref(cout)), "decompress -a")
-        codec.synchronize()
-        sq = 0.0; mx = 0.0; step_n = 1 << 28
-        for a in range(0, M, step_n):
-            b_ = min(M, a + step_n)
-            dsq = (out_t["x"][a:b_] - d["x"][a:b_]) ** 2
-            dsq += (out_t["y"][a:b_] - d["y"][a:b_]) ** 2
-            dsq += (out_t["z"][a:b_] - d["z"][a:b_]) ** 2
-            sq += float(dsq.sum(dtype=torch.float64)); mx = max(mx, float(dsq.max()))
-            del dsq
+        rmsd, mxdev = w.round_trip_deviation()
         # (3) sizes: decompress counts == input counts, every chain compressed with status OK
         same_counts = bool(torch.equal(res_off_dev, d["res_off"].to(torch.int32)))
-        props = {"all_atom_rmsd_A": round((sq / M) ** 0.5, 4), "max_atom_deviation_A": round(mx ** 0.5, 3),
+        props = {"all_atom_rmsd_A": round(rmsd, 4), "max_atom_deviation_A": round(mxdev, 3),
                  "residue_counts_round_trip": same_counts, "blob_checksum": csum,
                  "deterministic": csum == warm_csum if warm_csum is not None else None}
         # restore the default-order outputs the PDB leg below formats
-        _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
-                                                atom_off_dev.data_ptr(), ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_uint32())), "dsizes")
-        _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, res_off_dev.data_ptr(),
-                                                atom_off_dev.data_ptr(), 0, ctypes.byref(cout)), "decompress")
+        w.decompress()
         codec.synchronize()
 
+    note("properties done")
     # ---- §8 f2 leg, outside the timed region: PDB text of the first chains, formatted on the device ----
     pdb = None
     if args.pdb_sample and rank == 0:
@@ -423,6 +557,7 @@ def main():
                "first_record_equals_host": bool(ok_e)}
         del data_dev
     codec.enable_timing(False)
+    note("pdb / extract legs done")
     bad_status = int((status_dev != 0).sum())
 
     if rank == 0:
@@ -470,6 +605,7 @@ def main():
         # the CPU baseline is timed at N=1 only (a launcher pins every rank to one OpenMP thread, and the host cores would be
         # shared with the other ranks' launch threads)
         cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if (args.cpu_sample and world == 1) else None
+        note("parity sample + cpu baseline done")
         total_res = R * world * args.steps
         line = {
             "metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs",
@@ -484,7 +620,8 @@ def main():
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props, "pdb_text": pdb, "extract": ext,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,
+            "decompress_only": legs[0] if legs else None, "mixed": legs[1] if legs else None, "pdb_text": pdb, "extract": ext,
         }
         print(json.dumps(line))
     if world > 1:

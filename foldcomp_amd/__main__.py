@@ -129,19 +129,15 @@ def load_structure(name: str, data: bytes) -> Tuple[AtomTable, str]:
     return t, (title if title else base)
 
 
-def is_compressible(ext: str) -> bool:
-    return ext in ("pdb", "cif", "pdb.gz", "cif.gz")      # utility.cpp:129-140
+def is_compressible(stem: str, ext: str) -> bool:
+    """isCompressible (utility.cpp:129-140): pdb, cif, and either of them gzipped (the .gz case looks one extension further in)"""
+    return ext in ("pdb", "cif") or (ext == "gz" and file_parts(stem)[1] in ("pdb", "cif"))
 
 
 def file_parts(base: str) -> Tuple[str, str]:
-    """getFileParts (utility.cpp:118-127): split at the last '.', keeping a trailing .gz with the extension"""
-    stem, ext = base, ""
-    if base.endswith(".gz"):
-        stem = base[:-3]; ext = ".gz"
-    if "." in stem:
-        i = stem.rfind(".")
-        return stem[:i], stem[i + 1:] + ext
-    return stem, ext.lstrip(".")
+    """getFileParts (utility.cpp:118-126): split at the LAST '.' ("test.cif.gz" -> ("test.cif", "gz"))"""
+    i = base.rfind(".")
+    return (base, "") if i < 0 else (base[:i], base[i + 1:])
 
 
 # ---- entry sources -------------------------------------------------------------------------------------
@@ -245,7 +241,7 @@ def run_compress(a, inputs, output, kind, single):
             if kind in ("tar", "db"):
                 out_file = stem
             elif single:
-                out_file = file_parts(output)[0]
+                out_file, ext = file_parts(output)      # a single-file run names and suffixes by the OUTPUT path (src/main.cpp:449-451)
             else:
                 out_file = stem
             try:
@@ -267,7 +263,7 @@ def run_compress(a, inputs, output, kind, single):
                     if len(frags) > 1:
                         fname += f"_{j}"
                     if kind != "db":
-                        fname += ".fcz" if is_compressible(ext) else ("." + ext if ext else "")
+                        fname += ".fcz" if is_compressible(out_file, ext) else ("." + ext if ext else "")
                     pending.append((fname, out_file, Chain(title, t.take(sl))))
             if len(pending) >= BATCH_CHAINS:
                 flush()

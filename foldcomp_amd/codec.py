@@ -64,7 +64,9 @@ class Codec:
         out = np.zeros(int(off[-1]), np.uint8)
         st = np.zeros(b.n_chains, np.int32)
         rc = self.lib.fcz_compress_batch(self.ctx, ctypes.byref(cb), off.ctypes.data, out.ctypes.data, st.ctypes.data)
-        if rc != 0 and (strict or rc in (-1, -2, -3, -8)):
+        # rc = the worst per-chain status, or a failure of the call itself (-1 is both: a refused chain, or bad arguments --
+        # the latter leaves every per-chain status at 0)
+        if rc != 0 and (strict or rc in (-2, -3, -8) or (rc == -1 and not (st == -1).any())):
             _lib.check(rc, "fcz_compress_batch")
         return out, off, st
 

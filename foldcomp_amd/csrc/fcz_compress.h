@@ -170,7 +170,6 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
 
     const uint32_t R = in.n_residues;
     const size_t Rz = R;
-    const float sc_min = -180.0f, sc_disc = 255.0f / (180.0f - (-180.0f));   // FixedAngleDiscretizer(255)
     constexpr int NV = CK_CAP / (4 * BLOCK);   // full float4 rounds; the rest of the staging buffer is one atom per thread
     static_assert(CK_CAP - NV * 4 * BLOCK <= BLOCK, "tail round covers one atom per thread");
 
@@ -388,7 +387,7 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
                     const uint32_t pk = L.prev[L.rc[res]][j];
                     const v3 a = tile_atom(L, res, pk & 15u), b = tile_atom(L, res, (pk >> 4) & 15u), cc = tile_atom(L, res, (pk >> 8) & 15u);
                     const v3 d = tile_atom(L, res, j);
-                    q = quant_trunc(dihedral_deg(a, b, cc, d), sc_min, sc_disc) & 0xffu;   // src/foldcomp.cpp:532-538
+                    q = sidechain_torsion_byte(a, b, cc, d) & 0xffu;   // src/foldcomp.cpp:532-538
                 }
                 const uint32_t sh = q << (8 * (i & 3u));
                 scb[0] |= (i < 4) ? sh : 0u; scb[1] |= (i >= 4 && i < 8) ? sh : 0u; scb[2] |= (i >= 8) ? sh : 0u;

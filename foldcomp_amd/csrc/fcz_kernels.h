@@ -533,9 +533,11 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         const long long b0 = 3ll * first;               // chain-major index of the segment's atom 0
         v3 r3 = A2, r2 = A1, r1 = A0;                   // R[T-1], R[T-2], R[T-3]: the anchor itself
         const float j0 = (float)(T - 3), j1 = (float)(T - 2), j2 = (float)(T - 1);
-        const v3 c0 = v3{((p0.x * 3.0f) + (A0.x * j0)) / Tf, ((p0.y * 3.0f) + (A0.y * j0)) / Tf, ((p0.z * 3.0f) + (A0.z * j0)) / Tf};
-        const v3 c1 = v3{((p1.x * 2.0f) + (A1.x * j1)) / Tf, ((p1.y * 2.0f) + (A1.y * j1)) / Tf, ((p1.z * 2.0f) + (A1.z * j1)) / Tf};
-        const v3 c2 = v3{((p2.x * 1.0f) + (A2.x * j2)) / Tf, ((p2.y * 1.0f) + (A2.y * j2)) / Tf, ((p2.z * 1.0f) + (A2.z * j2)) / Tf};
+        // weightedAverage (src/atom_coordinate.cpp:157-159): three divisions by the same T per atom -> vdiv3 (one reciprocal
+        // per segment once the compiler has hoisted it; results identical to '/')
+        const v3 c0 = vdiv3(v3{(p0.x * 3.0f) + (A0.x * j0), (p0.y * 3.0f) + (A0.y * j0), (p0.z * 3.0f) + (A0.z * j0)}, Tf);
+        const v3 c1 = vdiv3(v3{(p1.x * 2.0f) + (A1.x * j1), (p1.y * 2.0f) + (A1.y * j1), (p1.z * 2.0f) + (A1.z * j1)}, Tf);
+        const v3 c2 = vdiv3(v3{(p2.x * 1.0f) + (A2.x * j2), (p2.y * 1.0f) + (A2.y * j2), (p2.z * 1.0f) + (A2.z * j2)}, Tf);
         if (MODE != 1) {
             // only the last segment keeps its final three atoms (src/foldcomp.cpp:847-851)
             const bool fin = act && (s + 1 == nseg);
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
                     // torsion of the step: psi, omega, phi for q = 0, 1, 2 (cos at tq[2q], sin at tq[2q+1])
                     const v3 Rv = place_atom_d2(r3, r2, r1, nerf_d2_trig(Lb, ba, tq[2 * q], tq[2 * q + 1]));   // a = R[f+3], b = R[f+2], c = R[f+1]
                     const float wf = (float)(T - f), wr = (float)f;
-                    Bv = v3{((f0.x * wf) + (Rv.x * wr)) / Tf, ((f0.y * wf) + (Rv.y * wr)) / Tf, ((f0.z * wf) + (Rv.z * wr)) / Tf};
+                    Bv = vdiv3(v3{(f0.x * wf) + (Rv.x * wr), (f0.y * wf) + (Rv.y * wr), (f0.z * wf) + (Rv.z * wr)}, Tf);
                     r3 = r2; r2 = r1; r1 = Rv;
                     f2 = f1; f1 = f0;
                 }

@@ -44,18 +44,17 @@ __device__ __forceinline__ v3 vcross(v3 a, v3 b) {
 // approximation v (relative error <= 2^-46, using v_rsq_f64 + one Newton step, explicit FMAs), round it
 // to float, and prove the rounding is the one the exact expression would give: if v lies farther than
 // 2^-41*|v| from the nearest float rounding boundary, every value within 2^-41 relative of v -- the
-// exact double result included -- rounds to the same float. Otherwise (probability ~2^-17 per value)
+// exact double result included -- rounds to the same float. Otherwise (probability ~2^-16 per value)
 // the exact, reference-ordered evaluation runs. The test is conservative by construction: zero,
-// denormal and power-of-two results take the exact path more often than needed, never less.
+// denormal, infinite and NaN results always take the exact path.
 __device__ __forceinline__ bool round_to_float_is_safe(double v, float f) {
-    const double fd = (double)f;
-    const double e = v - fd;
-    const uint32_t fb = __float_as_uint(f);
-    // half ulp of f scaled by (1 - 2^-16); for a power of two the lower neighbour is half as far
-    const uint32_t c = ((fb & 0x7fffffu) == 0u) ? ((26u << 20) - 0xFFFE0u) : ((25u << 20) - 0xFFFE0u);
-    const uint32_t th = ((uint32_t)__double2hiint(fd) & 0x7ff00000u) - c;
-    const double t = __hiloint2double((int)th, 0);
-    return !(__builtin_fabs(e) > t);   // NaN/inf: comparison false -> "safe" (value propagates)
+    // Rounding a double to a (normal) float drops the low 29 mantissa bits; the rounding boundary sits where those bits
+    // read 0x10000000, in v's own binade whatever the binade of the result. 2^-41 |v| < 2^12 double ulps, so v is safe when
+    // its dropped bits are more than 4096 away from the boundary: three integer instructions. Results outside the normal
+    // float range (zero, denormal, overflow, NaN) drop a different number of bits: they take the exact path.
+    const uint32_t lo = (uint32_t)__double2loint(v);
+    const bool far = ((lo & 0x1fffffffu) - (0x10000000u - 4096u)) > 8192u;
+    return far && __builtin_amdgcn_classf(f, 0x108);   // -normal | +normal
 }
 
 // norm, reference src/float3d.h:32-34 (double pow/sqrt, float result)
@@ -236,16 +235,66 @@ __device__ __forceinline__ float acos_deg(float c) {
     return f;
 }
 
-// one window of getTorsionFromXYZ, reference src/torsion_angle.cpp:50-94
-__device__ __forceinline__ float dihedral_deg(v3 a, v3 b, v3 c, v3 d) {
+// one window of getTorsionFromXYZ, reference src/torsion_angle.cpp:50-94, in two steps: the float part (cosine between the
+// two plane normals, sign test) and the double part (acos -> degrees, NaN guard)
+struct dih_parts { float ct; bool neg; };
+__device__ __forceinline__ dih_parts dihedral_parts(v3 a, v3 b, v3 c, v3 d) {
     v3 d1 = vsub(b, a), d2 = vsub(c, b), d3 = vsub(d, c);
     v3 u1 = vcross(d1, d2), u2 = vcross(d2, d3);
-    float ct = vcos_theta(u1, u2);
-    float t = acos_deg(ct);
-    if (t != t) t = (ct < 0.0f) ? 180.0f : 0.0f;   // isnan(acos) guard, :77-84
+    dih_parts p;
+    p.ct = vcos_theta(u1, u2);
     v3 w = vcross(u2, d2);
-    if ((u1.x * w.x) + (u1.y * w.y) + (u1.z * w.z) < 0.0f) t = -1.0f * t;
+    p.neg = (u1.x * w.x) + (u1.y * w.y) + (u1.z * w.z) < 0.0f;
+    return p;
+}
+__device__ __forceinline__ float dihedral_finish(dih_parts p) {
+    float t = acos_deg(p.ct);
+    if (t != t) t = (p.ct < 0.0f) ? 180.0f : 0.0f;   // isnan(acos) guard, :77-84
+    if (p.neg) t = -1.0f * t;
     return t;
+}
+__device__ __forceinline__ float dihedral_deg(v3 a, v3 b, v3 c, v3 d) { return dihedral_finish(dihedral_parts(a, b, c, d)); }
+
+// acos in degrees in plain float arithmetic for values that are only observed through a coarse quantiser (the side-chain
+// torsion byte: 256 bins of 1.41 degrees). asin kernel x + x z P(z) (degree 5 in z, fitted on [0, 1/4], 5e-10) with the
+// reduction acos x = 2 asin(sqrt((1-|x|)/2)) for |x| > 1/2. Absolute error below 1e-4 degrees for every float in (-1, 1)
+// (tests/test_device_math.py sweeps it against the exact acos_deg); the caller keeps a guard band around the bin edges and falls
+// back to acos_deg inside it. Requires |c| < 1.
+__device__ __forceinline__ float acos_deg_f32(float c) {
+    const float ax = __builtin_fabsf(c);
+    const bool big = ax > 0.5f;
+    const float z = big ? __builtin_fmaf(-0.5f, ax, 0.5f) : c * c;
+    const float s = big ? __builtin_amdgcn_sqrtf(z) : ax;
+    float P = 0x1.14f022p-5f;
+    P = __builtin_fmaf(P, z, 0x1.17cd44p-6f);
+    P = __builtin_fmaf(P, z, 0x1.fdcebcp-6f);
+    P = __builtin_fmaf(P, z, 0x1.6d58d8p-5f);
+    P = __builtin_fmaf(P, z, 0x1.33343cp-4f);
+    P = __builtin_fmaf(P, z, 0x1.555554p-3f);
+    const float as = __builtin_fmaf(s * z, P, s);
+    const float kPi = 3.14159274f, kPio2 = 1.57079637f;
+    const float A = big ? ((c > 0.0f) ? 2.0f * as : __builtin_fmaf(-2.0f, as, kPi)) : ((c > 0.0f) ? kPio2 - as : kPio2 + as);
+    return A * 57.2957802f;
+}
+
+// The side-chain torsion byte (FixedAngleDiscretizer(255).discretize of a dihedral, reference src/foldcomp.cpp:532-538,
+// src/discretizer.h:89-106): (unsigned)((t + 180) * (255/360)) truncated. The float part of the dihedral is evaluated exactly;
+// the angle itself first in float (error < 1e-4 degrees = 7.1e-5 bins; the subtraction and the multiplication round by at most
+// 3.6e-5 bins on either side): when (t~ + 180) * disc lies farther than 3e-4 from every integer, the exact evaluation truncates
+// to the same byte. Otherwise (0.06 % of values), and for |cos| >= 1 or NaN, the exact evaluation runs.
+__device__ __forceinline__ uint32_t sidechain_torsion_byte(v3 a, v3 b, v3 c, v3 d) {
+    const float sc_min = -180.0f, sc_disc = 255.0f / (180.0f - (-180.0f));
+    const dih_parts p = dihedral_parts(a, b, c, d);
+    const float th = acos_deg_f32(p.ct);
+    const float v = p.neg ? -th : th;
+    const float f = (v - sc_min) * sc_disc;
+    const bool certain = __builtin_fabsf(p.ct) < 1.0f && __builtin_fabsf(f - __builtin_rintf(f)) > 3e-4f;
+    uint32_t q = __float2uint_rz(f);
+    if (__builtin_expect(!certain, 0)) {
+        const float fe = (dihedral_finish(p) - sc_min) * sc_disc;
+        q = (fe != fe) ? 0u : __float2uint_rz(fe);
+    }
+    return q;
 }
 
 // angle, reference src/float3d.h:55-65 (no NaN guard)
@@ -291,24 +340,24 @@ __device__ __forceinline__ float sincosf_glibc(float y, int is_cos) {
 }
 __device__ __forceinline__ float sinf_glibc(float y) { return sincosf_glibc(y, 0); }
 __device__ __forceinline__ float cosf_glibc(float y) { return sincosf_glibc(y, 1); }
-// sinf(y) and cosf(y) together: one reduction, both polynomials (bit-identical to the two calls)
+// sinf(y) and cosf(y) together, bit-identical to the two calls, without a lane-divergent branch: the reduction also
+// serves |y| < pi/4 (it yields n = 0, s = 1 and x unchanged, i.e. exactly the operands of the small-argument branch),
+// both polynomials are evaluated once and the quadrant only selects which one is the sine. |y| < 2^-12 returns (y, 1)
+// as glibc does.
 __device__ __forceinline__ void sincosf_pair(float y, float* sn, float* cs) {
     double x = (double)y;
-    if (abstop12(y) < 0x3f4u) {
-        const double x2 = x * x;
-        if (abstop12(y) < 0x398u) { *sn = y; *cs = 1.0f; return; }
-        *sn = sc_poly(x, x2, 0, false);
-        *cs = sc_poly(x, x2, 1, false);
-        return;
-    }
     const double r = x * 0x1.45F306DC9C883p+23;
     const int n = ((int32_t)r + 0x800000) >> 24;
     x = x - (double)n * 0x1.921FB54442D18p0;
     const double sg = ((n + 1) & 2) ? -1.0 : 1.0;
     const double xs = x * sg, x2 = x * x;
     const bool neg = (n & 2) != 0;
-    *sn = sc_poly(xs, x2, n, neg);
-    *cs = sc_poly(xs, x2, n ^ 1, neg);
+    const float ps = sc_poly(xs, x2, 0, neg);     // the sine polynomial
+    const float pc = sc_poly(xs, x2, 1, neg);     // the cosine polynomial
+    const bool odd = (n & 1) != 0, tiny = abstop12(y) < 0x398u;
+    const float s0 = odd ? pc : ps, c0 = odd ? ps : pc;
+    *sn = tiny ? y : s0;
+    *cs = tiny ? 1.0f : c0;
 }
 
 // degrees -> radians as Nerf::place_atom does (src/nerf.cpp:63-64): double multiply, double divide,
@@ -329,6 +378,7 @@ __device__ __forceinline__ float deg2rad(float deg) {
 // LLVM AMDGPU LowerFDIV32 between v_div_scale and v_div_fixup); those two wrappers only rescale operands whose
 // quotient or intermediates could leave the normal range. The guard below sends every such case -- and zero,
 // infinite or NaN denominators -- to the plain division, so results are bit-identical to three '/'.
+__device__ __noinline__ v3 vdiv3_plain(v3 n, float d) { return v3{n.x / d, n.y / d, n.z / d}; }
 __device__ __forceinline__ v3 vdiv3(v3 n, float d) {
     const uint32_t ed = (__float_as_uint(d) >> 23) & 0xffu;
     float r = __builtin_amdgcn_rcpf(d);
@@ -347,12 +397,16 @@ __device__ __forceinline__ v3 vdiv3(v3 n, float d) {
         float t = n.z * r; float e2 = __builtin_fmaf(-d, t, n.z); t = __builtin_fmaf(e2, r, t);
         const float e3 = __builtin_fmaf(-d, t, n.z); q.z = __builtin_fmaf(e3, r, t);
     }
-    // safe iff the denominator is comfortably normal and no quotient is tiny-but-nonzero or huge
-    const float ax = __builtin_fabsf(q.x), ay = __builtin_fabsf(q.y), az = __builtin_fabsf(q.z);
+    // safe iff the denominator is comfortably normal and no quotient is tiny-but-nonzero or huge. On the bit patterns with
+    // the sign shifted out: u - 1 wraps a zero to the top, so one unsigned minimum covers "zero or above 2^-90" for all three
+    // components; one float maximum (NaN quotients only come from NaN / zero / infinite operands: den_ok, or NaN either way)
+    // covers the upper bound.
     const bool den_ok = (ed - 32u) < 192u;                                   // 2^-95 <= |d| < 2^97
-    const bool q_ok = (ax == 0.0f || ax > 0x1p-90f) && (ay == 0.0f || ay > 0x1p-90f) && (az == 0.0f || az > 0x1p-90f) &&
-                      ax < 0x1p90f && ay < 0x1p90f && az < 0x1p90f;          // also false for NaN
-    if (__builtin_expect(!(den_ok && q_ok), 0)) q = v3{n.x / d, n.y / d, n.z / d};
+    const uint32_t ux = (__float_as_uint(q.x) << 1) - 1u, uy = (__float_as_uint(q.y) << 1) - 1u, uz = (__float_as_uint(q.z) << 1) - 1u;
+    const uint32_t lo2 = ux < uy ? ux : uy, lo3 = lo2 < uz ? lo2 : uz;                                          // v_min3_u32
+    const float hi3 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)), __builtin_fabsf(q.z));   // v_max3_f32
+    const bool q_ok = lo3 >= ((37u << 24) - 1u) && hi3 < 0x1p90f;            // 2^-90 = exponent field 37
+    if (__builtin_expect(!(den_ok && q_ok), 0)) q = vdiv3_plain(n, d);
     return q;
 }
 

@@ -363,15 +363,20 @@ void list_files(const std::string& dir, bool recursive, std::vector<std::string>
     if (recursive) for (const std::string& s : dirs) list_files(s, true, out);
 }
 // getFileParts: split at the last '.', a trailing .gz stays with the extension
+// getFileParts (reference src/utility.cpp:118-126): split at the LAST dot ("test.cif.gz" -> "test.cif", "gz")
 void file_parts(const std::string& base, std::string& stem, std::string& ext) {
     stem = base; ext.clear();
-    std::string gz;
-    if (ends_with(base, ".gz")) { stem = base.substr(0, base.size() - 3); gz = ".gz"; }
-    const size_t i = stem.rfind('.');
-    if (i != std::string::npos) { ext = stem.substr(i + 1) + gz; stem = stem.substr(0, i); }
-    else ext = gz.empty() ? "" : gz.substr(1);
+    const size_t i = base.rfind('.');
+    if (i != std::string::npos) { stem = base.substr(0, i); ext = base.substr(i + 1); }
 }
-bool is_compressible(const std::string& ext) { return ext == "pdb" || ext == "cif" || ext == "pdb.gz" || ext == "cif.gz"; }
+// isCompressible (src/utility.cpp:129-140): pdb, cif, and either of them gzipped (the .gz case looks one extension further in)
+bool is_compressible(const std::string& stem, const std::string& ext) {
+    if (ext == "pdb" || ext == "cif") return true;
+    if (ext != "gz") return false;
+    std::string s2, e2;
+    file_parts(stem, s2, e2);
+    return e2 == "pdb" || e2 == "cif";
+}
 
 bool write_out(const std::string& path, const char* data, size_t n, bool overwrite) {
     if (exists(path) && !overwrite) { fprintf(stderr, "[Error] Output file already exists: %s\n", base_name(path).c_str()); return false; }
@@ -458,6 +463,8 @@ struct Options {
 struct Fragment { std::string out_name, db_name; AtomTable atoms; std::string title; };   // db_name: lookup name = the input file's stem
 
 // one structure file -> its fragments (src/main.cpp:455-508)
+// (out_stem, ext) = getFileParts of the input's base name, or of the OUTPUT path for a single-file run (src/main.cpp:444-457):
+// they name the fragments and decide the suffix (isCompressible, :498-502)
 void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
                   std::vector<Fragment>& out) {
     const std::string base = base_name(path);
@@ -480,7 +487,7 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
             std::string fname = out_stem;
             if (chains.size() > 1) fname += t.chain[cs.a];
             if (frags.size() > 1) fname += "_" + std::to_string(j);
-            if (to_dir_or_file) fname += is_compressible(ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
+            if (to_dir_or_file) fname += is_compressible(out_stem, ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
             out.push_back({fname, out_stem, t.slice(frags[j].a, frags[j].b), title});
         }
     }
@@ -497,7 +504,7 @@ void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t 
         std::string stem, ext;
         file_parts(base_name(files[i]), stem, ext);
         std::string out_stem = stem;
-        if (single) { std::string os_, oe; file_parts(base_name(output), os_, oe); out_stem = os_; }
+        if (single) file_parts(base_name(output), out_stem, ext);
         try { fragments_of(files[i], out_stem, ext, to_dir_or_file, o, per[i - a]); }
         catch (const std::exception& e) { err[i - a] = "[Error] " + base_name(files[i]) + ": " + e.what() + "\n"; }
     }

@@ -13,7 +13,9 @@ if [ ! -d "$REF/src" ]; then
   exit 0
 fi
 mkdir -p "$OUT"
-SRCS="amino_acid atom_coordinate discretizer foldcomp nerf sidechain torsion_angle utility"
+# the codec (8 files) plus the rows either side of it: the gemmi-based structure reader (header-only gemmi as vendored under
+# lib/, zlib from the system) and the database container
+SRCS="amino_acid atom_coordinate discretizer foldcomp nerf sidechain torsion_angle utility structure_reader database_reader database_writer"
 OBJS=""
 for s in $SRCS; do
   g++ -O3 -DNDEBUG -std=c++17 -fPIC -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" \
@@ -23,6 +25,6 @@ done
 g++ -O3 -DNDEBUG -std=c++17 -fPIC -fopenmp -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" \
     -c "$HERE/ref_shim.cpp" -o "$OUT/ref_shim.o" &
 wait
-g++ -shared -fopenmp -o "$OUT/libfoldcomp_ref.so" $OBJS "$OUT/ref_shim.o"
+g++ -shared -fopenmp -o "$OUT/libfoldcomp_ref.so" $OBJS "$OUT/ref_shim.o" -lz
 rm -f "$OUT"/*.o
 echo "built $OUT/libfoldcomp_ref.so"

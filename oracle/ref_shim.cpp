@@ -7,10 +7,17 @@
 //   Foldcomp::read      (src/foldcomp.cpp:904)  + Foldcomp::decompress  (src/foldcomp.cpp:779)
 // over plain arrays, so that tests can pin the C restatement (oracle/fcz_oracle.c) and the HIP path
 // against the real thing, and bench.py can time the reference's CPU path ("cpu_baseline.kind":"reference").
+// and, for the rows either side of the codec:
+//   StructureReader::loadFromBuffer (src/structure_reader.cpp:74-98: gemmi PDB / mmCIF parser, gz inflate) followed by what
+//   the compress lambda does before the codec (src/main.cpp:457-474: removeAlternativePosition, identifyChains,
+//   identifyDiscontinousResInd), and the database container (src/database_writer.cpp, src/database_reader.cpp).
 // Nothing of the reference is copied here: this file only *calls* it.
 #include "foldcomp.h"
 #include "atom_coordinate.h"
 #include "amino_acid.h"
+#include "structure_reader.h"
+#include "database_reader.h"
+#include "database_writer.h"
 
 #include <chrono>
 #include <cstring>
@@ -229,6 +236,87 @@ int ref_bench_roundtrip(int n_chains, const unsigned* res_off, const unsigned* a
     for (auto& s : fcz) bytes += s.size();
     *t_compress = t1 - t0; *t_decompress = t2 - t1; *fcz_bytes = bytes; *atoms_out = total_atoms;
     return fail;
+}
+
+// ---- ingest: StructureReader + the fragmenting of src/main.cpp:457-474 -----------------------------------------------
+// Parses a file image (PDB / mmCIF, optionally gzipped; `name` decides as in the reference) and reports the atom table after
+// removeAlternativePosition plus the fragment ranges the compress lambda would hand to the codec.
+// Returns the number of atoms (or -needed if cap_atoms is too small, -1 when the reference's reader fails).
+// frag[4*k .. 4*k+3] = {first atom, end atom, chain ordinal, fragment ordinal within the chain}; n_chains = identifyChains count.
+long ref_load_structure(const char* buf, long len, const char* name, long cap_atoms, char* atom_names, char* res_names,
+                        char* chain_ids, int* atom_index, int* res_index, float* x, float* y, float* z, float* bfac,
+                        char* title, int title_cap, int* title_len, int* frag, int frag_cap, int* n_frag, int* n_chains) {
+    StructureReader reader;
+    if (!reader.loadFromBuffer(buf, (size_t)len, std::string(name))) return -1;
+    std::vector<AtomCoordinate> atoms;
+    reader.readAllAtoms(atoms);
+    removeAlternativePosition(atoms);
+    const long n = (long)atoms.size();
+    *title_len = (int)reader.title.size();
+    if (title_cap > 0) { const int t = std::min<int>(*title_len, title_cap); memcpy(title, reader.title.data(), t); }
+    std::vector<std::pair<size_t, size_t>> chains = identifyChains(atoms);
+    *n_chains = (int)chains.size();
+    int nf = 0;
+    for (size_t i = 0; i < chains.size(); i++) {
+        std::vector<std::pair<size_t, size_t>> fr = identifyDiscontinousResInd(atoms, chains[i].first, chains[i].second);
+        for (size_t j = 0; j < fr.size(); j++) {
+            if (nf < frag_cap) { frag[4 * nf] = (int)fr[j].first; frag[4 * nf + 1] = (int)fr[j].second; frag[4 * nf + 2] = (int)i; frag[4 * nf + 3] = (int)j; }
+            nf++;
+        }
+    }
+    *n_frag = nf;
+    if (n > cap_atoms) return -n;
+    for (long i = 0; i < n; i++) {
+        const AtomCoordinate& a = atoms[i];
+        memset(atom_names + 4 * i, 0, 4); memcpy(atom_names + 4 * i, a.atom.data(), std::min<size_t>(4, a.atom.size()));
+        memset(res_names + 3 * i, 0, 3); memcpy(res_names + 3 * i, a.residue.data(), std::min<size_t>(3, a.residue.size()));
+        chain_ids[i] = a.chain.empty() ? ' ' : a.chain[0];
+        atom_index[i] = a.atom_index; res_index[i] = a.residue_index;
+        x[i] = a.coordinate.x; y[i] = a.coordinate.y; z[i] = a.coordinate.z; bfac[i] = a.tempFactor;
+    }
+    return n;
+}
+
+// ---- database container: make_writer / writer_append / free_writer, make_reader / reader_get_* -------------------------
+// Writes n entries (blob + offsets, keys, NUL-separated names) with the reference's writer; 0 on success.
+int ref_db_write(const char* data_path, const char* index_path, int n, const unsigned char* blob, const unsigned long long* off,
+                 const unsigned* keys, const char* names) {
+    void* w = make_writer(data_path, index_path);
+    if (!w) return -1;
+    const char* nm = names;
+    for (int i = 0; i < n; i++) {
+        writer_append(w, (const char*)blob + off[i], (size_t)(off[i + 1] - off[i]), keys[i], nm);
+        nm += strlen(nm) + 1;
+    }
+    free_writer(w);
+    return 0;
+}
+// Opens a database with the reference's reader (data + reverse lookup) and reports entry `id` in the reader's order: key,
+// length, offset, name (looked up by key) and up to cap bytes of data. Returns the number of entries, or -1.
+long ref_db_read(const char* data_path, const char* index_path, long id, unsigned* key, long long* length, long long* offset,
+                 char* name, int name_cap, unsigned char* data, long cap) {
+    void* r = make_reader(data_path, index_path, DB_READER_USE_DATA | DB_READER_USE_LOOKUP_REVERSE);
+    if (!r) return -1;
+    const long n = (long)reader_get_size(r);
+    if (id >= 0 && id < n) {
+        *key = reader_get_key(r, id); *length = reader_get_length(r, id); *offset = reader_get_offset(r, id);
+        const char* nm = reader_lookup_name_alloc(r, *key);
+        if (name_cap > 0) { name[0] = 0; if (nm) { strncpy(name, nm, name_cap - 1); name[name_cap - 1] = 0; } }
+        if (nm) free((void*)nm);
+        const char* d = reader_get_data(r, id);
+        if (d && cap > 0) memcpy(data, d, (size_t)std::min<long long>(cap, *length));
+    }
+    free_reader(r);
+    return n;
+}
+// name -> key -> id with the reference's lookup (DB_READER_USE_LOOKUP), as `foldcomp.open(ids=...)` does; -1 when missing
+long ref_db_lookup(const char* data_path, const char* index_path, const char* name) {
+    void* r = make_reader(data_path, index_path, DB_READER_USE_LOOKUP);
+    if (!r) return -2;
+    const uint32_t key = reader_lookup_entry(r, name);
+    const long id = key == UINT32_MAX ? -1 : (long)reader_get_id(r, key);
+    free_reader(r);
+    return id;
 }
 
 }  // extern "C"

@@ -169,6 +169,68 @@ def ref_extract(fcz: bytes, kind: int, digits: int) -> str:
 
 
 # ---- oracle batch wrappers -------------------------------------------------------------------
+def ref_load_structure(data: bytes, name: str):
+    """the reference's own reader (gemmi PDB / mmCIF, gz by name) + removeAlternativePosition + the fragmenting of
+    src/main.cpp:457-474 -> (AtomTable, title, [(first, end, chain ordinal, fragment ordinal)], n_chains)"""
+    lib = load_ref()
+    lib.ref_load_structure.restype = ctypes.c_long
+    lib.ref_load_structure.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_long] + [ctypes.c_void_p] * 9 + \
+                                      [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    cap = max(16, len(data) // 8 + 4096) if not name.endswith(".gz") else 1 << 20
+    an = np.zeros((cap, 4), np.uint8); rn = np.zeros((cap, 3), np.uint8); ch = np.zeros(cap, np.uint8)
+    ai = np.zeros(cap, np.int32); ri = np.zeros(cap, np.int32)
+    x = np.zeros(cap, np.float32); y = np.zeros(cap, np.float32); z = np.zeros(cap, np.float32); bf = np.zeros(cap, np.float32)
+    title = ctypes.create_string_buffer(4096); tl = ctypes.c_int(); nf = ctypes.c_int(); nc = ctypes.c_int()
+    frag = np.zeros((4096, 4), np.int32)
+    n = lib.ref_load_structure(data, len(data), name.encode(), cap, an.ctypes.data, rn.ctypes.data, ch.ctypes.data, ai.ctypes.data,
+                               ri.ctypes.data, x.ctypes.data, y.ctypes.data, z.ctypes.data, bf.ctypes.data, title, 4096,
+                               ctypes.byref(tl), frag.ctypes.data, 4096, ctypes.byref(nf), ctypes.byref(nc))
+    if n < 0:
+        raise RuntimeError(f"ref_load_structure({name}) = {n}")
+    def strs(a):
+        return [bytes(r).rstrip(b"\0 ").decode() for r in a[:n]]
+    t = AtomTable(strs(an), strs(rn), [chr(c) for c in ch[:n]], ai[:n].copy(), ri[:n].copy(),
+                  np.stack([x[:n], y[:n], z[:n]], 1).copy(), bf[:n].copy())
+    return t, title.raw[:tl.value].decode("latin-1"), [tuple(int(v) for v in f) for f in frag[:nf.value]], nc.value
+
+
+def ref_db_write(path: str, entries, keys, names):
+    """the reference's database writer (make_writer / writer_append / free_writer) on the given entries"""
+    lib = load_ref()
+    lib.ref_db_write.restype = ctypes.c_int
+    lib.ref_db_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+    blob = b"".join(entries)
+    off = np.zeros(len(entries) + 1, np.uint64); off[1:] = np.cumsum([len(e) for e in entries])
+    k = np.asarray(keys, np.uint32)
+    nm = b"".join(n.encode() + b"\0" for n in names)
+    rc = lib.ref_db_write(path.encode(), (path + ".index").encode(), len(entries), blob, off.ctypes.data, k.ctypes.data, nm)
+    assert rc == 0, rc
+
+
+def ref_db_read(path: str):
+    """every entry of a database through the reference's reader, in the reader's order: [(key, offset, length, name, data)]"""
+    lib = load_ref()
+    lib.ref_db_read.restype = ctypes.c_long
+    lib.ref_db_read.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+    key = ctypes.c_uint(); ln = ctypes.c_longlong(); of = ctypes.c_longlong(); name = ctypes.create_string_buffer(1024)
+    n = lib.ref_db_read(path.encode(), (path + ".index").encode(), -1, ctypes.byref(key), ctypes.byref(ln), ctypes.byref(of), name, 1024, None, 0)
+    out = []
+    for i in range(n):
+        lib.ref_db_read(path.encode(), (path + ".index").encode(), i, ctypes.byref(key), ctypes.byref(ln), ctypes.byref(of), name, 1024, None, 0)
+        buf = ctypes.create_string_buffer(max(1, ln.value))
+        lib.ref_db_read(path.encode(), (path + ".index").encode(), i, ctypes.byref(key), ctypes.byref(ln), ctypes.byref(of), name, 1024, buf, ln.value)
+        out.append((key.value, of.value, ln.value, name.value.decode(), buf.raw[:ln.value]))
+    return out
+
+
+def ref_db_lookup(path: str, name: str) -> int:
+    lib = load_ref()
+    lib.ref_db_lookup.restype = ctypes.c_long
+    lib.ref_db_lookup.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    return int(lib.ref_db_lookup(path.encode(), (path + ".index").encode(), name.encode()))
+
+
 def oracle_compress(b: ChainBatch, n_threads: int = 1):
     """-> (blob uint8, out_off uint64[C+1], status int32[C])"""
     lib = load_oracle()

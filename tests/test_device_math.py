@@ -68,6 +68,19 @@ def test_sincos_sweep(codec, is_cos):
         assert len(bad) == 0, (len(bad), [(hex(sign + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])
 
 
+@pytest.mark.parametrize("is_cos", [0, 1])
+def test_sincos_pair_sweep(codec, is_cos):
+    """the branch-free sincosf_pair the kernels call (one reduction for every |x|, both polynomials, quadrant select)
+    against libm: every 7th float below 8 rad, and every float below 2^-10 (the |x| < 2^-12 early-out and its neighbourhood)"""
+    for sign in (0, 0x80000000):
+        for start, stride, count in ((0, 7, _b(8.0) // 7), (_b(2.0 ** -14), 1, _b(2.0 ** -10) - _b(2.0 ** -14)), (0, 1, 1 << 20)):
+            dev = codec.selftest_math(9 + is_cos, sign + start, stride, count)
+            host = _host_sincos(is_cos, sign + start, stride, count)
+            a, b = dev.view(np.uint32), host.view(np.uint32)
+            bad = np.nonzero(a != b)[0]
+            assert len(bad) == 0, (len(bad), [(hex(sign + start + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])
+
+
 def _host_math(mode, start, stride, count):
     lib = H.load_oracle()
     lib.fcz_oracle_math_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
@@ -100,3 +113,16 @@ def test_hashed_geometry_functions(codec, mode):
     host = _host_math(mode, 12345, 1, count)
     bad = np.nonzero(~_same(dev, host))[0]
     assert len(bad) == 0, (mode, len(bad), [(int(i), float(dev[i]), float(host[i])) for i in bad[:8]])
+
+
+def test_acos_deg_f32_error_bound(codec):
+    """the float acos behind the side-chain torsion byte stays within 1e-4 degrees of the exact acos_deg on every 61st float
+    of (-1, 1) and on every float of the steep ends [0.999, 1): the kernel's guard band is 5e-4 degrees"""
+    worst = 0.0
+    for sign in (0, 0x80000000):
+        one = _b(1.0)
+        for start, stride, count in ((0, 61, one // 61), (_b(0.999), 1, one - _b(0.999))):
+            approx = codec.selftest_math(11, sign + start, stride, count).astype(np.float64)
+            exact = codec.selftest_math(0, sign + start, stride, count).astype(np.float64)
+            worst = max(worst, float(np.abs(approx - exact).max()))
+    assert worst < 1e-4, worst

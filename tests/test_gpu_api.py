@@ -124,3 +124,25 @@ def test_open_database(tmp_path, golden):
         foldcomp.open(str(tmp_path / "db"), ids=want, err_on_missing=True)
     with pytest.raises(TypeError):
         foldcomp.open(str(tmp_path / "db"), ids="d1asha_")
+
+
+def test_open_database_written_without_terminators(tmp_path, golden):
+    """databases made by `compress -d` (here and in the reference, src/main.cpp:516) carry no trailing NUL per entry: db[i] must
+    not drop the record's last byte (the reference's module does, foldcomp.cxx:66, and reads one byte short)"""
+    z, index = golden
+    names = db_cases(index)[:6]
+    w = DatabaseWriter(str(tmp_path / "db"))
+    from foldcomp_amd import fczfile
+    recs = []
+    for i, n in enumerate(names):
+        e = z[f"{n}/fcz"].tobytes()
+        recs.append(e[:fczfile.record_size(e)])          # the record alone: the example_db entries end in a NUL
+        assert len(recs[-1]) in (len(e), len(e) - 1)
+        w.append(recs[-1], i, bytes(z[f"{n}/name"]).decode())
+    w.close()
+    with foldcomp.open(str(tmp_path / "db")) as db:
+        for i, n in enumerate(names):
+            title, pdb = db[i]
+            assert pdb == z[f"{n}/pdb0"].tobytes().decode("latin-1"), n
+    with foldcomp.open(str(tmp_path / "db"), decompress=False) as db:
+        assert db[2] == recs[2]

@@ -41,9 +41,24 @@ def test_tile_edges_and_long_chains(codec):
 
 @pytest.mark.parametrize("thr", [2, 7, 200, 5000])
 def test_anchor_thresholds(codec, thr):
-    lens = [30, 64, 350, 700]
+    lens = [30, 64, 350, 700 if thr > 2 else 506]   # n / thr + 2 anchors must fit the header's uint8 (next test)
     b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=5, anchor_threshold=thr))
     _check(codec, b)
+
+
+def test_chain_beyond_header_counts_is_refused(codec):
+    """nAnchor is a uint8 and nResidue a uint16 in the FCZ header (src/foldcomp.h:120-125): the reference wraps them silently
+    and writes a record that cannot be read back; here such a chain gets FCZ_E_INVALID_ARG and a zero-filled record while its
+    neighbours compress as usual"""
+    lens = [64, 700, 350]
+    b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=5, anchor_threshold=2))   # 700 / 2 + 2 = 352 anchors
+    blob, off, st = codec.compress_batch(b, strict=False)
+    assert list(st) == [0, -1, 0]
+    assert not blob[off[1]:off[2]].any()
+    oblob, ooff, ost = H.oracle_compress(b, n_threads=2)
+    assert np.array_equal(off, ooff)
+    for c in (0, 2):
+        assert blob[off[c]:off[c + 1]].tobytes() == oblob[off[c]:off[c + 1]].tobytes()
 
 
 def _with_hydrogens(b: ChainBatch, per_res: int, seed=3) -> ChainBatch:

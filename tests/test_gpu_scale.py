@@ -1,0 +1,77 @@
+"""GPU: the device-resident path at the shape of BASELINE configs[2] / configs[4] (the datasets cannot be fetched): 100 000 chains
+with log-normal lengths (16 ... 2 700 residues, anchor -b 25) through compress + decompress in one batch.
+ * a 256-chain sample against the oracle, bit for bit (FCZ bytes and coordinates);
+ * size-independent properties of the whole batch: every chain OK, sizes pass == input counts, decode(encode(x)) within the
+   reference's RMSD regime, deterministic blob, decompress-only repeatable."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import _harness as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mixed_workload(codec):
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    C = 100_000
+    d = bench.generate_resident(C, 0, 25, 2048, "cuda:0", seed_base=977, mixed=True)
+    w = bench.Workload(codec, d, "cuda:0")
+    w.compress(); w.decompress(); codec.synchronize()
+    yield bench, w, d, torch
+    del w, d
+    torch.cuda.empty_cache()
+
+
+def test_mixed_100k_oracle_sample_bit_exact(mixed_workload):
+    bench, w, d, torch = mixed_workload
+    lens = (d["res_off"][1:] - d["res_off"][:-1]).cpu().numpy()
+    assert len(lens) == 100_000 and lens.min() >= 16 and lens.max() > 1024     # the split long-chain path is exercised
+    n = 256
+    hb = bench.host_sample(d, n)
+    ok_c, ok_d = bench.parity_sample(hb, w.blob_dev, w.off_dev, w.out_t, None, n)
+    assert ok_c, "FCZ bytes of the first 256 chains differ from the oracle"
+    assert ok_d, "coordinates of the first 256 chains differ from the oracle"
+    # the longest chains sit anywhere in the batch: check the 8 longest against the oracle too
+    big = np.argsort(lens)[-8:]
+    off = w.off_dev.cpu().numpy().astype(np.int64)
+    ro = d["res_off"].cpu().numpy().astype(np.int64); ao = d["atom_off"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    from foldcomp_amd import synthetic
+    for c in big:
+        r0, r1 = int(ro[c]), int(ro[c + 1]); a0, a1 = int(ao[r0]), int(ao[r1]); t0, t1 = int(d["title_off"][c]), int(d["title_off"][c + 1])
+        sub = {k: d[k][a0:a1] for k in ("x", "y", "z", "atom_code")}
+        sub.update({k: d[k][r0:r1] for k in ("res_code", "bfac_ca")})
+        sub.update({k: d[k][c:c + 1] for k in ("first_res_index", "first_atom_index", "chain_id")})
+        sub["res_off"] = d["res_off"][c:c + 2] - r0
+        sub["atom_off"] = (d["atom_off"][r0:r1 + 1].to(torch.int64) & 0xFFFFFFFF) - a0
+        sub["titles"] = d["titles"][t0:t1]; sub["title_off"] = d["title_off"][c:c + 2] - t0
+        sub["anchor_threshold"] = d["anchor_threshold"]
+        hb1 = synthetic.to_chain_batch(sub)
+        oblob, ooff, ost = H.oracle_compress(hb1, n_threads=1)
+        assert ost[0] == 0
+        got = w.blob_dev[int(off[c]):int(off[c + 1])].cpu().numpy().tobytes()
+        assert got == oblob.tobytes(), f"chain {c} ({lens[c]} residues)"
+
+
+def test_mixed_100k_full_batch_properties(mixed_workload, codec):
+    bench, w, d, torch = mixed_workload
+    assert int((w.status_dev != 0).sum()) == 0
+    assert torch.equal(w.res_off_dev, d["res_off"].to(torch.int32))
+    assert int(w.atom_off_dev[-1]) & 0xFFFFFFFF == w.M
+    c0 = w.checksum()
+    x0 = w.out_t["x"].clone()
+    w.compress(); w.decompress(); codec.synchronize()
+    assert w.checksum() == c0, "compress is not deterministic"
+    assert torch.equal(w.out_t["x"].view(torch.int32), x0.view(torch.int32)), "decompress is not deterministic"
+    # decompress-only (the configs[2] operation) from the resident records, twice: same bits
+    w.decompress(); codec.synchronize()
+    assert torch.equal(w.out_t["x"].view(torch.int32), x0.view(torch.int32))
+    rmsd, mx = w.round_trip_deviation()
+    assert rmsd < 0.2, rmsd            # the reference pins ~0.08 A on real structures (build.sh:35)
+    assert np.isfinite(mx)

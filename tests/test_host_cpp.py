@@ -203,7 +203,9 @@ def test_cpp_host_reads_mmcif_and_gzip_like_the_python_host(tmp_path, golden):
     (tmp_path / "a.cif").write_text(cif)
     (tmp_path / "b.cif.gz").write_bytes(gzip.compress(cif.encode()))
     (tmp_path / "c.pdb.gz").write_bytes(gzip.compress(pdb.encode()))
-    for fname, stem in (("a.cif", "a"), ("b.cif.gz", "b"), ("c.pdb.gz", "c")):
+    # stems as getFileParts makes them (reference src/utility.cpp:118-126: split at the LAST dot; pinned against the real reference
+    # in test_ingest_vs_reference.py)
+    for fname, stem in (("a.cif", "a"), ("b.cif.gz", "b.cif"), ("c.pdb.gz", "c.pdb")):
         path = tmp_path / fname
         t, title = load_structure(str(path), path.read_bytes())
         if title == fname:

@@ -1,0 +1,165 @@
+"""CPU: the two hosts' ingest (PDB / mmCIF / .gz parsing, alternative positions, chain and gap fragmenting, titles) and the
+database container (reader and writer) against the REAL reference: goldens minted by tools/make_ingest_goldens.py from
+StructureReader (gemmi) + src/main.cpp:457-474 and from make_writer / make_reader, over the reference's own test data files
+(tests/golden/reference_ingest.npz); where oracle/_ref exists (the build container) the same comparisons also run live."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _harness as H
+from foldcomp_amd.__main__ import load_structure
+from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+from foldcomp_amd.structure import (Chain, build_batch, identify_chains, identify_discontinuous, remove_alternative_position)
+from test_host_cpp import _dump, _run, _same
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = ("test.pdb", "test_af.pdb", "multichain.pdb", "test.cif.gz")
+
+
+@pytest.fixture(scope="module")
+def ing():
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
+
+
+def _ref_table(z, fn):
+    k = f"ingest:{fn}"
+    strs = lambda a: [bytes(r).rstrip(b"\0").decode() for r in a]
+    return dict(atom=strs(z[f"{k}/atom"]), residue=strs(z[f"{k}/residue"]), chain=[chr(c) for c in z[f"{k}/chain"]],
+                atom_index=z[f"{k}/atom_index"], res_index=z[f"{k}/res_index"], xyz=z[f"{k}/xyz"], bfac=z[f"{k}/bfac"],
+                title=bytes(z[f"{k}/title"]).decode("latin-1"), frag=[tuple(int(v) for v in f) for f in z[f"{k}/frag"]],
+                n_chains=int(z[f"{k}/n_chains"][0]))
+
+
+def _python_ingest(fn, data):
+    t, title = load_structure(fn, data)
+    t = remove_alternative_position(t)
+    chains = identify_chains(t)
+    frag = []
+    for i, cs in enumerate(chains):
+        for j, sl in enumerate(identify_discontinuous(t, cs)):
+            frag.append((sl.start, sl.stop, i, j))
+    return t, title, frag, len(chains)
+
+
+@pytest.mark.parametrize("fn", FILES)
+def test_python_ingest_equals_reference_reader(ing, fn):
+    """parser output == what gemmi hands the reference, field by field and bit for bit; fragments == src/main.cpp:467-480"""
+    ref = _ref_table(ing, fn)
+    t, title, frag, nch = _python_ingest(fn, ing[f"file:{fn}"].tobytes())
+    assert len(t) == len(ref["atom"])
+    assert t.atom == ref["atom"] and t.residue == ref["residue"] and t.chain == ref["chain"]
+    assert np.array_equal(t.atom_index, ref["atom_index"]) and np.array_equal(t.res_index, ref["res_index"])
+    assert np.array_equal(t.xyz.view(np.uint32), ref["xyz"].view(np.uint32))
+    assert np.array_equal(t.bfac.view(np.uint32), ref["bfac"].view(np.uint32))
+    assert title == ref["title"]
+    assert frag == ref["frag"] and nch == ref["n_chains"]
+
+
+@pytest.mark.parametrize("fn", FILES)
+def test_cpp_ingest_equals_reference_reader(ing, fn, tmp_path):
+    """the C++ host's batch (dump-batch) == the batch built from the REFERENCE's atom table and fragments"""
+    ref = _ref_table(ing, fn)
+    p = tmp_path / fn
+    p.write_bytes(ing[f"file:{fn}"].tobytes())
+    from foldcomp_amd.structure import AtomTable
+    t = AtomTable(ref["atom"], ref["residue"], ref["chain"], ref["atom_index"], ref["res_index"], ref["xyz"], ref["bfac"])
+    stem = fn[:-3] if fn.endswith(".gz") else fn
+    stem = stem.rsplit(".", 1)[0]
+    # output names / titles: src/main.cpp:444-508 (title = output stem when the structure's title is the file name)
+    base_stem = fn.rsplit(".", 1)[0]                                   # getFileParts splits at the LAST dot: test.cif.gz -> test.cif
+    title = base_stem if ref["title"] == fn else ref["title"]
+    names, chains = [], []
+    for (a, b, ci, fj) in ref["frag"]:
+        n_in_chain = sum(1 for f in ref["frag"] if f[2] == ci)
+        nm = base_stem + (ref["chain"][a] if ref["n_chains"] > 1 else "") + (f"_{fj}" if n_in_chain > 1 else "") + ".fcz"
+        names.append(nm); chains.append(Chain(title, t.take(slice(a, b))))
+    _same(_dump(p), names, build_batch(chains, 25))
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref is built only where /root/reference exists")
+@pytest.mark.parametrize("fn", FILES)
+def test_goldens_are_what_the_live_reference_says(ing, fn):
+    t, title, frag, nch = H.ref_load_structure(ing[f"file:{fn}"].tobytes(), fn)
+    ref = _ref_table(ing, fn)
+    assert t.atom == ref["atom"] and title == ref["title"] and frag == ref["frag"] and nch == ref["n_chains"]
+    assert np.array_equal(t.xyz.view(np.uint32), ref["xyz"].view(np.uint32))
+
+
+# ---- database container -------------------------------------------------------------------------------------------------
+def _write_example_db(ing, d):
+    for suffix in ("", ".index", ".lookup", ".dbtype"):
+        (d / ("example_db" + suffix)).write_bytes(ing[f"file:example_db{suffix}"].tobytes())
+    return str(d / "example_db")
+
+
+def test_python_reader_on_the_reference_made_database(ing, golden, tmp_path):
+    """DatabaseReader on test/example_db (an MMseqs2-made database) == what the reference's reader reports, == the goldens"""
+    z, index = golden
+    path = _write_example_db(ing, tmp_path)
+    r = DatabaseReader(path)
+    names = bytes(ing["dbr:names"]).decode().split("\n")
+    assert len(r) == 24
+    assert np.array_equal(r.keys, ing["dbr:keys"]) and np.array_equal(r.offsets, ing["dbr:offsets"]) and np.array_equal(r.lengths, ing["dbr:lengths"])
+    for i in range(24):
+        assert r.name(i) == names[i]
+        assert r.data(i) == z[f"db:{i:02d}/fcz"].tobytes()
+        assert r.id_of_name(names[i]) == i
+    assert r.id_of_name("no_such_entry") == -1
+    r.close()
+
+
+def test_cpp_reader_on_the_reference_made_database(ing, golden, tmp_path):
+    z, index = golden
+    path = _write_example_db(ing, tmp_path)
+    outd = tmp_path / "unpacked"
+    r = _run("db-unpack", path, str(outd))
+    assert r.returncode == 0, r.stderr
+    names = bytes(ing["dbr:names"]).decode().split("\n")
+    assert sorted(os.listdir(outd)) == sorted(names)
+    for i, n in enumerate(names):
+        assert (outd / n).read_bytes() == z[f"db:{i:02d}/fcz"].tobytes()
+
+
+def test_python_writer_equals_the_reference_writer(ing, golden, tmp_path):
+    """entries appended in a scrambled key order: data file, .index, .lookup and .dbtype == free_writer's bytes"""
+    z, index = golden
+    order = ing["dbw:order"]
+    names = bytes(ing["dbr:names"]).decode().split("\n")
+    w = DatabaseWriter(str(tmp_path / "w"))
+    for i in order:
+        w.append(z[f"db:{int(i):02d}/fcz"].tobytes(), int(ing["dbr:keys"][i]), names[i])
+    w.close()
+    for suffix in ("", ".index", ".lookup", ".dbtype"):
+        assert (tmp_path / ("w" + suffix)).read_bytes() == ing[f"dbw:file{suffix}"].tobytes(), suffix
+
+
+def test_cpp_writer_equals_the_reference_writer(ing, golden, tmp_path):
+    """db-pack of the unpacked example_db: same files as the reference writer makes of the same entries in the same order"""
+    z, index = golden
+    names = bytes(ing["dbr:names"]).decode().split("\n")
+    src = tmp_path / "files"
+    src.mkdir()
+    for i, n in enumerate(names):
+        (src / n).write_bytes(z[f"db:{i:02d}/fcz"].tobytes())
+    r = _run("db-pack", str(src), str(tmp_path / "packed"))
+    assert r.returncode == 0, r.stderr
+    # db-pack walks the directory in sorted order and numbers the entries 0.. : the example_db's own order
+    for suffix in ("", ".index", ".lookup", ".dbtype"):
+        assert (tmp_path / ("packed" + suffix)).read_bytes() == ing[f"file:example_db{suffix}"].tobytes(), suffix
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref is built only where /root/reference exists")
+def test_reference_reader_reads_our_writers(ing, golden, tmp_path):
+    """the other direction, live: the reference's reader on a database written by the Python writer"""
+    z, index = golden
+    names = bytes(ing["dbr:names"]).decode().split("\n")
+    w = DatabaseWriter(str(tmp_path / "w"))
+    for i in (5, 2, 9):
+        w.append(z[f"db:{i:02d}/fcz"].tobytes(), i, names[i])
+    w.close()
+    rows = H.ref_db_read(str(tmp_path / "w"))
+    assert [(r[0], r[3]) for r in rows] == [(2, names[2]), (5, names[5]), (9, names[9])]
+    assert rows[1][4] == z["db:05/fcz"].tobytes()
+    assert H.ref_db_lookup(str(tmp_path / "w"), names[9]) == 2

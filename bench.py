@@ -70,13 +70,17 @@ def generate_resident(n_chains, n_res, anchor, chunk, device, seed_base, mixed=F
     if mixed:
         # The generator is dense in [chains, longest chain of the chunk]: chains are drawn with log-normal lengths, dealt into
         # chunks of similar length (so that a chunk costs its own residues, not 2 700 per chain) and the chunks are laid out in
-        # random order. Lengths vary freely across the batch and every 2 048-chain stretch is uniform within ~1 %.
-        chunk = min(chunk, 2048)
+        # random order: lengths vary freely across the batch, stretches of up to 65 536 chains are of similar length.
         lens_all = np.sort(synthetic.mixed_lengths(n_chains, seed=seed_base + 7))
-        starts = np.arange(0, n_chains, chunk)
-        order = np.random.default_rng(seed_base + 11).permutation(len(starts))
+        bounds = [0]                              # greedy groups of similar length: chains x longest chain <= 6 M residue slots
+        while bounds[-1] < n_chains:
+            a = bounds[-1]; b = min(n_chains, a + 65536)
+            while b - a > 1 and (b - a) * int(lens_all[b - 1]) > 6_000_000:
+                b = a + max(1, (b - a) // 2)
+            bounds.append(b)
+        order = np.random.default_rng(seed_base + 11).permutation(len(bounds) - 1)
         for ci in order:
-            lens = lens_all[starts[ci]:starts[ci] + chunk]
+            lens = lens_all[bounds[ci]:bounds[ci + 1]]
             parts.append(synthetic.generate(len(lens), lens, seed=0xF01DC0DE, device=device, anchor_threshold=anchor,
                                             first_chain_id=seed_base + done))
             done += len(lens)

@@ -342,22 +342,22 @@ __device__ __forceinline__ float sinf_glibc(float y) { return sincosf_glibc(y, 0
 __device__ __forceinline__ float cosf_glibc(float y) { return sincosf_glibc(y, 1); }
 // sinf(y) and cosf(y) together, bit-identical to the two calls, without a lane-divergent branch: the reduction also
 // serves |y| < pi/4 (it yields n = 0, s = 1 and x unchanged, i.e. exactly the operands of the small-argument branch),
-// both polynomials are evaluated once and the quadrant only selects which one is the sine. |y| < 2^-12 returns (y, 1)
-// as glibc does.
+// both polynomials are evaluated once and the quadrant only selects which one is the sine. glibc multiplies the argument of
+// the sine polynomial and every coefficient of the cosine polynomial by a sign (+-1); every operation of both polynomials
+// is odd in that sign and IEEE rounding is symmetric, so the polynomials are evaluated unsigned and the sign bit is applied to
+// the float result: same bits, seven multiplications and two double selects fewer. |y| < 2^-12 returns (y, 1) as glibc does.
 __device__ __forceinline__ void sincosf_pair(float y, float* sn, float* cs) {
     double x = (double)y;
     const double r = x * 0x1.45F306DC9C883p+23;
     const int n = ((int32_t)r + 0x800000) >> 24;
     x = x - (double)n * 0x1.921FB54442D18p0;
-    const double sg = ((n + 1) & 2) ? -1.0 : 1.0;
-    const double xs = x * sg, x2 = x * x;
-    const bool neg = (n & 2) != 0;
-    const float ps = sc_poly(xs, x2, 0, neg);     // the sine polynomial
-    const float pc = sc_poly(xs, x2, 1, neg);     // the cosine polynomial
+    const double x2 = x * x;
+    const uint32_t ps = __float_as_uint(sc_poly(x, x2, 0, false)) ^ (((uint32_t)(n + 1) & 2u) << 30);   // sign table {1,-1,-1,1}[n & 3]
+    const uint32_t pc = __float_as_uint(sc_poly(x, x2, 1, false)) ^ (((uint32_t)n & 2u) << 30);         // negated cosine table for n & 2
     const bool odd = (n & 1) != 0, tiny = abstop12(y) < 0x398u;
-    const float s0 = odd ? pc : ps, c0 = odd ? ps : pc;
-    *sn = tiny ? y : s0;
-    *cs = tiny ? 1.0f : c0;
+    const uint32_t s0 = odd ? pc : ps, c0 = odd ? ps : pc;
+    *sn = tiny ? y : __uint_as_float(s0);
+    *cs = tiny ? 1.0f : __uint_as_float(c0);
 }
 
 // degrees -> radians as Nerf::place_atom does (src/nerf.cpp:63-64): double multiply, double divide,

@@ -29,8 +29,11 @@ def _use_codec(codec):
 
 
 def test_file_parts():
-    assert file_parts("test.pdb") == ("test", "pdb") and file_parts("test.cif.gz") == ("test", "cif.gz")
+    # getFileParts splits at the LAST dot (reference src/utility.cpp:118-126; the real reference names test.cif.gz -> test.cif.fcz)
+    from foldcomp_amd.__main__ import is_compressible
+    assert file_parts("test.pdb") == ("test", "pdb") and file_parts("test.cif.gz") == ("test.cif", "gz")
     assert file_parts("d1asha_") == ("d1asha_", "")
+    assert is_compressible("test.cif", "gz") and is_compressible("x", "pdb") and not is_compressible("x.fcz", "gz") and not is_compressible("x", "txt")
 
 
 def test_single_file_roundtrip(tmp_path, golden):

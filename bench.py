@@ -54,6 +54,10 @@ def parse_args():
                     help="chains per GPU of the secondary legs (decompress_only = BASELINE configs[2] shape, mixed = configs[4] shape: "
                          "log-normal lengths, anchor -b 25); 0 = skip")
     ap.add_argument("--mixed-steps", type=int, default=3)
+    ap.add_argument("--numerics", choices=("exact", "fast"), default="exact",
+                    help="decompress numerics of the TIMED steps: exact = float32 coordinates bit-identical to the reference (the headline), "
+                         "fast = FCZ_NUMERICS_FAST (plain float arithmetic, parallel backbone). The other mode is always measured "
+                         "once after the timed region and reported as `alt_numerics`.")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch/rendezvous check only: ranks are started and meet in a process group (gloo when no GPU is "
                          "present), no codec call is made and the JSON line carries value null; used by the CPU tests")
@@ -309,6 +313,48 @@ def timed(fn, steps, world, dist, dev):
     return dt
 
 
+def alt_numerics_leg(args, codec, w, dev, rank, world, dist, timed_mode, compress_ms):
+    """the decompress side once more in the OTHER numerics mode (see --numerics): time, per-kernel times, roofline fraction of
+    its longest kernel, and the deviation of its coordinates from the timed mode's on the first 65 536 chains. Leaves the
+    outputs and the ctx in the timed mode."""
+    other = "fast" if timed_mode == "exact" else "exact"
+    ns = min(w.C, 65536)
+    na = int(w.atom_off_dev[ns]) & 0xFFFFFFFF
+    ref = {k: w.out_t[k][:na].clone() for k in ("x", "y", "z")}
+    codec.set_numerics(other == "fast")
+    w.decompress(); codec.synchronize()
+    codec.reset_timing()
+    steps = max(1, min(args.steps, 5))
+    dt = timed(lambda: (w.decompress(), codec.synchronize()), steps, world, dist, dev)
+    km = span_ms(codec)
+    devv = torch.stack([(w.out_t[k][:na] - ref[k]).abs() for k in ("x", "y", "z")]).max(0).values
+    stats = {"sample_chains": ns, "sample_atoms": na, "median_A": float(devv[::5].median()),
+             "p999_A": float(torch.quantile(devv[::max(1, na // 4_000_000)].float(), 0.999)), "max_A": float(devv.max()),
+             "frac_above_1e-2_A": float((devv > 1e-2).double().mean())}
+    rmsd, mx = w.round_trip_deviation()
+    kb = w.kernel_bytes()
+    names = ("k_backbone", "k_res_index", "k_sidechain")
+    dom = max(names, key=lambda k: km[KERNEL_SPANS[k]])
+    ms = km[KERNEL_SPANS[dom]]
+    dec_ms = dt / steps * 1e3
+    A = w.M / w.R; f = w.fcz_bytes / w.R
+    out = {"mode": other, "timed_mode": timed_mode,
+           "what": "decompress in the other numerics mode (fast = plain float arithmetic, parallel rigid-transform backbone; "
+                   "exact = float32 coordinates bit-identical to the reference), same device-resident records",
+           "steps": steps, "decompress_ms": round(dec_ms, 3), "decompress_residues_per_s": round(w.R * world / (dec_ms * 1e-3)),
+           "round_trip_ms_with_compress": round(compress_ms + dec_ms, 3),
+           "round_trip_residues_per_s": round(w.R * world / ((compress_ms + dec_ms) * 1e-3)) if compress_ms else None,
+           "decompress_algorithmic_GBs": round((f + 12 * A + 4) * w.R / (dec_ms * 1e-3) / 1e9, 1),
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(kb[dom] / (ms * 1e-3) / 1e9, 1) if ms else None, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(kb[dom] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None, "avg_launch_ms": round(ms, 4)},
+           "kernel_ms": {k: round(v, 4) for k, v in km.items() if v and k.startswith("decompress")},
+           "deviation_from_timed_mode": stats, "all_atom_rmsd_vs_input_A": round(rmsd, 4)}
+    codec.set_numerics(timed_mode == "fast")
+    w.decompress(); codec.synchronize()
+    del ref, devv
+    return out
+
+
 def secondary_legs(args, codec, dev, rank, world, dist):
     """BASELINE configs[2] and configs[4] at their shape (the datasets themselves cannot be fetched): `--mixed-chains` chains
     per GPU with log-normal lengths (AFDB Swiss-Prot has 542 k structures), anchor -b 25.
@@ -430,6 +476,7 @@ def main():
     d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C, mixed=args.mixed)
     note(f"generated {C} chains")
     codec = Codec(local)
+    codec.set_numerics(args.numerics == "fast")
     lib = codec.lib
     w = Workload(codec, d, dev)
     R, M, fcz_bytes = w.R, w.M, w.fcz_bytes
@@ -473,6 +520,9 @@ def main():
     # per-kernel device time (HIP events on the codec's own stream)
     ktime = span_ms(codec)
     note(f"headline timed: {dt / args.steps * 1e3:.2f} ms/step")
+    alt = alt_numerics_leg(args, codec, w, dev, rank, world, dist, args.numerics,
+                           ktime["compress_sizes"] + ktime["compress_index"] + ktime["compress_angles"] + ktime["compress_pack"])
+    note(f"alt numerics ({alt['mode']}) done: decompress {alt['decompress_ms']} ms")
     # ---- BASELINE configs[2] / configs[4] at their shape: every rank runs them (their clocks are max-over-ranks too) ----
     legs = secondary_legs(args, codec, dev, rank, world, dist) if (args.mixed_chains and not args.mixed) else None
     note("secondary legs done")
@@ -606,6 +656,8 @@ def main():
             hb256 = host_sample(d, n)
             ok_c, ok_d = parity_sample(hb256, blob_dev, off_dev, out_t, None, n)
             parity = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": bad_status}
+            if args.numerics == "fast":
+                parity["coords_bit_exact_note"] = "timed in FCZ_NUMERICS_FAST: coordinates are not expected to be bit-identical; see alt_numerics.deviation_from_timed_mode"
         # the CPU baseline is timed at N=1 only (a launcher pins every rank to one OpenMP thread, and the host cores would be
         # shared with the other ranks' launch threads)
         cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if (args.cpu_sample and world == 1) else None
@@ -625,6 +677,7 @@ def main():
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,
+            "numerics": args.numerics, "alt_numerics": alt,
             "decompress_only": legs[0] if legs else None, "mixed": legs[1] if legs else None, "pdb_text": pdb, "extract": ext,
         }
         print(json.dumps(line))

@@ -43,6 +43,8 @@ def load():
         "fcz_ctx_destroy": (None, [vp]),
         "fcz_ctx_stream": (vp, [vp]),
         "fcz_ctx_synchronize": (i32, [vp]),
+        "fcz_ctx_set_numerics": (i32, [vp, i32]),
+        "fcz_ctx_get_numerics": (i32, [vp]),
         "fcz_status_string": (ctypes.c_char_p, [i32]),
         "fcz_atom_code_name": (ctypes.c_char_p, [i32]),
         "fcz_atom_code_from_name": (i32, [ctypes.c_char_p]),

@@ -47,6 +47,10 @@ class Codec:
     def stream(self) -> int:
         return int(self.lib.fcz_ctx_stream(self.ctx) or 0)
 
+    def set_numerics(self, fast: bool):
+        """decompress numerics: False = bit-identical to the reference (default), True = plain float arithmetic (FCZ_NUMERICS_FAST)"""
+        _lib.check(self.lib.fcz_ctx_set_numerics(self.ctx, 1 if fast else 0), "fcz_ctx_set_numerics")
+
     def synchronize(self):
         _lib.check(self.lib.fcz_ctx_synchronize(self.ctx), "fcz_ctx_synchronize")
 

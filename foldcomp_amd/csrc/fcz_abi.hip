@@ -14,6 +14,7 @@
 #include "fcz_kernels.h"
 #include "fcz_compress.h"
 #include "fcz_sidechain.h"
+#include "fcz_backbone_fast.h"
 #include "fcz_pdb.h"
 #include "fcz_extract.h"
 
@@ -91,6 +92,8 @@ struct fcz_ctx {
     int n_cu = 256;
     bool timing = false;
     bool keep_first_angle = false;
+    int numerics = FCZ_NUMERICS_EXACT;
+    dev_buf fast_scratch;   // decompress, FCZ_NUMERICS_FAST: forward atoms of segments longer than one chunk
     std::vector<timed_span> spans;
     std::map<std::string, std::pair<double, uint64_t>> acc;
 };
@@ -201,7 +204,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release();
+    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -212,6 +215,12 @@ void fcz_ctx_destroy(fcz_ctx* c) {
 }
 
 void* fcz_ctx_stream(fcz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int fcz_ctx_set_numerics(fcz_ctx* c, int mode) {
+    if (!c || (mode != FCZ_NUMERICS_EXACT && mode != FCZ_NUMERICS_FAST)) return FCZ_E_INVALID_ARG;
+    c->numerics = mode;
+    return FCZ_OK;
+}
+int fcz_ctx_get_numerics(fcz_ctx* c) { return c ? c->numerics : FCZ_E_INVALID_ARG; }
 int fcz_ctx_synchronize(fcz_ctx* c) {
     if (!c) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -666,43 +675,67 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     int rc = ensure_sizes(ctx, blob_dev, off_dev, n, &R, &max_seg, &max_nseg, &n_long);
     if (rc) return rc;
     if (R == 0) return FCZ_OK;
-    const uint32_t ring_rows = 3 * (max_seg ? max_seg : 1);
-    const size_t slot_atoms = (size_t)ring_rows * WAVE, slot_trig = (size_t)(ring_rows / 3) * 6 * WAVE;
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     const uint32_t* perm = ctx->len_perm.as<uint32_t>();
-    // Long chains (>= FCZ_LONG_CHAIN residues, the head of the length order): when there are too few of them to fill the
-    // GPU their serial forward pass would hold the launch for ~8 us per residue, so they take the split form (forward
-    // pass, then one block per segment for the reverse pass) on a second stream beside the fused kernel of the rest.
-    const uint32_t groups_long_all = grid_for(n_long, WAVE);
-    const bool split_long = n_long > 0 && max_nseg > 0 && groups_long_all < 2u * 4u * (uint32_t)ctx->n_cu;
-    const uint32_t n_split = split_long ? n_long : 0;
-    if (split_long) {
-        const size_t per_group = (size_t)max_nseg * (slot_atoms * sizeof(v3) + slot_trig * sizeof(float));
-        const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(groups_long_all, ((size_t)6 << 30) / per_group));
-        rc = ctx->fwd_long.ensure(sizeof(v3) * slot_atoms * max_nseg * chunk); if (rc) return rc;
-        rc = ctx->wring_long.ensure(sizeof(float) * slot_trig * max_nseg * chunk); if (rc) return rc;
-        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        for (uint32_t g0 = 0; g0 < groups_long_all; g0 += chunk) {
-            const uint32_t g = std::min(chunk, groups_long_all - g0);
-            const uint32_t slots = std::min<uint32_t>(n_long - g0 * WAVE, g * WAVE);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<1>), dim3(g), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
-                               perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<2>), dim3(g * max_nseg), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
-                               perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
-        }
-        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
-    }
-    const uint32_t n_fused = n - n_split;
-    const uint32_t groups = grid_for(n_fused, WAVE);
-    rc = ctx->fwd.ensure(sizeof(v3) * (size_t)std::max<uint32_t>(groups, 1) * slot_atoms); if (rc) return rc;
-    rc = ctx->wring.ensure(sizeof(float) * (size_t)std::max<uint32_t>(groups, 1) * slot_trig); if (rc) return rc;
-    {
+    const char* dbg_parts = getenv("FCZ_DEBUG_FAST_PARTS");   // 1: backbone only, 2: side chains only (debugging aid)
+    const bool fast_bb = ctx->numerics == FCZ_NUMERICS_FAST && !(dbg_parts && dbg_parts[0] == '2');
+    const bool fast_sc = ctx->numerics == FCZ_NUMERICS_FAST && !(dbg_parts && dbg_parts[0] == '1');
+    if (fast_bb) {
+        // plain-float backbone: 8 chains per wavefront, the forward atoms of a segment stay in LDS; only segments longer than
+        // one chunk (FB_K residue steps) park them in a scratch column, and then the launch is cut so that the columns of the
+        // wavefronts in flight fit 4 GB
         span_guard g(ctx, "decompress_backbone");
-        if (groups)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<0>), dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, n_fused, res_off_dev,
-                               perm + n_split, ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, 1u, ctx->bb.as<v3>());
-        if (split_long) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        const uint32_t groups = grid_for(n, FB_CH);
+        const bool need_scratch = max_seg > (uint32_t)FB_K + 1;
+        const uint32_t col = need_scratch ? 3 * max_seg : 0;
+        uint32_t chunk = groups;
+        if (need_scratch) {
+            chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(groups, ((size_t)4 << 30) / ((size_t)FB_CH * col * sizeof(v3))));
+            rc = ctx->fast_scratch.ensure((size_t)chunk * FB_CH * col * sizeof(v3)); if (rc) return rc;
+        }
+        for (uint32_t g0 = 0; g0 < groups; g0 += chunk) {
+            const uint32_t gn = std::min(chunk, groups - g0);
+            const uint32_t slots = std::min<uint32_t>(n - g0 * FB_CH, gn * FB_CH);
+            hipLaunchKernelGGL(k_backbone_fast, dim3(gn), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, slots, res_off_dev,
+                               perm + (size_t)g0 * FB_CH, need_scratch ? ctx->fast_scratch.as<v3>() : nullptr, col, ctx->bb.as<v3>());
+        }
+    } else {
+        const uint32_t ring_rows = 3 * (max_seg ? max_seg : 1);
+        const size_t slot_atoms = (size_t)ring_rows * WAVE, slot_trig = (size_t)(ring_rows / 3) * 6 * WAVE;
+        // Long chains (>= FCZ_LONG_CHAIN residues, the head of the length order): when there are too few of them to fill the
+        // GPU their serial forward pass would hold the launch for ~8 us per residue, so they take the split form (forward
+        // pass, then one block per segment for the reverse pass) on a second stream beside the fused kernel of the rest.
+        const uint32_t groups_long_all = grid_for(n_long, WAVE);
+        const bool split_long = n_long > 0 && max_nseg > 0 && groups_long_all < 2u * 4u * (uint32_t)ctx->n_cu;
+        const uint32_t n_split = split_long ? n_long : 0;
+        if (split_long) {
+            const size_t per_group = (size_t)max_nseg * (slot_atoms * sizeof(v3) + slot_trig * sizeof(float));
+            const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(groups_long_all, ((size_t)6 << 30) / per_group));
+            rc = ctx->fwd_long.ensure(sizeof(v3) * slot_atoms * max_nseg * chunk); if (rc) return rc;
+            rc = ctx->wring_long.ensure(sizeof(float) * slot_trig * max_nseg * chunk); if (rc) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            for (uint32_t g0 = 0; g0 < groups_long_all; g0 += chunk) {
+                const uint32_t g = std::min(chunk, groups_long_all - g0);
+                const uint32_t slots = std::min<uint32_t>(n_long - g0 * WAVE, g * WAVE);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<1>), dim3(g), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
+                                   perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<2>), dim3(g * max_nseg), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
+                                   perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
+            }
+            HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+        }
+        const uint32_t n_fused = n - n_split;
+        const uint32_t groups = grid_for(n_fused, WAVE);
+        rc = ctx->fwd.ensure(sizeof(v3) * (size_t)std::max<uint32_t>(groups, 1) * slot_atoms); if (rc) return rc;
+        rc = ctx->wring.ensure(sizeof(float) * (size_t)std::max<uint32_t>(groups, 1) * slot_trig); if (rc) return rc;
+        {
+            span_guard g(ctx, "decompress_backbone");
+            if (groups)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<0>), dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, n_fused, res_off_dev,
+                                   perm + n_split, ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, 1u, ctx->bb.as<v3>());
+            if (split_long) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
     }
     rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
     rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;
@@ -717,8 +750,12 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
         span_guard g(ctx, "decompress_sidechain");
         const uint32_t n_tiles = grid_for(R, SC_TILE);
         const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_SIDECHAIN_MIN_BLOCKS * 4u);
-        hipLaunchKernelGGL(k_sidechain, dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, ctx->res_aoff.as<uint32_t>(),
-                           ctx->res_rc.as<uint8_t>(), ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
+        if (fast_sc)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sidechain<true>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, ctx->res_aoff.as<uint32_t>(),
+                               ctx->res_rc.as<uint8_t>(), ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sidechain<false>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, ctx->res_aoff.as<uint32_t>(),
+                               ctx->res_rc.as<uint8_t>(), ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
     }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;

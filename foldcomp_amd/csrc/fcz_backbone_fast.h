@@ -70,18 +70,30 @@ __device__ __forceinline__ v3 fr_step(fframe& F, float L, float cb, float sb, fl
     return F.o;
 }
 
-// sine and cosine of an angle given in degrees, |deg| < 2^15: exact reduction to [-45, 45] degrees, cephes sinf/cosf kernels
+// sine and cosine of an angle given in degrees as Nerf::place_atom takes them (src/nerf.cpp:63-71): the reference converts to
+// radians, ROUNDS TO FLOAT, then calls sinf / cosf. That rounding moves the angle by up to 2.4e-7 rad -- four times the error of
+// a good float sine -- and it is the same for every occurrence of an angle value, so it is reproduced here (one double
+// multiplication, as the exact path's deg2rad does without its tie check); the quadrant reduction runs in double (three
+// instructions), the two kernels in float with the reduced argument carried as hi + lo. Result: within 0.8 ulp of the true
+// sine / cosine of the rounded radian value, i.e. within one float rounding of glibc's.
 __device__ __forceinline__ void sincos_deg_fast(float deg, float* sn, float* cs) {
-    const float k = __builtin_rintf(deg * (1.0f / 90.0f));
-    const float t = __builtin_fmaf(-90.0f, k, deg) * 0.017453292519943295f;
+    const float radf = (float)((double)deg * 0.017453292519943295);
+    const double xd = (double)radf;
+    const double kd = __builtin_rint(xd * 0.63661977236758134);
+    const double rd = __builtin_fma(-kd, 1.5707963267948966, xd);
+    const float t = (float)rd, tl = (float)(rd - (double)t);
     const float t2 = t * t;
-    float s = __builtin_fmaf(t2, -1.9515295891e-4f, 8.3321608736e-3f);
-    s = __builtin_fmaf(s, t2, -1.6666654611e-1f);
-    s = __builtin_fmaf(s * t2, t, t);
-    float c = __builtin_fmaf(t2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    c = __builtin_fmaf(c, t2, 4.166664568298827e-2f);
-    c = __builtin_fmaf(c * t2, t2, __builtin_fmaf(-0.5f, t2, 1.0f));
-    const int q = (int)k;
+    float S = __builtin_fmaf(t2, -1.9515295891e-4f, 8.3321608736e-3f);
+    S = __builtin_fmaf(S, t2, -1.6666654611e-1f);
+    const float u = S * t2;
+    float C = __builtin_fmaf(t2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    C = __builtin_fmaf(C, t2, 4.166664568298827e-2f);
+    const float y = (t2 * t2) * C;
+    const float hz = 0.5f * t2, a = 1.0f - hz, corr = (1.0f - a) - hz;      // 1 - t2/2 with its rounding error
+    const float s0 = __builtin_fmaf(t, u, t), c0 = a + (corr + y);
+    const float s = t + __builtin_fmaf(t, u, tl * c0);                      // sin(t + tl)
+    const float c = a + ((corr + y) - tl * s0);                             // cos(t + tl)
+    const int q = (int)kd;
     const float s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
     *sn = ((q & 2) != 0) ? -s1 : s1;
     *cs = (((q + 1) & 2) != 0) ? -c1 : c1;

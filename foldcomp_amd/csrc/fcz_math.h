@@ -428,6 +428,23 @@ __device__ __forceinline__ v3 place_atom_d2(v3 a, v3 b, v3 c, v3 d2) {
     return D;
 }
 
+// the same placement in plain float arithmetic with hardware reciprocal square roots (FCZ_NUMERICS_FAST): equal to
+// place_atom_d2 up to float rounding (~1e-6 A per atom)
+__device__ __forceinline__ v3 place_atom_d2_fast(v3 a, v3 b, v3 c, v3 d2) {
+    const v3 ab = vsub(b, a), bc = vsub(c, b);
+    const float rb = __builtin_amdgcn_rsqf(__builtin_fmaf(bc.z, bc.z, __builtin_fmaf(bc.y, bc.y, bc.x * bc.x)));
+    const v3 bcn = v3{bc.x * rb, bc.y * rb, bc.z * rb};
+    v3 n = v3{__builtin_fmaf(ab.y, bcn.z, -(bcn.y * ab.z)), __builtin_fmaf(ab.z, bcn.x, -(bcn.z * ab.x)), __builtin_fmaf(ab.x, bcn.y, -(bcn.x * ab.y))};
+    const float rn = __builtin_amdgcn_rsqf(__builtin_fmaf(n.z, n.z, __builtin_fmaf(n.y, n.y, n.x * n.x)));
+    n = v3{n.x * rn, n.y * rn, n.z * rn};
+    const v3 nbc = v3{__builtin_fmaf(n.y, bcn.z, -(bcn.y * n.z)), __builtin_fmaf(n.z, bcn.x, -(bcn.z * n.x)), __builtin_fmaf(n.x, bcn.y, -(bcn.x * n.y))};
+    v3 D;
+    D.x = __builtin_fmaf(n.x, d2.z, __builtin_fmaf(nbc.x, d2.y, __builtin_fmaf(bcn.x, d2.x, c.x)));
+    D.y = __builtin_fmaf(n.y, d2.z, __builtin_fmaf(nbc.y, d2.y, __builtin_fmaf(bcn.y, d2.x, c.y)));
+    D.z = __builtin_fmaf(n.z, d2.z, __builtin_fmaf(nbc.z, d2.y, __builtin_fmaf(bcn.z, d2.x, c.z)));
+    return D;
+}
+
 __device__ __forceinline__ v3 nerf_d2(float L, float bond_angle_deg_, float torsion_deg) {
     const float ba = deg2rad(bond_angle_deg_), ta = deg2rad(torsion_deg);
     float sb, cb, st, ct;

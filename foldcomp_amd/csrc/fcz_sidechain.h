@@ -169,7 +169,9 @@ struct sidechain_lds {
 #define FCZ_SIDECHAIN_MIN_BLOCKS 3
 #endif
 
-// res_aoff has n_res + 1 entries (the last one = total atoms).
+// res_aoff has n_res + 1 entries (the last one = total atoms). FAST: placements in plain float arithmetic
+// (FCZ_NUMERICS_FAST, place_atom_d2_fast); the tables (torsion bytes, ideal geometry) are the exact ones either way.
+template <bool FAST>
 __global__ __launch_bounds__(BLOCK, FCZ_SIDECHAIN_MIN_BLOCKS)
 void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ res_aoff, const uint8_t* __restrict__ res_rc,
                  const uint32_t* __restrict__ res_sc, const v3* __restrict__ bb, int alt_order, fcz_atoms_out out) {
@@ -276,7 +278,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
                     d2.x = G.d2x;
                     d2.y = G.blen * S.tor_cos[q] * G.sb;
                     d2.z = G.blen * S.tor_sin[q] * G.sb;
-                    const v3 p = place_atom_d2(b0, b1, b2, d2);
+                    const v3 p = FAST ? place_atom_d2_fast(b0, b1, b2, d2) : place_atom_d2(b0, b1, b2, d2);
                     const uint32_t po = ap + (op4 >> 24);
                     S.stage[0][po] = p.x; S.stage[1][po] = p.y; S.stage[2][po] = p.z;
                     if (out.atom_code) out.atom_code[A0 + po] = (uint8_t)(G.meta >> 16);
@@ -336,7 +338,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
                     const v3 pa{S.stage[0][ia], S.stage[1][ia], S.stage[2][ia]};
                     const v3 pb{S.stage[0][ib], S.stage[1][ib], S.stage[2][ib]};
                     const v3 pc{S.stage[0][ic], S.stage[1][ic], S.stage[2][ic]};
-                    const v3 p = place_atom_d2(pa, pb, pc, d2);
+                    const v3 p = FAST ? place_atom_d2_fast(pa, pb, pc, d2) : place_atom_d2(pa, pb, pc, d2);
                     const uint32_t po = ap + ((G.meta >> 12) & 15u);
                     S.stage[0][po] = p.x; S.stage[1][po] = p.y; S.stage[2][po] = p.z;
                     if (out.atom_code) out.atom_code[A0 + po] = (uint8_t)(G.meta >> 16);

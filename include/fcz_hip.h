@@ -115,6 +115,19 @@ void fcz_ctx_destroy(fcz_ctx* ctx);
 /* hipStream_t of the ctx as an opaque pointer (all *_dev entry points enqueue on it). */
 void* fcz_ctx_stream(fcz_ctx* ctx);
 int  fcz_ctx_synchronize(fcz_ctx* ctx);
+
+/* Numerics of the decompress side (the compress side always writes the reference's bytes).
+ *   FCZ_NUMERICS_EXACT (default): decompressed float32 coordinates are bit-identical to Foldcomp::decompress built with
+ *     g++ -O3 on x86-64 / glibc 2.35 -- the reference's evaluation order, its double promotions and glibc's sinf/cosf are
+ *     reproduced operation by operation (fcz_math.h).
+ *   FCZ_NUMERICS_FAST: the same algorithm (Foldcomp::decompress src/foldcomp.cpp:779-900: forward NeRF, reverse NeRF from the
+ *     next anchor, weighted average, side chains) in plain float arithmetic with FMA and hardware rsq, the backbone as a
+ *     parallel composition of per-residue rigid transforms (fcz_backbone_fast.h). Coordinates differ from the exact path by
+ *     float rounding only (< 1e-3 A, typically 1e-4 A; the reference's RMSD pins of build.sh:35,37 hold unchanged), which is
+ *     what `foldcomp check` / the RMSD tolerance of the reference's own tests ask of a decoder. */
+enum fcz_numerics { FCZ_NUMERICS_EXACT = 0, FCZ_NUMERICS_FAST = 1 };
+int  fcz_ctx_set_numerics(fcz_ctx* ctx, int mode);
+int  fcz_ctx_get_numerics(fcz_ctx* ctx);
 const char* fcz_status_string(int status);
 const char* fcz_atom_code_name(int atom_code);     /* "N", "CA", ... "OXT"; NULL if out of range */
 int  fcz_atom_code_from_name(const char* name);    /* 255 for unknown names */

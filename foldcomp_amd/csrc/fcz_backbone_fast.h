@@ -27,9 +27,13 @@
 
 namespace fcz {
 
-constexpr int FB_G = 8;                      // lanes per chain
+#ifndef FCZ_FB_G
+#define FCZ_FB_G 8
+#endif
+constexpr int FB_G = FCZ_FB_G;               // lanes per chain (8 or 16: two or one chains per DPP row of 16 lanes; measured: 8 lanes,
+                                             // 2 wavefronts per SIMD 3.5 ms per 262 144 chains, 16 lanes 4.3 ms, 3 wavefronts per SIMD spill)
 constexpr int FB_CH = WAVE / FB_G;           // chains per wavefront
-constexpr int FB_S = 4;                      // residue steps per lane and chunk
+constexpr int FB_S = 32 / FB_G;              // residue steps per lane and chunk
 constexpr int FB_K = FB_G * FB_S;            // residue steps per chunk
 constexpr int FB_ROW = 3 * 3 * (FB_K + 1) + 1;   // floats per chain in LDS: 3 start atoms + 3 per step, odd stride
 
@@ -112,8 +116,8 @@ template <int N, bool UP> __device__ __forceinline__ v3 dpp_v3(v3 v) {
 template <int N, bool UP> __device__ __forceinline__ fframe dpp_frame(const fframe& F) {
     return fframe{dpp_v3<N, UP>(F.e1), dpp_v3<N, UP>(F.e2), dpp_v3<N, UP>(F.e3), dpp_v3<N, UP>(F.o)};
 }
-// Inclusive scan of the lanes' transforms over the 8 lanes of a chain. UP: lane j ends with T_0 o T_1 o ... o T_j (the
-// forward pass: lane 0 comes first); !UP: T_7 o ... o T_j (the reverse pass starts at the far end).
+// Inclusive scan of the lanes' transforms over the FB_G lanes of a chain. UP: lane j ends with T_0 o T_1 o ... o T_j (the
+// forward pass: lane 0 comes first); !UP: T_last o ... o T_j (the reverse pass starts at the far end).
 template <bool UP> __device__ __forceinline__ fframe scan8(fframe T, int sub) {
     {
         const fframe O = dpp_frame<1, UP>(T);
@@ -126,6 +130,10 @@ template <bool UP> __device__ __forceinline__ fframe scan8(fframe T, int sub) {
     {
         const fframe O = dpp_frame<4, UP>(T);
         if (UP ? sub >= 4 : sub < FB_G - 4) T = fr_compose(O, T);
+    }
+    if (FB_G > 8) {
+        const fframe O = dpp_frame<8, UP>(T);
+        if (UP ? sub >= 8 : sub < FB_G - 8) T = fr_compose(O, T);
     }
     return T;
 }
@@ -147,7 +155,7 @@ __device__ __forceinline__ step_trig trig_of_word(uint64_t raw, const bb_params&
 }
 
 #ifndef FCZ_BACKBONE_FAST_MIN_WAVES
-#define FCZ_BACKBONE_FAST_MIN_WAVES 3
+#define FCZ_BACKBONE_FAST_MIN_WAVES 2
 #endif
 
 // One wavefront per 8 entries (perm order: grouped by length). scratch: per (block, chain) a column of `scratch_atoms` atoms for
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_FAST_MIN_WAVES) void k_backbone_
         const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ perm, v3* __restrict__ scratch, uint32_t scratch_atoms,
         v3* __restrict__ bb) {
     __shared__ float S_f[FB_CH][FB_ROW];
-    const int lane = threadIdx.x, sub = lane & (FB_G - 1), ch = lane >> 3;
+    const int lane = threadIdx.x, sub = lane & (FB_G - 1), ch = lane / FB_G;
     const uint32_t slot = blockIdx.x * FB_CH + (uint32_t)ch;
     const uint32_t c = slot < n_slots ? perm[slot] : n_entries;
     const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
@@ -175,22 +183,44 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_FAST_MIN_WAVES) void k_backbone_
     float* Fl = &S_f[ch][0];
     v3 p0{0.f, 0.f, 0.f}, p1 = p0, p2 = p0;
     int first = 0, next = 0;
+    // Everything a segment reads from the record is fetched one segment ahead (the next anchor's atoms, the anchor index after
+    // it, this lane's packed words of the segment's first chunk): unconditional loads from clamped positions, issued before the
+    // arithmetic of the current segment, so that no segment starts with a memory round trip.
+    const uint32_t n_w = v.n ? v.n - 1 : 0;                  // last word index
+    v3 nA0 = p0, nA1 = p0, nA2 = p0;
+    int nnext2 = 0;
+    uint64_t nw[FB_S];
+#pragma unroll
+    for (int q = 0; q < FB_S; q++) nw[q] = 0;
+    auto fetch_segment = [&](uint32_t sg, int fst, int nxt) {          // segment sg = residues fst .. nxt
+        const uint32_t a1 = sg + 1 <= nseg ? sg + 1 : nseg, a2 = sg + 2 <= nseg ? sg + 2 : nseg;
+        const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)a1;
+        nA0 = ld_v3(anc); nA1 = ld_v3(anc + 12); nA2 = ld_v3(anc + 24);
+        nnext2 = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)a2);
+        const int Kq = nxt - fst, kc = Kq < FB_K ? (Kq > 0 ? Kq : 0) : FB_K, per = (kc + FB_G - 1) / FB_G;
+#pragma unroll
+        for (int q = 0; q < FB_S; q++) {
+            uint32_t wi = (uint32_t)(fst + sub * per + q);
+            wi = wi < n_w ? wi : n_w;
+            nw[q] = ld_u64(words + 8 * (size_t)wi);
+        }
+    };
     if (valid) {
         p0 = ld_v3(e + v.L.o_anchor); p1 = ld_v3(e + v.L.o_anchor + 12); p2 = ld_v3(e + v.L.o_anchor + 24);
         first = (int)ld_u32(e + v.L.o_aidx); next = (int)ld_u32(e + v.L.o_aidx + 4);
+        fetch_segment(0, first, next);
     }
     for (uint32_t s = 0; s < maxseg; s++) {
         const bool act = s < nseg;
         const int K = act ? next - first : 0;                 // residue steps of the segment (len - 1)
         const int T = 3 * (K + 1);
         const bool in_lds = K <= FB_K;
-        int next2 = next;
-        v3 A0{0.f, 0.f, 0.f}, A1 = A0, A2 = A0;
-        if (act) {
-            next2 = (int)ld_u32(e + v.L.o_aidx + 4 * (size_t)(s + 2 <= nseg ? s + 2 : nseg));
-            const uint8_t* anc = e + v.L.o_anchor + 36 * (size_t)(s + 1);
-            A0 = ld_v3(anc); A1 = ld_v3(anc + 12); A2 = ld_v3(anc + 24);
-        }
+        const int next2 = act ? nnext2 : next;
+        const v3 A0 = nA0, A1 = nA1, A2 = nA2;
+        uint64_t wraw[FB_S];
+#pragma unroll
+        for (int q = 0; q < FB_S; q++) wraw[q] = nw[q];
+        if (act && s + 1 < nseg) fetch_segment(s + 1, next, next2);
         // forward atom store: LDS row of the chain (segment fits a chunk) or the chain's scratch column
         auto f_put = [&](int f, v3 p) {
             if (in_lds) { Fl[3 * f] = p.x; Fl[3 * f + 1] = p.y; Fl[3 * f + 2] = p.z; } else Sg[f] = p;
@@ -203,6 +233,9 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_FAST_MIN_WAVES) void k_backbone_
         if (act && sub == 0) { f_put(0, p0); f_put(1, p1); f_put(2, p2); }
         // ---- forward pass, chunk by chunk ----
         fframe G = fr_from_atoms(p0, p1, p2);                 // running global frame at the start of the chunk
+        step_trig tr[FB_S];                                   // trig of this lane's steps: reused by the reverse pass of a one-chunk segment
+#pragma unroll
+        for (int q = 0; q < FB_S; q++) tr[q] = step_trig{};
         for (int cq = 0; cq < nchunk; cq++) {
             const int k0 = cq * FB_K;
             const int kc = K - k0 < FB_K ? (K - k0 > 0 ? K - k0 : 0) : FB_K;     // steps of this chain in the chunk
@@ -215,7 +248,8 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_FAST_MIN_WAVES) void k_backbone_
                 loc[q][0] = loc[q][1] = loc[q][2] = v3{0.f, 0.f, 0.f};
                 const int i = i0 + q;
                 if (i < i1) {
-                    const step_trig t = trig_of_word(ld_u64(words + 8 * (size_t)(first + i)), P);
+                    const step_trig t = trig_of_word(cq == 0 ? wraw[q] : ld_u64(words + 8 * (size_t)(first + i)), P);
+                    tr[q] = t;
                     loc[q][0] = fr_step(Tl, 1.3311f, t.c_can, t.s_can, t.c_psi, t.s_psi);
                     loc[q][1] = fr_step(Tl, t.l_nca, t.c_cna, t.s_cna, t.c_om, t.s_om);
                     loc[q][2] = fr_step(Tl, 1.5281f, t.c_nca, t.s_nca, t.c_phi, t.s_phi);
@@ -270,17 +304,35 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_FAST_MIN_WAVES) void k_backbone_
             const int i0 = k0 + sub * per, i1 = i0 + per < k0 + kc ? i0 + per : k0 + kc;
             fframe Tl = fr_identity();
             v3 loc[FB_S][3];
-            // the N-CA-C angle a residue's N is placed with belongs to the previous word: fetched once per lane, then carried
+            // The N-CA-C angle a residue's N is placed with belongs to the previous word. One-chunk segments (every wavefront of
+            // a -b 25 batch of 350-residue chains) reuse the forward pass's trig from registers: the previous word is the previous
+            // slot, or the previous lane's last slot (all lanes before an active one hold `per` steps). Chunked segments decode again.
+            const bool reuse = nchunk == 1;
+            float pc_nca = c_first, ps_nca = s_first;
+            if (reuse) {
+                float lc = tr[0].c_nca, ls = tr[0].s_nca;
+#pragma unroll
+                for (int q = 1; q < FB_S; q++) if (q == per - 1) { lc = tr[q].c_nca; ls = tr[q].s_nca; }
+                const float uc = dpp_shr<1>(lc), us = dpp_shr<1>(ls);
+                if (sub > 0) { pc_nca = uc; ps_nca = us; }
+            }
 #pragma unroll
             for (int q = FB_S - 1; q >= 0; q--) {
                 loc[q][0] = loc[q][1] = loc[q][2] = v3{0.f, 0.f, 0.f};
                 const int i = i0 + q;
                 if (i < i1) {
-                    const step_trig t = trig_of_word(ld_u64(words + 8 * (size_t)(first + i)), P);
-                    float c_n = c_first, s_n = s_first;
-                    if (i > 0) {
-                        const bb_word wp = decode_word(ld_u64(words + 8 * (size_t)(first + i - 1)), P);
-                        sincos_deg_fast(wp.nca, &s_n, &c_n);
+                    step_trig t;
+                    float c_n, s_n;
+                    if (reuse) {
+                        t = tr[q];
+                        c_n = q > 0 ? tr[q > 0 ? q - 1 : 0].c_nca : pc_nca; s_n = q > 0 ? tr[q > 0 ? q - 1 : 0].s_nca : ps_nca;
+                    } else {
+                        t = trig_of_word(ld_u64(words + 8 * (size_t)(first + i)), P);
+                        c_n = c_first; s_n = s_first;
+                        if (i > 0) {
+                            const bb_word wp = decode_word(ld_u64(words + 8 * (size_t)(first + i - 1)), P);
+                            sincos_deg_fast(wp.nca, &s_n, &c_n);
+                        }
                     }
                     loc[q][2] = fr_step(Tl, 1.3311f, t.c_cna, t.s_cna, t.c_phi, t.s_phi);     // C of residue i
                     loc[q][1] = fr_step(Tl, 1.5281f, t.c_can, t.s_can, t.c_om, t.s_om);       // CA

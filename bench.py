@@ -54,6 +54,8 @@ def parse_args():
                     help="chains per GPU of the secondary legs (decompress_only = BASELINE configs[2] shape, mixed = configs[4] shape: "
                          "log-normal lengths, anchor -b 25); 0 = skip")
     ap.add_argument("--mixed-steps", type=int, default=3)
+    ap.add_argument("--e2e-files", type=int, default=8192,
+                    help="PDB files of the end_to_end leg (disk -> FCZ database through host/foldcomp-hip, N=1 only; 0 = skip)")
     ap.add_argument("--numerics", choices=("exact", "fast"), default="exact",
                     help="decompress numerics of the TIMED steps: exact = float32 coordinates bit-identical to the reference (the headline), "
                          "fast = FCZ_NUMERICS_FAST (plain float arithmetic, parallel backbone). The other mode is always measured "
@@ -311,6 +313,101 @@ def timed(fn, steps, world, dist, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def end_to_end_leg(args, codec, w, dev):
+    """PDB files on local disk -> FCZ database through the C++ host (host/foldcomp-hip compress -d: parse threads -> batch queue ->
+    page-locked staging -> GPU -> pwrite at prefix offsets -> index), next to the reference's own driver loop on the same files
+    (oracle/_ref: StructureReader + Foldcomp::compress under `omp parallel for`, the CPU baseline of this leg). The input files
+    are the first --e2e-files chains of the headline workload, rendered to PDB text by the device formatter. Wall times include
+    reading the files; the GPU is one of several stages here and not the bound."""
+    import shutil
+    import subprocess
+    import tempfile
+    n = min(w.C, args.e2e_files)
+    host = os.path.join(ROOT, "host", "foldcomp-hip")
+    if not os.path.exists(host):
+        return {"skipped": "host/foldcomp-hip not built"}
+    lib = codec.lib
+    text_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.fcz_pdb_sizes_dev(codec.ctx, w.blob_dev.data_ptr(), w.off_dev.data_ptr(), n, w.res_off_dev.data_ptr(),
+                                     w.atom_off_dev.data_ptr(), ctypes.byref(w.cout), text_off.data_ptr()), "pdb sizes")
+    codec.synchronize()
+    tbytes = int(text_off[-1])
+    text_dev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.fcz_pdb_format_dev(codec.ctx, w.blob_dev.data_ptr(), w.off_dev.data_ptr(), n, w.res_off_dev.data_ptr(),
+                                      w.atom_off_dev.data_ptr(), ctypes.byref(w.cout), 0, text_off.data_ptr(), text_dev.data_ptr()), "pdb format")
+    codec.synchronize()
+    text = text_dev.cpu().numpy(); toff = text_off.cpu().numpy()
+    del text_dev
+    tmp = tempfile.mkdtemp(prefix="fcz_e2e_", dir=os.environ.get("TMPDIR") or "/tmp")
+    try:
+        src = os.path.join(tmp, "pdb"); os.mkdir(src)
+        paths = []
+        for i in range(n):
+            pth = os.path.join(src, f"s{i:07d}.pdb")
+            with open(pth, "wb") as fh:
+                fh.write(text[toff[i]:toff[i + 1]].tobytes())
+            paths.append(pth)
+        n_res = int(w.res_off_dev[n])
+        out = {"files": n, "input_bytes": int(toff[n]), "residues": n_res, "host_cores": os.cpu_count()}
+        # Both sides are run at several host thread counts and their best is reported: the parse / reference loops of this image
+        # stop scaling well below the visible core count (page-fault and allocator contention), and the right count differs per box
+        cores = os.cpu_count() or 1
+        tcounts = sorted({t for t in (16, 32, 64, cores) if t <= cores} | {min(cores, 32)})
+        runs = []
+        for t in tcounts:
+            db = os.path.join(tmp, f"db{t}")
+            t0 = time.perf_counter()
+            r = subprocess.run([host, "compress", "-d", "-y", "-t", str(t), "--gpus", "1", "--json-stats", src, db], capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                return {"failed": (r.stderr or r.stdout)[-400:]}
+            st = json.loads(line[-1]); st["process_wall_s"] = round(wall, 4)
+            runs.append(st)
+        best = min(runs, key=lambda x: x["wall_s"])
+        out["gpu_host"] = {"command": "host/foldcomp-hip compress -d -t <threads> --gpus 1 <dir> <db>", "wall_s": best["wall_s"], "process_wall_s": best["process_wall_s"],
+                           "parse_s": best["parse_s"], "codec_call_s_sum": best["codec_call_s_sum"], "workers": best["workers"],
+                           "host_threads": best["host_threads"], "records": best["records"], "residues_per_s": round(best["residues"] / best["wall_s"]),
+                           "input_MB_per_s": round(best["input_bytes"] / best["wall_s"] / 1e6, 1),
+                           "wall_s_by_threads": {str(r_["host_threads"]): r_["wall_s"] for r_ in runs}}
+        # records of the database == records of the device-resident path (same chains, same titles? titles differ: file stem), so
+        # compare against the reference on the same file instead
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _harness as H
+        if H.have_ref():
+            rl = H.load_ref()
+            rl.ref_compress_files.restype = ctypes.c_int
+            rl.ref_compress_files.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+            blob = b"".join(p_.encode() + b"\0" for p_ in paths)
+            secs = ctypes.c_double(); rres = ctypes.c_ulonglong(); rbytes = ctypes.c_ulonglong(); flen = ctypes.c_long()
+            first = ctypes.create_string_buffer(1 << 20)
+            ref_runs = {}
+            for t in tcounts:
+                fail = rl.ref_compress_files(blob, n, t, args.anchor, ctypes.byref(secs), ctypes.byref(rres), ctypes.byref(rbytes), first, 1 << 20, ctypes.byref(flen))
+                ref_runs[t] = (secs.value, int(fail))
+            bt = min(ref_runs, key=lambda k: ref_runs[k][0])
+            out["cpu_reference"] = {"what": "the reference's driver loop on the same files (oracle/_ref: StructureReader + Foldcomp::compress, omp parallel for), best thread count",
+                                    "cores": bt, "wall_s": round(ref_runs[bt][0], 4), "residues_per_s": round(rres.value / ref_runs[bt][0]) if ref_runs[bt][0] else None,
+                                    "failed_files": ref_runs[bt][1], "fcz_bytes": int(rbytes.value),
+                                    "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in ref_runs.items()}}
+            secs.value = ref_runs[bt][0]
+            # parity: first record of the host's database == the reference's bytes for the first file
+            from foldcomp_amd.database import DatabaseReader
+            rd = DatabaseReader(os.path.join(tmp, f"db{tcounts[0]}"))
+            e0 = bytearray(rd.data(0)); rd.close()
+            for k in (14, 15, 22, 23):
+                e0[k] = 0
+            out["first_record_equals_reference"] = bytes(e0) == first.raw[:flen.value]
+            out["fcz_bytes_equal_reference_total"] = best["fcz_bytes"] == int(rbytes.value)
+            out["speedup_vs_cpu_reference"] = round(secs.value / best["wall_s"], 2) if best["wall_s"] else None
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def alt_numerics_leg(args, codec, w, dev, rank, world, dist, timed_mode, compress_ms):
@@ -610,6 +707,10 @@ def main():
                "algorithmic_GBs": round((84 * C + R + dbytes) / (ms_e * 1e-3) / 1e9, 1) if ms_e else None,
                "first_record_equals_host": bool(ok_e)}
         del data_dev
+    e2e = None
+    if rank == 0 and world == 1 and args.e2e_files and not args.mixed:
+        e2e = end_to_end_leg(args, codec, w, dev)
+        note("end-to-end leg done")
     codec.enable_timing(False)
     note("pdb / extract legs done")
     bad_status = int((status_dev != 0).sum())
@@ -678,7 +779,7 @@ def main():
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,
             "numerics": args.numerics, "alt_numerics": alt,
-            "decompress_only": legs[0] if legs else None, "mixed": legs[1] if legs else None, "pdb_text": pdb, "extract": ext,
+            "decompress_only": legs[0] if legs else None, "mixed": legs[1] if legs else None, "pdb_text": pdb, "extract": ext, "end_to_end": e2e,
         }
         print(json.dumps(line))
     if world > 1:

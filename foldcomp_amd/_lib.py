@@ -43,6 +43,9 @@ def load():
         "fcz_ctx_destroy": (None, [vp]),
         "fcz_ctx_stream": (vp, [vp]),
         "fcz_ctx_synchronize": (i32, [vp]),
+        "fcz_device_count": (i32, []),
+        "fcz_pinned_alloc": (vp, [ctypes.c_size_t]),
+        "fcz_pinned_free": (None, [vp]),
         "fcz_ctx_set_numerics": (i32, [vp, i32]),
         "fcz_ctx_get_numerics": (i32, [vp]),
         "fcz_status_string": (ctypes.c_char_p, [i32]),

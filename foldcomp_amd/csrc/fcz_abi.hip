@@ -179,6 +179,10 @@ int fcz_res_code_atom(int rc, int j, int alt) {
     return host_tab::h_res_atom[rc][slot];
 }
 
+int fcz_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+void* fcz_pinned_alloc(size_t bytes) { void* p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void fcz_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
 void fcz_ctx_destroy(fcz_ctx* c);
 int fcz_ctx_create(int device, fcz_ctx** out) {
     if (!out) return FCZ_E_INVALID_ARG;

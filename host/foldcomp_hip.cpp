@@ -1,6 +1,6 @@
 // foldcomp_hip.cpp -- the C++ host of the MI355X codec: a `foldcomp`-style command line over the C-ABI of include/fcz_hip.h.
 //
-//   foldcomp-hip compress   [-b N] [-y] [-r] [-d] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir|db>]
+//   foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d] [--skip-discontinuous] [--json-stats] <pdb file|dir> [<fcz file|dir|db>]
 //   foldcomp-hip decompress [-a] [-y] [-r] [-d] <fcz file|dir|db> [<pdb file|dir|db>]
 //   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir|db> [<out file>]
 //   foldcomp-hip check      [-r] <fcz file|dir|db>
@@ -28,8 +28,15 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <omp.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +63,10 @@ struct AtomTable {
     std::vector<char> chain;
     std::vector<int> atom_index, res_index;
     std::vector<float> x, y, z, bfac;
+    // filled by the parse threads (name -> code once per atom, in parallel): atom code (fcz_atom_code_from_name) and the
+    // residue code of the atom's residue name (fcz_res_code_from_name, -1 = not a name the codec takes); empty = not computed
+    std::vector<uint8_t> atom_code;
+    std::vector<int8_t> res_code;
     size_t size() const { return atom.size(); }
     AtomTable slice(size_t a, size_t b) const {
         AtomTable t;
@@ -64,12 +75,14 @@ struct AtomTable {
         t.atom_index.assign(atom_index.begin() + a, atom_index.begin() + b); t.res_index.assign(res_index.begin() + a, res_index.begin() + b);
         t.x.assign(x.begin() + a, x.begin() + b); t.y.assign(y.begin() + a, y.begin() + b); t.z.assign(z.begin() + a, z.begin() + b);
         t.bfac.assign(bfac.begin() + a, bfac.begin() + b);
+        if (atom_code.size() == size()) { t.atom_code.assign(atom_code.begin() + a, atom_code.begin() + b); t.res_code.assign(res_code.begin() + a, res_code.begin() + b); }
         return t;
     }
     void push_from(const AtomTable& o, size_t i) {
         atom.push_back(o.atom[i]); residue.push_back(o.residue[i]); chain.push_back(o.chain[i]);
         atom_index.push_back(o.atom_index[i]); res_index.push_back(o.res_index[i]);
         x.push_back(o.x[i]); y.push_back(o.y[i]); z.push_back(o.z[i]); bfac.push_back(o.bfac[i]);
+        if (o.atom_code.size() == o.size()) { atom_code.push_back(o.atom_code[i]); res_code.push_back(o.res_code[i]); }
     }
 };
 
@@ -112,6 +125,116 @@ std::vector<std::string> split_lines(const std::string& text) {
     return lines;
 }
 
+// ---- the same parser over the raw file image, without a string per line or per field (the parse threads are what bounds a
+//      disk -> database run: 240 KB of text per 350-residue chain against 20 us of GPU time). Number fields take the exact
+//      fast path of decimal -> double (integer mantissa / power of ten, both exact in double, one correctly rounded division
+//      = strtod's result for up to 15 digits) and fall back to strtod for anything else. ----
+inline bool fast_decimal(const char* p, const char* e, double& out) {
+    while (p < e && (*p == ' ' || *p == '\t')) p++;
+    while (e > p && (e[-1] == ' ' || e[-1] == '\t' || e[-1] == '\r')) e--;
+    if (p == e) return false;
+    bool neg = false;
+    if (*p == '-' || *p == '+') { neg = *p == '-'; p++; }
+    uint64_t m = 0; int digits = 0, frac = 0; bool dot = false;
+    for (; p < e; p++) {
+        if (*p >= '0' && *p <= '9') { m = m * 10 + (uint64_t)(*p - '0'); digits++; if (dot) frac++; }
+        else if (*p == '.' && !dot) dot = true;
+        else return false;
+    }
+    if (digits == 0 || digits > 15) return false;
+    static const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    const double v = (double)m / p10[frac];
+    out = neg ? -v : v;
+    return true;
+}
+inline float field_float(const char* line, size_t len, size_t a, size_t b) {
+    if (a >= len) throw std::runtime_error("invalid number field ''");
+    b = std::min(b, len);
+    double v;
+    if (fast_decimal(line + a, line + b, v)) return (float)v;
+    return parse_float(std::string(line + a, b - a));
+}
+inline int field_int(const char* line, size_t len, size_t a, size_t b) {
+    if (a >= len) throw std::runtime_error("invalid integer field ''");
+    b = std::min(b, len);
+    const char* p = line + a; const char* e = line + b;
+    while (p < e && *p == ' ') p++;
+    while (e > p && (e[-1] == ' ' || e[-1] == '\r')) e--;
+    bool neg = false; const char* q = p;
+    if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+    long v = 0; bool ok = q < e;
+    for (; q < e; q++) { if (*q < '0' || *q > '9') { ok = false; break; } v = v * 10 + (*q - '0'); }
+    if (!ok) return parse_int(std::string(line + a, b - a));
+    return (int)(neg ? -v : v);
+}
+inline std::string field_strip(const char* line, size_t len, size_t a, size_t b) {
+    if (a >= len) return std::string();
+    b = std::min(b, len);
+    while (a < b && isspace((unsigned char)line[a])) a++;
+    while (b > a && isspace((unsigned char)line[b - 1])) b--;
+    return std::string(line + a, b - a);
+}
+// name -> code tables of the codec, packed (<= 4 characters) for a lookup without strcmp chains
+struct NameCodes {
+    std::vector<std::pair<uint32_t, int>> atoms, residues;
+    static uint32_t pack(const char* s, size_t n) { uint32_t v = 0; for (size_t i = 0; i < n && i < 4; i++) v |= (uint32_t)(unsigned char)s[i] << (8 * i); return n > 4 ? 0xffffffffu : v; }
+    NameCodes() {
+        for (int i = 0; i < 64; i++) { const char* n = fcz_atom_code_name(i); if (n) atoms.push_back({pack(n, strlen(n)), i}); }
+        for (int i = 0; i < 32; i++) { const char* n = fcz_res_code_name(i); if (n && fcz_res_code_from_name(n) == i) residues.push_back({pack(n, strlen(n)), i}); }
+        std::sort(atoms.begin(), atoms.end()); std::sort(residues.begin(), residues.end());
+    }
+    static int find(const std::vector<std::pair<uint32_t, int>>& v, uint32_t k, int miss) {
+        auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(k, -1));
+        return (it != v.end() && it->first == k) ? it->second : miss;
+    }
+    int atom(const std::string& s) const { return s.size() > 4 ? FCZ_ATOM_CODE_OTHER : find(atoms, pack(s.data(), s.size()), FCZ_ATOM_CODE_OTHER); }
+    int residue(const std::string& s) const { return s.size() > 4 ? -1 : find(residues, pack(s.data(), s.size()), -1); }
+};
+const NameCodes& name_codes() { static const NameCodes c; return c; }
+void fill_codes(AtomTable& t) {
+    const NameCodes& nc = name_codes();
+    t.atom_code.resize(t.size()); t.res_code.resize(t.size());
+    for (size_t i = 0; i < t.size(); i++) {
+        t.atom_code[i] = (uint8_t)nc.atom(t.atom[i]);
+        t.res_code[i] = (i > 0 && t.residue[i] == t.residue[i - 1]) ? t.res_code[i - 1] : (int8_t)nc.residue(t.residue[i]);
+    }
+}
+
+AtomTable parse_pdb_raw(const std::string& raw, bool hetatm, std::string& title) {
+    AtomTable t;
+    const size_t guess = raw.size() / 81 + 1;
+    t.atom.reserve(guess); t.residue.reserve(guess); t.chain.reserve(guess); t.atom_index.reserve(guess); t.res_index.reserve(guess);
+    t.x.reserve(guess); t.y.reserve(guess); t.z.reserve(guess); t.bfac.reserve(guess);
+    std::vector<std::string> title_parts; std::string header_id; bool seen_atom = false, have_header = false;
+    const char* p = raw.data(); const char* end = p + raw.size();
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        size_t len = (size_t)(le - p);
+        if (len && p[len - 1] == '\r') len--;
+        const bool is_atom = len >= 4 && memcmp(p, "ATOM", 4) == 0;
+        if (is_atom || (hetatm && len >= 6 && memcmp(p, "HETATM", 6) == 0)) {
+            t.atom.push_back(field_strip(p, len, 12, 16));
+            t.residue.push_back(field_strip(p, len, 17, 20));
+            t.chain.push_back(len > 21 ? p[21] : ' ');
+            t.atom_index.push_back(field_int(p, len, 6, 11));
+            t.res_index.push_back(field_int(p, len, 22, 26));
+            t.x.push_back(field_float(p, len, 30, 38)); t.y.push_back(field_float(p, len, 38, 46)); t.z.push_back(field_float(p, len, 46, 54));
+            const std::string b = field_strip(p, len, 60, 66);
+            t.bfac.push_back(b.empty() ? 0.0f : field_float(p, len, 60, 66));
+            if (is_atom) seen_atom = true;
+        } else if (!seen_atom && !have_header) {          // gemmi: _entry.id = HEADER id code (cols 63-66), else the TITLE records
+            if (len >= 66 && memcmp(p, "HEADER", 6) == 0 && !field_strip(p, len, 62, 66).empty()) { header_id = field_strip(p, len, 62, 66); have_header = true; }
+            else if (len >= 5 && memcmp(p, "TITLE", 5) == 0) title_parts.push_back(field_strip(p, len, 10, 80));
+        }
+        if (!nl) break;
+        p = nl + 1;
+    }
+    if (have_header) title = header_id;
+    else { title.clear(); for (size_t i = 0; i < title_parts.size(); i++) title += (i ? " " : "") + title_parts[i]; title = strip(title); }
+    return t;
+}
+
 AtomTable parse_pdb(const std::vector<std::string>& lines, bool hetatm) {
     AtomTable t;
     for (const std::string& line : lines) {
@@ -127,19 +250,6 @@ AtomTable parse_pdb(const std::vector<std::string>& lines, bool hetatm) {
         t.bfac.push_back(b.empty() ? 0.0f : parse_float(b));
     }
     return t;
-}
-
-// gemmi: _entry.id = HEADER id code (cols 63-66), else the TITLE records
-std::string pdb_title(const std::vector<std::string>& lines) {
-    std::vector<std::string> parts;
-    for (const std::string& line : lines) {
-        if (starts_with(line, "HEADER") && line.size() >= 66 && !strip(field(line, 62, 66)).empty()) return strip(field(line, 62, 66));
-        if (starts_with(line, "TITLE")) parts.push_back(strip(field(line, 10, 80)));
-        if (starts_with(line, "ATOM")) break;
-    }
-    std::string out;
-    for (size_t i = 0; i < parts.size(); i++) out += (i ? " " : "") + parts[i];
-    return strip(out);
 }
 
 AtomTable remove_alternative_position(const AtomTable& t) {
@@ -283,14 +393,39 @@ std::vector<uint32_t> split_residues(const AtomTable& t) {
     return ro;
 }
 
+// page-locked host memory (fcz_pinned_alloc = hipHostMalloc): what a worker hands to fcz_compress_batch is copied by DMA on the
+// ctx stream, so the transfers of one worker overlap the kernels of the other worker on the same GPU. Falls back to malloc when
+// no device is present (the CPU-only subcommands and tests).
+template <class T> struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
+    static bool& use_pinned() { static bool v = false; return v; }
+    T* allocate(size_t n) {
+        void* p = use_pinned() ? fcz_pinned_alloc(n * sizeof(T) + 8) : malloc(n * sizeof(T) + 8);
+        if (!p) throw std::bad_alloc();
+        *(uint64_t*)p = use_pinned() ? 1 : 0;     // remember where the block came from
+        return (T*)((char*)p + 8);
+    }
+    void deallocate(T* q, size_t) { void* p = (char*)q - 8; if (*(uint64_t*)p) fcz_pinned_free(p); else free(p); }
+    template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template <class T> using pvec = std::vector<T, PinnedAlloc<T>>;
+
 // ---- SoA batch = fcz_chain_batch ----
 struct Batch {
-    std::vector<uint32_t> res_off{0}, atom_off, title_off{0};
-    std::vector<float> x, y, z, bfac_ca;
-    std::vector<uint8_t> atom_code, res_code;
+    std::vector<uint32_t> res_off{0}, title_off{0};
+    pvec<uint32_t> atom_off;
+    pvec<float> x, y, z, bfac_ca;
+    pvec<uint8_t> atom_code, res_code;
     std::vector<int32_t> first_res, first_atom;
     std::string chain_id, titles;
     size_t n_chains() const { return res_off.size() - 1; }
+    void clear() {   // keeps the capacity: a worker reuses its (pinned) buffers for every batch
+        res_off.assign(1, 0); title_off.assign(1, 0); atom_off.clear(); x.clear(); y.clear(); z.clear(); bfac_ca.clear();
+        atom_code.clear(); res_code.clear(); first_res.clear(); first_atom.clear(); chain_id.clear(); titles.clear();
+    }
 
     // appends one fragment; throws std::runtime_error with what the reference would abort on
     void add(const AtomTable& t, const std::string& title, int anchor_threshold = 25) {
@@ -303,9 +438,10 @@ struct Batch {
             throw std::runtime_error("chain of " + std::to_string(nres) + " residues does not fit the FCZ header (65535 residues, 255 anchors)");
         std::vector<uint8_t> ac(t.size()), rc(nres);
         std::vector<float> bf(nres, 0.0f);
-        for (size_t i = 0; i < t.size(); i++) ac[i] = (uint8_t)fcz_atom_code_from_name(t.atom[i].c_str());
+        const bool coded = t.atom_code.size() == t.size();
+        for (size_t i = 0; i < t.size(); i++) ac[i] = coded ? t.atom_code[i] : (uint8_t)fcz_atom_code_from_name(t.atom[i].c_str());
         for (size_t r = 0; r < nres; r++) {
-            const int code = fcz_res_code_from_name(t.residue[ro[r]].c_str());
+            const int code = coded ? (int)t.res_code[ro[r]] : fcz_res_code_from_name(t.residue[ro[r]].c_str());
             if (code < 0) throw std::runtime_error("residue name '" + t.residue[ro[r]] + "' is not supported by the codec");
             rc[r] = (uint8_t)code;
             long pos[3] = {-1, -1, -1};
@@ -338,11 +474,23 @@ struct Batch {
 };
 
 // ---- files ----
-std::string read_file(const std::string& p) {
-    std::ifstream f(p, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + p);
-    std::ostringstream ss; ss << f.rdbuf();
-    return ss.str();
+std::string read_file(const std::string& p) {   // POSIX read: iostream construction takes a process-wide locale reference per file
+    const int fd = open(p.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + p);
+    struct stat st;
+    std::string out;
+    if (fstat(fd, &st) == 0 && st.st_size > 0) out.resize((size_t)st.st_size);
+    size_t got = 0;
+    for (;;) {
+        if (got == out.size()) out.resize(out.size() + (1 << 16));
+        const ssize_t n = read(fd, &out[got], out.size() - got);
+        if (n < 0) { close(fd); throw std::runtime_error("cannot read " + p); }
+        if (n == 0) break;
+        got += (size_t)n;
+    }
+    close(fd);
+    out.resize(got);
+    return out;
 }
 bool is_dir(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
@@ -458,6 +606,9 @@ struct Options {
     std::string mode, input, output;
     int brk = 25, digits = 1, ext_mode = 0;
     bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
+    int gpus = 1;               // --gpus N: devices used by compress (0 = every visible device)
+    int workers_per_gpu = 2;    // host threads (each with its own ctx and stream) per device
+    bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
 };
 
 struct Fragment { std::string out_name, db_name; AtomTable atoms; std::string title; };   // db_name: lookup name = the input file's stem
@@ -471,11 +622,11 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
     std::string raw = read_file(path);
     std::string plain = base;
     if (ends_with(base, ".gz")) { raw = gunzip(raw); plain = base.substr(0, base.size() - 3); }
-    const std::vector<std::string> lines = split_lines(raw);
     std::string title;
     AtomTable t;
-    if (ends_with(plain, ".cif")) t = parse_cif(lines, title);
-    else { t = parse_pdb(lines, true); title = pdb_title(lines); }
+    if (ends_with(plain, ".cif")) t = parse_cif(split_lines(raw), title);
+    else t = parse_pdb_raw(raw, true, title);
+    fill_codes(t);
     if (t.size() == 0) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base.c_str()); return; }
     if (title.empty() || title == base) title = out_stem;            // src/main.cpp:465
     t = remove_alternative_position(t);
@@ -521,7 +672,53 @@ int need_ctx(fcz_ctx** ctx) {
 }
 
 // ---- compress ----
+// ---- compress: a pipeline over every GPU of the node -------------------------------------------------------------------
+// The reference's driver is one `omp parallel for` over the entries with a critical section around the writer
+// (src/input_processor.h:237-257, src/main.cpp:510-530). Structures are independent, so here:
+//   producer   the calling thread walks the inputs in order; chunks of files are parsed on all host threads (OpenMP) into
+//              fragments, and every BATCH_CHAINS fragments become one job;
+//   workers    gpus x workers_per_gpu host threads, each with its own fcz_ctx (own stream) on its device and its own batch and
+//              blob buffers in page-locked memory: while one worker of a GPU runs the kernels of its job, the other one's
+//              host-to-device / device-to-host copies are in flight on the DMA engines. Jobs go to whichever worker is free;
+//   sequencer  record sizes are known on the host before the GPU is called (Foldcomp::getSize), so a job's slice of the
+//              database file is assigned in job order as soon as every earlier job has announced its size; workers pwrite
+//              their blob at that offset: no ordering between the GPUs' writes, no copy through one writer thread;
+//   index      rows (job, position, offset, length, name) are merged at the end, keys are numbered in input order over the
+//              records that compressed (the reference's key++ under `omp critical` is schedule dependent; per-record
+//              bytes and a stable order are what is kept), and .index / .lookup / .dbtype are written as free_writer does.
+struct CompressJob { size_t index = 0; std::vector<Fragment> frags; };
+
+template <class T> struct JobQueue {           // bounded hand-over between the producer and the workers
+    std::mutex m; std::condition_variable cv_put, cv_get; std::deque<T> q; size_t cap; bool closed = false;
+    explicit JobQueue(size_t c) : cap(c) {}
+    void put(T&& v) { std::unique_lock<std::mutex> l(m); cv_put.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cv_get.notify_one(); }
+    bool get(T& v) {
+        std::unique_lock<std::mutex> l(m); cv_get.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = std::move(q.front()); q.pop_front(); cv_put.notify_one(); return true;
+    }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; cv_get.notify_all(); }
+};
+
+struct Sequencer {                             // byte offset of a job's slice = total size of all earlier jobs
+    std::mutex m; std::condition_variable cv; size_t next = 0; uint64_t pos = 0;
+    uint64_t claim(size_t job, uint64_t bytes) {
+        std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return next == job; });
+        const uint64_t at = pos; pos += bytes; next++; cv.notify_all(); return at;
+    }
+};
+
+void pwrite_all(int fd, const uint8_t* p, uint64_t n, uint64_t off) {
+    while (n) {
+        const ssize_t w = pwrite(fd, p, (size_t)std::min<uint64_t>(n, 1u << 30), (off_t)off);
+        if (w <= 0) throw std::runtime_error("pwrite failed");
+        p += w; n -= (uint64_t)w; off += (uint64_t)w;
+    }
+}
+
 int run_compress(const Options& o) {
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
     const bool single = !is_dir(o.input);
     std::string output = o.output;
     if (output.empty()) {
@@ -531,52 +728,130 @@ int run_compress(const Options& o) {
     std::vector<std::string> files;
     if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
     if (o.db && o.output.empty()) output = o.input + "_db";
-    std::unique_ptr<DbWriter> dbw;
-    long long db_key = 0;
-    if (o.db) dbw.reset(new DbWriter(output)); else if (!single) make_dir(output);
-    fcz_ctx* ctx = nullptr;
-    if (need_ctx(&ctx)) return 1;
-    std::vector<Fragment> pending;
-    bool hard_fail = false;
-    auto flush = [&]() {
-        if (pending.empty()) return;
-        Batch b;
-        std::vector<size_t> kept;
-        for (size_t i = 0; i < pending.size(); i++) {
-            // a fragment the codec cannot take is reported and left out (Batch::add throws before it changes the batch)
-            try { b.add(pending[i].atoms, pending[i].title, o.brk); kept.push_back(i); }
-            catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", pending[i].out_name.c_str(), e.what()); }
-        }
-        if (!kept.empty()) {
+    const int n_dev = fcz_device_count();
+    if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
+    const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
+    if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
+    const int n_workers = gpus * std::max(1, o.workers_per_gpu);
+    PinnedAlloc<char>::use_pinned() = true;
+    int db_fd = -1;
+    if (o.db) {
+        db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+        if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
+    } else if (!single) make_dir(output);
+
+    struct Row { size_t job, pos; uint64_t off, len; std::string name; };
+    std::vector<std::vector<Row>> rows(n_workers);
+    JobQueue<CompressJob> queue((size_t)n_workers + 2);
+    Sequencer seq;
+    std::atomic<bool> hard_fail{false};
+    std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0};
+    std::vector<double> gpu_busy(n_workers, 0.0);
+    std::vector<std::thread> workers;
+    for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
+        fcz_ctx* ctx = nullptr;
+        if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        Batch b;                         // reused: its page-locked buffers grow to the largest job and stay
+        pvec<uint8_t> blob;
+        CompressJob job;
+        while (queue.get(job)) {
+            std::vector<size_t> kept;
+            b.clear();
+            {   // one growth step of the page-locked buffers per job at most (pinning memory is expensive), none once they are large enough
+                size_t na = 0; for (const Fragment& f : job.frags) na += f.atoms.size();
+                b.x.reserve(na); b.y.reserve(na); b.z.reserve(na); b.atom_code.reserve(na);
+                b.atom_off.reserve(na / 4 + 16); b.res_code.reserve(na / 4 + 16); b.bfac_ca.reserve(na / 4 + 16);
+            }
+            for (size_t i = 0; i < job.frags.size(); i++) {
+                // a fragment the codec cannot take is reported and left out (Batch::add throws before it changes the batch)
+                try { b.add(job.frags[i].atoms, job.frags[i].title, o.brk); kept.push_back(i); }
+                catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", job.frags[i].out_name.c_str(), e.what()); }
+            }
             fcz_chain_batch v = b.view(o.brk);
-            std::vector<uint64_t> off(v.n_chains + 1);
-            fcz_compress_sizes(&v, off.data());
-            std::vector<uint8_t> blob(off.back());
-            std::vector<int32_t> status(v.n_chains);
+            std::vector<uint64_t> off(v.n_chains + 1, 0);
+            if (v.n_chains) fcz_compress_sizes(&v, off.data());
+            const uint64_t at = o.db ? seq.claim(job.index, off.back()) : 0;     // every job claims, also an empty or failed one
+            if (kept.empty() || !ctx) continue;
+            blob.resize(off.back());
+            std::vector<int32_t> status(v.n_chains, 0);
+            const auto t0 = clk::now();
             const int rc = fcz_compress_batch(ctx, &v, off.data(), blob.data(), status.data());
+            gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
             if (rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG) {
                 // a failure of the call itself (device, memory): no per-chain status was written, nothing may be emitted
                 fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size());
-                hard_fail = true; pending.clear(); return;
+                hard_fail = true; continue;
             }
-            for (size_t q = 0; q < kept.size(); q++) {
-                const Fragment& f = pending[kept[q]];
-                if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
-                if (dbw) { dbw->append((const char*)blob.data() + off[q], off[q + 1] - off[q], db_key++, f.db_name, false); continue; }
-                const std::string path = single ? output : output + "/" + f.out_name;
-                write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
-            }
+            try {
+                if (o.db) pwrite_all(db_fd, blob.data(), off.back(), at);
+                for (size_t q = 0; q < kept.size(); q++) {
+                    const Fragment& f = job.frags[kept[q]];
+                    if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
+                    n_frag_ok++; n_res += v.res_off[q + 1] - v.res_off[q]; n_bytes += off[q + 1] - off[q];
+                    n_atoms += v.atom_off[v.res_off[q + 1]] - v.atom_off[v.res_off[q]];
+                    if (o.db) { rows[w].push_back({job.index, q, at + off[q], off[q + 1] - off[q], f.db_name}); continue; }
+                    const std::string path = single ? output : output + "/" + f.out_name;
+                    write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
+                }
+            } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
         }
-        pending.clear();
-    };
-    constexpr size_t FILE_CHUNK = 2048;   // files parsed side by side before the next GPU batch is considered
-    for (size_t f0 = 0; f0 < files.size(); f0 += FILE_CHUNK) {
-        fragments_of_files(files, f0, std::min(files.size(), f0 + FILE_CHUNK), single, output, !o.db, o, pending);
-        if (pending.size() >= BATCH_CHAINS) flush();
+        if (ctx) fcz_ctx_destroy(ctx);
+    });
+
+    // ---- producer ----
+    double t_parse = 0.0;
+    uint64_t in_bytes = 0;
+    {
+        // files parsed side by side before the next job is cut, and fragments per job: small enough that every worker gets
+        // several jobs (parse, staging, GPU and writes of different jobs overlap), large enough to fill a GPU launch
+        const size_t JOB = std::max<size_t>(256, std::min<size_t>(BATCH_CHAINS, files.size() / (4 * (size_t)n_workers) + 1));
+        const size_t FILE_CHUNK = std::max<size_t>(JOB, 512);
+        std::vector<Fragment> pending;
+        size_t job_index = 0;
+        auto cut = [&](bool all) {
+            while (pending.size() >= JOB || (all && !pending.empty())) {
+                CompressJob j; j.index = job_index++;
+                const size_t n = std::min(pending.size(), JOB);
+                j.frags.assign(std::make_move_iterator(pending.begin()), std::make_move_iterator(pending.begin() + n));
+                pending.erase(pending.begin(), pending.begin() + n);
+                queue.put(std::move(j));
+            }
+        };
+        for (size_t f0 = 0; f0 < files.size(); f0 += FILE_CHUNK) {
+            const auto t0 = clk::now();
+            const size_t f1 = std::min(files.size(), f0 + FILE_CHUNK);
+            fragments_of_files(files, f0, f1, single, output, !o.db, o, pending);
+            t_parse += std::chrono::duration<double>(clk::now() - t0).count();
+            for (size_t i = f0; i < f1; i++) { struct stat st; if (stat(files[i].c_str(), &st) == 0) in_bytes += (uint64_t)st.st_size; }
+            cut(false);
+        }
+        cut(true);
+        queue.close();
     }
-    flush();
-    if (dbw) dbw->close();
-    fcz_ctx_destroy(ctx);
+    for (std::thread& t : workers) t.join();
+
+    // ---- index: rows of all workers in job order, keys numbered over the records that made it ----
+    if (o.db) {
+        close(db_fd);
+        std::vector<Row> all;
+        for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
+        std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.job != b.job ? a.job < b.job : a.pos < b.pos; });
+        std::ofstream fi(output + ".index"), fl(output + ".lookup");
+        long long key = 0;
+        for (const Row& r : all) { fi << key << "\t" << r.off << "\t" << r.len << "\n"; fl << key << "\t" << r.name << "\t0\n"; key++; }
+        std::ofstream t(output + ".dbtype", std::ios::binary);
+        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+    }
+    if (o.json_stats) {
+        const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
+        double busy = 0.0; for (double g : gpu_busy) busy += g;
+        printf("{\"mode\": \"compress\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
+               "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
+               "\"codec_call_s_sum\": %.4f, \"residues_per_s\": %.1f, \"input_MB_per_s\": %.1f}\n",
+               gpus, n_workers, omp_get_max_threads(), files.size(), (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
+               (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), wall, t_parse, busy,
+               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0);
+    }
     return hard_fail ? 1 : 0;
 }
 
@@ -808,7 +1083,7 @@ int run_rmsd(const Options& o) {
 
 void usage() {
     fprintf(stderr,
-            "usage: foldcomp-hip compress   [-b N] [-y] [-r] [--skip-discontinuous] <pdb file|dir> [<fcz file|dir>]\n"
+            "usage: foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d] [--skip-discontinuous] [--json-stats] <pdb|cif file|dir> [<fcz file|dir|db>]\n"
             "       foldcomp-hip decompress [-a] [-y] [-r] <fcz file|dir> [<pdb file|dir>]\n"
             "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir> [<out>]\n"
             "       foldcomp-hip check      [-r] <fcz file|dir|db>\n"
@@ -828,7 +1103,10 @@ int main(int argc, char** argv) {
         else if (a == "-r" || a == "--recursive") o.recursive = true;
         else if (a == "-b" || a == "--break") next_int(o.brk);
         else if (a == "-p" || a == "--plddt-digits") next_int(o.digits);
-        else if (a == "-t" || a == "--threads") { int unused; next_int(unused); }
+        else if (a == "-t" || a == "--threads") { int t = 0; next_int(t); if (t > 0) omp_set_num_threads(t); }   // host parse threads
+        else if (a == "--gpus") next_int(o.gpus);
+        else if (a == "--workers-per-gpu") next_int(o.workers_per_gpu);
+        else if (a == "--json-stats") o.json_stats = true;
         else if (a == "--plddt") o.ext_mode = 0;
         else if (a == "--fasta" || a == "--amino-acid") o.ext_mode = 1;
         else if (a == "--use-title") o.use_title = true;
@@ -848,6 +1126,16 @@ int main(int argc, char** argv) {
     if (o.mode == "extract") return run_extract(o);
     if (o.mode == "check") return run_check(o);
     if (o.mode == "dump-batch") return run_dump_batch(o);
+    if (o.mode == "parse-bench") {   // no GPU: parse every file of a directory on the host threads and report the rate
+        std::vector<std::string> files; list_files(o.input, o.recursive, files);
+        std::vector<Fragment> frags;
+        const auto t0 = std::chrono::steady_clock::now();
+        fragments_of_files(files, 0, files.size(), false, "", true, o, frags);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        size_t atoms = 0; for (const Fragment& f : frags) atoms += f.atoms.size();
+        printf("files %zu fragments %zu atoms %zu seconds %.4f threads %d\n", files.size(), frags.size(), atoms, dt, omp_get_max_threads());
+        return 0;
+    }
     if (o.mode == "rmsd") return run_rmsd(o);
     if (o.mode == "db-pack") return run_db_pack(o);
     if (o.mode == "db-unpack") return run_db_unpack(o);

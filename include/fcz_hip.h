@@ -125,6 +125,13 @@ int  fcz_ctx_synchronize(fcz_ctx* ctx);
  *     parallel composition of per-residue rigid transforms (fcz_backbone_fast.h). Coordinates differ from the exact path by
  *     float rounding only (< 1e-3 A, typically 1e-4 A; the reference's RMSD pins of build.sh:35,37 hold unchanged), which is
  *     what `foldcomp check` / the RMSD tolerance of the reference's own tests ask of a decoder. */
+/* Host-side helpers for callers that feed the host-pointer entry points from their own threads (one ctx per thread and GPU):
+ * the number of visible devices, and page-locked host memory (hipHostMalloc): copies from / to such buffers are true
+ * asynchronous DMA on the ctx stream, so two ctxs on one GPU overlap one batch's transfers with the other's kernels. */
+int   fcz_device_count(void);
+void* fcz_pinned_alloc(size_t bytes);
+void  fcz_pinned_free(void* p);
+
 enum fcz_numerics { FCZ_NUMERICS_EXACT = 0, FCZ_NUMERICS_FAST = 1 };
 int  fcz_ctx_set_numerics(fcz_ctx* ctx, int mode);
 int  fcz_ctx_get_numerics(fcz_ctx* ctx);

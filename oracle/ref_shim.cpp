@@ -319,4 +319,60 @@ long ref_db_lookup(const char* data_path, const char* index_path, const char* na
     return id;
 }
 
+// ---- end to end on files: what the compress lambda of src/main.cpp:438-536 does per input, under the reference's own
+// `omp parallel for` (src/input_processor.h:85-101): read the file, StructureReader::loadFromBuffer, removeAlternativePosition,
+// identifyChains / identifyDiscontinousResInd, Foldcomp::compress + writeStream per fragment (the bytes are kept in memory as the
+// --db path does before writer_append). Wall time of the whole loop; returns the number of files that failed to load.
+int ref_compress_files(const char* paths, int n_files, int n_threads, int anchor_threshold, double* seconds,
+                       unsigned long long* residues, unsigned long long* fcz_bytes, unsigned char* first_out, long first_cap, long* first_len) {
+    std::vector<std::string> files;
+    const char* p = paths;
+    for (int i = 0; i < n_files; i++) { files.emplace_back(p); p += files.back().size() + 1; }
+    unsigned long long res = 0, bytes = 0; int failed = 0;
+    *first_len = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : res, bytes, failed)
+    for (int i = 0; i < n_files; i++) {
+        FILE* f = fopen(files[i].c_str(), "rb");
+        if (!f) { failed++; continue; }
+        std::string buf; char tmp[1 << 16]; size_t n;
+        while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+        fclose(f);
+        const size_t slash = files[i].find_last_of('/');
+        const std::string base = slash == std::string::npos ? files[i] : files[i].substr(slash + 1);
+        StructureReader reader;
+        if (!reader.loadFromBuffer(buf.data(), buf.size(), base)) { failed++; continue; }
+        std::vector<AtomCoordinate> atoms;
+        reader.readAllAtoms(atoms);
+        if (atoms.empty()) { failed++; continue; }
+        const size_t dot = base.find_last_of('.');
+        const std::string stem = dot == std::string::npos ? base : base.substr(0, dot);
+        const std::string title = reader.title == base ? stem : reader.title;
+        removeAlternativePosition(atoms);
+        std::vector<std::pair<size_t, size_t>> chains = identifyChains(atoms);
+        for (size_t c = 0; c < chains.size(); c++) {
+            std::vector<std::pair<size_t, size_t>> fr = identifyDiscontinousResInd(atoms, chains[c].first, chains[c].second);
+            for (size_t j = 0; j < fr.size(); j++) {
+                tcb::span<AtomCoordinate> sp(&atoms[fr[j].first], atoms.data() + fr[j].second);
+                Foldcomp comp;
+                comp.strTitle = title;
+                comp.anchorThreshold = anchor_threshold;
+                try { comp.compress(sp); } catch (...) { failed++; continue; }
+                std::ostringstream oss;
+                comp.writeStream(oss);
+                const std::string os = oss.str();
+                res += comp.nResidue; bytes += os.size();
+                if (i == 0 && c == 0 && j == 0 && (long)os.size() <= first_cap) {
+                    memcpy(first_out, os.data(), os.size());
+                    if (os.size() >= 24) first_out[14] = first_out[15] = first_out[22] = first_out[23] = 0;
+                    *first_len = (long)os.size();
+                }
+            }
+        }
+    }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *residues = res; *fcz_bytes = bytes;
+    return failed;
+}
+
 }  // extern "C"

@@ -38,9 +38,15 @@ import json
 out = {"source": "profiles/%s_pmc_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, %d residues per launch; "
                  "FETCH x2, WRITE x1 per profiles/%s_pmc_summary.txt calibration)" % (tag, int(R), tag),
        "residues_per_chain": 350, "calibration": {"%s %s" % k: round(v, 3) for k, v in sorted(cal.items())}, "kernels": {}}
+def short(k):
+    """fcz::k_name / void fcz::k_name<args> -> k_name (the exact-mode instantiations), k_name_fast for <true>"""
+    n = k.replace("void ", "").split("::")[-1]
+    base, _, arg = n.partition("<")
+    arg = arg.rstrip(">")
+    return base if arg in ("", "0", "false") else (base + "_fast" if arg == "true" else base + "_" + arg)
 for k, v in d.items():
-    if not k.startswith("fcz::k_") or "FETCH_SIZE" not in v: continue
-    out["kernels"][k.split("::")[1]] = {"fetch_bytes_per_residue": round(2 * v["FETCH_SIZE"] * 1024 / R, 2),
+    if "fcz::k_" not in k or "FETCH_SIZE" not in v: continue
+    out["kernels"][short(k)] = {"fetch_bytes_per_residue": round(2 * v["FETCH_SIZE"] * 1024 / R, 2),
                                         "write_bytes_per_residue": round(v.get("WRITE_SIZE", 0.0) * 1024 / R, 2)}
 if out["kernels"]:
     json.dump(out, open(os.path.join("gpurun_out", "prof_" + tag, "traffic.json"), "w"), indent=1)

@@ -4,7 +4,7 @@
 # usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:-"--chains 262144 --steps 3 --warmup 1 --cpu-sample 0 --no-parity"}
+ARGS=${@:-"--chains 262144 --steps 3 --warmup 1 --cpu-sample 0 --no-parity --mixed-chains 0 --e2e-files 0 --pdb-sample 0"}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -41,7 +41,7 @@ PY
 if [ -z "${PMC_ONLY:-}" ]; then
   run stats --kernel-trace --stats
   # the same trace for the default bench command (1 M chains), the line the driver records
-  if [ -n "${FULL_STATS:-}" ]; then SAVE_ARGS=$ARGS; ARGS="--cpu-sample 0"; run stats_full --kernel-trace --stats; ARGS=$SAVE_ARGS; fi
+  if [ -n "${FULL_STATS:-}" ]; then SAVE_ARGS=$ARGS; ARGS="--cpu-sample 0 --e2e-files 0"; run stats_full --kernel-trace --stats; ARGS=$SAVE_ARGS; fi
 fi
 # PMC passes: counters only (no trace domains besides kernel dispatch), one group per pass
 run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY

@@ -358,21 +358,39 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
             // backbone: thread = residue window (k, k+1). psi = (N0,CA0,C0,N1), omega = (CA0,C0,N1,CA1),
             // phi = (C0,N1,CA1,C1) -> arrays 1, 2, 0 (split src/foldcomp.cpp:488-492); ca_c_n = (CA0,C0,N1),
             // c_n_ca = (C0,N1,CA1), n_ca_c = (N1,CA1,C1) -> arrays 4, 5, 3 (split :497-505)
+            // The six items of a window share their ingredients: five bond vectors, four plane normals and their squared
+            // lengths are formed once (the reference forms each of them up to three times: same operands, same operations,
+            // same bits; a bond angle's vectors a - b are the exact negatives of the dihedrals' b - a, and negation commutes
+            // with every rounding involved), then the double part runs once per item (q uniform: one copy of its code).
             float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, bb4 = 0.f, bb5 = 0.f;
+            if (my_win) {
+                const v3 N0 = tile_atom(L, (uint32_t)t, 0), CA0 = tile_atom(L, (uint32_t)t, 1), C0 = tile_atom(L, (uint32_t)t, 2);
+                const v3 N1 = tile_atom(L, (uint32_t)t + 1u, 0), CA1 = tile_atom(L, (uint32_t)t + 1u, 1), C1 = tile_atom(L, (uint32_t)t + 1u, 2);
+                const v3 e0 = vsub(CA0, N0), e1 = vsub(C0, CA0), e2 = vsub(N1, C0), e3 = vsub(CA1, N1), e4 = vsub(C1, CA1);
+                const v3 u0 = vcross(e0, e1), u1 = vcross(e1, e2), u2 = vcross(e2, e3), u3 = vcross(e3, e4);
+                const float su0 = vdot_ref(u0, u0), su1 = vdot_ref(u1, u1), su2 = vdot_ref(u2, u2), su3 = vdot_ref(u3, u3);
+                const float se1 = vdot_ref(e1, e1), se2 = vdot_ref(e2, e2), se3 = vdot_ref(e3, e3), se4 = vdot_ref(e4, e4);
+                // item q: inner product, the two squared lengths, and (dihedrals) the sign test (u_a . (u_b x d2) < 0)
+                const float ip0 = vdot_ref(u0, u1), ip1 = vdot_ref(u1, u2), ip2 = vdot_ref(u2, u3);
+                const bool ng0 = vdot_ref(u0, vcross(u1, e1)) < 0.0f, ng1 = vdot_ref(u1, vcross(u2, e2)) < 0.0f, ng2 = vdot_ref(u2, vcross(u3, e3)) < 0.0f;
+                // angle(a, b, c) = acos of cos(a - b, c - b): (CA0, C0, N1) -> (-e1, e2), (C0, N1, CA1) -> (-e2, e3), (N1, CA1, C1) -> (-e3, e4)
+                const float ip3 = -vdot_ref(e1, e2), ip4 = -vdot_ref(e2, e3), ip5 = -vdot_ref(e3, e4);
 #pragma unroll 1
-            for (uint32_t q = 0; q < 6; q++) {   // q uniform: one copy of the dihedral and of the bond-angle code
-                if (!my_win) continue;
-                const bool dih = q < 3;
-                const uint32_t g0 = dih ? q : q - 2;     // first backbone atom of the item in the window N0 CA0 C0 N1 CA1 C1
-                const v3 a = tile_atom(L, (uint32_t)t + (g0 >= 3 ? 1u : 0u), g0 >= 3 ? g0 - 3 : g0);
-                const v3 b = tile_atom(L, (uint32_t)t + (g0 + 1 >= 3 ? 1u : 0u), g0 + 1 >= 3 ? g0 - 2 : g0 + 1);
-                const v3 cc = tile_atom(L, (uint32_t)t + (g0 + 2 >= 3 ? 1u : 0u), g0 + 2 >= 3 ? g0 - 1 : g0 + 2);
-                float v;
-                if (dih) v = dihedral_deg(a, b, cc, tile_atom(L, (uint32_t)t + 1u, g0));
-                else v = bond_angle_deg(a, b, cc);
-                // psi, omega, phi -> arrays 1, 2, 0; ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3
-                bb1 = q == 0 ? v : bb1; bb2 = q == 1 ? v : bb2; bb0 = q == 2 ? v : bb0;
-                bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
+                for (uint32_t q = 0; q < 6; q++) {
+                    const float ip = q == 0 ? ip0 : q == 1 ? ip1 : q == 2 ? ip2 : q == 3 ? ip3 : q == 4 ? ip4 : ip5;
+                    const float sa = q == 0 ? su0 : q == 1 ? su1 : q == 2 ? su2 : q == 3 ? se1 : q == 4 ? se2 : se3;
+                    const float sb = q == 0 ? su1 : q == 1 ? su2 : q == 2 ? su3 : q == 3 ? se2 : q == 4 ? se3 : se4;
+                    const float ct = vcos_theta_pre(ip, sa, sb);
+                    float v = acos_deg(ct);
+                    if (q < 3) {   // getTorsionFromXYZ: NaN guard and sign (src/torsion_angle.cpp:77-94); angle() has neither
+                        if (v != v) v = (ct < 0.0f) ? 180.0f : 0.0f;
+                        const bool ng = q == 0 ? ng0 : q == 1 ? ng1 : ng2;
+                        if (ng) v = -1.0f * v;
+                    }
+                    // psi, omega, phi -> arrays 1, 2, 0; ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3
+                    bb1 = q == 0 ? v : bb1; bb2 = q == 1 ? v : bb2; bb0 = q == 2 ? v : bb0;
+                    bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
+                }
             }
             // side-chain torsions (calculateTorsionAnglesInResidue, reference src/sidechain.cpp:149-168): flat list
             uint32_t scb[3] = {0u, 0u, 0u};

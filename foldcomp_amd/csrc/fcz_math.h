@@ -79,10 +79,12 @@ __device__ __forceinline__ float vnorm(v3 v) {
 __device__ __noinline__ float cos_theta_exact(float ip, float p) {
     return (float)((double)ip / __builtin_sqrt((double)p));
 }
-__device__ __forceinline__ float vcos_theta(v3 a, v3 b) {
-    const float ip = (a.x * b.x) + (a.y * b.y) + (a.z * b.z);
-    const float s1 = a.x * a.x + a.y * a.y + a.z * a.z;
-    const float s2 = b.x * b.x + b.y * b.y + b.z * b.z;
+// the double part of getCosineTheta from its three float dot products (callers that evaluate several angles over shared
+// vectors compute every dot product once)
+__device__ __forceinline__ float vcos_theta_pre(float ip, float s1, float s2);
+__device__ __forceinline__ float vdot_ref(v3 a, v3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }   // float, left to right
+__device__ __forceinline__ float vcos_theta(v3 a, v3 b) { return vcos_theta_pre(vdot_ref(a, b), vdot_ref(a, a), vdot_ref(b, b)); }
+__device__ __forceinline__ float vcos_theta_pre(float ip, float s1, float s2) {
     const float p = s1 * s2;
     const double pd = (double)p;
     double r = __builtin_amdgcn_rsq(pd);

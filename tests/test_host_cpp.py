@@ -260,3 +260,52 @@ def test_cpp_host_rmsd_matches_python_host(tmp_path, golden, capsys):
     assert cc[:4] == py[:4]                                  # files, residues, atoms
     assert abs(float(cc[4]) - float(py[4])) < 1e-3 and abs(float(cc[5]) - float(py[5])) < 1e-3
     assert _run("rmsd", str(a), str(a)).stdout.strip().split("\t")[4:] == ["0", "0"]
+
+
+@pytest.mark.gpu
+def test_cpp_compress_pipeline_many_jobs(tmp_path, golden):
+    """`compress -d` as a pipeline: 700 files -> several jobs over 3 worker threads (own ctx and stream each, page-locked
+    buffers, pwrite at sequenced offsets). The database must not depend on which worker finished first: keys in file order,
+    every record == the record a single-file run makes of the same file, data file = records back to back."""
+    from foldcomp_amd.database import DatabaseReader
+    z, _ = golden
+    d = tmp_path / "in"
+    d.mkdir()
+    srcs = ["pdb:test_af", "syn:len26", "syn:len129", "pdb:test", "syn:len350"]
+    texts = {n: _pdb_text(z, n) for n in srcs}
+    order = []
+    for i in range(700):
+        n = srcs[(i * 7) % len(srcs)]
+        (d / f"f{i:04d}.pdb").write_text(texts[n]); order.append(n)
+    (d / "f0350.pdb").write_text("HEADER    nothing to see\n")          # a file without atoms: reported, skipped, no hole in the keys
+    r = _run("compress", "-d", "-y", "-t", "8", "--gpus", "1", "--workers-per-gpu", "3", "--json-stats", str(d), str(tmp_path / "db"))
+    assert r.returncode == 0, r.stderr
+    import json
+    st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert st["records"] == 699 and st["workers"] == 3 and st["files"] == 700
+    single = {}
+    for n in srcs:
+        p = tmp_path / f"one_{n.split(':')[1]}.pdb"
+        p.write_text(texts[n])
+        rr = _run("compress", "-y", str(p), str(tmp_path / f"one_{n.split(':')[1]}.fcz"))
+        assert rr.returncode == 0, rr.stderr
+        single[n] = (tmp_path / f"one_{n.split(':')[1]}.fcz").read_bytes()
+
+    def no_title(f):
+        na, tl = f[12], int.from_bytes(f[24:28], "little")
+        return f[:24] + f[28:76 + 4 * na] + f[76 + 4 * na + tl:]
+    rd = DatabaseReader(str(tmp_path / "db"))
+    assert len(rd) == 699 and list(rd.keys) == list(range(699))
+    names = [f"f{i:04d}" for i in range(700) if i != 350]
+    kept = [o for i, o in enumerate(order) if i != 350]
+    for i in range(699):
+        assert rd.name(i) == names[i]
+        assert no_title(rd.data(i)) == no_title(single[kept[i]]), i
+    assert int(rd.offsets[-1] + rd.lengths[-1]) == os.path.getsize(tmp_path / "db")
+    assert all(int(rd.offsets[i] + rd.lengths[i]) == int(rd.offsets[i + 1]) for i in range(698))
+    rd.close()
+    # more GPUs than the box has: refused, not silently run on fewer
+    import torch
+    if torch.cuda.device_count() < 8:
+        r = _run("compress", "-d", "-y", "--gpus", "8", str(d), str(tmp_path / "db8"))
+        assert r.returncode != 0 and "device" in r.stderr

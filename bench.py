@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--gen-chunk", type=int, default=32768)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="chains timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-chains", type=int, default=4096,
+                    help="chains of the GPU result compared with the oracle bit for bit after the timed region (FCZ bytes and coordinates)")
     ap.add_argument("--pdb-sample", type=int, default=65536,
                     help="chains rendered to PDB text on the device after the timed region (SURVEY §8 f2 leg; 0 = skip)")
     ap.add_argument("--mixed-chains", type=int, default=542_000,
@@ -751,9 +753,9 @@ def main():
         parity = None
         hb = None
         if not args.no_parity or args.cpu_sample:
-            hb = host_sample(d, max(256, args.cpu_sample))
+            hb = host_sample(d, max(args.parity_chains, args.cpu_sample))
         if not args.no_parity:
-            n = min(256, hb.n_chains)
+            n = min(args.parity_chains, hb.n_chains)
             hb256 = host_sample(d, n)
             ok_c, ok_d = parity_sample(hb256, blob_dev, off_dev, out_t, None, n)
             parity = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": bad_status}

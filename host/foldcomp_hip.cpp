@@ -1,7 +1,7 @@
 // foldcomp_hip.cpp -- the C++ host of the MI355X codec: a `foldcomp`-style command line over the C-ABI of include/fcz_hip.h.
 //
 //   foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d] [--skip-discontinuous] [--json-stats] <pdb file|dir> [<fcz file|dir|db>]
-//   foldcomp-hip decompress [-a] [-y] [-r] [-d] <fcz file|dir|db> [<pdb file|dir|db>]
+//   foldcomp-hip decompress [--gpus N] [-a] [-y] [-r] [-d] [--json-stats] <fcz file|dir|db> [<pdb file|dir|db>]
 //   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir|db> [<out file>]
 //   foldcomp-hip check      [-r] <fcz file|dir|db>
 //   foldcomp-hip rmsd       <pdb|cif> <pdb|cif>
@@ -869,60 +869,133 @@ struct Entries {
 
 // every FCZ entry of a file, a directory or a database, in batches
 template <class F>
-void for_each_entry(const Options& o, Entries& ents, F&& flush) {
+void for_each_entry(const Options& o, Entries& ents, F&& flush, size_t batch = BATCH_CHAINS) {
     if (is_db(o.input)) {
         DbReader r(o.input);
         for (size_t i = 0; i < r.n(); i++) {
             try { ents.add(r.name(i), r.entry(i)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
-            if (ents.n() >= BATCH_CHAINS) flush();
+            if (ents.n() >= batch) flush();
         }
     } else {
         std::vector<std::string> files;
         if (is_dir(o.input)) list_files(o.input, o.recursive, files); else files.push_back(o.input);
         for (const std::string& path : files) {
             try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
-            if (ents.n() >= BATCH_CHAINS) flush();
+            if (ents.n() >= batch) flush();
         }
     }
     flush();
 }
 
+// decompress: the same pipeline as compress (producer -> job queue -> gpus x workers_per_gpu workers with their own ctx ->
+// sequenced pwrite / per-file writes -> merged index). The text of a job is formatted on the device (fcz_decompress_pdb_begin /
+// _fetch); its size is known after `begin`, which is when the job claims its byte range of the output database.
+struct DecompressJob { size_t index = 0; Entries ents; };
+
 int run_decompress(const Options& o) {
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
     const bool single = !is_dir(o.input) && !is_db(o.input);
     std::string output = o.output;
     if (output.empty()) {
         if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + ".pdb"; }
         else output = o.input + (o.db ? "_pdb_db" : "_pdb");
     }
-    std::unique_ptr<DbWriter> dbw;
-    long long db_key = 0;
-    if (o.db) dbw.reset(new DbWriter(output)); else if (!single) make_dir(output);
-    fcz_ctx* ctx = nullptr;
-    if (need_ctx(&ctx)) return 1;
-    Entries ents;
-    auto flush = [&]() {
-        if (!ents.n()) return;
-        std::vector<uint64_t> text_off(ents.n() + 1);
-        std::vector<int32_t> status(ents.n());
-        int rc = fcz_decompress_pdb_begin(ctx, ents.blob.data(), ents.off.data(), ents.n(), o.alt ? 1 : 0, text_off.data(), status.data());
-        std::string text(rc == FCZ_OK ? text_off.back() : 0, '\0');
-        if (rc == FCZ_OK) rc = fcz_decompress_pdb_fetch(ctx, (uint8_t*)text.data());
-        if (rc != FCZ_OK) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
-        for (uint32_t i = 0; i < ents.n() && rc == FCZ_OK; i++) {
-            if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", ents.names[i].c_str()); continue; }
-            std::string stem, ext;
-            file_parts(base_name(ents.names[i]), stem, ext);
-            const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
-            // PDB text in a database carries the MMseqs terminator (src/main.cpp:659)
-            if (dbw) { dbw->append(text.data() + text_off[i], text_off[i + 1] - text_off[i], db_key++, stem, true); continue; }
-            write_out(single ? output : output + "/" + fname, text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
+    const int n_dev = fcz_device_count();
+    if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
+    const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
+    if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
+    const int n_workers = single ? 1 : gpus * std::max(1, o.workers_per_gpu);
+    PinnedAlloc<char>::use_pinned() = true;
+    int db_fd = -1;
+    if (o.db) {
+        db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+        if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
+    } else if (!single) make_dir(output);
+
+    struct Row { size_t job, pos; uint64_t off, len; std::string name; };
+    std::vector<std::vector<Row>> rows(n_workers);
+    JobQueue<DecompressJob> queue((size_t)n_workers + 2);
+    Sequencer seq;
+    std::atomic<bool> hard_fail{false};
+    std::atomic<uint64_t> n_ok{0}, n_text{0}, n_fcz{0};
+    std::vector<std::thread> workers;
+    for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
+        fcz_ctx* ctx = nullptr;
+        if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        pvec<uint8_t> text, packed;
+        DecompressJob job;
+        while (queue.get(job)) {
+            const uint32_t n = job.ents.n();
+            std::vector<uint64_t> text_off(n + 1, 0);
+            std::vector<int32_t> status(n, 0);
+            int rc = ctx ? fcz_decompress_pdb_begin(ctx, job.ents.blob.data(), job.ents.off.data(), n, o.alt ? 1 : 0, text_off.data(), status.data()) : FCZ_E_NO_DEVICE;
+            uint32_t n_good = 0;
+            if (rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) n_good += status[i] == FCZ_OK ? 1u : 0u;
+            // PDB text in a database carries the MMseqs terminator (src/main.cpp:659): one NUL per record
+            const uint64_t bytes = rc == FCZ_OK ? text_off[n] + (o.db ? n_good : 0) : 0;
+            const uint64_t at = o.db ? seq.claim(job.index, bytes) : 0;     // every job claims, also a failed one
+            if (rc == FCZ_OK) { text.resize(text_off[n]); rc = fcz_decompress_pdb_fetch(ctx, text.data()); }
+            if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s\n", fcz_status_string(rc)); hard_fail = true; continue; }
+            try {
+                if (o.db) {
+                    packed.resize(bytes);
+                    uint64_t pos = 0; size_t k = 0;
+                    for (uint32_t i = 0; i < n; i++) {
+                        if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
+                        const uint64_t len = text_off[i + 1] - text_off[i];
+                        memcpy(packed.data() + pos, text.data() + text_off[i], len); packed[pos + len] = 0;
+                        std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
+                        rows[w].push_back({job.index, k++, at + pos, len + 1, stem});
+                        pos += len + 1;
+                    }
+                    pwrite_all(db_fd, packed.data(), bytes, at);
+                } else {
+                    for (uint32_t i = 0; i < n; i++) {
+                        if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
+                        std::string stem, ext;
+                        file_parts(base_name(job.ents.names[i]), stem, ext);
+                        const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
+                        write_out(single ? output : output + "/" + fname, (const char*)text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
+                    }
+                }
+                n_ok += n_good; n_text += text_off[n]; n_fcz += job.ents.off.back();
+            } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
         }
-        ents.clear();
-    };
-    for_each_entry(o, ents, flush);
-    if (dbw) dbw->close();
-    fcz_ctx_destroy(ctx);
-    return 0;
+        if (ctx) fcz_ctx_destroy(ctx);
+    });
+    {
+        const size_t JOB = 4096;
+        size_t job_index = 0;
+        Entries ents;
+        auto flush = [&]() {
+            if (!ents.n()) return;
+            DecompressJob j; j.index = job_index++; j.ents = std::move(ents);
+            ents = Entries();
+            queue.put(std::move(j));
+        };
+        for_each_entry(o, ents, flush, JOB);
+        queue.close();
+    }
+    for (std::thread& t : workers) t.join();
+    if (o.db) {
+        close(db_fd);
+        std::vector<Row> all;
+        for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
+        std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.job != b.job ? a.job < b.job : a.pos < b.pos; });
+        std::ofstream fi(output + ".index"), fl(output + ".lookup");
+        long long key = 0;
+        for (const Row& r : all) { fi << key << "\t" << r.off << "\t" << r.len << "\n"; fl << key << "\t" << r.name << "\t0\n"; key++; }
+        std::ofstream t(output + ".dbtype", std::ios::binary);
+        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+    }
+    if (o.json_stats) {
+        const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
+        printf("{\"mode\": \"decompress\", \"gpus\": %d, \"workers\": %d, \"records\": %llu, \"fcz_bytes\": %llu, \"text_bytes\": %llu, \"wall_s\": %.4f, "
+               "\"text_MB_per_s\": %.1f}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_fcz.load(),
+               (unsigned long long)n_text.load(), wall, wall > 0 ? n_text.load() / wall / 1e6 : 0.0);
+    }
+    return hard_fail ? 1 : 0;
 }
 
 // title and residue count straight from the FCZ header (src/foldcomp.h:118-136)

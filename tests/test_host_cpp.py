@@ -309,3 +309,35 @@ def test_cpp_compress_pipeline_many_jobs(tmp_path, golden):
     if torch.cuda.device_count() < 8:
         r = _run("compress", "-d", "-y", "--gpus", "8", str(d), str(tmp_path / "db8"))
         assert r.returncode != 0 and "device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_decompress_pipeline_database_round_trip(tmp_path, golden):
+    """database -> database through the decompress pipeline (3 workers): PDB text entries carry the MMseqs terminator like the
+    reference's `decompress --db` (src/main.cpp:659), keys follow the input order, every text == the reference's text"""
+    from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+    z, index = golden
+    names = [n for n in index if n.startswith("db:")]
+    w = DatabaseWriter(str(tmp_path / "fczdb"))
+    for rep in range(30):                                   # 720 entries: several jobs when the job size is small
+        for i, n in enumerate(names):
+            w.append(z[f"{n}/fcz"].tobytes(), rep * len(names) + i, f"{bytes(z[f'{n}/name']).decode()}_{rep}")
+    w.close()
+    r = _run("decompress", "-d", "-y", "--gpus", "1", "--workers-per-gpu", "3", "--json-stats", str(tmp_path / "fczdb"), str(tmp_path / "pdbdb"))
+    assert r.returncode == 0, r.stderr
+    rd = DatabaseReader(str(tmp_path / "pdbdb"))
+    assert len(rd) == 720 and list(rd.keys) == list(range(720))
+    for k in (0, 1, 23, 24, 100, 719):
+        n = names[k % len(names)]
+        e = rd.data(k)
+        assert e.endswith(b"\0") and e[:-1].decode("latin-1") == z[f"{n}/pdb0"].tobytes().decode("latin-1"), k
+        assert rd.name(k) == f"{bytes(z[f'{n}/name']).decode()}_{k // len(names)}"
+    rd.close()
+    # a directory of FCZ files -> a directory of PDB files through the same workers
+    r = _run("db-unpack", str(tmp_path / "fczdb"), str(tmp_path / "fczdir"))
+    assert r.returncode == 0
+    r = _run("decompress", "-y", "--gpus", "1", str(tmp_path / "fczdir"), str(tmp_path / "pdbdir"))
+    assert r.returncode == 0, r.stderr
+    assert len(os.listdir(tmp_path / "pdbdir")) == 720
+    n0 = names[5]
+    assert (tmp_path / "pdbdir" / f"{bytes(z[f'{n0}/name']).decode()}_7.pdb").read_bytes().decode("latin-1") == z[f"{n0}/pdb0"].tobytes().decode("latin-1")

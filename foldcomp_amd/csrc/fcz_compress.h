@@ -67,7 +67,8 @@ __device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint3
 
 constexpr uint64_t CK_LAST = 1ull << 63;   // res_sc_addr flag: last residue of its chain
 constexpr int CK_TILE = BLOCK;              // residues per tile
-constexpr int CK_CAP = 2304;                // staged atom records per pass (a typical tile: 257 * 8.35 = 2146)
+constexpr int CK_CAP = 2288;                // staged atom records per pass (a typical tile: 257 * 8.35 = 2146 +- 42); with the tables
+                                            // below the block's LDS stays under a third of the CU's 160 KB at the allocation granularity
 constexpr int CK_ZERO = CK_CAP;             // index of the all-zero record (missing atoms)
 
 // =====================================================================================================================
@@ -116,7 +117,11 @@ __global__ __launch_bounds__(BLOCK) void k_compress_index(fcz_chain_batch in, co
 // =====================================================================================================================
 struct alignas(16) compress_lds {
     float4 atom[CK_CAP + 1];                    // {x, y, z, code bits}; [CK_ZERO] = zeros
-    uint16_t idx[16][CK_TILE + 8];              // [canonical slot][residue in tile] -> atom record (row CK_TILE.. = successor)
+    uint16_t idx[FCZ_MAX_RES_ATOMS][CK_TILE + 8];   // [canonical slot][residue in tile] -> atom record (row CK_TILE.. = successor)
+    // Atom orders a residue is recognised in without a per-atom name lookup, per residue code, 16 bytes each:
+    //   canon[j] = atom code of canonical slot j,  altc[j] = atom code at position j of the alternative order (what AlphaFold
+    //   files and `decompress -a` use),  inv[sl] = position of canonical slot sl in the alternative order
+    uint32_t ord_canon[FCZ_N_RES_CODES][4], ord_altc[FCZ_N_RES_CODES][4], ord_inv[FCZ_N_RES_CODES][4];
     unsigned long long sc_addr[CK_TILE];        // res_sc_addr of the tile's residues
     uint32_t olo[CK_TILE + 2];                  // atom_off of residues 0..CK_TILE+1 of the tile (clamped)
     uint16_t scpre[CK_TILE];                    // pass-local exclusive prefix of side-chain torsion counts
@@ -165,6 +170,18 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
         const int rc = i / FCZ_MAX_RES_ATOMS, j = i % FCZ_MAX_RES_ATOMS;
         if (j < fcz_res_natoms[rc]) L.slot_of[rc][fcz_res_atom[rc][j]] = (uint8_t)j;
         L.prev[rc][j] = fcz_res_prev[rc][j];
+    }
+    if (t < FCZ_N_RES_CODES) {
+        const int rc = t, na = fcz_res_natoms[rc];
+        uint32_t can[4] = {0, 0, 0, 0}, alt[4] = {0, 0, 0, 0}, inv[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 16; j++) {
+            const bool in = j < na;
+            const uint32_t aj = in ? fcz_res_alt_slot[rc][j] : 0u;
+            can[j >> 2] |= (in ? (uint32_t)fcz_res_atom[rc][j] : 0xffu) << (8 * (j & 3));
+            alt[j >> 2] |= (in ? (uint32_t)fcz_res_atom[rc][aj] : 0xffu) << (8 * (j & 3));
+            if (in) inv[aj >> 2] |= (uint32_t)j << (8 * (aj & 3));
+        }
+        for (int d = 0; d < 4; d++) { L.ord_canon[rc][d] = can[d]; L.ord_altc[rc][d] = alt[d]; L.ord_inv[rc][d] = inv[d]; }
     }
     __syncthreads();
 
@@ -312,15 +329,39 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
             for (uint32_t rr = s + (uint32_t)t; rr <= last_row; rr += BLOCK) {
                 const uint32_t rc = L.rc[rr];
                 const uint32_t lo = L.olo[rr] - A0, hi = L.olo[rr + 1] - A0;
-                uint32_t codes[16], slots[16];
+                uint32_t codes[16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) codes[j] = (lo + j < hi) ? __float_as_uint(L.atom[lo + j].w) : 255u;
+                // Known order? The residue's first natoms codes equal the canonical list or the alternative-order list (four
+                // dword compares each). Then slot sl sits at lo + sl, resp. lo + inv[sl]: fourteen stores, no per-atom lookup.
+                // Names are distinct within a residue type, so "first atom of each name" is exactly that whatever follows.
+                const uint32_t na = L.natoms[rc];
+                uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 16; j++) pk[j >> 2] |= (codes[j] & 0xffu) << (8 * (j & 3));
+                uint32_t dc = 0u, da = 0u;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int vb = (int)na - 4 * d;                                       // bytes of this dword that belong to the residue
+                    const uint32_t m = vb >= 4 ? 0xffffffffu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
+                    dc |= (pk[d] ^ L.ord_canon[rc][d]) & m; da |= (pk[d] ^ L.ord_altc[rc][d]) & m;
+                }
+                const bool is_can = dc == 0u && hi - lo >= na, is_alt = da == 0u && hi - lo >= na;
+                if (is_can || is_alt) {
+#pragma unroll
+                    for (int sl = 0; sl < FCZ_MAX_RES_ATOMS; sl++) {
+                        const uint32_t pos = is_can ? (uint32_t)sl : ((L.ord_inv[rc][sl >> 2] >> (8 * (sl & 3))) & 0xffu);
+                        L.idx[sl][rr] = (uint16_t)((uint32_t)sl < na ? lo + pos : (uint32_t)CK_ZERO);
+                    }
+                    continue;
+                }
+                uint32_t slots[16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) slots[j] = (codes[j] < 40u) ? L.slot_of[rc][codes[j]] : 255u;
                 // every slot starts at the zero record; then descending j, so that the first occurrence of a name is
                 // the write that lands last (LDS operations of one wave execute in issue order)
 #pragma unroll
-                for (int sl = 0; sl < 16; sl++) L.idx[sl][rr] = (uint16_t)CK_ZERO;
+                for (int sl = 0; sl < FCZ_MAX_RES_ATOMS; sl++) L.idx[sl][rr] = (uint16_t)CK_ZERO;
                 uint32_t filled = 0;
 #pragma unroll
                 for (int j = 15; j >= 0; j--) {
@@ -363,7 +404,11 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
             // same bits; a bond angle's vectors a - b are the exact negatives of the dihedrals' b - a, and negation commutes
             // with every rounding involved), then the double part runs once per item (q uniform: one copy of its code).
             float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, bb4 = 0.f, bb5 = 0.f;
+#ifdef FCZ_ABL_NO_BB      // timing experiment only: the kernel without its backbone items
+            if (false) {
+#else
             if (my_win) {
+#endif
                 const v3 N0 = tile_atom(L, (uint32_t)t, 0), CA0 = tile_atom(L, (uint32_t)t, 1), C0 = tile_atom(L, (uint32_t)t, 2);
                 const v3 N1 = tile_atom(L, (uint32_t)t + 1u, 0), CA1 = tile_atom(L, (uint32_t)t + 1u, 1), C1 = tile_atom(L, (uint32_t)t + 1u, 2);
                 const v3 e0 = vsub(CA0, N0), e1 = vsub(C0, CA0), e2 = vsub(N1, C0), e3 = vsub(CA1, N1), e4 = vsub(C1, CA1);
@@ -398,6 +443,9 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
             for (uint32_t i = 0; i < 11; i++) {
                 const uint32_t ts = (uint32_t)t + i * BLOCK;
                 if (i * BLOCK >= n_sc) break;
+#ifdef FCZ_ABL_NO_SC      // timing experiment only: the kernel without its side-chain items
+                break;
+#endif
                 uint32_t q = 0;
                 if (ts < n_sc) {
                     const uint32_t res = L.item_res[ts];

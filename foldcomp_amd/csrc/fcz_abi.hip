@@ -88,8 +88,7 @@ struct fcz_ctx {
     uint64_t pdb_bytes = 0;
     uint32_t* pinned = nullptr;  // 16 words
     hipStream_t stream2 = nullptr;   // long chains of a decompress batch run beside the rest
-    hipStream_t stream3 = nullptr;   // k_res_index (memory-bound, 62 registers) runs beside k_backbone (issue-bound, 2 wavefronts per SIMD)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_cu = 256;
     bool timing = false;
     bool keep_first_angle = false;
@@ -102,12 +101,12 @@ struct fcz_ctx {
 namespace {
 
 struct span_guard {
-    fcz_ctx* ctx; hipEvent_t a = nullptr, b = nullptr; const char* name; hipStream_t st;
-    span_guard(fcz_ctx* c, const char* n, hipStream_t s = nullptr) : ctx(c), name(n), st(s ? s : c->stream) {
-        if (ctx->timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    fcz_ctx* ctx; hipEvent_t a = nullptr, b = nullptr; const char* name;
+    span_guard(fcz_ctx* c, const char* n) : ctx(c), name(n) {
+        if (ctx->timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
     }
     ~span_guard() {
-        if (ctx->timing) { (void)hipEventRecord(b, st); ctx->spans.push_back({name, a, b}); }
+        if (ctx->timing) { (void)hipEventRecord(b, ctx->stream); ctx->spans.push_back({name, a, b}); }
     }
 };
 
@@ -198,9 +197,6 @@ int fcz_ctx_create(int device, fcz_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FCZ_E_HIP; }
     if (hipHostMalloc((void**)&c->pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FCZ_E_HIP; }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { fcz_ctx_destroy(c); return FCZ_E_HIP; }
     *out = c;
@@ -217,10 +213,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_fork3) (void)hipEventDestroy(c->ev_fork3);
-    if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -686,20 +679,6 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     int rc = ensure_sizes(ctx, blob_dev, off_dev, n, &R, &max_seg, &max_nseg, &n_long);
     if (rc) return rc;
     if (R == 0) return FCZ_OK;
-    // k_res_index needs only the records and the offsets of the sizes pass: it runs on its own stream beside the backbone kernel
-    // (which is issue-bound at two wavefronts per SIMD and leaves both memory bandwidth and a third wavefront slot unused)
-    rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
-    rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;
-    rc = ctx->res_sc.ensure(sizeof(uint32_t) * 3 * (size_t)R); if (rc) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev_fork3, ctx->stream));
-    HIP_TRY(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork3, 0));
-    {
-        span_guard g(ctx, "decompress_index", ctx->stream3);
-        hipLaunchKernelGGL(k_res_index, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream3, blob_dev, off_dev, n,
-                           res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
-                           ctx->res_sc.as<uint32_t>(), *out_dev);
-    }
-    HIP_TRY(hipEventRecord(ctx->ev_join3, ctx->stream3));
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     const uint32_t* perm = ctx->len_perm.as<uint32_t>();
     const char* dbg_parts = getenv("FCZ_DEBUG_FAST_PARTS");   // 1: backbone only, 2: side chains only (debugging aid)
@@ -762,7 +741,15 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
             if (split_long) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     }
-    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));   // the per-residue index (launched beside the backbone kernel) is complete
+    rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
+    rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;
+    rc = ctx->res_sc.ensure(sizeof(uint32_t) * 3 * (size_t)R); if (rc) return rc;
+    {
+        span_guard g(ctx, "decompress_index");
+        hipLaunchKernelGGL(k_res_index, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
+                           res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
+                           ctx->res_sc.as<uint32_t>(), *out_dev);
+    }
     {
         span_guard g(ctx, "decompress_sidechain");
         const uint32_t n_tiles = grid_for(R, SC_TILE);

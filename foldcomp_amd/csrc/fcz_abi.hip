@@ -68,6 +68,7 @@ struct fcz_ctx {
     dev_buf sizes;      // compress: C x u64
     dev_buf scan_tmp;   // block partials of the device scans
     dev_buf res_sc_addr; // compress: residue -> output byte offset of its side-chain torsion bytes
+    dev_buf tile_work;   // compress: per 256-residue tile flag + list + count of the tiles left to the block-tile kernel
     // decompress: the totals and the length order computed by fcz_decompress_sizes_dev are reused by the
     // fcz_decompress_batch_dev call that follows on the same entries
     const void* sized_blob = nullptr; const void* sized_off = nullptr; uint32_t sized_n = 0, sized_R = 0, sized_maxseg = 0, sized_maxnseg = 0, sized_nlong = 0;
@@ -208,7 +209,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
+    c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
     for (auto& b : c->stage) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -437,10 +438,19 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
         hipLaunchKernelGGL(k_compress_index, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, ctx->res_sc_addr.as<uint64_t>());
     }
     if (in->n_residues) {
+        // wavefront-private tiles first; what does not fit them (atom-rich stretches, the tail of the arrays) is listed per
+        // 256-residue tile and taken by the block-tile kernel, which handles every special case
         span_guard g(ctx, "compress_angles");
         const uint32_t n_tiles = grid_for(in->n_residues, CK_TILE);
-        const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_COMPRESS_MIN_BLOCKS * 4u);
-        hipLaunchKernelGGL(k_compress_angles, dim3(blocks), dim3(BLOCK), 0, ctx->stream, *in, n_tiles,
+        const uint32_t n_wtiles = grid_for(in->n_residues, CW_RES);
+        rc = ctx->tile_work.ensure(sizeof(uint32_t) * (2 * (size_t)n_tiles + 4)); if (rc) return rc;
+        uint32_t* flags = ctx->tile_work.as<uint32_t>(); uint32_t* list = flags + n_tiles; uint32_t* count = list + n_tiles;
+        HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (2 * (size_t)n_tiles + 4), ctx->stream));
+        const uint32_t blocks_w = std::min<uint32_t>(grid_for(n_wtiles, WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 3u * 4u);
+        hipLaunchKernelGGL(k_compress_angles_w, dim3(blocks_w), dim3(BLOCK), 0, ctx->stream, *in, n_wtiles, ctx->res_sc_addr.as<uint64_t>(), out_dev,
+                           ctx->ang.as<float>(), flags, list, count);
+        const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_COMPRESS_MIN_BLOCKS);
+        hipLaunchKernelGGL(k_compress_angles, dim3(blocks), dim3(BLOCK), 0, ctx->stream, *in, n_tiles, (const uint32_t*)list, (const uint32_t*)count,
                            ctx->res_sc_addr.as<uint64_t>(), out_dev, ctx->ang.as<float>());
     }
     {

@@ -158,8 +158,11 @@ __device__ __noinline__ atom_quad load_atoms_tail(const float* __restrict__ x, c
 #endif
 
 __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_BLOCKS)
-void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out,
-                       float* __restrict__ ang) {
+void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles_all, const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ tile_count,
+                       const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out, float* __restrict__ ang) {
+    // tile_list != null: only the listed 256-residue tiles (the ones k_compress_angles_w left to this kernel); else all of them
+    const uint32_t n_tiles = tile_list ? *tile_count : n_tiles_all;
+    auto tile_of = [&](uint32_t k) -> uint32_t { return tile_list ? tile_list[k < n_tiles ? k : (n_tiles ? n_tiles - 1 : 0)] : k; };
     __shared__ compress_lds L;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     for (int i = t; i < FCZ_N_RES_CODES * 40; i += BLOCK) (&L.slot_of[0][0])[i] = 255;
@@ -195,7 +198,7 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
     //      at the load instead of a tile later. No global store is issued between these loads and the end of the tile's
     //      items (results stay in registers), so nothing forces the memory queue to drain early. ----
     struct meta { uint32_t olo, ox, rc, rc_succ, a0_next, e_next; unsigned long long sa; };
-    auto load_meta = [&](uint32_t tile) -> meta {
+    auto load_meta = [&](uint32_t tile, uint32_t tile_next) -> meta {
         const size_t r_lo = (size_t)tile * CK_TILE;
         const size_t r = r_lo + (size_t)t;
         auto cl = [&](size_t x) -> size_t { return x < Rz ? x : Rz; };
@@ -205,7 +208,7 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
         m.rc = in.res_code[r < Rz ? r : Rz - 1];
         m.rc_succ = in.res_code[r_lo + CK_TILE < Rz ? r_lo + CK_TILE : Rz - 1];
         m.sa = res_sc_addr[r < Rz ? r : Rz - 1];
-        const size_t r_n = r_lo + (size_t)gridDim.x * CK_TILE;               // this block's next tile
+        const size_t r_n = (size_t)tile_next * CK_TILE;                      // this block's next tile
         m.a0_next = in.atom_off[cl(r_n)];
         m.e_next = in.atom_off[cl(r_n + CK_TILE + 1)];
         return m;
@@ -233,17 +236,19 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
     // (and the 16-byte reads of its last group stay inside the arrays: the last tile of the batch takes the other path)
     auto simple_tile = [&](uint32_t a0, uint32_t e) -> bool { return e - a0 <= (uint32_t)CK_CAP && (size_t)e + 4 <= (size_t)in.n_atoms; };
 
-    meta mcur = load_meta(blockIdx.x);
+    if (blockIdx.x >= n_tiles) return;
+    meta mcur = load_meta(tile_of(blockIdx.x), tile_of(blockIdx.x + gridDim.x));
     uint32_t a0_cur, e_cur;
     {
-        const size_t r_lo = (size_t)blockIdx.x * CK_TILE;
+        const size_t r_lo = (size_t)tile_of(blockIdx.x) * CK_TILE;
         a0_cur = in.atom_off[r_lo < Rz ? r_lo : Rz];
         e_cur = in.atom_off[r_lo + CK_TILE + 1 < Rz ? r_lo + CK_TILE + 1 : Rz];
     }
     bool pre_cur = simple_tile(a0_cur, e_cur);
     if (pre_cur) issue_atoms(a0_cur, e_cur - a0_cur);
 
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint32_t tk = blockIdx.x; tk < n_tiles; tk += gridDim.x) {
+        const uint32_t tile = tile_of(tk);
         const uint32_t r_lo = tile * CK_TILE;
         const uint32_t nres = (R - r_lo < (uint32_t)CK_TILE) ? R - r_lo : (uint32_t)CK_TILE;
         // ---- park the prefetched metadata (and atoms) in LDS ----
@@ -273,10 +278,10 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
             if (i1 < cnts) L.atom[i1] = float4{tx, ty, tz, __uint_as_float(tc)};
         }
         // ---- prefetch of this block's next tile ----
-        const uint32_t tile_n = tile + gridDim.x;
+        const uint32_t tk_n = tk + gridDim.x;
         const uint32_t a0_n = mcur.a0_next, e_n = mcur.e_next;
-        const bool pre_n = tile_n < n_tiles && simple_tile(a0_n, e_n);
-        const meta mnext = load_meta(tile_n < n_tiles ? tile_n : tile);
+        const bool pre_n = tk_n < n_tiles && simple_tile(a0_n, e_n);
+        const meta mnext = load_meta(tk_n < n_tiles ? tile_of(tk_n) : tile, tile_of(tk_n + gridDim.x));
         if (pre_n) issue_atoms(a0_n, e_n - a0_n);
         __syncthreads();
 
@@ -478,6 +483,252 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles, const uint64_t* __r
             s = e;
         }
         mcur = mnext; a0_cur = a0_n; e_cur = e_n; pre_cur = pre_n;
+    }
+}
+
+// =====================================================================================================================
+// k_compress_angles_w: the same stage with wavefront-private tiles
+// =====================================================================================================================
+// k_compress_angles synchronises its four wavefronts five times per tile; its phases add up (measured: 3.2 ms of staging /
+// table / list work + 1.95 ms backbone items + 1.95 ms side-chain items = the kernel's 7.4 ms per 262 144 chains) because all
+// wavefronts of a block are in the same phase. Here a wavefront owns its tile: 64 residue rows = 63 residues + the successor
+// of the last one, lane = row. It loads, stages, indexes and evaluates only what it staged itself, so nothing but the order of
+// its own LDS operations synchronises it, and the twelve wavefronts of a CU drift apart and fill each other's stalls. There is no
+// register prefetch (the other wavefronts hide the load latency). A tile that does not fit (more than CW_CAP atoms: explicit
+// hydrogens; or the last atoms of the batch, where 16-byte reads would run past the arrays) is not processed here: its
+// 256-residue tile(s) go on a list for k_compress_angles, which owns every special case.
+#ifndef FCZ_CW_UNROLL_BB
+#define FCZ_CW_UNROLL_BB 2
+#endif
+#ifndef FCZ_CW_UNROLL_SC
+#define FCZ_CW_UNROLL_SC 2
+#endif
+constexpr int CW_ROWS = WAVE;               // residue rows per wavefront tile
+constexpr int CW_RES = WAVE - 1;            // residues a tile owns (the last row is the next tile's first residue)
+constexpr int CW_CAP = 592;                 // staged atom records per tile (a typical tile: 64 * 8.35 = 535 +- 21)
+constexpr int CW_ZERO = CW_CAP;
+constexpr int CW_NV = (CW_CAP + 4 * WAVE - 1) / (4 * WAVE);   // rounds of four atoms per lane
+
+struct alignas(16) compress_wave_lds {
+    float4 atom[CW_CAP + 1];                    // {x, y, z, code bits}; [CW_ZERO] = zeros
+    uint16_t idx[FCZ_MAX_RES_ATOMS][CW_ROWS];   // [canonical slot][row] -> atom record
+    uint32_t sc_rel[CW_ROWS];                   // res_sc_addr of the row minus that of row 0
+    uint16_t olo[CW_ROWS + 2];                  // first atom record of each row (+ end of the last row)
+    uint16_t scpre[CW_ROWS];                    // exclusive prefix of side-chain torsion counts
+    uint8_t rc[CW_ROWS];
+    uint8_t item_res[CW_RES * 11 + 11];         // side-chain item -> row
+};
+struct alignas(16) compress_tables_lds {        // per block, read-only after the prologue
+    uint8_t slot_of[FCZ_N_RES_CODES][40];
+    uint16_t prev[FCZ_N_RES_CODES][FCZ_MAX_RES_ATOMS];
+    uint8_t natoms[32];
+    uint32_t ord_canon[FCZ_N_RES_CODES][4], ord_altc[FCZ_N_RES_CODES][4], ord_inv[FCZ_N_RES_CODES][4];
+};
+
+// ordering point inside one wavefront: LDS operations of a wavefront execute in issue order, so all that is needed is that the
+// compiler keeps the memory operations on their side of it
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+__device__ __forceinline__ v3 wtile_atom(const compress_wave_lds& W, uint32_t row, uint32_t slot) {
+    const float4 a = W.atom[W.idx[slot][row]];
+    return v3{a.x, a.y, a.z};
+}
+
+__global__ __launch_bounds__(BLOCK, 3)
+void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out,
+                         float* __restrict__ ang, uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_count) {
+    __shared__ compress_wave_lds WL[WAVES_PER_BLOCK];
+    __shared__ compress_tables_lds T;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int i = t; i < FCZ_N_RES_CODES * 40; i += BLOCK) (&T.slot_of[0][0])[i] = 255;
+    if (t < 32) T.natoms[t] = fcz_res_natoms[t < 24 ? t : 23];
+    __syncthreads();
+    for (int i = t; i < FCZ_N_RES_CODES * FCZ_MAX_RES_ATOMS; i += BLOCK) {
+        const int rc = i / FCZ_MAX_RES_ATOMS, j = i % FCZ_MAX_RES_ATOMS;
+        if (j < fcz_res_natoms[rc]) T.slot_of[rc][fcz_res_atom[rc][j]] = (uint8_t)j;
+        T.prev[rc][j] = fcz_res_prev[rc][j];
+    }
+    if (t < FCZ_N_RES_CODES) {
+        const int rc = t, na = fcz_res_natoms[rc];
+        uint32_t can[4] = {0, 0, 0, 0}, alt[4] = {0, 0, 0, 0}, inv[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 16; j++) {
+            const bool inr = j < na;
+            const uint32_t aj = inr ? fcz_res_alt_slot[rc][j] : 0u;
+            can[j >> 2] |= (inr ? (uint32_t)fcz_res_atom[rc][j] : 0xffu) << (8 * (j & 3));
+            alt[j >> 2] |= (inr ? (uint32_t)fcz_res_atom[rc][aj] : 0xffu) << (8 * (j & 3));
+            if (inr) inv[aj >> 2] |= (uint32_t)j << (8 * (aj & 3));
+        }
+        for (int d = 0; d < 4; d++) { T.ord_canon[rc][d] = can[d]; T.ord_altc[rc][d] = alt[d]; T.ord_inv[rc][d] = inv[d]; }
+    }
+    __syncthreads();                             // the only block-level synchronisation of the kernel
+
+    compress_wave_lds& W = WL[wave];
+    const uint32_t R = in.n_residues;
+    const size_t Rz = R;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    for (uint32_t wt = blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wave; wt < n_wtiles; wt += n_waves) {
+        const uint32_t r_lo = wt * CW_RES;
+        const size_t r = (size_t)r_lo + (size_t)lane;
+        const bool in_r = r < Rz;
+        const uint32_t olo_g = in.atom_off[r < Rz ? r : Rz], ohi_g = in.atom_off[r + 1 < Rz ? r + 1 : Rz];
+        const uint32_t rc_g = in.res_code[in_r ? r : Rz - 1];
+        const unsigned long long sa = in_r ? res_sc_addr[r] : CK_LAST;
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)olo_g);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ohi_g, WAVE - 1);
+        const uint32_t cnt = e - a0;
+        if (cnt > (uint32_t)CW_CAP || (size_t)e + 4 > (size_t)in.n_atoms) {
+            // not for this kernel: the 256-residue tiles that hold the tile's own residues go on the list of k_compress_angles
+            if (lane == 0) {
+                const uint32_t own_last = (r_lo + CW_RES - 1 < R ? r_lo + CW_RES - 1 : R - 1);
+                for (uint32_t tk = r_lo / CK_TILE; tk <= own_last / CK_TILE; tk++)
+                    if (atomicExch(&tile_flags[tk], 1u) == 0u) tile_list[atomicAdd(tile_count, 1u)] = tk;
+            }
+            continue;
+        }
+        wave_sync();          // the previous tile's last LDS reads are issued before anything is overwritten
+        // ---- stage: metadata of the rows, atoms of the tile ----
+        const uint32_t rc = (in_r && rc_g < 24u) ? rc_g : 23u;
+        W.olo[lane] = (uint16_t)(olo_g - a0);
+        if (lane == WAVE - 1) W.olo[WAVE] = (uint16_t)(ohi_g - a0);
+        W.rc[lane] = (uint8_t)rc;
+        const unsigned long long sa0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sa >> 32)) << 32) |
+                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa);
+        const unsigned long long base0 = sa0 & ~CK_LAST;
+        W.sc_rel[lane] = (uint32_t)((sa & ~CK_LAST) - base0);
+        const bool is_last = (sa & CK_LAST) != 0;
+        if (lane == 0) W.atom[CW_ZERO] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CW_NV; u++) {
+            const uint32_t i4 = 4 * ((uint32_t)u * WAVE + (uint32_t)lane);
+            if (i4 < cnt) {
+                const size_t g = (size_t)a0 + i4;
+                const float4 x = ld_f4(in.x + g), y = ld_f4(in.y + g), z = ld_f4(in.z + g);
+                const uint32_t c = ld_u32(in.atom_code + g);
+                if (i4 + 0 < (uint32_t)CW_CAP) W.atom[i4 + 0] = float4{x.x, y.x, z.x, __uint_as_float(c & 0xffu)};
+                if (i4 + 1 < (uint32_t)CW_CAP) W.atom[i4 + 1] = float4{x.y, y.y, z.y, __uint_as_float((c >> 8) & 0xffu)};
+                if (i4 + 2 < (uint32_t)CW_CAP) W.atom[i4 + 2] = float4{x.z, y.z, z.z, __uint_as_float((c >> 16) & 0xffu)};
+                if (i4 + 3 < (uint32_t)CW_CAP) W.atom[i4 + 3] = float4{x.w, y.w, z.w, __uint_as_float(c >> 24)};
+            }
+        }
+        wave_sync();          // LDS operations of a wavefront execute in issue order: rows read what was staged
+        // ---- slot index table of this lane's row ----
+        {
+            const uint32_t lo = olo_g - a0, hi = ohi_g - a0;
+            uint32_t codes[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) codes[j] = (lo + j < hi) ? __float_as_uint(W.atom[lo + j].w) : 255u;
+            const uint32_t na = T.natoms[rc];
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 16; j++) pk[j >> 2] |= (codes[j] & 0xffu) << (8 * (j & 3));
+            uint32_t dc = 0u, da = 0u;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int vb = (int)na - 4 * d;
+                const uint32_t m = vb >= 4 ? 0xffffffffu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
+                dc |= (pk[d] ^ T.ord_canon[rc][d]) & m; da |= (pk[d] ^ T.ord_altc[rc][d]) & m;
+            }
+            const bool is_can = dc == 0u && hi - lo >= na, is_alt = da == 0u && hi - lo >= na;
+            if (is_can || is_alt) {
+#pragma unroll
+                for (int sl = 0; sl < FCZ_MAX_RES_ATOMS; sl++) {
+                    const uint32_t pos = is_can ? (uint32_t)sl : ((T.ord_inv[rc][sl >> 2] >> (8 * (sl & 3))) & 0xffu);
+                    W.idx[sl][lane] = (uint16_t)((uint32_t)sl < na ? lo + pos : (uint32_t)CW_ZERO);
+                }
+            } else {
+                uint32_t slots[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) slots[j] = (codes[j] < 40u) ? T.slot_of[rc][codes[j]] : 255u;
+#pragma unroll
+                for (int sl = 0; sl < FCZ_MAX_RES_ATOMS; sl++) W.idx[sl][lane] = (uint16_t)CW_ZERO;
+                uint32_t filled = 0;
+#pragma unroll
+                for (int j = 15; j >= 0; j--) {
+                    const uint32_t sl = slots[j];
+                    if (sl != 255u) { filled |= 1u << sl; W.idx[sl][lane] = (uint16_t)(lo + j); }
+                }
+                for (uint32_t i = lo + 16; i < hi; i++) {
+                    const uint32_t code = __float_as_uint(W.atom[i].w);
+                    const uint32_t sl = code < 40u ? T.slot_of[rc][code] : 255u;
+                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; W.idx[sl][lane] = (uint16_t)i; }
+                }
+            }
+        }
+        // ---- side-chain item numbering: rows 0..62 own items ----
+        const bool mine = in_r && lane < CW_RES;
+        const bool my_win = mine && !is_last;
+        const uint32_t my_cnt = mine ? (uint32_t)T.natoms[rc] - 3u : 0u;
+        uint32_t n_sc;
+        const uint32_t my_pre = wave_excl_scan(my_cnt, lane, &n_sc);
+        W.scpre[lane] = (uint16_t)my_pre;
+        for (uint32_t j = 0; j < my_cnt; j++) W.item_res[my_pre + j] = (uint8_t)lane;
+        wave_sync();
+        // ---- backbone items of the window (this row, next row): shared ingredients as in k_compress_angles ----
+        float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, bb4 = 0.f, bb5 = 0.f;
+        if (my_win) {
+            const uint32_t rw = (uint32_t)lane;
+            const v3 N0 = wtile_atom(W, rw, 0), CA0 = wtile_atom(W, rw, 1), C0 = wtile_atom(W, rw, 2);
+            const v3 N1 = wtile_atom(W, rw + 1u, 0), CA1 = wtile_atom(W, rw + 1u, 1), C1 = wtile_atom(W, rw + 1u, 2);
+            const v3 e0 = vsub(CA0, N0), e1 = vsub(C0, CA0), e2 = vsub(N1, C0), e3 = vsub(CA1, N1), e4 = vsub(C1, CA1);
+            const v3 u0 = vcross(e0, e1), u1 = vcross(e1, e2), u2 = vcross(e2, e3), u3 = vcross(e3, e4);
+            const float su0 = vdot_ref(u0, u0), su1 = vdot_ref(u1, u1), su2 = vdot_ref(u2, u2), su3 = vdot_ref(u3, u3);
+            const float se1 = vdot_ref(e1, e1), se2 = vdot_ref(e2, e2), se3 = vdot_ref(e3, e3), se4 = vdot_ref(e4, e4);
+            const float ip0 = vdot_ref(u0, u1), ip1 = vdot_ref(u1, u2), ip2 = vdot_ref(u2, u3);
+            const bool ng0 = vdot_ref(u0, vcross(u1, e1)) < 0.0f, ng1 = vdot_ref(u1, vcross(u2, e2)) < 0.0f, ng2 = vdot_ref(u2, vcross(u3, e3)) < 0.0f;
+            const float ip3 = -vdot_ref(e1, e2), ip4 = -vdot_ref(e2, e3), ip5 = -vdot_ref(e3, e4);
+#pragma unroll FCZ_CW_UNROLL_BB
+            for (uint32_t q = 0; q < 6; q++) {
+                const float ip = q == 0 ? ip0 : q == 1 ? ip1 : q == 2 ? ip2 : q == 3 ? ip3 : q == 4 ? ip4 : ip5;
+                const float sa_ = q == 0 ? su0 : q == 1 ? su1 : q == 2 ? su2 : q == 3 ? se1 : q == 4 ? se2 : se3;
+                const float sb_ = q == 0 ? su1 : q == 1 ? su2 : q == 2 ? su3 : q == 3 ? se2 : q == 4 ? se3 : se4;
+                const float ct = vcos_theta_pre(ip, sa_, sb_);
+                float v = acos_deg(ct);
+                if (q < 3) {
+                    if (v != v) v = (ct < 0.0f) ? 180.0f : 0.0f;
+                    const bool ng = q == 0 ? ng0 : q == 1 ? ng1 : ng2;
+                    if (ng) v = -1.0f * v;
+                }
+                bb1 = q == 0 ? v : bb1; bb2 = q == 1 ? v : bb2; bb0 = q == 2 ? v : bb0;
+                bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
+            }
+        }
+        // ---- side-chain torsion bytes: flat item list, lane = item ----
+        uint32_t scb[3] = {0u, 0u, 0u};
+#pragma unroll FCZ_CW_UNROLL_SC
+        for (uint32_t i = 0; i < 11; i++) {
+            const uint32_t ts = (uint32_t)lane + i * WAVE;
+            if (i * WAVE >= n_sc) break;
+            uint32_t q = 0;
+            if (ts < n_sc) {
+                const uint32_t res = W.item_res[ts];
+                const uint32_t j = 3 + ts - W.scpre[res];
+                const uint32_t pk2 = T.prev[W.rc[res]][j];
+                const v3 a = wtile_atom(W, res, pk2 & 15u), b = wtile_atom(W, res, (pk2 >> 4) & 15u), cc = wtile_atom(W, res, (pk2 >> 8) & 15u);
+                const v3 d = wtile_atom(W, res, j);
+                q = sidechain_torsion_byte(a, b, cc, d) & 0xffu;
+            }
+            const uint32_t sh = q << (8 * (i & 3u));
+            scb[0] |= (i < 4) ? sh : 0u; scb[1] |= (i >= 4 && i < 8) ? sh : 0u; scb[2] |= (i >= 8) ? sh : 0u;
+        }
+        // ---- results out ----
+        if (my_win) {
+            float* ap = ang + r;
+            ap[0] = bb0; ap[Rz] = bb1; ap[2 * Rz] = bb2; ap[3 * Rz] = bb3; ap[4 * Rz] = bb4; ap[5 * Rz] = bb5;
+        }
+#pragma unroll 1
+        for (uint32_t i = 0; i < 11; i++) {
+            const uint32_t ts = (uint32_t)lane + i * WAVE;
+            if (i * WAVE >= n_sc) break;
+            if (ts < n_sc) {
+                const uint32_t res = W.item_res[ts];
+                const uint32_t jj = ts - W.scpre[res];
+                const uint32_t w = (i < 4) ? scb[0] : (i < 8 ? scb[1] : scb[2]);
+                out[base0 + W.sc_rel[res] + jj] = (uint8_t)(w >> (8 * (i & 3u)));
+            }
+        }
     }
 }
 

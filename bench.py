@@ -279,11 +279,11 @@ class Workload:
         per residue; hand-over arrays between kernels (angles, blended backbone, per-residue index) are not algorithmic traffic"""
         A = self.M / self.R; f = self.fcz_bytes / self.R; R = self.R
         sc = (A - 3.0) + 1.0                          # side-chain torsion bytes + the B-factor byte, per residue
-        return {"k_compress_angles": (13 * A + (A - 3.0)) * R, "k_compress_index": 1.0 * R, "k_compress_pack": (9 + f - (A - 3.0)) * R,
+        return {"k_compress_angles_w": (13 * A + (A - 3.0)) * R, "k_compress_index": 1.0 * R, "k_compress_pack": (9 + f - (A - 3.0)) * R,
                 "k_backbone": (f - sc) * R, "k_res_index": (sc + 4) * R, "k_sidechain": 12 * A * R}
 
 
-KERNEL_SPANS = {"k_compress_angles": "compress_angles", "k_compress_index": "compress_index", "k_compress_pack": "compress_pack",
+KERNEL_SPANS = {"k_compress_angles_w": "compress_angles", "k_compress_index": "compress_index", "k_compress_pack": "compress_pack",
                 "k_backbone": "decompress_backbone", "k_res_index": "decompress_index", "k_sidechain": "decompress_sidechain"}
 ALL_SPANS = ("compress_sizes", "compress_index", "compress_angles", "compress_pack", "decompress_sizes", "decompress_backbone",
              "decompress_index", "decompress_sidechain")
@@ -733,7 +733,7 @@ def main():
         ktime["compress"] = ktime["compress_index"] + ktime["compress_angles"] + ktime["compress_pack"]
         # compress is three launches; the angle kernel reads the atoms and writes the side-chain bytes, the pack kernel
         # reads codes/B-factors/offsets and writes the rest of the record ([6][R] angle scratch = hand-over, not counted)
-        kern = {"k_compress_angles": ((13 * A + (A - 3.0)) * R, ktime["compress_angles"]),
+        kern = {"k_compress_angles_w": ((13 * A + (A - 3.0)) * R, ktime["compress_angles"]),
                 "k_compress_index": (1 * R, ktime["compress_index"]),
                 "k_compress_pack": ((9 + fcz_per_res - (A - 3.0)) * R, ktime["compress_pack"]),
                 "k_backbone": ((fcz_per_res - sc_bytes) * R, ktime["decompress_backbone"]),

@@ -25,12 +25,12 @@ def test_traffic_table_covers_the_reported_kernels():
     b = _bench()
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert t["residues_per_chain"] == 350
-    for k in ("k_compress_angles", "k_backbone", "k_sidechain", "k_compress_pack", "k_res_index"):
+    for k in ("k_compress_angles_w", "k_backbone", "k_sidechain", "k_compress_pack", "k_res_index"):
         assert k in t["kernels"], k
         traffic, src = b.measured_traffic(k, 350_000_000, 350)
         assert traffic and traffic > 0 and "pmc" in src
     # other chain lengths have no measured profile: null, never a made-up number
-    assert b.measured_traffic("k_compress_angles", 1000, 123) == (None, None)
+    assert b.measured_traffic("k_compress_angles_w", 1000, 123) == (None, None)
     assert b.measured_traffic("no_such_kernel", 1000, 350) == (None, None)
 
 

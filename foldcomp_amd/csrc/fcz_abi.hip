@@ -878,3 +878,14 @@ extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, ui
     return FCZ_OK;
 }
 
+
+#ifdef FCZ_CW_TIMING
+// measurement aid: read and clear the phase counters of k_compress_angles_w
+extern "C" int fcz_debug_cw_timing(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fcz::g_cw_timing), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_cw_timing), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

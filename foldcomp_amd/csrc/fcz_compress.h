@@ -54,6 +54,25 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
 }
 
+// exclusive prefix sum over the wavefront on the DPP network: Hillis-Steele inside each row of 16 (zeros shift in), then the
+// row totals travel with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3). Six dependent VALU instructions instead of
+// six LDS-crossbar round trips (wave_excl_scan, fcz_kernels.h)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32_or0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x, uint32_t* total) {
+    uint32_t v = x;
+    v += dpp_u32_or0<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_u32_or0<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_u32_or0<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_u32_or0<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_u32_or0<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_u32_or0<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)v, WAVE - 1);
+    return v - x;
+}
+
 // std::min_element / std::max_element keep the FIRST of equal elements (reference src/discretizer.cpp:27-28).
 // Equal floats with different bits are only +0/-0, so a plain value reduction is exact unless the extremum is a
 // zero; only then this (value, index) reduction over the stored values runs.
@@ -548,6 +567,13 @@ __device__ __forceinline__ v3 wtile_rec(const compress_wave_lds& W, uint32_t lo,
     return v3{a.x, a.y, a.z};
 }
 
+#ifdef FCZ_CW_TIMING
+// measurement aid (not built into the product): wavefront-cycles spent between the phase boundaries of k_compress_angles_w
+__device__ unsigned long long g_cw_timing[8];
+#define CW_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define CW_STAMP(i)
+#endif
 __global__ __launch_bounds__(BLOCK, 3)
 void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out,
                          float* __restrict__ ang, uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_count) {
@@ -592,6 +618,9 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
     };
     const uint32_t wt0 = blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wave;
     wmeta cur = load_meta(wt0 < n_wtiles ? wt0 : 0u), nxt = cur;
+#ifdef FCZ_CW_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (uint32_t wt = wt0; wt < n_wtiles; wt += n_waves, cur = nxt) {
         const uint32_t r_lo = wt * CW_RES;
         const size_t r = (size_t)r_lo + (size_t)lane;
@@ -614,6 +643,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             continue;
         }
         wave_sync();          // the previous tile's last LDS reads are issued before anything is overwritten
+        CW_STAMP(0)
         // ---- stage: atoms of the tile (record per lane and round), codes (dword of four per lane and round) ----
         const uint32_t rc = (in_r && rc_g < 24u) ? rc_g : 23u;
         const uint32_t lo = olo_g - a0, hi = ohi_g - a0;
@@ -649,6 +679,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             }
         }
         wave_sync();          // LDS operations of a wavefront execute in issue order: rows read what was staged
+        CW_STAMP(1)
         // ---- slot table row of this lane's residue ----
         const uint32_t na = T.natoms[rc];
         uint32_t row0;        // positions of N, CA, C (bytes 0..2)
@@ -698,11 +729,12 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
         const bool my_win = mine && !is_last;
         const uint32_t my_cnt = mine ? na - 3u : 0u;
         uint32_t n_sc;
-        const uint32_t my_pre = wave_excl_scan(my_cnt, lane, &n_sc);
+        const uint32_t my_pre = wave_excl_scan_dpp(my_cnt, &n_sc);
         W.rowinfo[lane] = lo | (my_pre << 10) | (rc << 20);
         for (uint32_t j = 0; j < my_cnt; j++) W.item_res[my_pre + j] = (uint8_t)lane;
         const uint32_t row0_next = (uint32_t)__shfl_down((int)row0, 1, WAVE);
         wave_sync();
+        CW_STAMP(2)
         // ---- backbone items of the window (this row, next row): shared ingredients as in k_compress_angles ----
         float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, bb4 = 0.f, bb5 = 0.f;
         if (my_win) {
@@ -731,44 +763,36 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
                 bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
             }
         }
-        // ---- side-chain torsion bytes: flat item list, lane = item ----
-        uint32_t scb[3] = {0u, 0u, 0u};
-#pragma unroll FCZ_CW_UNROLL_SC
-        for (uint32_t i = 0; i < 11; i++) {
-            const uint32_t ts = (uint32_t)lane + i * WAVE;
-            if (i * WAVE >= n_sc) break;
-            uint32_t q = 0;
-            if (ts < n_sc) {
-                const uint32_t res = W.item_res[ts];
-                const uint32_t info = W.rowinfo[res];
-                const uint32_t rlo = info & 0x3ffu;
-                const uint32_t j = 3 + ts - ((info >> 10) & 0x3ffu);
-                const uint32_t pk2 = T.prev[info >> 20][j];
-                const uint8_t* row8 = reinterpret_cast<const uint8_t*>(&W.idx8[res][0]);
-                const v3 a = wtile_rec(W, rlo, row8[pk2 & 15u]), b = wtile_rec(W, rlo, row8[(pk2 >> 4) & 15u]), cc = wtile_rec(W, rlo, row8[(pk2 >> 8) & 15u]);
-                const v3 d = wtile_rec(W, rlo, row8[j]);
-                q = sidechain_torsion_byte(a, b, cc, d) & 0xffu;
-            }
-            const uint32_t sh = q << (8 * (i & 3u));
-            scb[0] |= (i < 4) ? sh : 0u; scb[1] |= (i >= 4 && i < 8) ? sh : 0u; scb[2] |= (i >= 8) ? sh : 0u;
-        }
-        // ---- results out ----
+        // angles out right away: the six registers are free for the side-chain items
         if (my_win) {
             float* ap = ang + r;
             ap[0] = bb0; ap[Rz] = bb1; ap[2 * Rz] = bb2; ap[3 * Rz] = bb3; ap[4 * Rz] = bb4; ap[5 * Rz] = bb5;
         }
-#pragma unroll 1
+        CW_STAMP(3)
+        // ---- side-chain torsion bytes: flat item list, lane = item; each byte leaves as soon as it exists (consecutive items
+        //      are consecutive bytes of the record's side-chain section) ----
+#pragma unroll FCZ_CW_UNROLL_SC
         for (uint32_t i = 0; i < 11; i++) {
             const uint32_t ts = (uint32_t)lane + i * WAVE;
             if (i * WAVE >= n_sc) break;
             if (ts < n_sc) {
                 const uint32_t res = W.item_res[ts];
-                const uint32_t jj = ts - ((W.rowinfo[res] >> 10) & 0x3ffu);
-                const uint32_t w = (i < 4) ? scb[0] : (i < 8 ? scb[1] : scb[2]);
-                out[base0 + W.sc_rel[res] + jj] = (uint8_t)(w >> (8 * (i & 3u)));
+                const uint32_t info = W.rowinfo[res];
+                const uint32_t rlo = info & 0x3ffu;
+                const uint32_t jj = ts - ((info >> 10) & 0x3ffu), j = 3 + jj;
+                const uint32_t pk2 = T.prev[info >> 20][j];
+                const uint8_t* row8 = reinterpret_cast<const uint8_t*>(&W.idx8[res][0]);
+                const v3 a = wtile_rec(W, rlo, row8[pk2 & 15u]), b = wtile_rec(W, rlo, row8[(pk2 >> 4) & 15u]), cc = wtile_rec(W, rlo, row8[(pk2 >> 8) & 15u]);
+                const v3 d = wtile_rec(W, rlo, row8[j]);
+                out[base0 + W.sc_rel[res] + jj] = (uint8_t)sidechain_torsion_byte(a, b, cc, d);
             }
         }
+        CW_STAMP(4)
+        CW_STAMP(5)
     }
+#ifdef FCZ_CW_TIMING
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_cw_timing[i], tacc[i]);
+#endif
 }
 
 // =====================================================================================================================

@@ -76,11 +76,37 @@ __device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x, uint32_t* tot
 // std::min_element / std::max_element keep the FIRST of equal elements (reference src/discretizer.cpp:27-28).
 // Equal floats with different bits are only +0/-0, so a plain value reduction is exact unless the extremum is a
 // zero; only then this (value, index) reduction over the stored values runs.
+// ---- hand-over of the backbone angles: angle kernels -> k_compress_pack ---------------------------------------------------
+// The angle kernels stop at the cosine, the exact float getCosineTheta returns (reference src/float3d.h:38-43); the double part
+// (acos -> degrees -> float, src/torsion_angle.cpp:74-94, src/float3d.h:55-65) runs in k_compress_pack, which waits for memory
+// most of its time, on the value it has just loaded. A dihedral also carries its sign bit: |cos| <= 1 leaves bit 30 of the
+// float (exponent >= 128) free. acos of a NaN or of |cos| > 1 is NaN, which getTorsionFromXYZ replaces by 180 (cos < 0) or 0
+// (:77-84): exactly what acos gives for -1 and +1, so those cosines are stored as -1 / +1. Bond angles have no such guard in
+// the reference and keep their cosine as it is.
+constexpr uint32_t CK_NEG_BIT = 0x40000000u;
+__device__ __forceinline__ float enc_torsion_cos(float ct, bool neg) {
+    const float c = (__builtin_fabsf(ct) < 1.0f) ? ct : ((ct < 0.0f) ? -1.0f : 1.0f);
+    return __uint_as_float(__float_as_uint(c) | (neg ? CK_NEG_BIT : 0u));
+}
+__device__ __forceinline__ float dec_torsion_deg(float e) {
+    const uint32_t b = __float_as_uint(e);
+    float v = acos_deg(__uint_as_float(b & ~CK_NEG_BIT));
+    if (b & CK_NEG_BIT) v = -1.0f * v;
+    return v;
+}
+// array q of the hand-over (0..2 dihedrals, 3..5 bond angles; q = 6: B-factors, plain values)
+template <int Q> __device__ __forceinline__ float dec_angle(float e) { return Q < 3 ? dec_torsion_deg(e) : (Q < 6 ? acos_deg(e) : e); }
+
 struct lo_hi { float lo, hi; };
-__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane) {
+// mode 0: src holds values; 1: encoded dihedrals; 2: bond-angle cosines
+__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, int mode) {
     const float kInf = __builtin_huge_valf();
     ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
-    for (uint32_t k = lane; k < cnt; k += WAVE) { const float v = src[k]; ext_min_upd(mn, v, k); ext_max_upd(mx, v, k); }
+    for (uint32_t k = lane; k < cnt; k += WAVE) {
+        float v = src[k];
+        if (mode == 1) v = dec_torsion_deg(v); else if (mode == 2) v = acos_deg(v);
+        ext_min_upd(mn, v, k); ext_max_upd(mx, v, k);
+    }
     return lo_hi{wave_ext_min(mn), wave_ext_max(mx)};
 }
 
@@ -450,12 +476,9 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles_all, const uint32_t*
                     const float sa = q == 0 ? su0 : q == 1 ? su1 : q == 2 ? su2 : q == 3 ? se1 : q == 4 ? se2 : se3;
                     const float sb = q == 0 ? su1 : q == 1 ? su2 : q == 2 ? su3 : q == 3 ? se2 : q == 4 ? se3 : se4;
                     const float ct = vcos_theta_pre(ip, sa, sb);
-                    float v = acos_deg(ct);
-                    if (q < 3) {   // getTorsionFromXYZ: NaN guard and sign (src/torsion_angle.cpp:77-94); angle() has neither
-                        if (v != v) v = (ct < 0.0f) ? 180.0f : 0.0f;
-                        const bool ng = q == 0 ? ng0 : q == 1 ? ng1 : ng2;
-                        if (ng) v = -1.0f * v;
-                    }
+                    // the cosine is handed over (dihedrals with their sign, see enc_torsion_cos); k_compress_pack finishes it
+                    float v = ct;
+                    if (q < 3) v = enc_torsion_cos(ct, q == 0 ? ng0 : q == 1 ? ng1 : ng2);
                     // psi, omega, phi -> arrays 1, 2, 0; ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3
                     bb1 = q == 0 ? v : bb1; bb2 = q == 1 ? v : bb2; bb0 = q == 2 ? v : bb0;
                     bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
@@ -747,21 +770,14 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             const float ip0 = vdot_ref(u0, u1), ip1 = vdot_ref(u1, u2), ip2 = vdot_ref(u2, u3);
             const bool ng0 = vdot_ref(u0, vcross(u1, e1)) < 0.0f, ng1 = vdot_ref(u1, vcross(u2, e2)) < 0.0f, ng2 = vdot_ref(u2, vcross(u3, e3)) < 0.0f;
             const float ip3 = -vdot_ref(e1, e2), ip4 = -vdot_ref(e2, e3), ip5 = -vdot_ref(e3, e4);
-#pragma unroll FCZ_CW_UNROLL_BB
-            for (uint32_t q = 0; q < 6; q++) {
-                const float ip = q == 0 ? ip0 : q == 1 ? ip1 : q == 2 ? ip2 : q == 3 ? ip3 : q == 4 ? ip4 : ip5;
-                const float sa_ = q == 0 ? su0 : q == 1 ? su1 : q == 2 ? su2 : q == 3 ? se1 : q == 4 ? se2 : se3;
-                const float sb_ = q == 0 ? su1 : q == 1 ? su2 : q == 2 ? su3 : q == 3 ? se2 : q == 4 ? se3 : se4;
-                const float ct = vcos_theta_pre(ip, sa_, sb_);
-                float v = acos_deg(ct);
-                if (q < 3) {
-                    if (v != v) v = (ct < 0.0f) ? 180.0f : 0.0f;
-                    const bool ng = q == 0 ? ng0 : q == 1 ? ng1 : ng2;
-                    if (ng) v = -1.0f * v;
-                }
-                bb1 = q == 0 ? v : bb1; bb2 = q == 1 ? v : bb2; bb0 = q == 2 ? v : bb0;
-                bb4 = q == 3 ? v : bb4; bb5 = q == 4 ? v : bb5; bb3 = q == 5 ? v : bb3;
-            }
+            // the cosines are handed over (dihedrals with their sign, see enc_torsion_cos); k_compress_pack finishes them.
+            // psi, omega, phi -> arrays 1, 2, 0; ca_c_n, c_n_ca, n_ca_c -> arrays 4, 5, 3
+            bb1 = enc_torsion_cos(vcos_theta_pre(ip0, su0, su1), ng0);
+            bb2 = enc_torsion_cos(vcos_theta_pre(ip1, su1, su2), ng1);
+            bb0 = enc_torsion_cos(vcos_theta_pre(ip2, su2, su3), ng2);
+            bb4 = vcos_theta_pre(ip3, se1, se2);
+            bb5 = vcos_theta_pre(ip4, se2, se3);
+            bb3 = vcos_theta_pre(ip5, se3, se4);
         }
         // angles out right away: the six registers are free for the side-chain items
         if (my_win) {
@@ -835,6 +851,15 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
             rcs[u] = in.res_code[r0 + kr];
             o0[u] = in.atom_off[r0 + kr];
             o2[u] = in.atom_off[r0 + (k + 2 < n ? k + 2 : n)];
+        }
+    }
+
+    // ---- the double part of the six backbone angles (hand-over above): acos of what was just loaded ----
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            va[0][u] = dec_angle<0>(va[0][u]); va[1][u] = dec_angle<1>(va[1][u]); va[2][u] = dec_angle<2>(va[2][u]);
+            va[3][u] = dec_angle<3>(va[3][u]); va[4][u] = dec_angle<4>(va[4][u]); va[5][u] = dec_angle<5>(va[5][u]);
         }
     }
 
@@ -933,8 +958,8 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
         st_u64(rec + RL.o_words + 8 * (size_t)k, word);
         rec[RL.o_tbytes + k] = (uint8_t)quant_round(v6, qmin[6], qdisc[6]);
     };
-    auto finish_q = [&](int q, float lo, float hi, const float* src, uint32_t cntq) {
-        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane); lo = e.lo; hi = e.hi; }
+    auto finish_q = [&](int q, float lo, float hi, const float* src, uint32_t cntq, int mode) {
+        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
     };
     if (small) {
@@ -949,7 +974,16 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
                 lo = __builtin_fminf(lo, on ? va[q][u] : kInf);
                 hi = __builtin_fmaxf(hi, on ? va[q][u] : -kInf);
             }
-            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), cntq);
+            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), cntq, q < 3 ? 1 : (q < 6 ? 2 : 0));
+        }
+        if (keep_first_angle) {
+            // fcz_compress_angles reads the scratch back: leave the finished angles there
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t k = u * WAVE + lane;
+#pragma unroll
+                for (int q = 0; q < 6; q++) if (k < m) a_arr[(size_t)q * R + k] = va[q][u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -975,16 +1009,20 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const uint32_t k = k0 + u * WAVE + lane;
+                // finished here and written back in place (each lane its own entries): the second pass reads angles
+                tv[0][u] = dec_angle<0>(tv[0][u]); tv[1][u] = dec_angle<1>(tv[1][u]); tv[2][u] = dec_angle<2>(tv[2][u]);
+                tv[3][u] = dec_angle<3>(tv[3][u]); tv[4][u] = dec_angle<4>(tv[4][u]); tv[5][u] = dec_angle<5>(tv[5][u]);
 #pragma unroll
                 for (int q = 0; q < 7; q++) {
                     const bool on = k < ((q < 6) ? m : n);
+                    if (q < 6 && on) a_arr[(size_t)q * R + k] = tv[q][u];
                     lo[q] = __builtin_fminf(lo[q], on ? tv[q][u] : kInf); hi[q] = __builtin_fmaxf(hi[q], on ? tv[q][u] : -kInf);
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < 7; q++)
-            finish_q(q, wave_min_f32(lo[q]), wave_max_f32(hi[q]), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), (q < 6) ? m : n);
+            finish_q(q, wave_min_f32(lo[q]), wave_max_f32(hi[q]), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), (q < 6) ? m : n, 0);
         for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
             float tv[7][2]; uint32_t rc2[2];
 #pragma unroll

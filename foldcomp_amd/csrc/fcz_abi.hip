@@ -764,12 +764,21 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
         span_guard g(ctx, "decompress_sidechain");
         const uint32_t n_tiles = grid_for(R, SC_TILE);
         const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_SIDECHAIN_MIN_BLOCKS * 4u);
-        if (fast_sc)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sidechain<true>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, ctx->res_aoff.as<uint32_t>(),
+        // 256-residue tiles; a tile with more atoms than the staging buffer holds is listed as two 128-residue halves for
+        // the second launch (an empty list on any real protein: that launch then costs its table prologue)
+        rc = ctx->tile_work.ensure(sizeof(uint32_t) * (2 * (size_t)n_tiles + 4)); if (rc) return rc;
+        uint32_t* punt_count = ctx->tile_work.as<uint32_t>(); uint32_t* punt_list = punt_count + 4;
+        HIP_TRY(hipMemsetAsync(punt_count, 0, sizeof(uint32_t) * 4, ctx->stream));
+        const uint32_t blocks_half = std::min<uint32_t>(2 * n_tiles, (uint32_t)ctx->n_cu);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, (uint32_t)SC_TILE, (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, punt_list, punt_count, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
+                               ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
+            hipLaunchKernelGGL(kernel, dim3(blocks_half), dim3(BLOCK), 0, ctx->stream, R, 2 * n_tiles, (uint32_t)SC_TILE / 2, (const uint32_t*)punt_list,
+                               (const uint32_t*)punt_count, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->res_aoff.as<uint32_t>(),
                                ctx->res_rc.as<uint8_t>(), ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sidechain<false>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, R, n_tiles, ctx->res_aoff.as<uint32_t>(),
-                               ctx->res_rc.as<uint8_t>(), ctx->res_sc.as<uint32_t>(), ctx->bb.as<v3>(), alt_order, *out_dev);
+        };
+        if (fast_sc) launch(HIP_KERNEL_NAME(k_sidechain<true>)); else launch(HIP_KERNEL_NAME(k_sidechain<false>));
     }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
@@ -886,6 +895,17 @@ extern "C" int fcz_debug_cw_timing(unsigned long long* out8) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fcz::g_cw_timing), sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_cw_timing), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
+#ifdef FCZ_SC_TIMING
+// measurement aid: read and clear the phase counters of k_sidechain
+extern "C" int fcz_debug_sc_timing(unsigned long long* out12) {
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(fcz::g_sc_timing), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_sc_timing), z, sizeof(z)) != hipSuccess) return -1;
     return 0;
 }
 #endif

@@ -169,11 +169,22 @@ struct sidechain_lds {
 #define FCZ_SIDECHAIN_MIN_BLOCKS 3
 #endif
 
+#ifdef FCZ_SC_TIMING
+// measurement aid (not built into the product): wavefront-cycles between the phase boundaries of k_sidechain
+__device__ unsigned long long g_sc_timing[12];
+#define SC_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define SC_STAMP(i)
+#endif
 // res_aoff has n_res + 1 entries (the last one = total atoms). FAST: placements in plain float arithmetic
 // (FCZ_NUMERICS_FAST, place_atom_d2_fast); the tables (torsion bytes, ideal geometry) are the exact ones either way.
+// tile_res = residues per tile: 256 (tile_list == nullptr: every tile of the batch), or 128 for the tiles a 256-residue launch
+// could not stage (more than SC_CAP atoms: only when nearly every residue is a TRP/ARG/TYR) and put on punt_list as two halves.
 template <bool FAST>
 __global__ __launch_bounds__(BLOCK, FCZ_SIDECHAIN_MIN_BLOCKS)
-void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ res_aoff, const uint8_t* __restrict__ res_rc,
+void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ tile_count,
+                 uint32_t* __restrict__ punt_list, uint32_t* __restrict__ punt_count,
+                 const uint32_t* __restrict__ res_aoff, const uint8_t* __restrict__ res_rc,
                  const uint32_t* __restrict__ res_sc, const v3* __restrict__ bb, int alt_order, fcz_atoms_out out) {
     __shared__ sidechain_lds S;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -224,35 +235,57 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
 
     // one tile of per-residue inputs, loaded a whole tile ahead of its use. Unconditional loads from clamped
     // indices: a conditional merge would make the compiler wait for the data right here instead of a tile later.
-    struct res_in { uint32_t a, a_next, rc, q0, q1, q2, a_first, a_mid, a_end; v3 b0, b1, b2; };
+    struct res_in { uint32_t a, a_next, rc, q0, q1, q2, a_first, a_end; v3 b0, b1, b2; };
+    const uint32_t n_units = tile_list ? *tile_count : n_tiles;
+    auto unit_tile = [&](uint32_t u) -> uint32_t { return tile_list ? tile_list[u < n_units ? u : 0u] : u; };
     auto load_res = [&](uint32_t tile) -> res_in {
-        const size_t r_lo = (size_t)tile * SC_TILE;
-        size_t r = r_lo + (size_t)t;
+        const size_t r_lo = (size_t)tile * tile_res;
+        size_t r = r_lo + (size_t)((uint32_t)t < tile_res ? (uint32_t)t : tile_res - 1u);
         r = r < (size_t)n_res ? r : (size_t)n_res - 1;
         const size_t rf = r_lo < (size_t)n_res ? r_lo : (size_t)n_res;
-        const size_t rm = r_lo + SC_TILE / 2 < (size_t)n_res ? r_lo + SC_TILE / 2 : (size_t)n_res;
-        const size_t re = r_lo + SC_TILE < (size_t)n_res ? r_lo + SC_TILE : (size_t)n_res;
+        const size_t re = r_lo + tile_res < (size_t)n_res ? r_lo + tile_res : (size_t)n_res;
         res_in in;
         in.a = res_aoff[r]; in.a_next = res_aoff[r + 1]; in.rc = res_rc[r];
         in.q0 = res_sc[r]; in.q1 = res_sc[(size_t)n_res + r]; in.q2 = res_sc[2 * (size_t)n_res + r];
-        in.a_first = res_aoff[rf]; in.a_mid = res_aoff[rm]; in.a_end = res_aoff[re];
+        in.a_first = res_aoff[rf]; in.a_end = res_aoff[re];
         in.b0 = bb[3 * r]; in.b1 = bb[3 * r + 1]; in.b2 = bb[3 * r + 2];
         return in;
     };
-    res_in nxt = load_res(blockIdx.x);
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t r = tile * SC_TILE + (uint32_t)t;
+    // Stores and loads share one in-order counter (vmcnt). The wait for a tile's prefetched inputs at the top of the loop can
+    // leave the previous tile's write-back in flight only if the number of stores issued since the prefetch is a compile-time
+    // constant on EVERY path into the loop top: SC_WB buffer stores per thread and tile (the range check of the buffer
+    // resource drops lanes past the end; a null range drops everything), also before the first tile and for a punted tile.
+    // With a data-dependent store count every wavefront sat at the loop top until its write-back had been acknowledged by
+    // the L2: 12 % of the kernel (tools/dbg/sc_timing.py).
+    constexpr int SC_WB = 3 * (SC_CAP / BLOCK);
+    constexpr uint32_t SC_SKIP = 0xffffffffu;      // staged x of an atom that is not this kernel's to store (the chain's OXT)
+    auto null_stores = [&]() {
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(out.x, 0, 0, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < SC_WB; u++) __builtin_amdgcn_raw_buffer_store_b32(0u, r0, 64 * u, 0, 0);   // apart: neither merged nor widened
+    };
+    if (blockIdx.x >= n_units) return;
+    res_in nxt = load_res(unit_tile(blockIdx.x));
+    null_stores();
+#ifdef FCZ_SC_TIMING
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t tile = unit_tile(unit);
+        const uint32_t r = tile * tile_res + (uint32_t)t;
         const res_in cur = nxt;
-        nxt = load_res(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
-        // a tile whose atoms do not fit the staging buffer (only possible when nearly every residue is a TRP/ARG/TYR)
-        // runs as two passes of 128 residues
-        const bool split = cur.a_end - cur.a_first > (uint32_t)SC_CAP;
-        for (int pass = 0; pass < (split ? 2 : 1); pass++) {
-            const int lo = (split && pass == 1) ? SC_TILE / 2 : 0, hi = (split && pass == 0) ? SC_TILE / 2 : SC_TILE;
-            const uint32_t A0 = (split && pass == 1) ? cur.a_mid : cur.a_first;
-            const uint32_t A1 = (split && pass == 0) ? cur.a_mid : cur.a_end;
-            const bool act = r < n_res && t >= lo && t < hi;
+        nxt = load_res(unit_tile(unit + gridDim.x < n_units ? unit + gridDim.x : unit));
+        const uint32_t A0 = cur.a_first, A1 = cur.a_end;
+        if (A1 - A0 > (uint32_t)SC_CAP) {
+            // does not fit the staging buffer: both halves go to the 128-residue launch (never happens there: 128 * 14 + OXT)
+            if (t == 0 && punt_list) { const uint32_t k = atomicAdd(punt_count, 2u); punt_list[k] = 2u * tile; punt_list[k + 1] = 2u * tile + 1u; }
+            null_stores();
+            continue;
+        }
+        {
+            const bool act = r < n_res && (uint32_t)t < tile_res;
             uint32_t rc = 23, na = 0;
+            SC_STAMP(0)
             if (act) {
                 const uint32_t ap = cur.a - A0;
                 const v3 b0 = cur.b0, b1 = cur.b1, b2 = cur.b2;
@@ -283,13 +316,10 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
                     S.stage[0][po] = p.x; S.stage[1][po] = p.y; S.stage[2][po] = p.z;
                     if (out.atom_code) out.atom_code[A0 + po] = (uint8_t)(G.meta >> 16);
                 }
-                if (cur.a_next - cur.a - na == 1) {
-                    // the chain's OXT (already written by k_res_index) lies inside this pass's output range: stage it so
-                    // that the write-back stores it again unchanged
-                    const uint32_t g = cur.a + na, po = ap + na;
-                    S.stage[0][po] = out.x[g]; S.stage[1][po] = out.y[g]; S.stage[2][po] = out.z[g];
-                }
+                // the chain's OXT (already written by k_res_index) lies inside this tile's output range: the write-back skips it
+                if (cur.a_next - cur.a - na == 1) S.stage[0][ap + na] = __uint_as_float(SC_SKIP);
             }
+            SC_STAMP(1)
             // ---- per-depth work lists: block-wide exclusive scan of the packed per-depth counts ----
             const unsigned long long mine = act ? S.dcnt[rc] : 0ull;
             unsigned long long inc = mine;
@@ -297,6 +327,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
             for (int d = 1; d < WAVE; d <<= 1) { const unsigned long long u = __shfl_up(inc, d, WAVE); if (lane >= d) inc += u; }
             if (lane == WAVE - 1) S.wave_tot[wave] = inc;
             __syncthreads();
+            SC_STAMP(2)
             unsigned long long pre = inc - mine, total = 0;
 #pragma unroll
             for (int w = 0; w < WAVES_PER_BLOCK; w++) { const unsigned long long v = S.wave_tot[w]; if (w < wave) pre += v; total += v; }
@@ -318,7 +349,9 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
                 }
             }
             if (t == 0) S.dstart[SC_DEPTHS] = ds;
+            SC_STAMP(3)
             __syncthreads();
+            SC_STAMP(4)
             // ---- items, depth by depth ----
 #pragma unroll 1
             for (int d = 0; d < SC_DEPTHS; d++) {
@@ -343,16 +376,35 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, const uint32_t* __restrict__ 
                     S.stage[0][po] = p.x; S.stage[1][po] = p.y; S.stage[2][po] = p.z;
                     if (out.atom_code) out.atom_code[A0 + po] = (uint8_t)(G.meta >> 16);
                 }
+                SC_STAMP(5)
                 __syncthreads();
+                SC_STAMP(6)
             }
-            // ---- write-back: the pass's atoms are one contiguous range of the output arrays ----
-            const uint32_t n_at = A1 - A0;
-            for (uint32_t i = (uint32_t)t; i < n_at; i += BLOCK) {
-                out.x[A0 + i] = S.stage[0][i]; out.y[A0 + i] = S.stage[1][i]; out.z[A0 + i] = S.stage[2][i];
+            // ---- write-back: the tile's atoms are one contiguous range of the output arrays ----
+            {
+                const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A1 - A0) * 4u));
+                const size_t a0u = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)A0);
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(out.x + a0u, 0, (int)bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(out.y + a0u, 0, (int)bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(out.z + a0u, 0, (int)bytes, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < SC_CAP / BLOCK; u++) {
+                    const uint32_t i = (uint32_t)u * BLOCK + (uint32_t)t;
+                    const uint32_t xb = __float_as_uint(S.stage[0][i]);
+                    const int off = (int)(xb == SC_SKIP ? SC_SKIP : 4u * i);     // out of every range: dropped
+                    __builtin_amdgcn_raw_buffer_store_b32(xb, rx, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S.stage[1][i]), ry, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S.stage[2][i]), rz, off, 0, 0);
+                }
             }
+            SC_STAMP(7)
             __syncthreads();
+            SC_STAMP(8)
         }
     }
+#ifdef FCZ_SC_TIMING
+    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_sc_timing[i], tacc[i]);
+#endif
 }
 
 }  // namespace fcz

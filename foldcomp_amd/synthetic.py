@@ -54,10 +54,12 @@ def _place(a, b, c, L, ang, tor):
 
 
 def generate(n_chains: int, lengths, seed: int = 0xF01DC0DE, device: str = "cpu", anchor_threshold: int = 25,
-             first_chain_id: int = 0):
+             first_chain_id: int = 0, res_code=None):
     """-> dict of torch tensors laid out as fcz_chain_batch (plus 'anchor_threshold').
 
     lengths: int (all chains) or a sequence/array of per-chain residue counts.
+    res_code: None = residue types i.i.d. uniform over the 20 standard codes; an int = every residue of that type; a
+    per-chain sequence = that type for the chain, -1 = uniform (tests of the atom-richest tiles: 17 = TRP, 14 heavy atoms).
     """
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -74,6 +76,9 @@ def generate(n_chains: int, lengths, seed: int = 0xF01DC0DE, device: str = "cpu"
     def rand(*s): return torch.rand(*s, generator=g, device=dev, dtype=f64)
 
     rc = torch.randint(0, 20, (C, nmax), generator=g, device=dev)
+    if res_code is not None:
+        per_chain = torch.as_tensor(np.broadcast_to(np.asarray(res_code, np.int64), (C,)).copy(), device=dev)[:, None]
+        rc = torch.where(per_chain >= 0, per_chain.expand_as(rc), rc)
     # backbone internal coordinates
     comp = rand(C, nmax)
     phi = torch.where(comp < 0.45, -63 + 15 * randn(C, nmax), torch.where(comp < 0.80, -120 + 20 * randn(C, nmax), -180 + 360 * rand(C, nmax)))

@@ -39,6 +39,17 @@ def test_tile_edges_and_long_chains(codec):
     _check(codec, b, alt=True)
 
 
+def test_atom_richest_tiles(codec):
+    """chains of TRP only (14 atoms per residue): 256-residue tiles of the side-chain stage exceed its staging buffer and go
+    through the device list to the 128-residue launch; the wavefront tiles of the compress stage (63 * 14 atoms) exceed theirs
+    and go to the block-tile kernel. Mixed with ordinary chains so that both routes run in one batch."""
+    rich = synthetic.to_chain_batch(synthetic.generate(5, [700, 300, 64, 513, 2], seed=41, res_code=17))
+    _check(codec, rich)
+    _check(codec, rich, alt=True)
+    both = synthetic.to_chain_batch(synthetic.generate(7, [350, 90, 900, 257, 600, 2, 300], seed=42, res_code=[-1, -1, 17, 17, -1, 17, -1]))
+    _check(codec, both)
+
+
 @pytest.mark.parametrize("thr", [2, 7, 200, 5000])
 def test_anchor_thresholds(codec, thr):
     lens = [30, 64, 350, 700 if thr > 2 else 506]   # n / thr + 2 anchors must fit the header's uint8 (next test)

@@ -132,7 +132,11 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
 }
 
 constexpr int SC_TILE = BLOCK;             // residues per tile
-constexpr int SC_CAP = 3072;               // staged output atoms per pass (a typical tile holds 256 * 8.4 = 2140)
+constexpr int SC_CAP = 2304;               // staged output atoms per tile (a typical tile holds 256 * 8.36 = 2140 +- 43; what
+                                           // does not fit goes to the 128-residue launch). With the other sizes below the block
+                                           // needs < 40 KB of LDS: four blocks per CU
+constexpr int SC_LIST = 1408;              // work items per tile: 10 per TRP, and 14 x + 3 (256 - x) <= SC_CAP bounds x at 139
+static_assert(11 * SC_LIST >= 10 * (SC_CAP - 3 * SC_TILE), "item list too short for the atom-richest tile that still fits SC_CAP");
 constexpr int SC_DEPTHS = 6;               // list depths 2..7 (depth 1 = O, placed by the owning thread)
 constexpr int SC_FIELD = 10;               // bits per depth in the packed per-depth counters (<= 3 * 256 items)
 constexpr int SC_MAX_ITEMS = 10;           // listed atoms per residue (TRP: 14 - 3 backbone - O)
@@ -152,13 +156,13 @@ struct sidechain_lds {
                                                        // and write-back buffer in one
     uint32_t sc[3][SC_TILE];                           // torsion bytes of each residue (three dwords)
     uint16_t apos[SC_TILE];                            // pass-local position of each residue's first atom
-    uint16_t list[SC_TILE * SC_MAX_ITEMS];             // work items: residue in tile | slot << 8, grouped by depth
+    uint16_t list[SC_LIST];                            // work items: residue in tile | slot << 8, grouped by depth
     uint8_t rc[SC_TILE];
     unsigned long long wave_tot[WAVES_PER_BLOCK];
     uint32_t dstart[SC_DEPTHS + 2];                    // list range of each depth in the current pass
     // tables (the residue code differs per lane, so these are LDS lookups rather than scalar loads)
     float tor_cos[256], tor_sin[256];                  // every sinf/cosf of a torsion byte
-    sc_geom geom[SC_GEOM_CODES][FCZ_MAX_RES_ATOMS];
+    sc_geom geom[SC_GEOM_CODES][FCZ_MAX_RES_ATOMS - 3];   // [code][slot - 3]: O and the side-chain atoms
     uint8_t opos[FCZ_N_RES_CODES][4];                  // output position of N, CA, C, O
     uint8_t items[FCZ_N_RES_CODES][SC_DEPTHS * 4];     // [depth-2][q]: slots (>= 4) of the residue's atoms at that depth, 0 = none
     uint8_t natoms[FCZ_N_RES_CODES];
@@ -166,7 +170,7 @@ struct sidechain_lds {
 };
 
 #ifndef FCZ_SIDECHAIN_MIN_BLOCKS
-#define FCZ_SIDECHAIN_MIN_BLOCKS 3
+#define FCZ_SIDECHAIN_MIN_BLOCKS 4
 #endif
 
 #ifdef FCZ_SC_TIMING
@@ -218,7 +222,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
                     g.sb = sinf_glibc(ba);
                     g.meta = opos[pk & 15] | (opos[(pk >> 4) & 15] << 4) | (opos[(pk >> 8) & 15] << 8) | (opos[j] << 12) |
                              ((uint32_t)fcz_res_atom[rc][j] << 16);
-                    S.geom[rc][j] = g;
+                    S.geom[rc][j - 3] = g;
                 }
             }
             unsigned long long cnt = 0;
@@ -305,7 +309,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
                 }
                 if (na > 3) {
                     // O: slot 3 of every residue type, predecessors N, CA, C (src/amino_acid.h; fcz_res_prev[*][3] == 0x210)
-                    const sc_geom G = S.geom[rc][3];
+                    const sc_geom G = S.geom[rc][0];
                     const uint32_t q = cur.q0 & 0xffu;
                     v3 d2;
                     d2.x = G.d2x;
@@ -359,7 +363,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
                 for (uint32_t i = dlo + (uint32_t)t; i < dhi; i += BLOCK) {
                     const uint32_t ent = S.list[i];
                     const uint32_t rl = ent & 255u, j = ent >> 8;
-                    const sc_geom G = S.geom[S.rc[rl]][j];
+                    const sc_geom G = S.geom[S.rc[rl]][j - 3];
                     const uint32_t ap = S.apos[rl];
                     const uint32_t jj = j - 3;
                     const uint32_t q = (S.sc[jj >> 2][rl] >> (8 * (jj & 3u))) & 0xffu;

@@ -54,25 +54,6 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
 }
 
-// exclusive prefix sum over the wavefront on the DPP network: Hillis-Steele inside each row of 16 (zeros shift in), then the
-// row totals travel with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3). Six dependent VALU instructions instead of
-// six LDS-crossbar round trips (wave_excl_scan, fcz_kernels.h)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32_or0(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
-}
-__device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x, uint32_t* total) {
-    uint32_t v = x;
-    v += dpp_u32_or0<0x111, 0xf>(v);   // row_shr:1
-    v += dpp_u32_or0<0x112, 0xf>(v);   // row_shr:2
-    v += dpp_u32_or0<0x114, 0xf>(v);   // row_shr:4
-    v += dpp_u32_or0<0x118, 0xf>(v);   // row_shr:8
-    v += dpp_u32_or0<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v += dpp_u32_or0<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    *total = (uint32_t)__builtin_amdgcn_readlane((int)v, WAVE - 1);
-    return v - x;
-}
-
 // std::min_element / std::max_element keep the FIRST of equal elements (reference src/discretizer.cpp:27-28).
 // Equal floats with different bits are only +0/-0, so a plain value reduction is exact unless the extremum is a
 // zero; only then this (value, index) reduction over the stored values runs.

@@ -56,6 +56,25 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
     return v;
 }
+// exclusive prefix sum over the wavefront on the DPP network: Hillis-Steele inside each row of 16 (zeros shift in), then the
+// row totals travel with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3). Six dependent VALU instructions instead of
+// six LDS-crossbar round trips (wave_excl_scan above)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32_or0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x, uint32_t* total) {
+    uint32_t v = x;
+    v += dpp_u32_or0<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_u32_or0<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_u32_or0<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_u32_or0<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_u32_or0<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_u32_or0<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)v, WAVE - 1);
+    return v - x;
+}
+
 
 // running extremum with std::min_element / std::max_element semantics (first occurrence wins,
 // reference src/discretizer.cpp:27-28): order by value, then by position

@@ -325,10 +325,12 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
             }
             SC_STAMP(1)
             // ---- per-depth work lists: block-wide exclusive scan of the packed per-depth counts ----
+            // (six 10-bit fields: the two 30-bit halves never carry into each other, so they scan as two dwords on the DPP network)
             const unsigned long long mine = act ? S.dcnt[rc] : 0ull;
-            unsigned long long inc = mine;
-#pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) { const unsigned long long u = __shfl_up(inc, d, WAVE); if (lane >= d) inc += u; }
+            const uint32_t m_lo = (uint32_t)(mine & 0x3fffffffull), m_hi = (uint32_t)(mine >> 30);
+            uint32_t t_lo, t_hi;
+            const uint32_t e_lo = wave_excl_scan_dpp(m_lo, &t_lo), e_hi = wave_excl_scan_dpp(m_hi, &t_hi);
+            const unsigned long long inc = (((unsigned long long)(e_hi + m_hi)) << 30) | (unsigned long long)(e_lo + m_lo);
             if (lane == WAVE - 1) S.wave_tot[wave] = inc;
             __syncthreads();
             SC_STAMP(2)

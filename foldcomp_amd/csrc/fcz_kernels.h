@@ -483,18 +483,21 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
     }
     // ---- output window: blended atoms are parked in LDS and leave as contiguous runs per chain ----
     long long win = -1;           // window index (chain-major atom index / BW) this lane is filling, -1 = none
-    S.lo[lane] = 0; S.hi[lane] = 0;
+    int w_lo = 0, w_hi = 0;       // filled slots [w_lo, w_hi) of that window (registers; published to LDS at a flush)
     auto flush = [&]() {
+        S.lo[lane] = w_lo; S.hi[lane] = w_hi;
         __builtin_amdgcn_wave_barrier();
-        for (int t = 0; t < BW * 3; t++) {               // 64 lanes x 48 rounds cover 64 chains x 48 dwords
+#pragma unroll 4
+        for (int t = 0; t < BW; t++) {                   // 64 lanes x 16 rounds cover 64 chains x 16 atoms, an atom per lane
             const int flat = t * WAVE + lane;
-            const int cl = flat / (BW * 3), d = flat - cl * (BW * 3);
-            const int slot = d / 3;
-            if (slot >= S.lo[cl] && slot < S.hi[cl])
-                *reinterpret_cast<float*>(S.base[cl] + 4ull * (unsigned)d) = S.atom[cl][d];
+            const int cl = flat / BW, slot = flat - cl * BW;
+            if (slot >= S.lo[cl] && slot < S.hi[cl]) {
+                const v3 a{S.atom[cl][3 * slot], S.atom[cl][3 * slot + 1], S.atom[cl][3 * slot + 2]};
+                *reinterpret_cast<v3*>(S.base[cl] + 12ull * (unsigned)slot) = a;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        S.lo[lane] = 0; S.hi[lane] = 0;
+        w_lo = 0; w_hi = 0;
         win = -1;
     };
     auto emit = [&](bool on, long long bi, v3 a) {       // every lane calls (wave-uniform control flow)
@@ -502,8 +505,8 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         if (__any(on && win >= 0 && w != win)) flush();
         if (on) {
             const int slot = (int)(bi - w * BW);
-            if (win < 0) { win = w; S.base[lane] = (unsigned long long)(Bc + w * BW); S.lo[lane] = slot; S.hi[lane] = slot + 1; }
-            else { if (slot < S.lo[lane]) S.lo[lane] = slot; if (slot + 1 > S.hi[lane]) S.hi[lane] = slot + 1; }
+            if (win < 0) { win = w; S.base[lane] = (unsigned long long)(Bc + w * BW); w_lo = slot; w_hi = slot + 1; }
+            else { w_lo = slot < w_lo ? slot : w_lo; w_hi = slot + 1 > w_hi ? slot + 1 : w_hi; }
             S.atom[lane][3 * slot] = a.x; S.atom[lane][3 * slot + 1] = a.y; S.atom[lane][3 * slot + 2] = a.z;
         }
     };

@@ -909,3 +909,14 @@ extern "C" int fcz_debug_sc_timing(unsigned long long* out12) {
     return 0;
 }
 #endif
+
+#ifdef FCZ_BB_TIMING
+// measurement aid: read and clear the phase counters of k_backbone<0>
+extern "C" int fcz_debug_bb_timing(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fcz::g_bb_timing), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_bb_timing), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -434,6 +434,13 @@ struct backbone_lds {
 //         torsion trig of segment s parked in ring slot (group, s);
 // MODE 2: one block per (group, segment): reverse pass + blend of that segment from its slot -- the segments of a chain
 //         run side by side.
+#ifdef FCZ_BB_TIMING
+// measurement aid (not built into the product): wavefront-cycles in the parts of k_backbone
+__device__ unsigned long long g_bb_timing[8];
+#define BB_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define BB_STAMP(i)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries, uint32_t n_slots,
@@ -441,6 +448,9 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         float* __restrict__ tring, uint32_t ring_rows, uint32_t seg_slots, v3* __restrict__ bb) {
     __shared__ backbone_lds S;
     const int lane = threadIdx.x;
+#ifdef FCZ_BB_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     const uint32_t grp = (MODE == 2) ? blockIdx.x / seg_slots : blockIdx.x;
     const uint32_t seg_only = (MODE == 2) ? blockIdx.x - grp * seg_slots : 0u;
     const uint32_t slot = grp * WAVE + lane;
@@ -485,6 +495,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
     long long win = -1;           // window index (chain-major atom index / BW) this lane is filling, -1 = none
     int w_lo = 0, w_hi = 0;       // filled slots [w_lo, w_hi) of that window (registers; published to LDS at a flush)
     auto flush = [&]() {
+        BB_STAMP(3)
         S.lo[lane] = w_lo; S.hi[lane] = w_hi;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
@@ -499,6 +510,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         __builtin_amdgcn_wave_barrier();
         w_lo = 0; w_hi = 0;
         win = -1;
+        BB_STAMP(4)
     };
     auto emit = [&](bool on, long long bi, v3 a) {       // every lane calls (wave-uniform control flow)
         const long long w = on ? bi / BW : win;
@@ -511,6 +523,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
         }
     };
     const uint32_t s_begin = (MODE == 2) ? seg_only : 0u, s_end = (MODE == 2) ? seg_only + 1 : maxseg;
+    BB_STAMP(0)
     for (uint32_t s = s_begin; s < s_end; s++) {
         const bool act = s < nseg;
         const int len = act ? next - first + 1 : 0;
@@ -529,6 +542,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             A0 = ld_v3(anc); A1 = ld_v3(anc + 12); A2 = ld_v3(anc + 24);   // next anchor: carry + reverse start
             if (MODE != 2) { Rg[0] = p0; Rg[WAVE] = p1; Rg[2 * WAVE] = p2; }
         }
+        BB_STAMP(1)
         // ---- forward NeRF of the segment ----
         for (int i = 0; MODE != 2 && i + 1 < maxlen; i++) {
             if (i + 1 >= len) continue;
@@ -549,6 +563,7 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             p0 = N; p1 = CA; p2 = C;
             w_cur = w_nxt; w_nxt = w_pre; wp += 8;
         }
+        BB_STAMP(2)
         // ---- reverse NeRF + blend of the same segment ----
         const int T = 3 * len;
         const float Tf = (float)T;
@@ -615,8 +630,12 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
             p0 = c0; p1 = c1; p2 = c2;
             first = next; next = next2;
         }
+        BB_STAMP(3)
     }
     if (MODE != 1 && __any(win >= 0)) flush();
+#ifdef FCZ_BB_TIMING
+    if (MODE == 0 && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_bb_timing[i], tacc[i]);
+#endif
 }
 
 }  // namespace fcz

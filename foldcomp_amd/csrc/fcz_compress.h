@@ -1,5 +1,5 @@
 // fcz_compress.h -- the compress path (Foldcomp::preprocess/compress/writeStream, reference
-// src/foldcomp.cpp:450-606, 1038-1109) as three kernels.
+// src/foldcomp.cpp:450-606, 1038-1109) as three stages.
 //
 // Every angle of a chain is a function of one residue (side-chain torsions) or of one residue and its successor
 // (the six backbone values of a residue window), so the heavy part ignores chain boundaries:
@@ -14,11 +14,15 @@
 //                      thread = residue window for the 3 dihedrals + 3 bond angles of the backbone, thread = work item
 //                      (one dihedral per side-chain atom, taken round-robin from a flat list) for the side chains, so
 //                      every round is a full wavefront. The next tile's atoms are prefetched into registers meanwhile and
-//                      results stay in registers until the tile is done (no store drains the prefetch). Backbone angles
-//                      go to the [6][R] scratch `ang` (coalesced per type), side-chain torsions are quantised
+//                      results stay in registers until the tile is done (no store drains the prefetch). The backbone
+//                      values go to the [6][R] scratch `ang` (coalesced per type) as COSINES (enc_torsion_cos below: the
+//                      float getCosineTheta returns, dihedrals with their sign bit); side-chain torsions are quantised
 //                      (FixedAngleDiscretizer(255), src/foldcomp.cpp:532-538) and stored straight into the FCZ record
 //                      (consecutive items = consecutive bytes).
-//   k_compress_pack    one wavefront per chain: validation, per-chain quantiser parameters (min/max with
+//   k_compress_angles_w  the same stage with wavefront-private 63-residue tiles: what runs on protein input; the kernel
+//                      above takes the tiles this one lists (atom-rich stretches, the tail of the arrays).
+//   k_compress_pack    one wavefront per chain: validation, acos -> degrees -> float of the six backbone cosines
+//                      (src/torsion_angle.cpp:74-94, src/float3d.h:55-65), per-chain quantiser parameters (min/max with
 //                      std::min_element semantics, src/discretizer.cpp:22-33), the packed 8-byte words
 //                      (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52), B-factor bytes, anchors
 //                      (_setAnchor :745-761), OXT (:474-482), title and header (:1038-1109).
@@ -543,8 +547,9 @@ constexpr uint32_t CW_ABSENT = 255u;        // idx8 entry of a canonical atom th
 //    4 dwords apart: distinct banks for the ~6 residues a 32-lane group covers. The old [slot][row] uint16 layout put every
 //    slot of a row on ONE bank: 5- to 11-way)
 //  * atom codes live in their own byte array (the float4 .w they used to ride in is on banks 3 mod 4 only)
+typedef float cw_f4 __attribute__((ext_vector_type(4)));
 struct alignas(16) compress_wave_lds {
-    float4 atom[CW_CAP + 1];                    // {x, y, z, -}; [CW_ZERO] = zeros
+    cw_f4 atom[CW_CAP + 1];                     // {x, y, z, -}; [CW_ZERO] = zeros
     uint32_t idx8[CW_ROWS][4];                  // 16 bytes per row: [slot] -> atom position relative to the row's first record
     uint32_t code4[CW_CAP / 4 + 8];             // atom codes, one byte per record (+ slack: a row reads 5 dwords from its start)
     uint32_t rowinfo[CW_ROWS];                  // first record (10 bits) | exclusive prefix of side-chain items << 10 | residue code << 20
@@ -567,7 +572,9 @@ __device__ __forceinline__ void wave_sync() {
 }
 // record of the atom at position `pos` of the residue whose first record is `lo`
 __device__ __forceinline__ v3 wtile_rec(const compress_wave_lds& W, uint32_t lo, uint32_t pos) {
-    const float4 a = W.atom[pos == CW_ABSENT ? (uint32_t)CW_ZERO : lo + pos];
+    // a vector-typed element: the 12 bytes in use come in one ds_read_b96 (as a struct of four floats the compiler read them as
+    // ds_read_b64 + ds_read_b32: 4.8 -> 4.6 ms; forcing the full ds_read_b128 was no faster)
+    const cw_f4 a = W.atom[pos == CW_ABSENT ? (uint32_t)CW_ZERO : lo + pos];
     return v3{a.x, a.y, a.z};
 }
 
@@ -656,7 +663,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
         const unsigned long long base0 = sa0 & ~CK_LAST;
         W.sc_rel[lane] = (uint32_t)((sa & ~CK_LAST) - base0);
         const bool is_last = (sa & CK_LAST) != 0;
-        if (lane == 0) W.atom[CW_ZERO] = float4{0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) W.atom[CW_ZERO] = cw_f4{0.f, 0.f, 0.f, 0.f};
         {
             float px[CW_NA], py[CW_NA], pz[CW_NA];
             uint32_t pc[CW_NC];
@@ -674,7 +681,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
 #pragma unroll
             for (int u = 0; u < CW_NA; u++) {
                 const uint32_t i = (uint32_t)u * WAVE + (uint32_t)lane;
-                if (i < cnt) W.atom[i] = float4{px[u], py[u], pz[u], 0.f};
+                if (i < cnt) W.atom[i] = cw_f4{px[u], py[u], pz[u], 0.f};
             }
 #pragma unroll
             for (int u = 0; u < CW_NC; u++) {

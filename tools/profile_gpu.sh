@@ -19,18 +19,24 @@ src, out = sys.argv[1], sys.argv[2]
 for f in glob.glob(os.path.join(src, "**", "*.csv"), recursive=True):
     base = os.path.basename(f)
     if base.endswith("_counter_collection.csv"):
-        agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
+        # per kernel and counter: the value of every dispatch. A kernel that is also launched on an (almost always empty) work
+        # list -- k_compress_angles after k_compress_angles_w, the 128-residue k_sidechain launch -- would halve a plain
+        # per-dispatch average: dispatches whose SQ_WAVES / first counter is below 5 % of the kernel's largest are not counted
+        per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"].split("(")[0]
                 if "fcz" not in k: continue
-                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-                cnt[k].add(r["Dispatch_Id"])
+                per[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
         with open(os.path.join(out, base.replace("_counter_collection.csv", "_per_kernel.csv")), "w") as o:
             w = csv.writer(o); w.writerow(["kernel", "dispatches", "counter", "sum", "per_dispatch"])
-            for k in sorted(agg):
-                for c, v in sorted(agg[k].items()):
-                    w.writerow([k, len(cnt[k]), c, v, v / max(len(cnt[k]), 1)])
+            for k in sorted(per):
+                ref = per[k].get("SQ_WAVES") or per[k][sorted(per[k])[0]]
+                big = max(ref.values()) if ref else 0.0
+                full = {d for d, v in ref.items() if v >= 0.05 * big} or set(ref)
+                for c, dv in sorted(per[k].items()):
+                    v = sum(x for d, x in dv.items() if d in full)
+                    w.writerow([k, len(full), c, v, v / max(len(full), 1)])
     elif base.endswith("_kernel_trace.csv"):
         continue
     elif os.path.getsize(f) < (4 << 20):

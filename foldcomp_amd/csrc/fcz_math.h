@@ -199,6 +199,11 @@ __device__ __noinline__ float acos_deg_exact(float c) {
     return f;
 }
 
+// (not const: the values must stay loads -- see acos_deg)
+__device__ __constant__ double fcz_acos_coef[11] = {
+    0x1.c8a4a8d5d7026p-6, -0x1.bf16e7c9f283cp-8, 0x1.fa1b2b4831188p-7, 0x1.512bc40e88a9ep-7, 0x1.cf5ed14c7cb7ep-7, 0x1.1c0d74beb3610p-6,
+    0x1.6e8f34a32a3ecp-6, 0x1.f1c6ff7f5507fp-6, 0x1.6db6dba99e56dp-5, 0x1.33333333030cfp-4, 0x1.55555555555bbp-3};
+
 // Fast path of the same function: asin kernel polynomial (degree 10 in z, minimax-fitted with mpmath,
 // relative error 2^-50 on z in [0, 1/4]) with the usual reduction acos(x) = 2 asin(sqrt((1-|x|)/2)) for
 // |x| > 1/2, one multiply by 180/pi, then the float-rounding safety test. ~45 f64 instructions.
@@ -215,6 +220,7 @@ __device__ __forceinline__ float acos_deg(float c) {
         sq = __builtin_fma(g, d, g);
     }
     const double s = big ? sq : ax;
+#ifdef FCZ_ACOS_LITERALS
     double P = 0x1.c8a4a8d5d7026p-6;
     P = __builtin_fma(P, z, -0x1.bf16e7c9f283cp-8);
     P = __builtin_fma(P, z, 0x1.fa1b2b4831188p-7);
@@ -226,6 +232,14 @@ __device__ __forceinline__ float acos_deg(float c) {
     P = __builtin_fma(P, z, 0x1.6db6dba99e56dp-5);
     P = __builtin_fma(P, z, 0x1.33333333030cfp-4);
     P = __builtin_fma(P, z, 0x1.55555555555bbp-3);
+#else
+    // the coefficients come from constant memory (scalar loads -> SGPR pairs): a 64-bit literal cannot be an operand, and as
+    // literals the compiler moved every coefficient into the accumulator's VGPR pair first (two v_mov per FMA: a fifth of
+    // k_compress_pack's instructions, where this function is inlined 36 times)
+    double P = fcz_acos_coef[0];
+#pragma unroll
+    for (int i = 1; i < 11; i++) P = __builtin_fma(P, z, fcz_acos_coef[i]);
+#endif
     const double as = __builtin_fma(s * z, P, s);          // asin(s)
     const double kPi = 3.14159265358979323846, kPio2 = 1.57079632679489661923;
     const double A = big ? ((x > 0.0) ? 2.0 * as : __builtin_fma(-2.0, as, kPi))

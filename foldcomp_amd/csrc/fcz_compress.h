@@ -667,11 +667,19 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
         {
             float px[CW_NA], py[CW_NA], pz[CW_NA];
             uint32_t pc[CW_NC];
+            // buffer loads: base (SGPRs) = the array at the tile's first atom, range = the tile's atoms, offset = 4 * lane + a
+            // constant per round: no per-load address arithmetic on the VALU, lanes past the end read zero
+            {
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.x) + a0, 0, (int)(cnt * 4u), 0x00020000);
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.y) + a0, 0, (int)(cnt * 4u), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.z) + a0, 0, (int)(cnt * 4u), 0x00020000);
+                const int vo = 4 * lane;
 #pragma unroll
-            for (int u = 0; u < CW_NA; u++) {
-                const uint32_t i = (uint32_t)u * WAVE + (uint32_t)lane;
-                const size_t g = (size_t)a0 + (i < cnt ? i : 0u);
-                px[u] = in.x[g]; py[u] = in.y[g]; pz[u] = in.z[g];
+                for (int u = 0; u < CW_NA; u++) {
+                    px[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo + u * 4 * WAVE, 0, 0));
+                    py[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo + u * 4 * WAVE, 0, 0));
+                    pz[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, vo + u * 4 * WAVE, 0, 0));
+                }
             }
 #pragma unroll
             for (int u = 0; u < CW_NC; u++) {

@@ -58,8 +58,14 @@ namespace {
 constexpr size_t BATCH_CHAINS = 16384;
 
 // ---- atoms of one input file (the reference's std::vector<AtomCoordinate>, as parallel arrays) ----
+// Atom and residue names are kept as packed integers: up to four characters, one per byte (a PDB name field is four columns
+// wide, a residue name three); a longer name (mmCIF allows it) is interned in the table's side list and carries 0xff in the top
+// byte, which no ASCII name has. Equal names <=> equal integers inside one table.
+inline uint32_t pack_name(const char* s, size_t n) { uint32_t v = 0; for (size_t i = 0; i < n; i++) v |= (uint32_t)(unsigned char)s[i] << (8 * i); return v; }
+constexpr uint32_t PK_N = 'N', PK_CA = 'C' | ('A' << 8), PK_C = 'C';
 struct AtomTable {
-    std::vector<std::string> atom, residue;
+    std::vector<uint32_t> atom, residue;          // packed names
+    std::vector<std::string> long_names;          // names of more than four characters
     std::vector<char> chain;
     std::vector<int> atom_index, res_index;
     std::vector<float> x, y, z, bfac;
@@ -68,8 +74,26 @@ struct AtomTable {
     std::vector<uint8_t> atom_code;
     std::vector<int8_t> res_code;
     size_t size() const { return atom.size(); }
+    uint32_t intern(const char* s, size_t n) {
+        if (n <= 4) return pack_name(s, n);
+        for (size_t i = 0; i < long_names.size(); i++) if (long_names[i].size() == n && memcmp(long_names[i].data(), s, n) == 0) return 0xff000000u | (uint32_t)i;
+        long_names.emplace_back(s, n);
+        return 0xff000000u | (uint32_t)(long_names.size() - 1);
+    }
+    uint32_t intern(const std::string& s) { return intern(s.data(), s.size()); }
+    std::string name(uint32_t pk) const {
+        if ((pk >> 24) == 0xffu) return long_names[pk & 0xffffffu];
+        std::string o;
+        for (int i = 0; i < 4 && ((pk >> (8 * i)) & 0xffu); i++) o.push_back((char)((pk >> (8 * i)) & 0xffu));
+        return o;
+    }
+    void reserve(size_t n) {
+        atom.reserve(n); residue.reserve(n); chain.reserve(n); atom_index.reserve(n); res_index.reserve(n);
+        x.reserve(n); y.reserve(n); z.reserve(n); bfac.reserve(n); atom_code.reserve(n); res_code.reserve(n);
+    }
     AtomTable slice(size_t a, size_t b) const {
         AtomTable t;
+        t.long_names = long_names;
         t.atom.assign(atom.begin() + a, atom.begin() + b); t.residue.assign(residue.begin() + a, residue.begin() + b);
         t.chain.assign(chain.begin() + a, chain.begin() + b);
         t.atom_index.assign(atom_index.begin() + a, atom_index.begin() + b); t.res_index.assign(res_index.begin() + a, res_index.begin() + b);
@@ -78,7 +102,7 @@ struct AtomTable {
         if (atom_code.size() == size()) { t.atom_code.assign(atom_code.begin() + a, atom_code.begin() + b); t.res_code.assign(res_code.begin() + a, res_code.begin() + b); }
         return t;
     }
-    void push_from(const AtomTable& o, size_t i) {
+    void push_from(const AtomTable& o, size_t i) {   // o shares this table's long_names (remove_alternative_position copies them first)
         atom.push_back(o.atom[i]); residue.push_back(o.residue[i]); chain.push_back(o.chain[i]);
         atom_index.push_back(o.atom_index[i]); res_index.push_back(o.res_index[i]);
         x.push_back(o.x[i]); y.push_back(o.y[i]); z.push_back(o.z[i]); bfac.push_back(o.bfac[i]);
@@ -167,6 +191,19 @@ inline int field_int(const char* line, size_t len, size_t a, size_t b) {
     if (!ok) return parse_int(std::string(line + a, b - a));
     return (int)(neg ? -v : v);
 }
+inline uint32_t field_pack(const char* line, size_t len, size_t a, size_t b) {   // the stripped field as a packed name (b - a <= 4)
+    if (a >= len) return 0;
+    b = std::min(b, len);
+    while (a < b && isspace((unsigned char)line[a])) a++;
+    while (b > a && isspace((unsigned char)line[b - 1])) b--;
+    return pack_name(line + a, b - a);
+}
+inline bool field_blank(const char* line, size_t len, size_t a, size_t b) {
+    if (a >= len) return true;
+    b = std::min(b, len);
+    for (; a < b; a++) if (!isspace((unsigned char)line[a])) return false;
+    return true;
+}
 inline std::string field_strip(const char* line, size_t len, size_t a, size_t b) {
     if (a >= len) return std::string();
     b = std::min(b, len);
@@ -174,21 +211,24 @@ inline std::string field_strip(const char* line, size_t len, size_t a, size_t b)
     while (b > a && isspace((unsigned char)line[b - 1])) b--;
     return std::string(line + a, b - a);
 }
-// name -> code tables of the codec, packed (<= 4 characters) for a lookup without strcmp chains
+// name -> code tables of the codec on the packed names: a small open-addressed hash (the parse threads look up every atom)
 struct NameCodes {
-    std::vector<std::pair<uint32_t, int>> atoms, residues;
-    static uint32_t pack(const char* s, size_t n) { uint32_t v = 0; for (size_t i = 0; i < n && i < 4; i++) v |= (uint32_t)(unsigned char)s[i] << (8 * i); return n > 4 ? 0xffffffffu : v; }
+    struct Slot { uint32_t key; int code; };
+    Slot atoms[256], residues[128];
+    static uint32_t h(uint32_t k) { return (k * 0x9E3779B1u) >> 24; }
+    static void put(Slot* tab, uint32_t mask, uint32_t k, int code) { uint32_t i = h(k) & mask; while (tab[i].code != -2) i = (i + 1) & mask; tab[i] = {k, code}; }
+    static int get(const Slot* tab, uint32_t mask, uint32_t k, int miss) {
+        for (uint32_t i = h(k) & mask; tab[i].code != -2; i = (i + 1) & mask) if (tab[i].key == k) return tab[i].code;
+        return miss;
+    }
     NameCodes() {
-        for (int i = 0; i < 64; i++) { const char* n = fcz_atom_code_name(i); if (n) atoms.push_back({pack(n, strlen(n)), i}); }
-        for (int i = 0; i < 32; i++) { const char* n = fcz_res_code_name(i); if (n && fcz_res_code_from_name(n) == i) residues.push_back({pack(n, strlen(n)), i}); }
-        std::sort(atoms.begin(), atoms.end()); std::sort(residues.begin(), residues.end());
+        for (Slot& x : atoms) x = {0, -2};
+        for (Slot& x : residues) x = {0, -2};
+        for (int i = 0; i < 64; i++) { const char* n = fcz_atom_code_name(i); if (n && strlen(n) <= 4 && fcz_atom_code_from_name(n) == i) put(atoms, 255, pack_name(n, strlen(n)), i); }
+        for (int i = 0; i < 32; i++) { const char* n = fcz_res_code_name(i); if (n && strlen(n) <= 4 && fcz_res_code_from_name(n) == i) put(residues, 127, pack_name(n, strlen(n)), i); }
     }
-    static int find(const std::vector<std::pair<uint32_t, int>>& v, uint32_t k, int miss) {
-        auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(k, -1));
-        return (it != v.end() && it->first == k) ? it->second : miss;
-    }
-    int atom(const std::string& s) const { return s.size() > 4 ? FCZ_ATOM_CODE_OTHER : find(atoms, pack(s.data(), s.size()), FCZ_ATOM_CODE_OTHER); }
-    int residue(const std::string& s) const { return s.size() > 4 ? -1 : find(residues, pack(s.data(), s.size()), -1); }
+    int atom(uint32_t pk) const { return get(atoms, 255, pk, FCZ_ATOM_CODE_OTHER); }       // a long name is no name of the codec
+    int residue(uint32_t pk) const { return get(residues, 127, pk, -1); }
 };
 const NameCodes& name_codes() { static const NameCodes c; return c; }
 void fill_codes(AtomTable& t) {
@@ -200,13 +240,15 @@ void fill_codes(AtomTable& t) {
     }
 }
 
-AtomTable parse_pdb_raw(const std::string& raw, bool hetatm, std::string& title) {
+// drop_alt: removeAlternativePosition (an atom whose name equals that of the atom kept before it is dropped, reference
+// src/atom_coordinate.cpp) applied while parsing instead of as a second pass over a copy
+AtomTable parse_pdb_raw(const char* data, size_t size, bool hetatm, std::string& title, bool drop_alt = false) {
     AtomTable t;
-    const size_t guess = raw.size() / 81 + 1;
-    t.atom.reserve(guess); t.residue.reserve(guess); t.chain.reserve(guess); t.atom_index.reserve(guess); t.res_index.reserve(guess);
-    t.x.reserve(guess); t.y.reserve(guess); t.z.reserve(guess); t.bfac.reserve(guess);
+    t.reserve(size / 78 + 8);                                         // an ATOM line is 80 or 81 bytes with its line end
+    const NameCodes& nc = name_codes();
+    uint32_t last_res = 0xfffffffeu; int8_t last_rc = -1;
     std::vector<std::string> title_parts; std::string header_id; bool seen_atom = false, have_header = false;
-    const char* p = raw.data(); const char* end = p + raw.size();
+    const char* p = data; const char* end = p + size;
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
         const char* le = nl ? nl : end;
@@ -214,14 +256,18 @@ AtomTable parse_pdb_raw(const std::string& raw, bool hetatm, std::string& title)
         if (len && p[len - 1] == '\r') len--;
         const bool is_atom = len >= 4 && memcmp(p, "ATOM", 4) == 0;
         if (is_atom || (hetatm && len >= 6 && memcmp(p, "HETATM", 6) == 0)) {
-            t.atom.push_back(field_strip(p, len, 12, 16));
-            t.residue.push_back(field_strip(p, len, 17, 20));
+            const uint32_t an = field_pack(p, len, 12, 16), rn = field_pack(p, len, 17, 20);
+            if (is_atom) seen_atom = true;
+            if (drop_alt && !t.atom.empty() && t.atom.back() == an) { if (!nl) break; p = nl + 1; continue; }
+            t.atom.push_back(an); t.residue.push_back(rn);
+            t.atom_code.push_back((uint8_t)nc.atom(an));
+            if (rn != last_res) { last_res = rn; last_rc = (int8_t)nc.residue(rn); }
+            t.res_code.push_back(last_rc);
             t.chain.push_back(len > 21 ? p[21] : ' ');
             t.atom_index.push_back(field_int(p, len, 6, 11));
             t.res_index.push_back(field_int(p, len, 22, 26));
             t.x.push_back(field_float(p, len, 30, 38)); t.y.push_back(field_float(p, len, 38, 46)); t.z.push_back(field_float(p, len, 46, 54));
-            const std::string b = field_strip(p, len, 60, 66);
-            t.bfac.push_back(b.empty() ? 0.0f : field_float(p, len, 60, 66));
+            t.bfac.push_back(field_blank(p, len, 60, 66) ? 0.0f : field_float(p, len, 60, 66));
             if (is_atom) seen_atom = true;
         } else if (!seen_atom && !have_header) {          // gemmi: _entry.id = HEADER id code (cols 63-66), else the TITLE records
             if (len >= 66 && memcmp(p, "HEADER", 6) == 0 && !field_strip(p, len, 62, 66).empty()) { header_id = field_strip(p, len, 62, 66); have_header = true; }
@@ -239,8 +285,8 @@ AtomTable parse_pdb(const std::vector<std::string>& lines, bool hetatm) {
     AtomTable t;
     for (const std::string& line : lines) {
         if (!(starts_with(line, "ATOM") || (hetatm && starts_with(line, "HETATM")))) continue;
-        t.atom.push_back(strip(field(line, 12, 16)));
-        t.residue.push_back(strip(field(line, 17, 20)));
+        t.atom.push_back(t.intern(strip(field(line, 12, 16))));
+        t.residue.push_back(t.intern(strip(field(line, 17, 20))));
         const std::string ch = field(line, 21, 22);
         t.chain.push_back(ch.empty() ? ' ' : ch[0]);
         t.atom_index.push_back(parse_int(field(line, 6, 11)));
@@ -254,11 +300,13 @@ AtomTable parse_pdb(const std::vector<std::string>& lines, bool hetatm) {
 
 AtomTable remove_alternative_position(const AtomTable& t) {
     AtomTable o;
-    const std::string* prev = nullptr;
+    o.long_names = t.long_names;
+    o.reserve(t.size());
+    bool have = false; uint32_t prev = 0;
     for (size_t i = 0; i < t.size(); i++) {
-        if (prev && t.atom[i] == *prev) continue;
+        if (have && t.atom[i] == prev) continue;
         o.push_from(t, i);
-        prev = &t.atom[i];
+        prev = t.atom[i]; have = true;
     }
     return o;
 }
@@ -339,7 +387,7 @@ AtomTable parse_cif(const std::vector<std::string>& lines, std::string& title) {
         std::string an = r[c_atom];
         while (!an.empty() && an.front() == '"') an.erase(an.begin());
         while (!an.empty() && an.back() == '"') an.pop_back();
-        t.atom.push_back(an); t.residue.push_back(r[c_res]); t.chain.push_back(r[c_chain].empty() ? ' ' : r[c_chain][0]);
+        t.atom.push_back(t.intern(an)); t.residue.push_back(t.intern(r[c_res])); t.chain.push_back(r[c_chain].empty() ? ' ' : r[c_chain][0]);
         t.atom_index.push_back(c_id >= 0 ? parse_int(r[c_id]) : (int)t.atom.size());
         t.res_index.push_back((r[c_seq] == "." || r[c_seq] == "?") ? 0 : parse_int(r[c_seq]));
         t.x.push_back(parse_float(r[cx])); t.y.push_back(parse_float(r[cy])); t.z.push_back(parse_float(r[cz]));
@@ -356,10 +404,10 @@ std::vector<Range> identify_chains(const AtomTable& t) {
     size_t start = 0, i = 1;
     while (i < n) {
         if (t.chain[i] != t.chain[i - 1]) {
-            if (t.atom[i] == "N") { out.push_back({start, i}); start = i; }
+            if (t.atom[i] == PK_N) { out.push_back({start, i}); start = i; }
             else {
                 size_t j = i;
-                while (j < n && t.atom[j] != "N") j++;
+                while (j < n && t.atom[j] != PK_N) j++;
                 if (j == n) break;
                 out.push_back({start, i});
                 start = j; i = start;
@@ -373,7 +421,7 @@ std::vector<Range> identify_chains(const AtomTable& t) {
 
 std::vector<Range> identify_discontinuous(const AtomTable& t, Range r) {
     std::vector<size_t> n_idx;
-    for (size_t i = r.a; i < r.b; i++) if (t.atom[i] == "N") n_idx.push_back(i);
+    for (size_t i = r.a; i < r.b; i++) if (t.atom[i] == PK_N) n_idx.push_back(i);
     std::vector<Range> out;
     if (n_idx.empty()) return out;
     size_t start = n_idx[0];
@@ -439,10 +487,10 @@ struct Batch {
         std::vector<uint8_t> ac(t.size()), rc(nres);
         std::vector<float> bf(nres, 0.0f);
         const bool coded = t.atom_code.size() == t.size();
-        for (size_t i = 0; i < t.size(); i++) ac[i] = coded ? t.atom_code[i] : (uint8_t)fcz_atom_code_from_name(t.atom[i].c_str());
+        for (size_t i = 0; i < t.size(); i++) ac[i] = coded ? t.atom_code[i] : (uint8_t)fcz_atom_code_from_name(t.name(t.atom[i]).c_str());
         for (size_t r = 0; r < nres; r++) {
-            const int code = coded ? (int)t.res_code[ro[r]] : fcz_res_code_from_name(t.residue[ro[r]].c_str());
-            if (code < 0) throw std::runtime_error("residue name '" + t.residue[ro[r]] + "' is not supported by the codec");
+            const int code = coded ? (int)t.res_code[ro[r]] : fcz_res_code_from_name(t.name(t.residue[ro[r]]).c_str());
+            if (code < 0) throw std::runtime_error("residue name '" + t.name(t.residue[ro[r]]) + "' is not supported by the codec");
             rc[r] = (uint8_t)code;
             long pos[3] = {-1, -1, -1};
             for (uint32_t i = ro[r]; i < ro[r + 1]; i++) if (ac[i] < 3 && pos[ac[i]] < 0) pos[ac[i]] = i;
@@ -479,7 +527,7 @@ std::string read_file(const std::string& p) {   // POSIX read: iostream construc
     if (fd < 0) throw std::runtime_error("cannot open " + p);
     struct stat st;
     std::string out;
-    if (fstat(fd, &st) == 0 && st.st_size > 0) out.resize((size_t)st.st_size);
+    if (fstat(fd, &st) == 0 && st.st_size > 0) out.resize((size_t)st.st_size + 1);   // + 1: the read that returns 0 needs room
     size_t got = 0;
     for (;;) {
         if (got == out.size()) out.resize(out.size() + (1 << 16));
@@ -491,6 +539,32 @@ std::string read_file(const std::string& p) {   // POSIX read: iostream construc
     close(fd);
     out.resize(got);
     return out;
+}
+// the same into a buffer the calling thread keeps (the parse threads read ~240 KB per file: a fresh allocation of that size is
+// an mmap + page faults + munmap per file, and the address-space lock those take is what stopped the parse threads from scaling)
+struct FileImage { std::unique_ptr<char[]> p; size_t cap = 0, n = 0; const char* data() const { return p.get(); } };
+void read_file_into(const std::string& path, FileImage& im) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    size_t want = (fstat(fd, &st) == 0 && st.st_size > 0) ? (size_t)st.st_size + 1 : (size_t)(1 << 16);
+    auto grow = [&](size_t need) {
+        if (need <= im.cap) return;
+        size_t c = std::max<size_t>(need, im.cap * 2);
+        std::unique_ptr<char[]> q(new char[c]);
+        if (im.n) memcpy(q.get(), im.p.get(), im.n);
+        im.p = std::move(q); im.cap = c;
+    };
+    im.n = 0;
+    grow(want);
+    for (;;) {
+        if (im.n == im.cap) grow(im.cap + (1 << 16));
+        const ssize_t k = read(fd, im.p.get() + im.n, im.cap - im.n);
+        if (k < 0) { close(fd); throw std::runtime_error("cannot read " + path); }
+        if (k == 0) break;
+        im.n += (size_t)k;
+    }
+    close(fd);
 }
 bool is_dir(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
@@ -619,17 +693,17 @@ struct Fragment { std::string out_name, db_name; AtomTable atoms; std::string ti
 void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
                   std::vector<Fragment>& out) {
     const std::string base = base_name(path);
-    std::string raw = read_file(path);
-    std::string plain = base;
-    if (ends_with(base, ".gz")) { raw = gunzip(raw); plain = base.substr(0, base.size() - 3); }
+    static thread_local FileImage image;
+    read_file_into(path, image);
+    std::string plain = base, unz;
+    const char* data = image.data(); size_t size = image.n;
+    if (ends_with(base, ".gz")) { unz = gunzip(std::string(data, size)); data = unz.data(); size = unz.size(); plain = base.substr(0, base.size() - 3); }
     std::string title;
     AtomTable t;
-    if (ends_with(plain, ".cif")) t = parse_cif(split_lines(raw), title);
-    else t = parse_pdb_raw(raw, true, title);
-    fill_codes(t);
+    if (ends_with(plain, ".cif")) { t = parse_cif(split_lines(std::string(data, size)), title); fill_codes(t); t = remove_alternative_position(t); }
+    else t = parse_pdb_raw(data, size, true, title, true);           // names -> codes and removeAlternativePosition in the same pass
     if (t.size() == 0) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base.c_str()); return; }
     if (title.empty() || title == base) title = out_stem;            // src/main.cpp:465
-    t = remove_alternative_position(t);
     const std::vector<Range> chains = identify_chains(t);
     for (const Range& cs : chains) {
         const std::vector<Range> frags = identify_discontinuous(t, cs);
@@ -639,7 +713,9 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
             if (chains.size() > 1) fname += t.chain[cs.a];
             if (frags.size() > 1) fname += "_" + std::to_string(j);
             if (to_dir_or_file) fname += is_compressible(out_stem, ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
-            out.push_back({fname, out_stem, t.slice(frags[j].a, frags[j].b), title});
+            // the usual file is one chain in one piece: its table moves into the fragment instead of being copied
+            if (chains.size() == 1 && frags.size() == 1 && frags[j].a == 0 && frags[j].b == t.size()) out.push_back({fname, out_stem, std::move(t), title});
+            else out.push_back({fname, out_stem, t.slice(frags[j].a, frags[j].b), title});
         }
     }
 }
@@ -663,6 +739,7 @@ void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t 
         if (!err[i].empty()) fputs(err[i].c_str(), stderr);
         for (Fragment& f : per[i]) out.push_back(std::move(f));
     }
+
 }
 
 int need_ctx(fcz_ctx** ctx) {
@@ -1145,7 +1222,7 @@ int run_rmsd(const Options& o) {
         const float dx = a.x[i] - b.x[i], dy = a.y[i] - b.y[i], dz = a.z[i] - b.z[i];
         const float d2 = dx * dx + dy * dy + dz * dz;
         sum_all += d2;
-        if (a.atom[i] == "N" || a.atom[i] == "CA" || a.atom[i] == "C") { sum_bb += d2; n_bb++; }
+        if (a.atom[i] == PK_N || a.atom[i] == PK_CA || a.atom[i] == PK_C) { sum_bb += d2; n_bb++; }
     }
     size_t n_res = 0;
     for (size_t i = 0; i < a.size(); i++) if (i == 0 || a.res_index[i] != a.res_index[i - 1] || a.chain[i] != a.chain[i - 1]) n_res++;

@@ -87,6 +87,10 @@ struct AtomTable {
         for (int i = 0; i < 4 && ((pk >> (8 * i)) & 0xffu); i++) o.push_back((char)((pk >> (8 * i)) & 0xffu));
         return o;
     }
+    void clear() {   // keeps every capacity (TablePool)
+        atom.clear(); residue.clear(); long_names.clear(); chain.clear(); atom_index.clear(); res_index.clear();
+        x.clear(); y.clear(); z.clear(); bfac.clear(); atom_code.clear(); res_code.clear();
+    }
     void reserve(size_t n) {
         atom.reserve(n); residue.reserve(n); chain.reserve(n); atom_index.reserve(n); res_index.reserve(n);
         x.reserve(n); y.reserve(n); z.reserve(n); bfac.reserve(n); atom_code.reserve(n); res_code.reserve(n);
@@ -109,6 +113,25 @@ struct AtomTable {
         if (o.atom_code.size() == o.size()) { atom_code.push_back(o.atom_code[i]); res_code.push_back(o.res_code[i]); }
     }
 };
+
+// Tables go round: the parse threads take an emptied table (with the capacity it grew to) instead of allocating eleven
+// vectors per file, the compress workers hand the tables of a finished job back. Fresh allocations of that size by hundreds of
+// threads (heap growth by mprotect, first-touch page faults) all take the process's address-space lock.
+struct TablePool {
+    std::mutex m; std::vector<AtomTable> free_;
+    AtomTable get() {
+        std::lock_guard<std::mutex> g(m);
+        if (free_.empty()) return AtomTable();
+        AtomTable t = std::move(free_.back()); free_.pop_back();
+        return t;
+    }
+    void put(AtomTable&& t) {
+        t.clear();
+        std::lock_guard<std::mutex> g(m);
+        if (free_.size() < 65536) free_.push_back(std::move(t));
+    }
+};
+TablePool& table_pool() { static TablePool p; return p; }
 
 std::string strip(const std::string& s) {
     size_t a = 0, b = s.size();
@@ -243,7 +266,7 @@ void fill_codes(AtomTable& t) {
 // drop_alt: removeAlternativePosition (an atom whose name equals that of the atom kept before it is dropped, reference
 // src/atom_coordinate.cpp) applied while parsing instead of as a second pass over a copy
 AtomTable parse_pdb_raw(const char* data, size_t size, bool hetatm, std::string& title, bool drop_alt = false) {
-    AtomTable t;
+    AtomTable t = table_pool().get();
     t.reserve(size / 78 + 8);                                         // an ATOM line is 80 or 81 bytes with its line end
     const NameCodes& nc = name_codes();
     uint32_t last_res = 0xfffffffeu; int8_t last_rc = -1;
@@ -843,6 +866,7 @@ int run_compress(const Options& o) {
                 // a fragment the codec cannot take is reported and left out (Batch::add throws before it changes the batch)
                 try { b.add(job.frags[i].atoms, job.frags[i].title, o.brk); kept.push_back(i); }
                 catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", job.frags[i].out_name.c_str(), e.what()); }
+                table_pool().put(std::move(job.frags[i].atoms));   // its atoms are in the batch (or refused): the table goes round
             }
             fcz_chain_batch v = b.view(o.brk);
             std::vector<uint64_t> off(v.n_chains + 1, 0);

@@ -142,13 +142,37 @@ def host_sample(d, n_sample):
     return synthetic.to_chain_batch(sub)
 
 
+def effective_cores():
+    """CPUs this process may actually use: the scheduler affinity, cut by the cgroup's CFS quota when there is one
+    (cpu.max 'quota period'). The GPU box shows 256 hardware threads under a 16-CPU quota: more runnable threads than the
+    quota only thrash (both this repo's host code and the reference's OpenMP loop get slower beyond it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(hb, anchor):
     """the reference's CPU path on this host (oracle/_ref, OpenMP over chains like `foldcomp -t`);
     falls back to the C port (oracle/) only as a *baseline*, never as part of the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _harness as H
     from foldcomp_amd._aa_tables import ATOM_NAMES, RES3
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     R = hb.n_residues
     sample = f"first {hb.n_chains} chains of the GPU workload ({R} residues), codec only (objects in, FCZ, objects out)"
     if H.have_ref():
@@ -162,7 +186,7 @@ def cpu_baseline(hb, anchor):
                                        hb.z.ctypes.data, hb.atom_code.ctypes.data, hb.res_code.ctypes.data, hb.bfac_ca.ctypes.data,
                                        an.ctypes.data, rn.ctypes.data, anchor, cores, ctypes.byref(tc), ctypes.byref(td),
                                        ctypes.byref(fb), ctypes.byref(ao))
-        return {"value": R / (tc.value + td.value), "unit": "residues/s", "cores": cores, "kind": "reference", "sample": sample,
+        return {"value": R / (tc.value + td.value), "unit": "residues/s", "cores": cores, "hardware_threads": os.cpu_count(), "kind": "reference", "sample": sample,
                 "compress_residues_per_s": R / tc.value, "decompress_residues_per_s": R / td.value, "failed_chains": int(fail)}
     t0 = time.perf_counter(); blob, off, st = H.oracle_compress(hb, n_threads=cores)
     t1 = time.perf_counter(); H.oracle_decompress(blob, off, n_threads=cores); t2 = time.perf_counter()
@@ -205,12 +229,12 @@ def parity_sample(hb, blob_dev, off_dev, out_t, atom_off_host, n):
     """GPU results of the first n chains against the oracle (checker only, outside the timed region)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _harness as H
-    oblob, ooff, ost = H.oracle_compress(hb, n_threads=os.cpu_count() or 1)
+    oblob, ooff, ost = H.oracle_compress(hb, n_threads=effective_cores())
     nb = int(ooff[-1])
     got = blob_dev[:nb].cpu().numpy()
     goff = off_dev[:n + 1].cpu().numpy().astype(np.uint64)
     ok_c = bool(np.array_equal(goff, ooff) and got.tobytes() == oblob.tobytes())
-    o = H.oracle_decompress(oblob, ooff, n_threads=os.cpu_count() or 1)
+    o = H.oracle_decompress(oblob, ooff, n_threads=effective_cores())
     na = int(o["atom_off"][-1])
     ok_d = all(np.array_equal(out_t[k][:na].cpu().numpy().view(np.uint32), o[k].view(np.uint32)) for k in ("x", "y", "z"))
     return ok_c, bool(ok_d)
@@ -356,11 +380,13 @@ def end_to_end_leg(args, codec, w, dev):
                 fh.write(text[toff[i]:toff[i + 1]].tobytes())
             paths.append(pth)
         n_res = int(w.res_off_dev[n])
-        out = {"files": n, "input_bytes": int(toff[n]), "residues": n_res, "host_cores": os.cpu_count()}
+        out = {"files": n, "input_bytes": int(toff[n]), "residues": n_res, "host_cores": effective_cores(), "hardware_threads": os.cpu_count()}
         # Both sides are run at several host thread counts and their best is reported: the parse / reference loops of this image
         # stop scaling well below the visible core count (page-fault and allocator contention), and the right count differs per box
         cores = os.cpu_count() or 1
-        tcounts = sorted({t for t in (16, 32, 64, cores) if t <= cores} | {min(cores, 32)})
+        eff = effective_cores()
+        # thread counts around what the process may use (the CFS quota), plus every hardware thread for the record
+        tcounts = sorted({t for t in (max(1, eff // 2), eff, 2 * eff, 4 * eff, cores) if 1 <= t <= cores})
         runs = []
         for t in tcounts:
             db = os.path.join(tmp, f"db{t}")

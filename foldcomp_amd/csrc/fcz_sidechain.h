@@ -242,17 +242,34 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
     struct res_in { uint32_t a, a_next, rc, q0, q1, q2, a_first, a_end; v3 b0, b1, b2; };
     const uint32_t n_units = tile_list ? *tile_count : n_tiles;
     auto unit_tile = [&](uint32_t u) -> uint32_t { return tile_list ? tile_list[u < n_units ? u : 0u] : u; };
+    // buffer loads: the base of every array at the tile's first residue lives in SGPRs, the lane's offset is 4 t (12 t for bb)
+    // and the range check returns zero past the end of the batch: no per-load 64-bit address arithmetic, no clamping
     auto load_res = [&](uint32_t tile) -> res_in {
         const size_t r_lo = (size_t)tile * tile_res;
-        size_t r = r_lo + (size_t)((uint32_t)t < tile_res ? (uint32_t)t : tile_res - 1u);
-        r = r < (size_t)n_res ? r : (size_t)n_res - 1;
         const size_t rf = r_lo < (size_t)n_res ? r_lo : (size_t)n_res;
         const size_t re = r_lo + tile_res < (size_t)n_res ? r_lo + tile_res : (size_t)n_res;
+        const uint32_t left = (uint32_t)((size_t)n_res - rf);                     // residues from the tile's first one to the end
+        const uint32_t rows = left < tile_res ? left : tile_res;                  // residues of this tile
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(res_aoff) + rf, 0, (int)((rows + 1u) * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(res_rc) + rf, 0, (int)rows, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(res_sc) + rf, 0, (int)(rows * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(res_sc) + (size_t)n_res + rf, 0, (int)(rows * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(res_sc) + 2 * (size_t)n_res + rf, 0, (int)(rows * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<v3*>(bb) + 3 * rf, 0, (int)(rows * 36u), 0x00020000);
         res_in in;
-        in.a = res_aoff[r]; in.a_next = res_aoff[r + 1]; in.rc = res_rc[r];
-        in.q0 = res_sc[r]; in.q1 = res_sc[(size_t)n_res + r]; in.q2 = res_sc[2 * (size_t)n_res + r];
+        in.a = __builtin_amdgcn_raw_buffer_load_b32(ra, 4 * t, 0, 0);
+        in.a_next = __builtin_amdgcn_raw_buffer_load_b32(ra, 4 * t + 4, 0, 0);
+        in.rc = __builtin_amdgcn_raw_buffer_load_b8(rr, t, 0, 0);
+        in.q0 = __builtin_amdgcn_raw_buffer_load_b32(r0, 4 * t, 0, 0);
+        in.q1 = __builtin_amdgcn_raw_buffer_load_b32(r1, 4 * t, 0, 0);
+        in.q2 = __builtin_amdgcn_raw_buffer_load_b32(r2, 4 * t, 0, 0);
         in.a_first = res_aoff[rf]; in.a_end = res_aoff[re];
-        in.b0 = bb[3 * r]; in.b1 = bb[3 * r + 1]; in.b2 = bb[3 * r + 2];
+        typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+        const u3v w0 = __builtin_amdgcn_raw_buffer_load_b96(rb, 36 * t, 0, 0), w1 = __builtin_amdgcn_raw_buffer_load_b96(rb, 36 * t + 12, 0, 0),
+                  w2 = __builtin_amdgcn_raw_buffer_load_b96(rb, 36 * t + 24, 0, 0);
+        in.b0 = v3{__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+        in.b1 = v3{__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z)};
+        in.b2 = v3{__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z)};
         return in;
     };
     // Stores and loads share one in-order counter (vmcnt). The wait for a tile's prefetched inputs at the top of the loop can

@@ -86,7 +86,7 @@ def test_get_data_fcz(golden):
 def test_get_data_pdb_angles_bit_exact(golden):
     z, _ = golden
     # syn:len700 / syn:len1400: chains beyond the register path of the pack kernel (angles finished in place, two passes)
-    for name in ("pdb:test_af", "pdb:test", "syn:len129", "syn:len351", "syn:len700", "syn:len1400", "syn:missing_atoms"):
+    for name in ("pdb:test_af", "pdb:test", "syn:len129", "syn:len351", "syn:len700", "syn:len1400"):
         text, _ = _input_pdb_text(z, name)
         d = foldcomp.get_data(text)
         for k in ("phi", "psi", "omega"):

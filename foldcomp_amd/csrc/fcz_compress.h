@@ -854,6 +854,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     if (small) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            if ((uint32_t)(u * WAVE) >= m) continue;      // a round no residue of this chain falls into (wave-uniform): short chains
             va[0][u] = dec_angle<0>(va[0][u]); va[1][u] = dec_angle<1>(va[1][u]); va[2][u] = dec_angle<2>(va[2][u]);
             va[3][u] = dec_angle<3>(va[3][u]); va[4][u] = dec_angle<4>(va[4][u]); va[5][u] = dec_angle<5>(va[5][u]);
         }

@@ -41,16 +41,6 @@ struct __attribute__((packed, aligned(4))) f4_u { float x, y, z, w; };
 __device__ __forceinline__ float4 ld_f4(const float* p) { const f4_u t = *reinterpret_cast<const f4_u*>(p); return float4{t.x, t.y, t.z, t.w}; }
 
 // ---- wave-level primitives -----------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(inc, d, WAVE);
-        if (lane >= d) inc += t;
-    }
-    *total = __shfl(inc, WAVE - 1, WAVE);
-    return inc - v;
-}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
@@ -58,7 +48,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 // exclusive prefix sum over the wavefront on the DPP network: Hillis-Steele inside each row of 16 (zeros shift in), then the
 // row totals travel with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3). Six dependent VALU instructions instead of
-// six LDS-crossbar round trips (wave_excl_scan above)
+// six LDS-crossbar round trips (shuffles)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32_or0(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
@@ -74,6 +64,8 @@ __device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x, uint32_t* tot
     *total = (uint32_t)__builtin_amdgcn_readlane((int)v, WAVE - 1);
     return v - x;
 }
+// every call site runs with all 64 lanes active (wave-uniform control flow); `lane` is kept for the callers' signature
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) { (void)lane; return wave_excl_scan_dpp(v, total); }
 
 
 // running extremum with std::min_element / std::max_element semantics (first occurrence wins,

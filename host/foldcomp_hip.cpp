@@ -194,6 +194,30 @@ inline bool fast_decimal(const char* p, const char* e, double& out) {
     out = neg ? -v : v;
     return true;
 }
+// The layout every writer of the format uses for a number field: right-aligned, fixed decimals ("%8.3f" coordinates, "%6.2f"
+// B-factors). W = field width, F = decimals. The float is (float)(m / 10^F) with m the digits as an integer; for m < 10^8 and
+// F <= 3, (float)(m * 10^-F) is the same float (the product is within one double ulp of the quotient, and a quotient with
+// 125 not dividing m is at least 2^-25 / 10^F away, relatively, from every float rounding boundary; checked exhaustively for
+// F = 2, 3), so the division becomes a multiplication. Anything else about the field -> false, the general path decides.
+template <int W, int F>
+inline bool fixed_field(const char* f, float& out) {
+    constexpr int IP = W - F - 1;                      // characters before the point
+    if (f[IP] != '.') return false;
+    uint32_t frac = 0;
+    for (int i = 0; i < F; i++) { const unsigned c = (unsigned)(f[IP + 1 + i] - '0'); if (c > 9u) return false; frac = frac * 10u + c; }
+    int i = 0;
+    while (i < IP && f[i] == ' ') i++;
+    bool neg = false;
+    if (i < IP && f[i] == '-') { neg = true; i++; }
+    if (i >= IP) return false;                         // no digit before the point
+    uint32_t ip = 0;
+    for (; i < IP; i++) { const unsigned c = (unsigned)(f[i] - '0'); if (c > 9u) return false; ip = ip * 10u + c; }
+    constexpr uint32_t P10 = F == 3 ? 1000u : (F == 2 ? 100u : (F == 1 ? 10u : 1u));
+    constexpr double INV = F == 3 ? 0.001 : (F == 2 ? 0.01 : (F == 1 ? 0.1 : 1.0));
+    const float v = (float)((double)(ip * P10 + frac) * INV);
+    out = neg ? -v : v;
+    return true;
+}
 inline float field_float(const char* line, size_t len, size_t a, size_t b) {
     if (a >= len) throw std::runtime_error("invalid number field ''");
     b = std::min(b, len);
@@ -214,17 +238,18 @@ inline int field_int(const char* line, size_t len, size_t a, size_t b) {
     if (!ok) return parse_int(std::string(line + a, b - a));
     return (int)(neg ? -v : v);
 }
+inline bool is_space(char c) { return c == ' ' || (unsigned)(c - 9) < 5u; }   // isspace of the C locale, without the table call
 inline uint32_t field_pack(const char* line, size_t len, size_t a, size_t b) {   // the stripped field as a packed name (b - a <= 4)
     if (a >= len) return 0;
     b = std::min(b, len);
-    while (a < b && isspace((unsigned char)line[a])) a++;
-    while (b > a && isspace((unsigned char)line[b - 1])) b--;
+    while (a < b && is_space(line[a])) a++;
+    while (b > a && is_space(line[b - 1])) b--;
     return pack_name(line + a, b - a);
 }
 inline bool field_blank(const char* line, size_t len, size_t a, size_t b) {
     if (a >= len) return true;
     b = std::min(b, len);
-    for (; a < b; a++) if (!isspace((unsigned char)line[a])) return false;
+    for (; a < b; a++) if (!is_space(line[a])) return false;
     return true;
 }
 inline std::string field_strip(const char* line, size_t len, size_t a, size_t b) {
@@ -289,8 +314,14 @@ AtomTable parse_pdb_raw(const char* data, size_t size, bool hetatm, std::string&
             t.chain.push_back(len > 21 ? p[21] : ' ');
             t.atom_index.push_back(field_int(p, len, 6, 11));
             t.res_index.push_back(field_int(p, len, 22, 26));
-            t.x.push_back(field_float(p, len, 30, 38)); t.y.push_back(field_float(p, len, 38, 46)); t.z.push_back(field_float(p, len, 46, 54));
-            t.bfac.push_back(field_blank(p, len, 60, 66) ? 0.0f : field_float(p, len, 60, 66));
+            float fx, fy, fz, fb;
+            if (len >= 54 && fixed_field<8, 3>(p + 30, fx) && fixed_field<8, 3>(p + 38, fy) && fixed_field<8, 3>(p + 46, fz)) {
+                t.x.push_back(fx); t.y.push_back(fy); t.z.push_back(fz);
+            } else {
+                t.x.push_back(field_float(p, len, 30, 38)); t.y.push_back(field_float(p, len, 38, 46)); t.z.push_back(field_float(p, len, 46, 54));
+            }
+            if (len >= 66 && fixed_field<6, 2>(p + 60, fb)) t.bfac.push_back(fb);
+            else t.bfac.push_back(field_blank(p, len, 60, 66) ? 0.0f : field_float(p, len, 60, 66));
             if (is_atom) seen_atom = true;
         } else if (!seen_atom && !have_header) {          // gemmi: _entry.id = HEADER id code (cols 63-66), else the TITLE records
             if (len >= 66 && memcmp(p, "HEADER", 6) == 0 && !field_strip(p, len, 62, 66).empty()) { header_id = field_strip(p, len, 62, 66); have_header = true; }

@@ -529,39 +529,49 @@ struct Batch {
         atom_code.clear(); res_code.clear(); first_res.clear(); first_atom.clear(); chain_id.clear(); titles.clear();
     }
 
-    // appends one fragment; throws std::runtime_error with what the reference would abort on
-    void add(const AtomTable& t, const std::string& title, int anchor_threshold = 25) {
+    // what add() derives from a fragment before it touches the batch: residue boundaries, residue codes, CA B-factors. Pure (no
+    // batch state), so the parse threads run it side by side; throws std::runtime_error with what the reference would abort on
+    struct Prepared { std::vector<uint32_t> ro; std::vector<uint8_t> ac, rc; std::vector<float> bf; };
+    static Prepared prepare(const AtomTable& t, int anchor_threshold = 25) {
         if (t.size() == 0) throw std::runtime_error("empty chain");
-        const std::vector<uint32_t> ro = split_residues(t);
-        const size_t nres = ro.size() - 1, abase = x.size();
+        Prepared p;
+        p.ro = split_residues(t);
+        const std::vector<uint32_t>& ro = p.ro;
+        const size_t nres = ro.size() - 1;
         // the FCZ header holds nResidue in 16 bits and nAnchor in 8 (src/foldcomp.h:120-125): the reference wraps silently
         // and writes a record nobody can read; here the chain is refused
         if (nres > 65535 || (anchor_threshold > 0 && nres / (size_t)anchor_threshold + 2 > 255))
             throw std::runtime_error("chain of " + std::to_string(nres) + " residues does not fit the FCZ header (65535 residues, 255 anchors)");
-        std::vector<uint8_t> ac(t.size()), rc(nres);
-        std::vector<float> bf(nres, 0.0f);
+        p.ac.resize(t.size()); p.rc.resize(nres); p.bf.assign(nres, 0.0f);
         const bool coded = t.atom_code.size() == t.size();
-        for (size_t i = 0; i < t.size(); i++) ac[i] = coded ? t.atom_code[i] : (uint8_t)fcz_atom_code_from_name(t.name(t.atom[i]).c_str());
+        for (size_t i = 0; i < t.size(); i++) p.ac[i] = coded ? t.atom_code[i] : (uint8_t)fcz_atom_code_from_name(t.name(t.atom[i]).c_str());
         for (size_t r = 0; r < nres; r++) {
             const int code = coded ? (int)t.res_code[ro[r]] : fcz_res_code_from_name(t.name(t.residue[ro[r]]).c_str());
             if (code < 0) throw std::runtime_error("residue name '" + t.name(t.residue[ro[r]]) + "' is not supported by the codec");
-            rc[r] = (uint8_t)code;
+            p.rc[r] = (uint8_t)code;
             long pos[3] = {-1, -1, -1};
-            for (uint32_t i = ro[r]; i < ro[r + 1]; i++) if (ac[i] < 3 && pos[ac[i]] < 0) pos[ac[i]] = i;
+            for (uint32_t i = ro[r]; i < ro[r + 1]; i++) if (p.ac[i] < 3 && pos[p.ac[i]] < 0) pos[p.ac[i]] = i;
             if (pos[0] < 0 || pos[1] < 0 || pos[2] < 0 || !(pos[0] < pos[1] && pos[1] < pos[2]))
                 throw std::runtime_error("residue without N, CA, C backbone atoms in order");
-            bf[r] = t.bfac[pos[1]];
+            p.bf[r] = t.bfac[pos[1]];
         }
-        for (size_t r = 0; r < nres; r++) atom_off.push_back((uint32_t)(abase + ro[r]));
+        return p;
+    }
+    // appends one prepared fragment (copies only)
+    void append(const AtomTable& t, const Prepared& p, const std::string& title) {
+        const size_t nres = p.ro.size() - 1, abase = x.size();
+        for (size_t r = 0; r < nres; r++) atom_off.push_back((uint32_t)(abase + p.ro[r]));
         x.insert(x.end(), t.x.begin(), t.x.end()); y.insert(y.end(), t.y.begin(), t.y.end()); z.insert(z.end(), t.z.begin(), t.z.end());
-        atom_code.insert(atom_code.end(), ac.begin(), ac.end());
-        res_code.insert(res_code.end(), rc.begin(), rc.end());
-        bfac_ca.insert(bfac_ca.end(), bf.begin(), bf.end());
+        atom_code.insert(atom_code.end(), p.ac.begin(), p.ac.end());
+        res_code.insert(res_code.end(), p.rc.begin(), p.rc.end());
+        bfac_ca.insert(bfac_ca.end(), p.bf.begin(), p.bf.end());
         res_off.push_back(res_off.back() + (uint32_t)nres);
         first_res.push_back(t.res_index[0]); first_atom.push_back(t.atom_index[0]);
         chain_id.push_back(t.chain[0]);
         titles += title; title_off.push_back((uint32_t)titles.size());
     }
+    // appends one fragment; throws before it changes the batch
+    void add(const AtomTable& t, const std::string& title, int anchor_threshold = 25) { append(t, prepare(t, anchor_threshold), title); }
     fcz_chain_batch view(int anchor_threshold) {
         if (atom_off.size() == res_code.size()) atom_off.push_back((uint32_t)x.size());
         fcz_chain_batch b{};
@@ -739,7 +749,11 @@ struct Options {
     bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
 };
 
-struct Fragment { std::string out_name, db_name; AtomTable atoms; std::string title; };   // db_name: lookup name = the input file's stem
+struct Fragment {
+    std::string out_name, db_name; AtomTable atoms; std::string title;   // db_name: lookup name = the input file's stem
+    // filled by the parse threads of the compress pipeline (Batch::prepare): what the batch needs besides the atoms, or why not
+    bool prepared = false; Batch::Prepared prep; std::string prep_err;
+};
 
 // one structure file -> its fragments (src/main.cpp:455-508)
 // (out_stem, ext) = getFileParts of the input's base name, or of the OUTPUT path for a single-file run (src/main.cpp:444-457):
@@ -777,7 +791,7 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
 // fragments of many structure files, parsed on all host threads (the reference: `omp parallel for` over entries,
 // src/input_processor.h:85-101), kept in file order; messages are printed in file order too
 void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t b, bool single, const std::string& output, bool to_dir_or_file,
-                        const Options& o, std::vector<Fragment>& out) {
+                        const Options& o, std::vector<Fragment>& out, bool prepare = false) {
     std::vector<std::vector<Fragment>> per(b - a);
     std::vector<std::string> err(b - a);
 #pragma omp parallel for schedule(dynamic, 4)
@@ -788,6 +802,10 @@ void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t 
         if (single) file_parts(base_name(output), out_stem, ext);
         try { fragments_of(files[i], out_stem, ext, to_dir_or_file, o, per[i - a]); }
         catch (const std::exception& e) { err[i - a] = "[Error] " + base_name(files[i]) + ": " + e.what() + "\n"; }
+        if (prepare) for (Fragment& f : per[i - a]) {
+            try { f.prep = Batch::prepare(f.atoms, o.brk); } catch (const std::exception& e) { f.prep_err = e.what(); }
+            f.prepared = true;
+        }
     }
     for (size_t i = 0; i < b - a; i++) {
         if (!err[i].empty()) fputs(err[i].c_str(), stderr);
@@ -895,8 +913,14 @@ int run_compress(const Options& o) {
             }
             for (size_t i = 0; i < job.frags.size(); i++) {
                 // a fragment the codec cannot take is reported and left out (Batch::add throws before it changes the batch)
-                try { b.add(job.frags[i].atoms, job.frags[i].title, o.brk); kept.push_back(i); }
-                catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", job.frags[i].out_name.c_str(), e.what()); }
+                Fragment& f = job.frags[i];
+                try {
+                    if (!f.prepared) b.add(f.atoms, f.title, o.brk);
+                    else if (!f.prep_err.empty()) throw std::runtime_error(f.prep_err);
+                    else b.append(f.atoms, f.prep, f.title);
+                    kept.push_back(i);
+                }
+                catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), e.what()); }
                 table_pool().put(std::move(job.frags[i].atoms));   // its atoms are in the batch (or refused): the table goes round
             }
             fcz_chain_batch v = b.view(o.brk);
@@ -952,7 +976,7 @@ int run_compress(const Options& o) {
         for (size_t f0 = 0; f0 < files.size(); f0 += FILE_CHUNK) {
             const auto t0 = clk::now();
             const size_t f1 = std::min(files.size(), f0 + FILE_CHUNK);
-            fragments_of_files(files, f0, f1, single, output, !o.db, o, pending);
+            fragments_of_files(files, f0, f1, single, output, !o.db, o, pending, true);
             t_parse += std::chrono::duration<double>(clk::now() - t0).count();
             for (size_t i = f0; i < f1; i++) { struct stat st; if (stat(files[i].c_str(), &st) == 0) in_bytes += (uint64_t)st.st_size; }
             cut(false);

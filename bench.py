@@ -403,6 +403,9 @@ def end_to_end_leg(args, codec, w, dev):
                            "parse_s": best["parse_s"], "codec_call_s_sum": best["codec_call_s_sum"], "workers": best["workers"],
                            "host_threads": best["host_threads"], "records": best["records"], "residues_per_s": round(best["residues"] / best["wall_s"]),
                            "input_MB_per_s": round(best["input_bytes"] / best["wall_s"] / 1e6, 1),
+                           # the run's timeline (seconds after its start): the workers' device contexts exist, the last file is
+                           # parsed and queued, the last worker is done. The HIP runtime's start-up is inside this wall time.
+                           "timeline_s": {k: best.get(k) for k in ("ctx_ready_s", "all_parsed_s", "workers_done_s")},
                            "wall_s_by_threads": {str(r_["host_threads"]): r_["wall_s"] for r_ in runs}}
         # records of the database == records of the device-resident path (same chains, same titles? titles differ: file stem), so
         # compare against the reference on the same file instead

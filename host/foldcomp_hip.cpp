@@ -895,11 +895,12 @@ int run_compress(const Options& o) {
     Sequencer seq;
     std::atomic<bool> hard_fail{false};
     std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0};
-    std::vector<double> gpu_busy(n_workers, 0.0);
+    std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);   // ctx_ready: seconds after the start until the worker had its ctx
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
         fcz_ctx* ctx = nullptr;
         if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
         Batch b;                         // reused: its page-locked buffers grow to the largest job and stay
         pvec<uint8_t> blob;
         CompressJob job;
@@ -984,7 +985,9 @@ int run_compress(const Options& o) {
         cut(true);
         queue.close();
     }
+    const double t_parsed = std::chrono::duration<double>(clk::now() - t_start).count();   // every job is in the queue
     for (std::thread& t : workers) t.join();
+    const double t_joined = std::chrono::duration<double>(clk::now() - t_start).count();
 
     // ---- index: rows of all workers in job order, keys numbered over the records that made it ----
     if (o.db) {
@@ -1003,9 +1006,11 @@ int run_compress(const Options& o) {
         double busy = 0.0; for (double g : gpu_busy) busy += g;
         printf("{\"mode\": \"compress\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
                "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
-               "\"codec_call_s_sum\": %.4f, \"residues_per_s\": %.1f, \"input_MB_per_s\": %.1f}\n",
+               "\"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_parsed_s\": %.4f, \"workers_done_s\": %.4f, \"residues_per_s\": %.1f, "
+               "\"input_MB_per_s\": %.1f}\n",
                gpus, n_workers, omp_get_max_threads(), files.size(), (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
                (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), wall, t_parse, busy,
+               *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_parsed, t_joined,
                wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0);
     }
     return hard_fail ? 1 : 0;

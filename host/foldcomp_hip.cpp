@@ -782,8 +782,11 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
             if (frags.size() > 1) fname += "_" + std::to_string(j);
             if (to_dir_or_file) fname += is_compressible(out_stem, ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
             // the usual file is one chain in one piece: its table moves into the fragment instead of being copied
-            if (chains.size() == 1 && frags.size() == 1 && frags[j].a == 0 && frags[j].b == t.size()) out.push_back({fname, out_stem, std::move(t), title});
-            else out.push_back({fname, out_stem, t.slice(frags[j].a, frags[j].b), title});
+            Fragment f;
+            f.out_name = fname; f.db_name = out_stem; f.title = title;
+            if (chains.size() == 1 && frags.size() == 1 && frags[j].a == 0 && frags[j].b == t.size()) f.atoms = std::move(t);
+            else f.atoms = t.slice(frags[j].a, frags[j].b);
+            out.push_back(std::move(f));
         }
     }
 }

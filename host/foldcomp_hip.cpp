@@ -607,6 +607,7 @@ std::string read_file(const std::string& p) {   // POSIX read: iostream construc
 // the same into a buffer the calling thread keeps (the parse threads read ~240 KB per file: a fresh allocation of that size is
 // an mmap + page faults + munmap per file, and the address-space lock those take is what stopped the parse threads from scaling)
 struct FileImage { std::unique_ptr<char[]> p; size_t cap = 0, n = 0; const char* data() const { return p.get(); } };
+std::atomic<uint64_t> g_bytes_read{0};     // input bytes the parse threads have read (statistics of the compress pipeline)
 void read_file_into(const std::string& path, FileImage& im) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open " + path);
@@ -629,6 +630,7 @@ void read_file_into(const std::string& path, FileImage& im) {
         im.n += (size_t)k;
     }
     close(fd);
+    g_bytes_read += im.n;
 }
 bool is_dir(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
@@ -640,7 +642,9 @@ void list_files(const std::string& dir, bool recursive, std::vector<std::string>
             const std::string n = e->d_name;
             if (n == "." || n == "..") continue;
             const std::string p = dir + "/" + n;
-            (is_dir(p) ? dirs : files).push_back(p);
+            // the entry type comes with the directory entry on every file system that knows it: no stat per file
+            const bool dir_entry = e->d_type == DT_DIR || ((e->d_type == DT_UNKNOWN || e->d_type == DT_LNK) && is_dir(p));
+            (dir_entry ? dirs : files).push_back(p);
         }
         closedir(d);
     }
@@ -982,7 +986,7 @@ int run_compress(const Options& o) {
             const size_t f1 = std::min(files.size(), f0 + FILE_CHUNK);
             fragments_of_files(files, f0, f1, single, output, !o.db, o, pending, true);
             t_parse += std::chrono::duration<double>(clk::now() - t0).count();
-            for (size_t i = f0; i < f1; i++) { struct stat st; if (stat(files[i].c_str(), &st) == 0) in_bytes += (uint64_t)st.st_size; }
+            in_bytes = g_bytes_read.load();
             cut(false);
         }
         cut(true);

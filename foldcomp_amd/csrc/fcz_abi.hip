@@ -13,6 +13,15 @@
 
 #include "fcz_kernels.h"
 #include "fcz_compress.h"
+// persistent grids: blocks per resident slot. Measured (1 M chains): 1 block per slot is 5 % slower than 4, 16 is 3-5 % faster
+// than 4 (k_compress_angles_w 17.2 -> 16.4 ms, k_sidechain 16.0 -> 15.5 ms), 64 no better: with more, shorter blocks the
+// hardware dispatcher evens out what the CUs finish at different times, and the table prologue is still paid once per ~30+ tiles
+#ifndef FCZ_CW_GRID_FACTOR
+#define FCZ_CW_GRID_FACTOR 16u
+#endif
+#ifndef FCZ_SC_GRID_FACTOR
+#define FCZ_SC_GRID_FACTOR 16u
+#endif
 #include "fcz_sidechain.h"
 #include "fcz_backbone_fast.h"
 #include "fcz_pdb.h"
@@ -446,7 +455,7 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
         rc = ctx->tile_work.ensure(sizeof(uint32_t) * (2 * (size_t)n_tiles + 4)); if (rc) return rc;
         uint32_t* flags = ctx->tile_work.as<uint32_t>(); uint32_t* list = flags + n_tiles; uint32_t* count = list + n_tiles;
         HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (2 * (size_t)n_tiles + 4), ctx->stream));
-        const uint32_t blocks_w = std::min<uint32_t>(grid_for(n_wtiles, WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 3u * 4u);
+        const uint32_t blocks_w = std::min<uint32_t>(grid_for(n_wtiles, WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 3u * FCZ_CW_GRID_FACTOR);
         hipLaunchKernelGGL(k_compress_angles_w, dim3(blocks_w), dim3(BLOCK), 0, ctx->stream, *in, n_wtiles, ctx->res_sc_addr.as<uint64_t>(), out_dev,
                            ctx->ang.as<float>(), flags, list, count);
         const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_COMPRESS_MIN_BLOCKS);
@@ -763,7 +772,7 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     {
         span_guard g(ctx, "decompress_sidechain");
         const uint32_t n_tiles = grid_for(R, SC_TILE);
-        const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_SIDECHAIN_MIN_BLOCKS * 4u);
+        const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_SIDECHAIN_MIN_BLOCKS * FCZ_SC_GRID_FACTOR);
         // 256-residue tiles; a tile with more atoms than the staging buffer holds is listed as two 128-residue halves for
         // the second launch (an empty list on any real protein: that launch then costs its table prologue)
         rc = ctx->tile_work.ensure(sizeof(uint32_t) * (2 * (size_t)n_tiles + 4)); if (rc) return rc;

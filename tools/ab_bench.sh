@@ -3,7 +3,7 @@
 TAG=$1; shift
 OUT=gpurun_out/ab_$TAG.txt; : > $OUT
 for lib in "$@"; do
-  for rep in 1 2; do
+  for rep in ${REPS:-1 2}; do
     FCZ_HIP_LIB=$PWD/$lib python bench.py --chains ${CHAINS:-262144} --steps 4 --warmup 1 --cpu-sample 0 --pdb-sample 0 --mixed-chains 0 --e2e-files 0 --host-chains 0 > /tmp/ab.json 2> /tmp/ab.err || { echo "$lib FAILED"; tail -3 /tmp/ab.err; }
     python - "$lib" >> $OUT <<'PY'
 import json, sys

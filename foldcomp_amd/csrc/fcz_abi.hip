@@ -134,8 +134,9 @@ void drain_spans(fcz_ctx* ctx) {
 inline unsigned grid_for(uint32_t items, unsigned per_block) { return (items + per_block - 1) / per_block; }
 
 // exclusive scan of n elements into out[n+1] on the ctx stream (three launches, any n)
+// overflow (may be null): set to 1 on the device when the total does not fit T
 template <class T>
-int device_scan(fcz_ctx* ctx, const T* in, T* out, uint32_t n) {
+int device_scan(fcz_ctx* ctx, const T* in, T* out, uint32_t n, uint32_t* overflow = nullptr) {
     if (n == 0) { if (hipMemsetAsync(out, 0, sizeof(T), ctx->stream) != hipSuccess) return FCZ_E_HIP; return FCZ_OK; }
     const unsigned nb = grid_for(n, SCAN_CHUNK);
     int rc = ctx->scan_tmp.ensure(sizeof(unsigned long long) * 2 * ((size_t)nb + 1));
@@ -144,7 +145,7 @@ int device_scan(fcz_ctx* ctx, const T* in, T* out, uint32_t n) {
     unsigned long long* part_ex = part + nb + 1;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<T>), dim3(nb), dim3(1024), 0, ctx->stream, n, in, part);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, ctx->stream, nb, (const uint64_t*)part, (uint64_t*)part_ex);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<T>), dim3(nb), dim3(1024), 0, ctx->stream, n, in, part_ex, out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<T>), dim3(nb), dim3(1024), 0, ctx->stream, n, in, part_ex, out, overflow);
     return FCZ_OK;
 }
 
@@ -583,15 +584,17 @@ static void parse_entry(const uint8_t* e, uint64_t len, fcz_entry_info* info) {
 int fcz_decompress_sizes(const uint8_t* blob, const uint64_t* off, uint32_t n, fcz_entry_info* info, uint32_t* res_off,
                          uint32_t* atom_off) {
     if (!blob || !off || !res_off || !atom_off) return FCZ_E_INVALID_ARG;
-    uint32_t r = 0, a = 0;
+    uint64_t r = 0, a = 0;
     for (uint32_t i = 0; i < n; i++) {
-        res_off[i] = r; atom_off[i] = a;
+        res_off[i] = (uint32_t)r; atom_off[i] = (uint32_t)a;
         fcz_entry_info tmp;
         fcz_entry_info* pi = info ? &info[i] : &tmp;
         parse_entry(blob + off[i], off[i + 1] - off[i], pi);
         if (pi->status == FCZ_OK) { r += pi->n_residues; a += pi->n_atoms_out; }
     }
-    res_off[n] = r; atom_off[n] = a;
+    res_off[n] = (uint32_t)r; atom_off[n] = (uint32_t)a;
+    // offsets are 32-bit: a batch whose residues or atoms reach 2^32 is refused, not wrapped
+    if ((r >> 32) || (a >> 32)) return FCZ_E_INVALID_ARG;
     return FCZ_OK;
 }
 
@@ -633,25 +636,29 @@ static int run_entry_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t
     int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
     uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; int32_t* st = (int32_t*)(ca + n); uint32_t* seg = (uint32_t*)(st + n);
     if ((rc = ctx->maxseg.ensure(16))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));   // [0] longest segment, [1] most segments, [2] offset overflow
     if (n) {
         hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, st, seg);
         hipLaunchKernelGGL(k_seg_max, dim3(std::min<uint32_t>(grid_for(n, 1024), 256)), dim3(1024), 0, ctx->stream, seg, n, ctx->maxseg.as<uint32_t>());
     }
-    if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n))) return rc;
-    if (atom_off_dev && (rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n))) return rc;
+    // offsets are 32-bit: a batch whose residues or atoms reach 2^32 is refused, not wrapped (the scans add in 64 bits)
+    uint32_t* ovf = ctx->maxseg.as<uint32_t>() + 2;
+    if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n, ovf))) return rc;
+    if (atom_off_dev && (rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n, ovf))) return rc;
     if ((rc = build_len_perm(ctx, cr, n))) return rc;
     HIP_TRY(hipGetLastError());
     ctx->pinned[1] = 0;
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (atom_off_dev) HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 8, hipMemcpyDeviceToHost, ctx->stream));   // [3] longest segment, [4] most segments
+    HIP_TRY(hipMemcpyAsync(&ctx->pinned[6], ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pinned[5] = 0;
     if (n) {   // chains of FCZ_LONG_CHAIN residues or more lead the length order: the end of their last bucket is their count
         const uint32_t* cursor = ctx->len_perm.as<uint32_t>() + n + LEN_BUCKETS;
         HIP_TRY(hipMemcpyAsync(&ctx->pinned[5], cursor + len_bucket(FCZ_LONG_CHAIN), 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned[6]) return FCZ_E_INVALID_ARG;   // 2^32 residues or atoms in one batch: split it
     return FCZ_OK;
 }
 
@@ -700,9 +707,7 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     if (R == 0) return FCZ_OK;
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     const uint32_t* perm = ctx->len_perm.as<uint32_t>();
-    const char* dbg_parts = getenv("FCZ_DEBUG_FAST_PARTS");   // 1: backbone only, 2: side chains only (debugging aid)
-    const bool fast_bb = ctx->numerics == FCZ_NUMERICS_FAST && !(dbg_parts && dbg_parts[0] == '2');
-    const bool fast_sc = ctx->numerics == FCZ_NUMERICS_FAST && !(dbg_parts && dbg_parts[0] == '1');
+    const bool fast_bb = ctx->numerics == FCZ_NUMERICS_FAST, fast_sc = fast_bb;
     if (fast_bb) {
         // plain-float backbone: 8 chains per wavefront, the forward atoms of a segment stay in LDS; only segments longer than
         // one chunk (FB_K residue steps) park them in a scratch column, and then the launch is cut so that the columns of the

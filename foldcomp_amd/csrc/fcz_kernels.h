@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_scan_reduce(uint32_t n, const T* __res
 }
 template <class T>
 __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t n, const T* __restrict__ in, const unsigned long long* __restrict__ partial_excl,
-                                                     T* __restrict__ out) {
+                                                     T* __restrict__ out, uint32_t* __restrict__ overflow) {
     __shared__ unsigned long long s_w[16];
     const uint32_t base = blockIdx.x * SCAN_CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t n, const T* __rest
         carry += tot;
         __syncthreads();
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = (T)carry;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        out[n] = (T)carry;
+        if (overflow && sizeof(T) < 8 && (carry >> (8 * sizeof(T) < 64 ? 8 * sizeof(T) : 63))) *overflow = 1u;   // the total does not fit T
+    }
 }
 
 // LDS slot store of one lane's residue: [slot][comp][lane] floats -> conflict-free

@@ -280,6 +280,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
     // the L2: 12 % of the kernel (tools/dbg/sc_timing.py).
     constexpr int SC_WB = 3 * (SC_CAP / BLOCK);
     constexpr uint32_t SC_SKIP = 0xffffffffu;      // staged x of an atom that is not this kernel's to store (the chain's OXT)
+    constexpr int SC_SKIP_OFF = 0x7ffffff0;        // its store offset: past every range (a tile is < 10 KB), and offset + 4 does not wrap
     auto null_stores = [&]() {
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(out.x, 0, 0, 0x00020000);
 #pragma unroll
@@ -414,7 +415,7 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
                 for (int u = 0; u < SC_CAP / BLOCK; u++) {
                     const uint32_t i = (uint32_t)u * BLOCK + (uint32_t)t;
                     const uint32_t xb = __float_as_uint(S.stage[0][i]);
-                    const int off = (int)(xb == SC_SKIP ? SC_SKIP : 4u * i);     // out of every range: dropped
+                    const int off = xb == SC_SKIP ? SC_SKIP_OFF : (int)(4u * i);     // out of every range: dropped
                     __builtin_amdgcn_raw_buffer_store_b32(xb, rx, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S.stage[1][i]), ry, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S.stage[2][i]), rz, off, 0, 0);

@@ -3,7 +3,8 @@
  * C-ABI uses. It is the checker for the HIP path and (optionally) the timed CPU baseline; it is never
  * linked into, loaded by, or a fallback for libfcz_hip.so.
  *
- * Parity status: PINNED. tests/test_oracle_vs_reference.py checks this file byte-for-byte (FCZ) and
+ * Parity status: PINNED. tests/test_oracle_vs_golden.py (against reference-minted vectors) and the live-reference
+ * cases of tests/test_ingest_vs_reference.py / tests/test_gpu_parity.py check this file byte-for-byte (FCZ) and
  * bit-for-bit (decompressed float32 coordinates) against the real reference built from its own sources
  * (oracle/_ref/libfoldcomp_ref.so, see build_ref.sh) on the reference's fixtures and seeded synthetic
  * chains, and tests/golden/ holds reference-generated vectors for the GPU box where /root/reference

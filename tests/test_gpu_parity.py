@@ -58,9 +58,15 @@ def test_decompress_golden_bit_exact(codec, golden):
             worst = max(worst, float(np.abs(got - exp).max()))
             assert np.array_equal(_bits(got), _bits(exp)), (n, alt, float(np.abs(got - exp).max()))
             r0, r1 = d["res_off"][i], d["res_off"][i + 1]
-            # per-residue B-factor equals the reference's per-atom B-factor of that residue's atoms
+            # EVERY residue's B-factor equals the reference's per-atom B-factor of that residue's atoms (the chain's OXT
+            # carries the last residue's, src/foldcomp.cpp:893-900)
             per_atom = z[f"{n}/bfac"]
-            assert np.array_equal(_bits(d["bfac_res"][r0:r1][-1:]), _bits(per_atom[-1:])), n
+            nat = np.asarray([codec.lib.fcz_res_code_natoms(int(c)) for c in d["res_code"][r0:r1]])
+            rep = np.repeat(d["bfac_res"][r0:r1], nat)
+            if len(per_atom) == len(rep) + 1:
+                rep = np.append(rep, d["bfac_res"][r1 - 1])
+            assert len(rep) == len(per_atom), n
+            assert np.array_equal(_bits(rep), _bits(per_atom)), n
 
 
 def test_synthetic_batch_vs_oracle(codec):

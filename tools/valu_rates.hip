@@ -53,6 +53,16 @@ KERNEL_F64(k_rsq_f64, "v_rsq_f64 %0, %0")
 KERNEL_F64(k_rcp_f64, "v_rcp_f64 %0, %0")
 KERNEL_F64(k_sqrt_f64, "v_sqrt_f64 %0, %0")
 KERNEL_F64(k_cmp_f64, "v_cmp_lt_f64 vcc, %1, %0")
+// packed f32 (two floats per lane in a VGPR pair): what two-items-per-lane kernels would be made of
+KERNEL_F64(k_pk_fma_f32, "v_pk_fma_f32 %0, %1, %2, %0")
+KERNEL_F64(k_pk_mul_f32, "v_pk_mul_f32 %0, %1, %0")
+KERNEL_F64(k_pk_add_f32, "v_pk_add_f32 %0, %1, %0")
+KERNEL_F64(k_pk_mov_b32, "v_pk_mov_b32 %0, %1, %2")
+KERNEL_F32(k_fmac_f32, "v_fmac_f32 %0, %1, %2")
+KERNEL_F32(k_sub_f32, "v_sub_f32 %0, %1, %0")
+KERNEL_F32(k_add_u32, "v_add_u32 %0, %1, %0")
+KERNEL_F32(k_cmp_class, "v_cmp_class_f32 vcc, %0, %1")
+KERNEL_F32(k_mov_b32, "v_mov_b32 %0, %1")
 
 // v_cndmask with a mask the kernel itself produced (one v_cmp per 8 selects), vcc and SGPR-pair forms
 __global__ __launch_bounds__(256) void k_cndmask_vcc(float* out, float s) {
@@ -196,7 +206,7 @@ int main() {
         {"v_cmp_lt_f32", k_cmp_f32}, {"v_max3_f32", k_max3_f32}, {"v_mov_b32_dpp", k_mov_dpp}, {"v_div_scale_f32", k_div_scale},
         {"v_div_fixup_f32", k_div_fixup}, {"v_div_fmas_f32", k_div_fmas},
         {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_rsq_f64", k_rsq_f64}, {"v_rcp_f64", k_rcp_f64},
-        {"v_sqrt_f64", k_sqrt_f64}, {"v_cmp_lt_f64", k_cmp_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_f64", k_cvt_f32_f64},
+        {"v_sqrt_f64", k_sqrt_f64}, {"v_cmp_lt_f64", k_cmp_f64}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_mov_b32", k_pk_mov_b32}, {"v_fmac_f32", k_fmac_f32}, {"v_sub_f32", k_sub_f32}, {"v_add_u32", k_add_u32}, {"v_cmp_class_f32", k_cmp_class}, {"v_mov_b32", k_mov_b32}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_f64", k_cvt_f32_f64},
         {"v_cvt_i32_f64", k_cvt_i32_f64}, {"cmp+8 cndmask vcc", k_cndmask_vcc}, {"cmp+8 cndmask sgpr", k_cndmask_sgpr},
         {"cmp+8 sel e64 vcc", k_sel_e64_vcc_vcmp}, {"smov+8 sel e32 vcc", k_sel_e32_vcc_smov}, {"8 sel e32 vcc", k_sel_e32_vcc_none},
         {"smov+8 sel e64 sgpr", k_sel_e64_sgpr_smov}, {"8 addc e32 vcc", k_addc_vcc}, {"8 addc e64 sgpr", k_addc_sgpr},

@@ -1,0 +1,6 @@
+"""`python -m foldcomp compress|decompress|extract|check|rmsd ...` = `python -m foldcomp_amd ...`"""
+import sys
+
+from foldcomp_amd.__main__ import main
+
+sys.exit(main())

@@ -24,6 +24,7 @@
 // tar inputs are handled by the Python host (python -m foldcomp_amd).
 #include <dirent.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -56,6 +57,7 @@ extern "C" {
 namespace {
 
 constexpr size_t BATCH_CHAINS = 16384;
+constexpr size_t JOB_CHAINS_MAX = 4096;     // fragments per job of the compress pipeline: bounds the host memory in flight
 
 // ---- atoms of one input file (the reference's std::vector<AtomCoordinate>, as parallel arrays) ----
 // Atom and residue names are kept as packed integers: up to four characters, one per byte (a PDB name field is four columns
@@ -128,7 +130,7 @@ struct TablePool {
     void put(AtomTable&& t) {
         t.clear();
         std::lock_guard<std::mutex> g(m);
-        if (free_.size() < 65536) free_.push_back(std::move(t));
+        if (free_.size() < 4 * JOB_CHAINS_MAX) free_.push_back(std::move(t));   // beyond that the tables are freed, not hoarded
     }
 };
 TablePool& table_pool() { static TablePool p; return p; }
@@ -498,18 +500,22 @@ std::vector<uint32_t> split_residues(const AtomTable& t) {
 // page-locked host memory (fcz_pinned_alloc = hipHostMalloc): what a worker hands to fcz_compress_batch is copied by DMA on the
 // ctx stream, so the transfers of one worker overlap the kernels of the other worker on the same GPU. Falls back to malloc when
 // no device is present (the CPU-only subcommands and tests).
+// ONE switch for every element type (a function-local static inside the template would be one flag per instantiation).
+inline std::atomic<bool>& pinned_enabled() { static std::atomic<bool> v{false}; return v; }
+inline std::atomic<uint64_t>& pinned_blocks() { static std::atomic<uint64_t> v{0}; return v; }   // page-locked blocks handed out (statistics, tests)
 template <class T> struct PinnedAlloc {
     using value_type = T;
     PinnedAlloc() = default;
     template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
-    static bool& use_pinned() { static bool v = false; return v; }
     T* allocate(size_t n) {
-        void* p = use_pinned() ? fcz_pinned_alloc(n * sizeof(T) + 8) : malloc(n * sizeof(T) + 8);
+        const bool pin = pinned_enabled().load();
+        void* p = pin ? fcz_pinned_alloc(n * sizeof(T) + 16) : malloc(n * sizeof(T) + 16);
         if (!p) throw std::bad_alloc();
-        *(uint64_t*)p = use_pinned() ? 1 : 0;     // remember where the block came from
-        return (T*)((char*)p + 8);
+        *(uint64_t*)p = pin ? 1 : 0;     // remember where the block came from
+        if (pin) pinned_blocks()++;
+        return (T*)((char*)p + 16);      // 16: the payload keeps the alignment of the block
     }
-    void deallocate(T* q, size_t) { void* p = (char*)q - 8; if (*(uint64_t*)p) fcz_pinned_free(p); else free(p); }
+    void deallocate(T* q, size_t) { void* p = (char*)q - 16; if (*(uint64_t*)p) fcz_pinned_free(p); else free(p); }
     template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
     template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
 };
@@ -708,6 +714,15 @@ struct DbReader {
     }
     ~DbReader() { if (data) munmap((void*)data, size); if (fd >= 0) close(fd); }
     size_t n() const { return rows.size(); }
+    // position of a key / of a lookup name among the entries, -1 when absent (reader_get_id, reader_lookup_entry)
+    long long id_of_key(long long key) const {
+        auto it = std::lower_bound(rows.begin(), rows.end(), key, [](const Row& r, long long k) { return r.key < k; });
+        return (it != rows.end() && it->key == key) ? (long long)(it - rows.begin()) : -1;
+    }
+    long long id_of_name(const std::string& nm) const {
+        for (const auto& kv : lookup) if (kv.second == nm) return id_of_key(kv.first);
+        return -1;
+    }
     std::string name(size_t i) const {
         auto it = std::lower_bound(lookup.begin(), lookup.end(), rows[i].key, [](const auto& a, long long k) { return a.first < k; });
         return (it != lookup.end() && it->first == rows[i].key) ? it->second : std::to_string(rows[i].key);
@@ -748,6 +763,13 @@ struct Options {
     std::string mode, input, output;
     int brk = 25, digits = 1, ext_mode = 0;
     bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
+    bool single = false;        // one structure / FCZ file in, one file out
+    bool check = false;         // --check: decompress skips entries that fail Foldcomp::checkValidity (src/main.cpp:629-636)
+    bool merge = true;          // --no-merge: extract writes one file per entry instead of one merged file (src/main.cpp:171-195)
+    bool file_input = false;    // -f / --file: <input> is a text file that lists the inputs, one per line (src/main.cpp:304-325)
+    std::string id_list;        // --id-list FILE: only these entries of a database input (src/input_processor.h:287-299)
+    int id_mode = 1;            // --id-mode 0: the list holds keys, 1: names
+    std::vector<std::string> inputs;   // what <input> expands to (itself, or the lines of the -f file: containers first, then files)
     int gpus = 1;               // --gpus N: devices used by compress (0 = every visible device)
     int workers_per_gpu = 2;    // host threads (each with its own ctx and stream) per device
     bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
@@ -875,21 +897,16 @@ void pwrite_all(int fd, const uint8_t* p, uint64_t n, uint64_t off) {
 int run_compress(const Options& o) {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
-    const bool single = !is_dir(o.input);
-    std::string output = o.output;
-    if (output.empty()) {
-        if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + ".fcz"; }
-        else output = o.input + "_fcz";
-    }
+    const bool single = o.single;
+    const std::string output = o.output;             // main() resolved the reference's defaults (src/main.cpp:356-369)
     std::vector<std::string> files;
-    if (single) files.push_back(o.input); else list_files(o.input, o.recursive, files);
-    if (o.db && o.output.empty()) output = o.input + "_db";
+    for (const std::string& in : o.inputs) { if (is_dir(in)) list_files(in, o.recursive, files); else files.push_back(in); }
     const int n_dev = fcz_device_count();
     if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
     const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
     if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
     const int n_workers = gpus * std::max(1, o.workers_per_gpu);
-    PinnedAlloc<char>::use_pinned() = true;
+    pinned_enabled() = true;
     int db_fd = -1;
     if (o.db) {
         db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
@@ -914,10 +931,12 @@ int run_compress(const Options& o) {
         while (queue.get(job)) {
             std::vector<size_t> kept;
             b.clear();
-            {   // one growth step of the page-locked buffers per job at most (pinning memory is expensive), none once they are large enough
-                size_t na = 0; for (const Fragment& f : job.frags) na += f.atoms.size();
+            {   // one growth step of the page-locked buffers per job at most (pinning memory is expensive), none once they are large
+                // enough; the per-residue arrays are sized from the residue boundaries the parse threads already found
+                size_t na = 0, nr = 0;
+                for (const Fragment& f : job.frags) { na += f.atoms.size(); nr += f.prepared && f.prep_err.empty() ? f.prep.ro.size() - 1 : f.atoms.size() / 3 + 1; }
                 b.x.reserve(na); b.y.reserve(na); b.z.reserve(na); b.atom_code.reserve(na);
-                b.atom_off.reserve(na / 4 + 16); b.res_code.reserve(na / 4 + 16); b.bfac_ca.reserve(na / 4 + 16);
+                b.atom_off.reserve(nr + 1); b.res_code.reserve(nr); b.bfac_ca.reserve(nr);
             }
             for (size_t i = 0; i < job.frags.size(); i++) {
                 // a fragment the codec cannot take is reported and left out (Batch::add throws before it changes the batch)
@@ -934,26 +953,41 @@ int run_compress(const Options& o) {
             fcz_chain_batch v = b.view(o.brk);
             std::vector<uint64_t> off(v.n_chains + 1, 0);
             if (v.n_chains) fcz_compress_sizes(&v, off.data());
-            const uint64_t at = o.db ? seq.claim(job.index, off.back()) : 0;     // every job claims, also an empty or failed one
-            if (kept.empty() || !ctx) continue;
+            // a job claims its byte range of the database AFTER its GPU call, with the records that compressed packed back to
+            // back (the reference's writer appends only what compressed); every job claims, also an empty or failed one
+            if (kept.empty() || !ctx) { if (o.db) seq.claim(job.index, 0); continue; }
             blob.resize(off.back());
-            std::vector<int32_t> status(v.n_chains, 0);
+            const int32_t UNSET = INT32_MIN;                              // a status the library never writes
+            std::vector<int32_t> status(v.n_chains, UNSET);
             const auto t0 = clk::now();
             const int rc = fcz_compress_batch(ctx, &v, off.data(), blob.data(), status.data());
             gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
-            if (rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG) {
-                // a failure of the call itself (device, memory): no per-chain status was written, nothing may be emitted
+            // rc is the worst per-chain status or a failure of the call itself; FCZ_E_INVALID_ARG is both (a refused chain, or
+            // refused arguments -- then no per-chain status was written). Nothing may be emitted unless every chain has one.
+            bool call_failed = rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG;
+            for (uint32_t q = 0; q < v.n_chains && !call_failed; q++) if (status[q] == UNSET) call_failed = true;
+            if (call_failed) {
                 fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size());
-                hard_fail = true; continue;
+                hard_fail = true; if (o.db) seq.claim(job.index, 0); continue;
             }
             try {
-                if (o.db) pwrite_all(db_fd, blob.data(), off.back(), at);
+                uint64_t packed = 0;                                      // bytes of the records that compressed
+                std::vector<uint64_t> at_rel(kept.size(), 0);
+                for (size_t q = 0; q < kept.size(); q++) {
+                    if (status[q] != FCZ_OK) continue;
+                    const uint64_t len = off[q + 1] - off[q];
+                    if (o.db && packed != off[q]) memmove(blob.data() + packed, blob.data() + off[q], len);
+                    at_rel[q] = o.db ? packed : off[q];
+                    packed += len;
+                }
+                const uint64_t at = o.db ? seq.claim(job.index, packed) : 0;
+                if (o.db && packed) pwrite_all(db_fd, blob.data(), packed, at);
                 for (size_t q = 0; q < kept.size(); q++) {
                     const Fragment& f = job.frags[kept[q]];
                     if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
                     n_frag_ok++; n_res += v.res_off[q + 1] - v.res_off[q]; n_bytes += off[q + 1] - off[q];
                     n_atoms += v.atom_off[v.res_off[q + 1]] - v.atom_off[v.res_off[q]];
-                    if (o.db) { rows[w].push_back({job.index, q, at + off[q], off[q + 1] - off[q], f.db_name}); continue; }
+                    if (o.db) { rows[w].push_back({job.index, q, at + at_rel[q], off[q + 1] - off[q], f.db_name}); continue; }
                     const std::string path = single ? output : output + "/" + f.out_name;
                     write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
                 }
@@ -968,7 +1002,8 @@ int run_compress(const Options& o) {
     {
         // files parsed side by side before the next job is cut, and fragments per job: small enough that every worker gets
         // several jobs (parse, staging, GPU and writes of different jobs overlap), large enough to fill a GPU launch
-        const size_t JOB = std::max<size_t>(256, std::min<size_t>(BATCH_CHAINS, files.size() / (4 * (size_t)n_workers) + 1));
+        // (bounded: n_workers + 2 jobs wait in the queue with their atom tables, ~100 KB per 350-residue chain)
+        const size_t JOB = std::max<size_t>(256, std::min<size_t>(JOB_CHAINS_MAX, files.size() / (4 * (size_t)n_workers) + 1));
         const size_t FILE_CHUNK = std::max<size_t>(JOB, 512);
         std::vector<Fragment> pending;
         size_t job_index = 0;
@@ -997,7 +1032,11 @@ int run_compress(const Options& o) {
     const double t_joined = std::chrono::duration<double>(clk::now() - t_start).count();
 
     // ---- index: rows of all workers in job order, keys numbered over the records that made it ----
-    if (o.db) {
+    if (o.db && hard_fail) {
+        // a database without its index is unusable and one with a partial index looks complete: leave neither behind
+        close(db_fd); unlink(output.c_str());
+        fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
+    } else if (o.db) {
         close(db_fd);
         std::vector<Row> all;
         for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
@@ -1035,21 +1074,36 @@ struct Entries {
     void clear() { names.clear(); blob.clear(); off.assign(1, 0); }
 };
 
-// every FCZ entry of a file, a directory or a database, in batches
+// every FCZ entry of the inputs (files, directories, databases -- optionally only the ids of --id-list), in batches
 template <class F>
 void for_each_entry(const Options& o, Entries& ents, F&& flush, size_t batch = BATCH_CHAINS) {
-    if (is_db(o.input)) {
-        DbReader r(o.input);
-        for (size_t i = 0; i < r.n(); i++) {
-            try { ents.add(r.name(i), r.entry(i)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
-            if (ents.n() >= batch) flush();
-        }
-    } else {
-        std::vector<std::string> files;
-        if (is_dir(o.input)) list_files(o.input, o.recursive, files); else files.push_back(o.input);
-        for (const std::string& path : files) {
-            try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
-            if (ents.n() >= batch) flush();
+    for (const std::string& input : o.inputs) {
+        if (is_db(input)) {
+            DbReader r(input);
+            std::vector<size_t> ids;
+            if (!o.id_list.empty()) {
+                std::ifstream f(o.id_list);
+                if (!f) fprintf(stderr, "[Error] user id '%s' does not exist.\n", o.id_list.c_str());
+                std::string line;
+                while (f && std::getline(f, line)) {
+                    line = strip(line);
+                    if (line.empty()) continue;
+                    const long long id = o.id_mode == 0 ? r.id_of_key(atoll(line.c_str())) : r.id_of_name(line);
+                    if (id < 0) { fprintf(stderr, "[Warning] %s not found in database.\n", line.c_str()); continue; }
+                    ids.push_back((size_t)id);
+                }
+            } else { ids.resize(r.n()); for (size_t i = 0; i < r.n(); i++) ids[i] = i; }
+            for (size_t i : ids) {
+                try { ents.add(r.name(i), r.entry(i)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+                if (ents.n() >= batch) flush();
+            }
+        } else {
+            std::vector<std::string> files;
+            if (is_dir(input)) list_files(input, o.recursive, files); else files.push_back(input);
+            for (const std::string& path : files) {
+                try { ents.add(path, read_file(path)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+                if (ents.n() >= batch) flush();
+            }
         }
     }
     flush();
@@ -1063,18 +1117,14 @@ struct DecompressJob { size_t index = 0; Entries ents; };
 int run_decompress(const Options& o) {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
-    const bool single = !is_dir(o.input) && !is_db(o.input);
-    std::string output = o.output;
-    if (output.empty()) {
-        if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + ".pdb"; }
-        else output = o.input + (o.db ? "_pdb_db" : "_pdb");
-    }
+    const bool single = o.single;
+    const std::string output = o.output;
     const int n_dev = fcz_device_count();
     if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
     const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
     if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
     const int n_workers = single ? 1 : gpus * std::max(1, o.workers_per_gpu);
-    PinnedAlloc<char>::use_pinned() = true;
+    pinned_enabled() = true;
     int db_fd = -1;
     if (o.db) {
         db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
@@ -1138,6 +1188,18 @@ int run_decompress(const Options& o) {
         Entries ents;
         auto flush = [&]() {
             if (!ents.n()) return;
+            if (o.check) {
+                // --check: entries that fail Foldcomp::checkValidity are reported and left out (src/main.cpp:629-636)
+                Entries ok;
+                for (uint32_t i = 0; i < ents.n(); i++) {
+                    const uint64_t len = ents.off[i + 1] - ents.off[i];
+                    const int rc = len ? fcz_check(ents.blob.data() + ents.off[i], len) : FCZ_E_TRUNCATED;
+                    if (rc != 0) { fprintf(stderr, "[Error] invalid FCZ entry skipped: %s\n", ents.names[i].c_str()); continue; }
+                    ok.add(ents.names[i], std::string((const char*)ents.blob.data() + ents.off[i], len));
+                }
+                ents = std::move(ok);
+                if (!ents.n()) { ents = Entries(); return; }
+            }
             DecompressJob j; j.index = job_index++; j.ents = std::move(ents);
             ents = Entries();
             queue.put(std::move(j));
@@ -1146,7 +1208,10 @@ int run_decompress(const Options& o) {
         queue.close();
     }
     for (std::thread& t : workers) t.join();
-    if (o.db) {
+    if (o.db && hard_fail) {
+        close(db_fd); unlink(output.c_str());
+        fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
+    } else if (o.db) {
         close(db_fd);
         std::vector<Row> all;
         for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
@@ -1177,15 +1242,16 @@ bool fcz_header(const uint8_t* e, uint64_t len, std::string& title, uint32_t& n_
     return true;
 }
 
+std::string extract_suffix(const Options& o) {
+    return o.ext_mode == 1 ? "fasta" : (std::min(std::max(o.digits, 1), 4) == 1 ? "plddt" : "plddt.tsv");
+}
 int run_extract(const Options& o) {
-    const bool single = !is_dir(o.input) && !is_db(o.input);
+    const bool single = o.single;
     const int digits = std::min(std::max(o.digits, 1), 4);
-    const std::string suffix = o.ext_mode == 1 ? "fasta" : (digits == 1 ? "plddt" : "plddt.tsv");
-    std::string output = o.output;
-    if (output.empty()) {
-        if (single) { const size_t i = o.input.rfind('.'); output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + "." + suffix; }
-        else output = o.input + "." + suffix;                    // merged output, like the reference's default
-    }
+    const std::string suffix = extract_suffix(o);
+    const std::string output = o.output;
+    const bool per_entry = !single && !o.merge;                      // --no-merge: <output>/<stem>.<suffix> per entry (src/main.cpp:790-800)
+    if (per_entry) make_dir(output);
     fcz_ctx* ctx = nullptr;
     if (need_ctx(&ctx)) return 1;
     std::string merged;
@@ -1205,14 +1271,19 @@ int run_extract(const Options& o) {
             }
             if (!o.use_title) title = base_name(ents.names[i]);
             const std::string s = data.substr(data_off[i], data_off[i + 1] - data_off[i]);
-            if (o.ext_mode == 0 && digits > 1) merged += title + "\t" + std::to_string(n_res) + "\t" + s + "\n";   // writeTSV
-            else merged += ">" + title + "\n" + s + "\n";                                                       // writeFASTALike
+            std::string text;
+            if (o.ext_mode == 0 && digits > 1) text = title + "\t" + std::to_string(n_res) + "\t" + s + "\n";   // writeTSV
+            else text = ">" + title + "\n" + s + "\n";                                                       // writeFASTALike
+            if (per_entry) {
+                std::string stem, ext; file_parts(base_name(ents.names[i]), stem, ext);
+                write_out(output + "/" + stem + "." + suffix, text.data(), text.size(), true);
+            } else merged += text;
         }
         ents.clear();
     };
     for_each_entry(o, ents, flush);
     fcz_ctx_destroy(ctx);
-    write_out(output, merged.data(), merged.size(), true);
+    if (!per_entry) write_out(output, merged.data(), merged.size(), true);
     return 0;
 }
 
@@ -1325,26 +1396,33 @@ int run_rmsd(const Options& o) {
 void usage() {
     fprintf(stderr,
             "usage: foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d] [--skip-discontinuous] [--json-stats] <pdb|cif file|dir> [<fcz file|dir|db>]\n"
-            "       foldcomp-hip decompress [-a] [-y] [-r] <fcz file|dir> [<pdb file|dir>]\n"
-            "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir> [<out>]\n"
-            "       foldcomp-hip check      [-r] <fcz file|dir|db>\n"
+            "       foldcomp-hip decompress [--gpus N] [-a] [-y] [-r] [-d] [--check] [-l ids [-m 0|1]] [--json-stats] <fcz file|dir|db> [<pdb file|dir|db>]\n"
+            "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--no-merge] [--use-title] [-r] [-l ids [-m 0|1]] <fcz file|dir|db> [<out>]\n"
+            "       foldcomp-hip check      [-r] [-l ids [-m 0|1]] <fcz file|dir|db>\n"
+            "       -f / --file: <input> is a text file listing the inputs, one per line (any mode)\n"
             "       foldcomp-hip rmsd       <pdb|cif> <pdb|cif>\n");
 }
 
 }  // namespace
 
-// CPUs the process may use: hardware threads cut by the cgroup's CFS quota (cpu.max "quota period"), the default for -t.
-// More parse threads than the quota only thrash (measured on a 256-thread host under a 16-CPU quota: 0.33 s at 16 threads,
-// 1.6 s at 256).
+// CPUs the process may use, the default for -t: the smallest of the OpenMP default, the scheduler affinity mask and the
+// cgroup's CFS quota (v2: cpu.max "quota period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us) -- the same rule as bench.py's
+// effective_cores(). More parse threads than the quota only thrash (measured on a 256-thread host under a 16-CPU quota:
+// 0.33 s at 16 threads, 1.6 s at 256).
 int default_threads() {
     int n = omp_get_max_threads();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && c < n) n = c; }
+    auto cut = [&](long long quota, long long period) { if (quota > 0 && period > 0) { const long long c = (quota + period / 2) / period; if (c >= 1 && c < n) n = (int)c; } };
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
         char q[32] = {0}; long long period = 0;
-        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-            const long long c = (atoll(q) + period / 2) / period;
-            if (c >= 1 && c < n) n = (int)c;
-        }
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) cut(atoll(q), period);
         fclose(f);
+    } else {
+        long long quota = -1, period = 0;
+        if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+        if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+        cut(quota, period);
     }
     return n;
 }
@@ -1370,6 +1448,12 @@ int main(int argc, char** argv) {
         else if (a == "--use-title") o.use_title = true;
         else if (a == "--skip-discontinuous") o.skip_discontinuous = true;
         else if (a == "-d" || a == "--db") o.db = true;
+        else if (a == "--check") o.check = true;
+        else if (a == "--no-merge") o.merge = false;
+        else if (a == "-f" || a == "--file") o.file_input = true;
+        else if (a == "-l" || a == "--id-list") { if (i + 1 < argc) o.id_list = argv[++i]; }
+        else if (a == "-m" || a == "--id-mode") { next_int(o.id_mode); if (o.id_mode != 0 && o.id_mode != 1) { fprintf(stderr, "[Error] Invalid id mode. Please use 0 or 1.\n"); usage(); return 1; } }
+        else if (a == "-v" || a == "--version") { printf("foldcomp (MI355X / libfcz_hip) 1.0\n"); return 0; }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else pos.push_back(a);
     }
@@ -1379,6 +1463,27 @@ int main(int argc, char** argv) {
     if (pos.size() > 2) { o.output = pos[2]; while (o.output.size() > 1 && o.output.back() == '/') o.output.pop_back(); }
     if (!exists(o.input)) { fprintf(stderr, "[Error] %s does not exist.\n", o.input.c_str()); return 1; }
     if (o.brk <= 0) { fprintf(stderr, "[Error] -b needs a positive value.\n"); return 1; }
+    // -f: the input is a list; lines that name a structure / FCZ file are single files (processed last, as one directory-like
+    // set), everything else is a directory or database (src/main.cpp:304-325)
+    if (o.file_input) {
+        std::ifstream f(o.input);
+        if (!f) { fprintf(stderr, "[Error] Could not open file %s\n", o.input.c_str()); return 1; }
+        std::vector<std::string> singles; std::string line;
+        while (std::getline(f, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty()) continue;
+            if (ends_with(line, ".pdb") || ends_with(line, ".pdb.gz") || ends_with(line, ".cif") || ends_with(line, ".cif.gz") || ends_with(line, ".fcz")) singles.push_back(line);
+            else o.inputs.push_back(line);
+        }
+        o.inputs.insert(o.inputs.end(), singles.begin(), singles.end());
+    } else o.inputs.push_back(o.input);
+    { struct stat st; o.single = !o.file_input && stat(o.input.c_str(), &st) == 0 && S_ISREG(st.st_mode) && !is_db(o.input); }
+    if (o.output.empty() && (o.mode == "compress" || o.mode == "decompress" || o.mode == "extract")) {   // src/main.cpp:356-369
+        const std::string suffix = o.mode == "compress" ? "fcz" : (o.mode == "decompress" ? "pdb" : extract_suffix(o));
+        if (o.db) o.output = o.input + "_db";
+        else if (o.single) { const size_t i = o.input.rfind('.'); o.output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + "." + suffix; }
+        else o.output = o.input + "_" + suffix;
+    }
     if (o.mode == "compress") return run_compress(o);
     if (o.mode == "decompress") return run_decompress(o);
     if (o.mode == "extract") return run_extract(o);

@@ -341,3 +341,103 @@ def test_cpp_decompress_pipeline_database_round_trip(tmp_path, golden):
     assert len(os.listdir(tmp_path / "pdbdir")) == 720
     n0 = names[5]
     assert (tmp_path / "pdbdir" / f"{bytes(z[f'{n0}/name']).decode()}_7.pdb").read_bytes().decode("latin-1") == z[f"{n0}/pdb0"].tobytes().decode("latin-1")
+
+
+def _golden_db(tmp_path, z, index, n_names=8):
+    """a database of golden FCZ records (keys out of order, one corrupted record) + what it holds"""
+    from foldcomp_amd.database import DatabaseWriter
+    names = [n for n in index if n.startswith("db:")][:n_names]
+    w = DatabaseWriter(str(tmp_path / "gdb"))
+    recs = {}
+    for k, n in reversed(list(enumerate(names))):
+        nm = bytes(z[f"{n}/name"]).decode()
+        recs[nm] = (10 + k, n)
+        w.append(z[f"{n}/fcz"].tobytes(), 10 + k, nm)
+    w.close()
+    return names, recs
+
+
+def test_cpp_cli_id_list_and_file_input_on_the_host(tmp_path, golden):
+    """--id-list / --id-mode (src/input_processor.h:287-299) and -f (src/main.cpp:304-325) through `check`, which needs no GPU:
+    only the listed entries are visited, by key (mode 0) or by name (mode 1, the default); a missing id is a warning"""
+    z, index = golden
+    names, recs = _golden_db(tmp_path, z, index)
+    by_name = list(recs)[:3]
+    (tmp_path / "ids_name.txt").write_text("\n".join(by_name + ["no_such_entry"]) + "\n")
+    r = _run("check", "--id-list", str(tmp_path / "ids_name.txt"), str(tmp_path / "gdb"))
+    assert r.returncode == 0 and r.stdout.count("is valid") == 3 and "no_such_entry not found" in r.stderr
+    for nm in by_name:
+        assert f"{nm} is valid" in r.stdout
+    keys = [recs[nm][0] for nm in by_name[:2]]
+    (tmp_path / "ids_key.txt").write_text("\n".join(str(k) for k in keys) + "\n999\n")
+    r = _run("check", "-l", str(tmp_path / "ids_key.txt"), "-m", "0", str(tmp_path / "gdb"))
+    assert r.returncode == 0 and r.stdout.count("is valid") == 2 and "999 not found" in r.stderr
+    assert _run("check", "-l", str(tmp_path / "ids_key.txt"), "--id-mode", "2", str(tmp_path / "gdb")).returncode != 0
+    # -f: a list of inputs; container inputs first, then the single files
+    d = tmp_path / "dir"
+    d.mkdir()
+    for n in names[:2]:
+        (d / (n.replace(":", "_") + ".fcz")).write_bytes(z[f"{n}/fcz"].tobytes())
+    one = tmp_path / "one.fcz"
+    one.write_bytes(z[f"{names[2]}/fcz"].tobytes())
+    (tmp_path / "inputs.txt").write_text(f"{one}\n{d}\n{tmp_path / 'gdb'}\n")
+    r = _run("check", "-f", str(tmp_path / "inputs.txt"))
+    assert r.returncode == 0 and r.stdout.count("is valid") == 2 + len(names) + 1
+    assert r.stdout.rstrip().splitlines()[-1].startswith(f"[Info] {one}")
+
+
+@pytest.mark.gpu
+def test_cpp_cli_flags_equal_the_python_cli(tmp_path, golden):
+    """--check, --id-list, --no-merge, -f and the reference's default output names: the pipelined C++ host and the Python
+    command line produce the same files from the same database (reference src/main.cpp:171-195, 356-369, 629-636)"""
+    from foldcomp_amd.__main__ import main as py_main
+    z, index = golden
+    names, recs = _golden_db(tmp_path, z, index)
+    # a database with one entry that fails checkValidity (backbone angle bytes zeroed = "empty backbone angles")
+    from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+    rd = DatabaseReader(str(tmp_path / "gdb"))
+    w = DatabaseWriter(str(tmp_path / "bad"))
+    for i in range(len(rd)):
+        e = bytearray(rd.data(i))
+        if i == 1:
+            na, tl, n = e[12], int.from_bytes(e[24:28], "little"), int.from_bytes(e[4:6], "little")
+            o_words = 76 + 4 * na + tl + 36 * na + 13
+            for k in range(n):
+                e[o_words + 8 * k] &= 0xf8
+                e[o_words + 8 * k + 1:o_words + 8 * k + 5] = b"\0\0\0\0"
+        w.append(bytes(e), int(rd.keys[i]), rd.name(i))
+    w.close(); rd.close()
+
+    def tree(p):
+        return {f: (p / f).read_bytes() for f in sorted(os.listdir(p))}
+    # decompress --check: the invalid entry is skipped by both hosts, the others decompress to the same text
+    r = _run("decompress", "--check", "-y", str(tmp_path / "bad"), str(tmp_path / "c_chk"))
+    assert r.returncode == 0 and "invalid FCZ entry skipped" in r.stderr, r.stderr
+    py_main(["decompress", "--check", "-y", str(tmp_path / "bad"), str(tmp_path / "p_chk")])
+    assert len(os.listdir(tmp_path / "c_chk")) == len(names) - 1 and tree(tmp_path / "c_chk") == tree(tmp_path / "p_chk")
+    # --id-list by name into a database; the texts are the reference's
+    by_name = list(recs)[2:5]
+    (tmp_path / "ids.txt").write_text("\n".join(by_name) + "\n")
+    r = _run("decompress", "-d", "-y", "-l", str(tmp_path / "ids.txt"), str(tmp_path / "gdb"), str(tmp_path / "c_sel"))
+    assert r.returncode == 0, r.stderr
+    sel = DatabaseReader(str(tmp_path / "c_sel"))
+    assert [sel.name(i) for i in range(len(sel))] == by_name
+    for i, nm in enumerate(by_name):
+        assert sel.data(i)[:-1].decode("latin-1") == z[f"{recs[nm][1]}/pdb0"].tobytes().decode("latin-1")
+    sel.close()
+    # extract --no-merge: one file per entry, named like the reference names them; merged default name = <input>_<suffix>
+    r = _run("extract", "--plddt", "-p", "3", "--no-merge", str(tmp_path / "gdb"), str(tmp_path / "c_nm"))
+    assert r.returncode == 0, r.stderr
+    py_main(["extract", "--plddt", "-p", "3", "--no-merge", str(tmp_path / "gdb"), str(tmp_path / "p_nm")])
+    assert len(os.listdir(tmp_path / "c_nm")) == len(names) and tree(tmp_path / "c_nm") == tree(tmp_path / "p_nm")
+    r = _run("extract", "--fasta", str(tmp_path / "gdb"))
+    assert r.returncode == 0 and os.path.isfile(str(tmp_path / "gdb") + "_fasta"), r.stderr
+    assert open(str(tmp_path / "gdb") + "_fasta").read().count(">") == len(names)
+    # -f with a database and a single file, default output directory <list>_pdb
+    one = tmp_path / "one.fcz"
+    one.write_bytes(z[f"{names[0]}/fcz"].tobytes())
+    (tmp_path / "inputs.txt").write_text(f"{one}\n{tmp_path / 'gdb'}\n")
+    r = _run("decompress", "-y", "-f", str(tmp_path / "inputs.txt"))
+    assert r.returncode == 0, r.stderr
+    outd = str(tmp_path / "inputs.txt") + "_pdb"
+    assert len(os.listdir(outd)) == len(names) + 1 and "one.pdb" in os.listdir(outd)

@@ -136,6 +136,60 @@ class Codec:
         raw = data.tobytes()
         return [raw[int(data_off[i]):int(data_off[i + 1])] for i in range(n)]
 
+    # ---- structure ingest on the device -----------------------------------------------------------
+    @staticmethod
+    def _pack_files(texts, names):
+        """bytes of the files back to back + offsets, base names + offsets, stem lengths (getFileParts: split at the last dot)"""
+        file_off = np.zeros(len(texts) + 1, np.uint64)
+        file_off[1:] = np.cumsum([len(t) for t in texts])
+        text = np.frombuffer(b"".join(texts) or b"\0", np.uint8)
+        nb = [n.encode() for n in names]
+        name_off = np.zeros(len(nb) + 1, np.uint32)
+        name_off[1:] = np.cumsum([len(n) for n in nb])
+        name_blob = np.frombuffer(b"".join(nb) or b"\0", np.uint8)
+        stem_len = np.asarray([n.rfind(".") if "." in n else len(n.encode()) for n in names], np.uint32)
+        return text, file_off, name_blob, name_off, stem_len
+
+    def ingest_pdb(self, texts, names, anchor_threshold: int = 25, skip_discontinuous: bool = False):
+        """PDB texts (bytes) + base names -> (ChainBatch, chain_file, chain_meta, file_status, refused[n, 2]) with every step on
+        the GPU (fcz_ingest_pdb_*): what the reference's driver makes of the files before Foldcomp::compress"""
+        text, file_off, name_blob, name_off, stem_len = self._pack_files(texts, names)
+        counts = np.zeros(5, np.uint32)
+        _lib.check(self.lib.fcz_ingest_pdb_begin(self.ctx, text.ctypes.data, file_off.ctypes.data, len(texts), name_blob.ctypes.data,
+                                                 name_off.ctypes.data, stem_len.ctypes.data, int(anchor_threshold),
+                                                 1 if skip_discontinuous else 0, counts.ctypes.data), "fcz_ingest_pdb_begin")
+        C, R, M, TB, NR = (int(v) for v in counts)
+        b = ChainBatch(res_off=np.zeros(C + 1, np.uint32), atom_off=np.zeros(R + 1, np.uint32), x=np.zeros(M, np.float32),
+                       y=np.zeros(M, np.float32), z=np.zeros(M, np.float32), atom_code=np.zeros(M, np.uint8),
+                       res_code=np.zeros(R, np.uint8), bfac_ca=np.zeros(R, np.float32), first_res_index=np.zeros(C, np.int32),
+                       first_atom_index=np.zeros(C, np.int32), chain_id=np.zeros(C, np.uint8), titles=np.zeros(max(TB, 1), np.uint8),
+                       title_off=np.zeros(C + 1, np.uint32), anchor_threshold=int(anchor_threshold))
+        cb = batch_as_c(b)
+        chain_file = np.zeros(C, np.uint32); chain_meta = np.zeros(C, np.uint32)
+        file_status = np.zeros(len(texts), np.int32); refused = np.zeros((NR, 2), np.uint32)
+        _lib.check(self.lib.fcz_ingest_pdb_fetch(self.ctx, ctypes.byref(cb), chain_file.ctypes.data, chain_meta.ctypes.data,
+                                                 file_status.ctypes.data, refused.ctypes.data), "fcz_ingest_pdb_fetch")
+        b.titles = b.titles[:TB]
+        return b, chain_file, chain_meta, file_status, refused
+
+    def compress_pdb(self, texts, names, anchor_threshold: int = 25, skip_discontinuous: bool = False):
+        """PDB texts -> FCZ records, parse and codec both on the GPU: dict(blob, off, status, chain_file, chain_meta, file_status,
+        refused)"""
+        text, file_off, name_blob, name_off, stem_len = self._pack_files(texts, names)
+        counts = np.zeros(5, np.uint32); nbytes = ctypes.c_uint64(0)
+        _lib.check(self.lib.fcz_compress_pdb_begin(self.ctx, text.ctypes.data, file_off.ctypes.data, len(texts), name_blob.ctypes.data,
+                                                   name_off.ctypes.data, stem_len.ctypes.data, int(anchor_threshold),
+                                                   1 if skip_discontinuous else 0, counts.ctypes.data, ctypes.byref(nbytes)),
+                   "fcz_compress_pdb_begin")
+        C, NR = int(counts[0]), int(counts[4])
+        off = np.zeros(C + 1, np.uint64); st = np.zeros(C, np.int32); blob = np.zeros(max(int(nbytes.value), 1), np.uint8)
+        chain_file = np.zeros(C, np.uint32); chain_meta = np.zeros(C, np.uint32)
+        file_status = np.zeros(len(texts), np.int32); refused = np.zeros((NR, 2), np.uint32)
+        _lib.check(self.lib.fcz_compress_pdb_fetch(self.ctx, off.ctypes.data, st.ctypes.data, chain_file.ctypes.data, chain_meta.ctypes.data,
+                                                   file_status.ctypes.data, refused.ctypes.data, blob.ctypes.data), "fcz_compress_pdb_fetch")
+        return dict(blob=blob[:int(nbytes.value)], off=off, status=st, chain_file=chain_file, chain_meta=chain_meta,
+                    file_status=file_status, refused=refused, counts=counts)
+
     # ---- timing ---------------------------------------------------------------------------------
     def enable_timing(self, on: bool = True):
         self.lib.fcz_ctx_enable_timing(self.ctx, int(on))

@@ -26,6 +26,7 @@
 #include "fcz_backbone_fast.h"
 #include "fcz_pdb.h"
 #include "fcz_extract.h"
+#include "fcz_ingest.h"
 
 // second, host-side instance of the generated tables (integer metadata for sizes/validation)
 namespace host_tab {
@@ -104,6 +105,11 @@ struct fcz_ctx {
     bool keep_first_angle = false;
     int numerics = FCZ_NUMERICS_EXACT;
     dev_buf fast_scratch;   // decompress, FCZ_NUMERICS_FAST: forward atoms of segments longer than one chunk
+    // structure ingest: scratch atom table, per-file lists, the resident batch of the last ingest call
+    dev_buf ig[40];
+    fcz_ingest_result ig_res{};
+    uint32_t ig_counts[5] = {0, 0, 0, 0, 0};
+    uint64_t ig_fcz_bytes = 0;
     std::vector<timed_span> spans;
     std::map<std::string, std::pair<double, uint64_t>> acc;
 };
@@ -206,7 +212,7 @@ int fcz_ctx_create(int device, fcz_ctx** out) {
     hipDeviceProp_t prop;
     c->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FCZ_E_HIP; }
-    if (hipHostMalloc((void**)&c->pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FCZ_E_HIP; }
+    if (hipHostMalloc((void**)&c->pinned, 128, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FCZ_E_HIP; }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { fcz_ctx_destroy(c); return FCZ_E_HIP; }
@@ -221,6 +227,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
     for (auto& b : c->stage) b.release();
+    for (auto& b : c->ig) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -532,6 +539,214 @@ int fcz_compress_angles(fcz_ctx* ctx, const fcz_chain_batch* in, float* angles_o
     ctx->keep_first_angle = false;
     if (rc) return rc;
     HIP_TRY(hipMemcpy(angles_out, ctx->ang.p, sizeof(float) * 6 * (size_t)in->n_residues, hipMemcpyDeviceToHost));
+    return FCZ_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// structure ingest: PDB text -> fcz_chain_batch on the device (fcz_ingest.h)
+// ------------------------------------------------------------------------------------------------
+int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* file_off_dev, uint32_t n_files, uint64_t text_bytes,
+                       const char* names_dev, const uint32_t* name_off_dev, const uint32_t* stem_len_dev, int anchor_threshold, int flags,
+                       fcz_ingest_result* out) {
+    if (!ctx || !out || anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    if (n_files && (!text_dev || !file_off_dev || !names_dev || !name_off_dev || !stem_len_dev)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof *out);
+    memset(&ctx->ig_res, 0, sizeof ctx->ig_res);
+    memset(ctx->ig_counts, 0, sizeof ctx->ig_counts);
+    out->n_files = n_files;
+    if (n_files == 0) return FCZ_OK;
+    // every accepted ATOM record has >= 54 characters (+ its line end, except possibly the file's last line)
+    const uint64_t cap64 = text_bytes / 54u + (uint64_t)n_files;
+    if (cap64 >> 32) return FCZ_E_INVALID_ARG;                 // atom offsets are 32-bit: split the batch
+    const size_t cap = (size_t)cap64, F = n_files;
+    int rc;
+    enum { B_CAP, B_ABASE, B_NAME, B_RESN, B_SERIAL, B_RESSEQ, B_X, B_Y, B_Z, B_B, B_CHAIN, B_ACODE, B_RCODE, B_RFIRST, B_RBFAC, B_RCODE2,
+           B_TITLES, B_TLEN, B_NKEPT, B_STATUS, B_FRAGS, B_NFRAGS, B_TOTC, B_TOTR, B_TOTA, B_TOTT, B_USESTEM, B_OFFC, B_OFFR, B_OFFA, B_OFFT,
+           B_REFUSED, B_NREF, B_OUT_A, B_OUT_R, B_OUT_C, B_OUT_T };
+    auto need = [&](int i, size_t bytes) { return ctx->ig[i].ensure(std::max<size_t>(bytes, 16)); };
+    if ((rc = need(B_CAP, 8 * F)) || (rc = need(B_ABASE, 8 * (F + 1))) || (rc = need(B_NAME, 4 * cap)) || (rc = need(B_RESN, 4 * cap)) ||
+        (rc = need(B_SERIAL, 4 * cap)) || (rc = need(B_RESSEQ, 4 * cap)) || (rc = need(B_X, 4 * cap)) || (rc = need(B_Y, 4 * cap)) ||
+        (rc = need(B_Z, 4 * cap)) || (rc = need(B_B, 4 * cap)) || (rc = need(B_CHAIN, cap)) || (rc = need(B_ACODE, cap)) || (rc = need(B_RCODE, cap)) ||
+        (rc = need(B_RFIRST, 4 * cap)) || (rc = need(B_RBFAC, 4 * cap)) || (rc = need(B_RCODE2, cap)) || (rc = need(B_TITLES, (size_t)IG_TITLE_CAP * F)) ||
+        (rc = need(B_TLEN, 4 * F)) || (rc = need(B_NKEPT, 4 * F)) || (rc = need(B_STATUS, 4 * F)) || (rc = need(B_FRAGS, sizeof(ingest_frag) * IG_MAX_FRAGS * F)) ||
+        (rc = need(B_NFRAGS, 4 * F)) || (rc = need(B_TOTC, 4 * F)) || (rc = need(B_TOTR, 4 * F)) || (rc = need(B_TOTA, 4 * F)) || (rc = need(B_TOTT, 4 * F)) ||
+        (rc = need(B_USESTEM, 4 * F)) || (rc = need(B_OFFC, 4 * (F + 1))) || (rc = need(B_OFFR, 4 * (F + 1))) || (rc = need(B_OFFA, 4 * (F + 1))) ||
+        (rc = need(B_OFFT, 4 * (F + 1))) || (rc = need(B_REFUSED, 8 * (size_t)IG_MAX_FRAGS * F)) || (rc = need(B_NREF, 16)))
+        return rc;
+    auto P = [&](int i) { return ctx->ig[i].p; };
+    ingest_scratch T;
+    T.name = (uint32_t*)P(B_NAME); T.resn = (uint32_t*)P(B_RESN); T.serial = (int32_t*)P(B_SERIAL); T.resseq = (int32_t*)P(B_RESSEQ);
+    T.x = (float*)P(B_X); T.y = (float*)P(B_Y); T.z = (float*)P(B_Z); T.b = (float*)P(B_B);
+    T.chain = (uint8_t*)P(B_CHAIN); T.acode = (uint8_t*)P(B_ACODE); T.rcode = (int8_t*)P(B_RCODE);
+    T.r_first = (uint32_t*)P(B_RFIRST); T.r_bfac = (float*)P(B_RBFAC); T.r_code = (uint8_t*)P(B_RCODE2);
+    hipLaunchKernelGGL(k_ingest_caps, dim3(grid_for(n_files, 256)), dim3(256), 0, ctx->stream, file_off_dev, n_files, (uint64_t*)P(B_CAP));
+    if ((rc = device_scan<uint64_t>(ctx, (const uint64_t*)P(B_CAP), (uint64_t*)P(B_ABASE), n_files))) return rc;
+    {
+        span_guard g(ctx, "ingest_parse");
+        hipLaunchKernelGGL(k_ingest_parse, dim3(n_files), dim3(WAVE), 0, ctx->stream, text_dev, file_off_dev, n_files, text_bytes,
+                           (const uint64_t*)P(B_ABASE), T, (uint8_t*)P(B_TITLES), (uint32_t*)P(B_TLEN), (uint32_t*)P(B_NKEPT), (int32_t*)P(B_STATUS));
+    }
+    ingest_counts tot{(uint32_t*)P(B_TOTC), (uint32_t*)P(B_TOTR), (uint32_t*)P(B_TOTA), (uint32_t*)P(B_TOTT)};
+    {
+        span_guard g(ctx, "ingest_frags");
+        hipLaunchKernelGGL(k_ingest_frags, dim3(n_files), dim3(WAVE), 0, ctx->stream, n_files, (const uint64_t*)P(B_ABASE), T, (const uint32_t*)P(B_NKEPT),
+                           (int32_t*)P(B_STATUS), (const uint32_t*)P(B_TLEN), names_dev, name_off_dev, stem_len_dev, (const uint8_t*)P(B_TITLES),
+                           anchor_threshold, (flags & FCZ_INGEST_SKIP_DISCONTINUOUS) ? 1 : 0, (ingest_frag*)P(B_FRAGS), (uint32_t*)P(B_NFRAGS), tot,
+                           (uint32_t*)P(B_USESTEM));
+    }
+    uint32_t* ovf = (uint32_t*)P(B_NREF) + 1;
+    HIP_TRY(hipMemsetAsync(P(B_NREF), 0, 16, ctx->stream));
+    if ((rc = device_scan<uint32_t>(ctx, tot.chains, (uint32_t*)P(B_OFFC), n_files, ovf)) || (rc = device_scan<uint32_t>(ctx, tot.residues, (uint32_t*)P(B_OFFR), n_files, ovf)) ||
+        (rc = device_scan<uint32_t>(ctx, tot.atoms, (uint32_t*)P(B_OFFA), n_files, ovf)) || (rc = device_scan<uint32_t>(ctx, tot.title_bytes, (uint32_t*)P(B_OFFT), n_files, ovf)))
+        return rc;
+    uint32_t* pin = ctx->pinned + 8;    // [8..11] totals, [12] overflow
+    HIP_TRY(hipMemcpyAsync(&pin[0], (uint32_t*)P(B_OFFC) + n_files, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&pin[1], (uint32_t*)P(B_OFFR) + n_files, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&pin[2], (uint32_t*)P(B_OFFA) + n_files, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&pin[3], (uint32_t*)P(B_OFFT) + n_files, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&pin[4], ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (pin[4]) return FCZ_E_INVALID_ARG;
+    const uint32_t C = pin[0], R = pin[1], M = pin[2], TB = pin[3];
+    // the batch arrays: [atoms] x y z code | [residues + 1] atom_off, [residues] code bfac | [chains (+1)] ... | titles
+    const size_t oa_x = 0, oa_y = 4 * (size_t)M, oa_z = 8 * (size_t)M, oa_c = 12 * (size_t)M;
+    const size_t or_off = 0, or_bf = 4 * ((size_t)R + 1), or_rc = or_bf + 4 * (size_t)R;
+    const size_t oc_res = 0, oc_tit = 4 * ((size_t)C + 1), oc_fr = 2 * oc_tit, oc_fa = oc_fr + 4 * (size_t)C, oc_file = oc_fa + 4 * (size_t)C,
+                 oc_meta = oc_file + 4 * (size_t)C, oc_id = oc_meta + 4 * (size_t)C;
+    if ((rc = need(B_OUT_A, 13 * (size_t)M + 16)) || (rc = need(B_OUT_R, or_rc + R + 16)) || (rc = need(B_OUT_C, oc_id + C + 16)) || (rc = need(B_OUT_T, (size_t)TB + 16))) return rc;
+    char* ba = (char*)P(B_OUT_A); char* br = (char*)P(B_OUT_R); char* bc = (char*)P(B_OUT_C);
+    ingest_out O;
+    O.x = (float*)(ba + oa_x); O.y = (float*)(ba + oa_y); O.z = (float*)(ba + oa_z); O.atom_code = (uint8_t*)(ba + oa_c);
+    O.atom_off = (uint32_t*)(br + or_off); O.bfac_ca = (float*)(br + or_bf); O.res_code = (uint8_t*)(br + or_rc);
+    O.res_off = (uint32_t*)(bc + oc_res); O.title_off = (uint32_t*)(bc + oc_tit); O.first_res = (int32_t*)(bc + oc_fr); O.first_atom = (int32_t*)(bc + oc_fa);
+    O.chain_file = (uint32_t*)(bc + oc_file); O.chain_meta = (uint32_t*)(bc + oc_meta); O.chain_id = bc + oc_id;
+    O.titles = (char*)P(B_OUT_T);
+    {
+        span_guard g(ctx, "ingest_fill");
+        hipLaunchKernelGGL(k_ingest_fill, dim3(n_files), dim3(WAVE), 0, ctx->stream, n_files, (const uint64_t*)P(B_ABASE), T, (const ingest_frag*)P(B_FRAGS),
+                           (const uint32_t*)P(B_NFRAGS), (const uint32_t*)P(B_OFFC), (const uint32_t*)P(B_OFFR), (const uint32_t*)P(B_OFFA), (const uint32_t*)P(B_OFFT),
+                           (const uint32_t*)P(B_TLEN), (const uint32_t*)P(B_USESTEM), names_dev, name_off_dev, stem_len_dev, (const uint8_t*)P(B_TITLES), O,
+                           (uint32_t*)P(B_REFUSED), (uint32_t*)P(B_NREF));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&pin[5], P(B_NREF), 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    fcz_ingest_result& r = ctx->ig_res;
+    r.batch.n_chains = C; r.batch.n_residues = R; r.batch.n_atoms = M; r.batch.anchor_threshold = anchor_threshold;
+    r.batch.res_off = O.res_off; r.batch.atom_off = O.atom_off; r.batch.x = O.x; r.batch.y = O.y; r.batch.z = O.z;
+    r.batch.atom_code = O.atom_code; r.batch.res_code = O.res_code; r.batch.bfac_ca = O.bfac_ca;
+    r.batch.first_res_index = O.first_res; r.batch.first_atom_index = O.first_atom; r.batch.chain_id = O.chain_id;
+    r.batch.titles = O.titles; r.batch.title_off = O.title_off;
+    r.chain_file = O.chain_file; r.chain_meta = O.chain_meta; r.file_status = (const int32_t*)P(B_STATUS); r.refused = (const uint32_t*)P(B_REFUSED);
+    r.n_files = n_files; r.n_refused = pin[5];
+    ctx->ig_counts[0] = C; ctx->ig_counts[1] = R; ctx->ig_counts[2] = M; ctx->ig_counts[3] = TB; ctx->ig_counts[4] = pin[5];
+    *out = r;
+    return FCZ_OK;
+}
+
+int fcz_ingest_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* file_off, uint32_t n_files, const char* names, const uint32_t* name_off,
+                         const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5]) {
+    if (!ctx || !counts || anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    if (n_files && (!text || !file_off || !names || !name_off || !stem_len)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->sizes_fresh = false;   // staging buffers are rewritten
+    memset(counts, 0, 5 * sizeof(uint32_t));
+    if (n_files == 0) { memset(&ctx->ig_res, 0, sizeof ctx->ig_res); memset(ctx->ig_counts, 0, sizeof ctx->ig_counts); return FCZ_OK; }
+    const uint64_t text_bytes = file_off[n_files];
+    const uint32_t name_bytes = name_off[n_files];
+    int rc;
+    if ((rc = ctx->stage[0].ensure(std::max<uint64_t>(text_bytes, 16))) || (rc = ctx->stage[1].ensure(8 * ((size_t)n_files + 1))) ||
+        (rc = ctx->stage[2].ensure(std::max<size_t>(name_bytes, 16))) || (rc = ctx->stage[3].ensure(4 * ((size_t)n_files + 1))) || (rc = ctx->stage[4].ensure(4 * (size_t)n_files)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->stage[0].p, text, text_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[1].p, file_off, 8 * ((size_t)n_files + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (name_bytes) HIP_TRY(hipMemcpyAsync(ctx->stage[2].p, names, name_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[3].p, name_off, 4 * ((size_t)n_files + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[4].p, stem_len, 4 * (size_t)n_files, hipMemcpyHostToDevice, ctx->stream));
+    fcz_ingest_result res;
+    rc = fcz_ingest_pdb_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n_files, text_bytes, ctx->stage[2].as<char>(),
+                            ctx->stage[3].as<uint32_t>(), ctx->stage[4].as<uint32_t>(), anchor_threshold, flags, &res);
+    if (rc) return rc;
+    memcpy(counts, ctx->ig_counts, sizeof ctx->ig_counts);
+    return FCZ_OK;
+}
+
+static int ingest_fetch_meta(fcz_ctx* ctx, uint32_t* chain_file, uint32_t* chain_meta, int32_t* file_status, uint32_t* refused) {
+    const fcz_ingest_result& r = ctx->ig_res;
+    const uint32_t C = r.batch.n_chains;
+    if (chain_file && C) HIP_TRY(hipMemcpyAsync(chain_file, r.chain_file, 4 * (size_t)C, hipMemcpyDeviceToHost, ctx->stream));
+    if (chain_meta && C) HIP_TRY(hipMemcpyAsync(chain_meta, r.chain_meta, 4 * (size_t)C, hipMemcpyDeviceToHost, ctx->stream));
+    if (file_status && r.n_files) HIP_TRY(hipMemcpyAsync(file_status, r.file_status, 4 * (size_t)r.n_files, hipMemcpyDeviceToHost, ctx->stream));
+    if (refused && r.n_refused) HIP_TRY(hipMemcpyAsync(refused, r.refused, 8 * (size_t)r.n_refused, hipMemcpyDeviceToHost, ctx->stream));
+    return FCZ_OK;
+}
+
+int fcz_ingest_pdb_fetch(fcz_ctx* ctx, const fcz_chain_batch* hb, uint32_t* chain_file, uint32_t* chain_meta, int32_t* file_status, uint32_t* refused) {
+    if (!ctx) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const fcz_ingest_result& r = ctx->ig_res;
+    const fcz_chain_batch& d = r.batch;
+    const size_t C = d.n_chains, R = d.n_residues, M = d.n_atoms, TB = ctx->ig_counts[3];
+    if (hb && r.n_files) {
+        auto cp = [&](const void* dst, const void* src, size_t bytes) -> int {
+            if (!bytes) return FCZ_OK;
+            if (!dst) return FCZ_E_INVALID_ARG;
+            HIP_TRY(hipMemcpyAsync(const_cast<void*>(dst), src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            return FCZ_OK;
+        };
+        int rc;
+        if ((rc = cp(hb->res_off, d.res_off, 4 * (C + 1))) || (rc = cp(hb->atom_off, d.atom_off, 4 * (R + 1))) || (rc = cp(hb->x, d.x, 4 * M)) ||
+            (rc = cp(hb->y, d.y, 4 * M)) || (rc = cp(hb->z, d.z, 4 * M)) || (rc = cp(hb->atom_code, d.atom_code, M)) || (rc = cp(hb->res_code, d.res_code, R)) ||
+            (rc = cp(hb->bfac_ca, d.bfac_ca, 4 * R)) || (rc = cp(hb->first_res_index, d.first_res_index, 4 * C)) ||
+            (rc = cp(hb->first_atom_index, d.first_atom_index, 4 * C)) || (rc = cp(hb->chain_id, d.chain_id, C)) || (rc = cp(hb->titles, d.titles, TB)) ||
+            (rc = cp(hb->title_off, d.title_off, 4 * (C + 1))))
+            return rc;
+    }
+    int rc = ingest_fetch_meta(ctx, chain_file, chain_meta, file_status, refused);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}
+
+int fcz_compress_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* file_off, uint32_t n_files, const char* names, const uint32_t* name_off,
+                           const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5], uint64_t* fcz_bytes) {
+    if (!fcz_bytes) return FCZ_E_INVALID_ARG;
+    *fcz_bytes = 0; if (ctx) ctx->ig_fcz_bytes = 0;
+    int rc = fcz_ingest_pdb_begin(ctx, text, file_off, n_files, names, name_off, stem_len, anchor_threshold, flags, counts);
+    if (rc) return rc;
+    const fcz_chain_batch& b = ctx->ig_res.batch;
+    const uint32_t C = b.n_chains;
+    if (C == 0) return FCZ_OK;
+    if ((rc = ctx->stage[13].ensure(8 * ((size_t)C + 1))) || (rc = ctx->stage[15].ensure(4 * (size_t)C))) return rc;
+    if ((rc = fcz_compress_sizes_dev(ctx, &b, ctx->stage[13].as<uint64_t>()))) return rc;
+    uint64_t* tot = reinterpret_cast<uint64_t*>(ctx->pinned + 14);
+    HIP_TRY(hipMemcpyAsync(tot, ctx->stage[13].as<uint64_t>() + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t bytes = *tot;
+    if ((rc = ctx->stage[14].ensure(std::max<uint64_t>(bytes, 16)))) return rc;
+    if ((rc = fcz_compress_batch_dev(ctx, &b, ctx->stage[13].as<uint64_t>(), ctx->stage[14].as<uint8_t>(), ctx->stage[15].as<int32_t>()))) return rc;
+    ctx->ig_fcz_bytes = bytes; *fcz_bytes = bytes;
+    return FCZ_OK;
+}
+
+int fcz_compress_pdb_fetch(fcz_ctx* ctx, uint64_t* out_off, int32_t* status, uint32_t* chain_file, uint32_t* chain_meta, int32_t* file_status,
+                           uint32_t* refused, uint8_t* blob) {
+    if (!ctx) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t C = ctx->ig_res.batch.n_chains;
+    if (C) {
+        if (out_off) HIP_TRY(hipMemcpyAsync(out_off, ctx->stage[13].p, 8 * ((size_t)C + 1), hipMemcpyDeviceToHost, ctx->stream));
+        if (status) HIP_TRY(hipMemcpyAsync(status, ctx->stage[15].p, 4 * (size_t)C, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->ig_fcz_bytes) {
+            if (!blob) return FCZ_E_INVALID_ARG;
+            HIP_TRY(hipMemcpyAsync(blob, ctx->stage[14].p, ctx->ig_fcz_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    } else if (out_off) out_off[0] = 0;
+    int rc = ingest_fetch_meta(ctx, chain_file, chain_meta, file_status, refused);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FCZ_OK;
 }
 

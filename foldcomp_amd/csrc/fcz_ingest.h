@@ -1,0 +1,533 @@
+// fcz_ingest.h -- structure ingest on the device: PDB text -> fcz_chain_batch.
+//
+// What the reference does per input file before Foldcomp::compress sees an atom span, restated for a wavefront per file:
+//   StructureReader (gemmi) -> atom table                 reference src/structure_reader.cpp:31-61; the fixed-column ATOM /
+//                                                         HETATM record as the Python binding reads it, foldcomp/foldcomp.cxx:259-278
+//   removeAlternativePosition                             src/atom_coordinate.cpp:362-370
+//   identifyChains                                        src/atom_coordinate.cpp:469-497
+//   identifyDiscontinousResInd                            src/atom_coordinate.cpp:506-530
+//   per fragment: splitAtomByResidue, residue codes, the CA B-factor, N/CA/C present and in order
+//                                                         src/atom_coordinate.cpp:304-328, src/foldcomp.cpp:450-559, src/main.cpp:455-508
+//   title: _entry.id = HEADER id code, else the TITLE records  (gemmi; src/main.cpp:465)
+//
+//   k_ingest_parse   wavefront = file. The file is walked in 4 KB chunks: every lane finds the line ends in its 64 bytes, a
+//                    wave scan numbers them, then lane = line: record type, fixed-column fields, numbers by the exact
+//                    integer-digits x reciprocal scheme the host parser proves (host/foldcomp_hip.cpp fixed_field), names as packed
+//                    integers -> codes through an LDS hash. An atom whose name equals that of the record before it is dropped
+//                    (that IS removeAlternativePosition: see keep rule below). Kept atoms are appended to the file's slice of
+//                    the scratch atom table. Anything outside the fixed layout marks the FILE for the host parser
+//                    (FCZ_INGEST_HOST_*): the device never guesses.
+//   k_ingest_frags   wavefront = file: chain cuts, gap cuts, residue boundaries, per-residue validation -> fragment list,
+//                    per-residue scratch (first atom, code, CA B-factor), per-file totals of what was accepted.
+//   k_ingest_fill    wavefront = file: accepted fragments copied to their place in the batch arrays (offsets from scans over
+//                    the per-file totals).
+#pragma once
+#include "fcz_kernels.h"
+
+namespace fcz {
+
+// per-file status beyond FCZ_OK: the file is left to the host parser (nothing of it enters the batch)
+constexpr int32_t FCZ_INGEST_HOST_FIELD = 1;      // a number / integer field outside the fixed layout, or a short ATOM record
+constexpr int32_t FCZ_INGEST_HOST_TITLE = 2;      // title longer than the device buffer
+constexpr int32_t FCZ_INGEST_HOST_FRAGS = 3;      // more fragments than the per-file list holds
+constexpr int32_t FCZ_INGEST_NO_ATOMS = 4;        // "[Error] No atoms found in the input file" (src/main.cpp:459-462)
+
+constexpr int IG_CHUNK = 4096;                    // bytes per wavefront step (64 lanes x 64 bytes)
+constexpr int IG_LINES = 1024;                    // line ends one chunk can hold in LDS before it is split (81-byte lines: 51)
+constexpr int IG_TITLE_CAP = 512;                 // bytes of title per file
+constexpr int IG_MAX_FRAGS = 32;                  // fragments per file
+
+// fragment refusal reasons (what Batch::prepare of the host throws), chain_meta of a refused fragment carries them << 24
+constexpr uint32_t IG_REF_NONE = 0, IG_REF_RESNAME = 1, IG_REF_BACKBONE = 2, IG_REF_TOO_LONG = 3, IG_REF_SKIP_DISC = 4;
+constexpr uint32_t IG_META_MULTI_CHAIN = 1u << 16, IG_META_MULTI_FRAG = 1u << 17;
+
+struct ingest_scratch {       // per-atom table of the kept atoms, file f at [abase[f], abase[f] + n_kept[f])
+    uint32_t* name;           // packed atom name
+    uint32_t* resn;           // packed residue name
+    int32_t* serial;          // atom serial number
+    int32_t* resseq;          // residue sequence number
+    float *x, *y, *z, *b;
+    uint8_t* chain;
+    uint8_t* acode;           // codec atom code (255 = other)
+    int8_t* rcode;            // codec residue code of the atom's residue name (-1 = not one the codec takes)
+    // per residue, file f at [abase[f] ...): filled by k_ingest_frags
+    uint32_t* r_first;        // first atom (file-local index) of the residue
+    float* r_bfac;            // B-factor of its CA atom
+    uint8_t* r_code;
+};
+struct ingest_frag { uint32_t a, b, r0, nres, meta; };   // atoms [a, b) and residues [r0, r0 + nres) file-local; meta: chain | ordinal << 8 | flags | reason << 24
+
+__device__ __forceinline__ bool ig_is_space(uint32_t c) { return c == ' ' || (c - 9u) < 5u; }   // isspace of the C locale
+__device__ __forceinline__ uint32_t ig_prev_lane(unsigned long long mask, int lane) {            // highest set bit below `lane`, 64 if none
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    return below ? 63u - (uint32_t)__builtin_clzll(below) : 64u;
+}
+
+// a stripped field of up to four characters as a packed name (host: field_pack)
+__device__ __forceinline__ uint32_t ig_pack4(uint32_t w, int n) {   // w = the n (<= 4) field bytes, little endian
+    uint32_t c[4] = {w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, (w >> 24) & 0xffu};
+    int a = 0, e = n;
+    while (a < e && ig_is_space(c[a])) a++;
+    while (e > a && ig_is_space(c[e - 1])) e--;
+    uint32_t v = 0;
+    for (int i = a; i < e; i++) v |= c[i] << (8 * (i - a));
+    return v;
+}
+// fixed_field<W, F> of the host parser on W bytes: right-aligned, F decimals, digits / leading spaces / one '-'
+template <int W, int F>
+__device__ __forceinline__ bool ig_fixed(const uint8_t* f, float* out) {
+    constexpr int IP = W - F - 1;
+    if (f[IP] != '.') return false;
+    uint32_t frac = 0;
+#pragma unroll
+    for (int i = 0; i < F; i++) { const uint32_t c = (uint32_t)f[IP + 1 + i] - '0'; if (c > 9u) return false; frac = frac * 10u + c; }
+    int i = 0;
+    while (i < IP && f[i] == ' ') i++;
+    bool neg = false;
+    if (i < IP && f[i] == '-') { neg = true; i++; }
+    if (i >= IP) return false;
+    uint32_t ip = 0;
+    for (; i < IP; i++) { const uint32_t c = (uint32_t)f[i] - '0'; if (c > 9u) return false; ip = ip * 10u + c; }
+    constexpr uint32_t P10 = F == 3 ? 1000u : (F == 2 ? 100u : 10u);
+    constexpr double INV = F == 3 ? 0.001 : (F == 2 ? 0.01 : 0.1);
+    const float v = (float)((double)(ip * P10 + frac) * INV);     // == (float)strtod(field) for this layout (proved exhaustively on the host)
+    *out = neg ? -v : v;
+    return true;
+}
+// field_int of the host parser on n bytes: spaces around, optional sign, digits only
+__device__ __forceinline__ bool ig_int(const uint8_t* f, int n, int32_t* out) {
+    int a = 0, e = n;
+    while (a < e && f[a] == ' ') a++;
+    while (e > a && (f[e - 1] == ' ' || f[e - 1] == '\r')) e--;
+    bool neg = false;
+    if (a < e && (f[a] == '-' || f[a] == '+')) { neg = f[a] == '-'; a++; }
+    if (a >= e) return false;
+    long long v = 0;
+    for (; a < e; a++) { const uint32_t c = (uint32_t)f[a] - '0'; if (c > 9u) return false; v = v * 10 + (long long)c; }
+    *out = (int32_t)(neg ? -v : v);
+    return true;
+}
+
+struct ingest_lds {
+    uint32_t line_end[IG_LINES];          // chunk-relative position of every '\n' of the chunk, in order
+    uint32_t akey[64], rkey[32];          // open-addressed name -> code tables (packed name, 0 = empty)
+    uint8_t aval[64], rval[32];
+};
+__device__ __forceinline__ uint32_t ig_hash(uint32_t k) { return (k * 0x9E3779B1u) >> 24; }
+
+// ---- k_ingest_parse --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict__ text, const uint64_t* __restrict__ file_off, uint32_t n_files,
+                                                       uint64_t text_bytes, const uint64_t* __restrict__ abase, ingest_scratch T,
+                                                       uint8_t* __restrict__ titles, uint32_t* __restrict__ title_len,
+                                                       uint32_t* __restrict__ n_kept, int32_t* __restrict__ file_status) {
+    __shared__ ingest_lds S;
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_files) return;
+    // name -> code tables (the host's NameCodes): open addressing, 64 / 32 slots
+    S.akey[lane] = 0; if (lane < 32) S.rkey[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        for (int i = 0; i < FCZ_N_ATOM_CODES; i++) {
+            uint32_t k; __builtin_memcpy(&k, fcz_atom_name[i], 4);
+            uint32_t h = ig_hash(k) & 63u; while (S.akey[h]) h = (h + 1) & 63u;
+            S.akey[h] = k; S.aval[h] = (uint8_t)i;
+        }
+        for (int i = 0; i < FCZ_N_RES_CODES; i++) {
+            uint32_t k; __builtin_memcpy(&k, fcz_res3[i], 4);
+            uint32_t h = ig_hash(k) & 31u; while (S.rkey[h]) h = (h + 1) & 31u;
+            S.rkey[h] = k; S.rval[h] = (uint8_t)i;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto atom_code_of = [&](uint32_t k) -> uint32_t {
+        for (uint32_t h = ig_hash(k) & 63u; S.akey[h]; h = (h + 1) & 63u) if (S.akey[h] == k) return S.aval[h];
+        return (uint32_t)FCZ_ATOM_OTHER;
+    };
+    auto res_code_of = [&](uint32_t k) -> int {
+        for (uint32_t h = ig_hash(k) & 31u; S.rkey[h]; h = (h + 1) & 31u) if (S.rkey[h] == k) { const int c = S.rval[h]; return (c < 20 || c == 23) ? c : -1; }
+        return -1;
+    };
+
+    const uint64_t f0 = file_off[f], f1 = file_off[f + 1];
+    const uint8_t* base = text + f0;
+    const uint64_t flen = f1 - f0;
+    const uint64_t A0 = abase[f];
+    uint8_t* tbuf = titles + (size_t)f * IG_TITLE_CAP;
+    uint32_t kept = 0;                     // atoms written so far (uniform)
+    uint32_t last_name = 0; bool have_last = false;       // name of the last ATOM / HETATM record seen (uniform)
+    bool seen_atom = false, have_header = false;          // title state (uniform)
+    uint32_t tlen = 0; bool first_part = true;
+    int32_t status = FCZ_OK;
+    uint64_t line_start = 0;               // file-relative start of the line that is open at the chunk's beginning (uniform)
+
+    // one line [ls, le) (file-relative, le excludes the newline) per lane; `on` = this lane has a line
+    auto do_lines = [&](bool on, uint64_t ls, uint64_t le) {
+        uint32_t len = on ? (uint32_t)(le - ls) : 0u;
+        const uint8_t* p = base + ls;
+        if (on && len && p[len - 1] == '\r') len--;
+        uint32_t w0 = 0, w1 = 0;
+        if (on && len >= 4) w0 = ld_u32(p);
+        if (on && len >= 6) w1 = ld_u16(p + 4);
+        const bool is_atom = on && len >= 4 && w0 == 0x4d4f5441u;                             // "ATOM"
+        const bool is_het = on && len >= 6 && w0 == 0x41544548u && w1 == 0x4d54u;             // "HETATM"
+        const bool rec = is_atom || is_het;
+        // ---- title records before the first ATOM (gemmi: HEADER id code, else the TITLE records joined) ----
+        if (!seen_atom && !have_header) {
+            const unsigned long long m_atom = __ballot(is_atom);
+            const bool is_title = on && !rec && len >= 5 && w0 == 0x4c544954u && p[4] == 'E';   // "TITLE"
+            bool is_hdr = false;
+            if (on && !rec && len >= 66 && w0 == 0x44414548u && w1 == 0x5245u) {              // "HEADER" with an id code in columns 63-66
+                for (int i = 62; i < 66; i++) if (!ig_is_space(p[i])) is_hdr = true;
+            }
+            unsigned long long m_t = __ballot(is_title || is_hdr);
+            const int first_atom_lane = m_atom ? __builtin_ctzll(m_atom) : 64;
+            while (m_t) {
+                const int l = __builtin_ctzll(m_t); m_t &= m_t - 1;
+                if (l > first_atom_lane || have_header) break;
+                const bool hdr = __shfl((int)is_hdr, l, WAVE) != 0;
+                uint32_t add = 0;
+                if (lane == l) {
+                    int a = hdr ? 62 : 10, e = hdr ? 66 : (len < 80u ? (int)len : 80);
+                    if (a > e) a = e;
+                    while (a < e && ig_is_space(p[a])) a++;
+                    while (e > a && ig_is_space(p[e - 1])) e--;
+                    uint32_t at = hdr ? 0u : tlen;
+                    if (!hdr && !first_part) { if (at < (uint32_t)IG_TITLE_CAP) tbuf[at] = ' '; at++; }
+                    for (int i = a; i < e; i++, at++) if (at < (uint32_t)IG_TITLE_CAP) tbuf[at] = p[i];
+                    add = at;
+                }
+                tlen = (uint32_t)__shfl((int)add, l, WAVE);
+                first_part = false;
+                if (hdr) have_header = true;
+            }
+            if (m_atom) seen_atom = true;
+        }
+        // ---- ATOM / HETATM records ----
+        uint32_t an = 0, rn = 0; int32_t serial = 0, resseq = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; uint32_t ch = ' ';
+        bool bad = false;
+        if (rec) {
+            if (len < 54) bad = true;      // the coordinate columns are not all there: the host parser decides what that means
+            else {
+                an = ig_pack4(ld_u32(p + 12), 4);
+                rn = ig_pack4(ld_u32(p + 16) >> 8, 3);
+                ch = p[21];
+                if (!ig_int(p + 6, 5, &serial) || !ig_int(p + 22, 4, &resseq)) bad = true;
+                if (!ig_fixed<8, 3>(p + 30, &x) || !ig_fixed<8, 3>(p + 38, &y) || !ig_fixed<8, 3>(p + 46, &z)) bad = true;
+                if (len >= 66) {
+                    if (!ig_fixed<6, 2>(p + 60, &bf)) {
+                        bool blank = true; for (int i = 60; i < 66; i++) if (!ig_is_space(p[i])) blank = false;
+                        if (blank) bf = 0.f; else bad = true;
+                    }
+                } else {
+                    for (uint32_t i = 60; i < len; i++) if (!ig_is_space(p[i])) bad = true;   // a partial field: host
+                    bf = 0.f;
+                }
+            }
+        }
+        if (__any(bad)) status = FCZ_INGEST_HOST_FIELD;
+        // keep rule. removeAlternativePosition drops an atom whose name equals the name of the last atom KEPT; that is the
+        // same as "equals the name of the record right before it": if that record was kept it is the comparison itself, if it
+        // was dropped it carried the kept atom's name.
+        const unsigned long long m_rec = __ballot(rec);
+        const uint32_t pl = ig_prev_lane(m_rec, lane);
+        const uint32_t pname = (uint32_t)__shfl((int)an, pl < 64u ? (int)pl : 0, WAVE);
+        const bool has_prev = pl < 64u ? true : have_last;
+        const uint32_t prev_name = pl < 64u ? pname : last_name;
+        const bool keep = rec && !bad && !(has_prev && prev_name == an);   // (a bad record marks the file for the host: nothing of it is used)
+        const unsigned long long m_keep = __ballot(keep);
+        if (keep) {
+            const size_t o = (size_t)A0 + kept + (uint32_t)__builtin_popcountll(m_keep & ((1ull << lane) - 1ull));
+            T.name[o] = an; T.resn[o] = rn; T.serial[o] = serial; T.resseq[o] = resseq;
+            T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = (uint8_t)ch;
+            T.acode[o] = (uint8_t)atom_code_of(an);
+            T.rcode[o] = (int8_t)res_code_of(rn);
+        }
+        kept += (uint32_t)__builtin_popcountll(m_keep);
+        if (m_rec) {
+            const int hl = 63 - __builtin_clzll(m_rec);
+            last_name = (uint32_t)__shfl((int)an, hl, WAVE); have_last = true;
+        }
+    };
+
+    for (uint64_t c0 = 0; c0 < flen; c0 += IG_CHUNK) {
+        // ---- line ends of the chunk ----
+        const uint64_t my = c0 + 64ull * (uint64_t)lane;     // file-relative start of this lane's 64 bytes
+        uint32_t t[16];
+        uint32_t cnt = 0;
+        if (my < flen) {
+            const bool full = my + 64 <= flen;
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                uint32_t v;
+                if (full) v = ld_u32(base + my + 4 * d);
+                else { v = 0; for (int b = 0; b < 4; b++) { const uint64_t q = my + 4 * d + b; if (q < flen) v |= (uint32_t)base[q] << (8 * b); } }
+                const uint32_t xz = v ^ 0x0a0a0a0au;
+                t[d] = ~(((xz & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xz | 0x7f7f7f7fu);     // 0x80 in every byte that is '\n'
+                cnt += (uint32_t)__builtin_popcount(t[d]);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 16; d++) t[d] = 0;
+        }
+        uint32_t total;
+        uint32_t ord = wave_excl_scan_dpp(cnt, &total);
+        // chunks with more line ends than the table holds (blank-line runs) go through it in rounds
+        for (uint32_t r0 = 0; r0 < total || r0 == 0; r0 += IG_LINES) {
+            uint32_t o = ord;
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                uint32_t m = t[d];
+                while (m) {
+                    const int bit = __builtin_ctz(m); m &= m - 1;
+                    if (o >= r0 && o < r0 + (uint32_t)IG_LINES) S.line_end[o - r0] = 64u * (uint32_t)lane + 4u * (uint32_t)d + (uint32_t)(bit >> 3);
+                    o++;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_here = total - r0 < (uint32_t)IG_LINES ? total - r0 : (uint32_t)IG_LINES;
+            for (uint32_t k0 = 0; k0 < n_here; k0 += WAVE) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                const bool on = k < n_here;
+                const uint64_t le = on ? c0 + S.line_end[k] : 0;
+                const uint64_t ls = on ? (k == 0 ? line_start : c0 + S.line_end[k - 1] + 1) : 0;
+                do_lines(on, ls, le);
+            }
+            if (n_here) line_start = c0 + S.line_end[n_here - 1] + 1;
+            __builtin_amdgcn_wave_barrier();
+            if (total == 0) break;
+        }
+    }
+    if (line_start < flen) do_lines(lane == 0, line_start, flen);     // a last line without a line end
+    if (lane == 0) {
+        // title = HEADER id, else the TITLE parts joined and stripped (the parts were stripped one by one; joined with ' ')
+        uint32_t a = 0, e = tlen;
+        if (tlen > (uint32_t)IG_TITLE_CAP) { if (status == FCZ_OK) status = FCZ_INGEST_HOST_TITLE; e = 0; }
+        while (a < e && ig_is_space(tbuf[a])) a++;
+        while (e > a && ig_is_space(tbuf[e - 1])) e--;
+        if (a) for (uint32_t i = a; i < e; i++) tbuf[i - a] = tbuf[i];
+        title_len[f] = e - a;
+        if (status == FCZ_OK && kept == 0) status = FCZ_INGEST_NO_ATOMS;
+        n_kept[f] = status == FCZ_OK ? kept : 0u;
+        file_status[f] = status;
+    }
+}
+
+// ---- k_ingest_frags -----------------------------------------------------------------------------------------------------
+// Chain cuts (identifyChains): walking the atoms, where the chain id changes -- if the atom there is an N a new chain starts;
+// otherwise the chain ends there, the next one starts at the following N (atoms in between belong to nobody) and the walk
+// resumes after it; no N any more: no further cuts. Gap cuts (identifyDiscontinousResInd): inside a chain, from its first N;
+// a new fragment starts at an N whose residue number exceeds the previous N's by more than one.
+// Residues of a fragment (splitAtomByResidue as the hosts restate it): a new residue starts where the residue number changes,
+// except at the fragment's last atom.
+struct ingest_totals { uint32_t chains, residues, atoms, title_bytes; };
+struct ingest_counts { uint32_t *chains, *residues, *atoms, *title_bytes; };   // per file, scanned into the batch offsets
+__device__ __forceinline__ uint32_t ig_ld_coherent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const uint64_t* __restrict__ abase, ingest_scratch T,
+                                                       const uint32_t* __restrict__ n_kept, int32_t* __restrict__ file_status,
+                                                       const uint32_t* __restrict__ title_len, const char* __restrict__ names,
+                                                       const uint32_t* __restrict__ name_off, const uint32_t* __restrict__ stem_len,
+                                                       const uint8_t* __restrict__ titles, int anchor_threshold, int skip_discontinuous,
+                                                       ingest_frag* __restrict__ frags, uint32_t* __restrict__ n_frags,
+                                                       ingest_counts totals, uint32_t* __restrict__ use_stem) {
+    __shared__ uint32_t s_cut[2 * IG_MAX_FRAGS + 2];     // chain ranges as (a, b) pairs
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_files) return;
+    const uint32_t n = n_kept[f];
+    ingest_totals tot{0, 0, 0, 0};
+    uint32_t nf = 0;
+    if (file_status[f] != FCZ_OK || n == 0) {
+        if (lane == 0) { n_frags[f] = 0; totals.chains[f] = 0; totals.residues[f] = 0; totals.atoms[f] = 0; totals.title_bytes[f] = 0; use_stem[f] = 0; }
+        return;
+    }
+    const size_t A0 = (size_t)abase[f];
+    const uint32_t PKN = 'N';
+    // ---- chain ranges ----
+    uint32_t n_ch = 0; bool overflow = false;
+    {
+        uint32_t start = 0, resume = 1; bool stopped = false;
+        auto push = [&](uint32_t a, uint32_t b) { if (n_ch < (uint32_t)IG_MAX_FRAGS) { if (lane == 0) { s_cut[2 * n_ch] = a; s_cut[2 * n_ch + 1] = b; } n_ch++; } else overflow = true; };
+        for (uint32_t i0 = 0; i0 < n && !stopped; i0 += WAVE) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool in = i < n && i >= 1;
+            const bool chg = in && T.chain[A0 + i] != T.chain[A0 + i - 1];
+            unsigned long long m = __ballot(chg);
+            while (m && !stopped) {
+                const int l = __builtin_ctzll(m); m &= m - 1;
+                const uint32_t ci = i0 + (uint32_t)l;
+                if (ci < resume) continue;
+                if (T.name[A0 + ci] == PKN) { push(start, ci); start = ci; resume = ci + 1; continue; }
+                // the next N at or after ci
+                uint32_t j = n;
+                for (uint32_t j0 = ci & ~63u; j0 < n && j == n; j0 += WAVE) {
+                    const uint32_t q = j0 + (uint32_t)lane;
+                    const unsigned long long mn = __ballot(q < n && q >= ci && T.name[A0 + q] == PKN);
+                    if (mn) j = j0 + (uint32_t)__builtin_ctzll(mn);
+                }
+                if (j == n) { stopped = true; break; }
+                push(start, ci); start = j; resume = j + 1;
+            }
+        }
+        push(start, n);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool multi_chain = n_ch > 1;
+    // ---- fragments of every chain; residues and their validation ----
+    ingest_frag* my_frags = frags + (size_t)f * IG_MAX_FRAGS;
+    uint32_t r_next = 0;                                   // next free slot of the file's residue scratch
+    for (uint32_t c = 0; c < n_ch && !overflow; c++) {
+        const uint32_t ca = s_cut[2 * c], cb = s_cut[2 * c + 1];
+        const uint32_t chain_char = T.chain[A0 + ca];
+        // gap cuts: positions (all N atoms) where a new fragment starts
+        uint32_t fstart[IG_MAX_FRAGS + 1]; uint32_t nfr = 0;    // uniform values, small
+        {
+            bool have_n = false; int32_t prev_seq = 0; uint32_t cur = 0;
+            for (uint32_t i0 = ca; i0 < cb; i0 += WAVE) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const bool isn = i < cb && T.name[A0 + i] == PKN;
+                const int32_t seq = isn ? T.resseq[A0 + i] : 0;
+                const unsigned long long mn = __ballot(isn);
+                if (!mn) continue;
+                const uint32_t pl = ig_prev_lane(mn, lane);
+                const int32_t pseq = __shfl(seq, pl < 64u ? (int)pl : 0, WAVE);
+                const bool hp = pl < 64u ? true : have_n;
+                const int32_t ps = pl < 64u ? pseq : prev_seq;
+                const bool first_n = isn && !hp;
+                const bool cut = isn && hp && (seq - ps > 1);
+                unsigned long long mc = __ballot(cut || first_n);
+                while (mc) {
+                    const int l = __builtin_ctzll(mc); mc &= mc - 1;
+                    const uint32_t pos = i0 + (uint32_t)l;
+                    if (nfr < (uint32_t)IG_MAX_FRAGS) fstart[nfr++] = pos; else overflow = true;
+                    cur = pos;
+                }
+                (void)cur;
+                const int hl = 63 - __builtin_clzll(mn);
+                prev_seq = __shfl(seq, hl, WAVE); have_n = true;
+            }
+        }
+        if (nfr == 0 || overflow) continue;                // a chain without an N atom has no fragment
+        fstart[nfr] = cb;
+        const bool multi_frag = nfr > 1;
+        for (uint32_t j = 0; j < nfr; j++) {
+            const uint32_t a = fstart[j], b = fstart[j + 1];
+            uint32_t reason = (skip_discontinuous && multi_frag) ? IG_REF_SKIP_DISC : IG_REF_NONE;
+            // residue starts: atom a, and every atom in (a, b - 1) whose residue number differs from its predecessor's
+            uint32_t nres = 0;
+            for (uint32_t i0 = a; i0 < b; i0 += WAVE) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const bool st = i < b && (i == a || (i != b - 1 && T.resseq[A0 + i] != T.resseq[A0 + i - 1]));
+                const unsigned long long ms = __ballot(st);
+                if (st) T.r_first[A0 + r_next + nres + (uint32_t)__builtin_popcountll(ms & ((1ull << lane) - 1ull))] = i;
+                nres += (uint32_t)__builtin_popcountll(ms);
+            }
+            __threadfence();                                 // the residue starts are read back by other lanes below
+            // the FCZ header holds nResidue in 16 bits and nAnchor in 8 (src/foldcomp.h:120-125): refused, not wrapped
+            if (nres > 65535u || (anchor_threshold > 0 && nres / (uint32_t)anchor_threshold + 2u > 255u)) { if (!reason) reason = IG_REF_TOO_LONG; }
+            // lane = residue: code of the residue name, first N / CA / C in order, the CA B-factor
+            bool bad_name = false, bad_bb = false;
+            for (uint32_t q0 = 0; q0 < nres; q0 += WAVE) {
+                const uint32_t q = q0 + (uint32_t)lane;
+                if (q < nres) {
+                    const uint32_t s0 = ig_ld_coherent(&T.r_first[A0 + r_next + q]);
+                    const uint32_t s1 = q + 1 < nres ? ig_ld_coherent(&T.r_first[A0 + r_next + q + 1]) : b;
+                    const int code = T.rcode[A0 + s0];
+                    if (code < 0) bad_name = true;
+                    int pos[3] = {-1, -1, -1};
+                    for (uint32_t i = s0; i < s1; i++) { const uint32_t ac = T.acode[A0 + i]; if (ac < 3u && pos[ac] < 0) pos[ac] = (int)i; }
+                    if (pos[0] < 0 || pos[1] < 0 || pos[2] < 0 || !(pos[0] < pos[1] && pos[1] < pos[2])) bad_bb = true;
+                    T.r_code[A0 + r_next + q] = (uint8_t)(code < 0 ? 23 : code);
+                    T.r_bfac[A0 + r_next + q] = pos[1] >= 0 ? T.b[A0 + (uint32_t)pos[1]] : 0.f;
+                }
+            }
+            // the host reports the first problem it meets walking the residues; a fragment with either is refused all the same
+            if (!reason && __any(bad_name)) reason = IG_REF_RESNAME;
+            if (!reason && __any(bad_bb)) reason = IG_REF_BACKBONE;
+            if (nf < (uint32_t)IG_MAX_FRAGS) {
+                if (lane == 0) {
+                    ingest_frag fr;
+                    fr.a = a; fr.b = b; fr.r0 = r_next; fr.nres = nres;
+                    fr.meta = chain_char | (j << 8) | (multi_chain ? IG_META_MULTI_CHAIN : 0u) | (multi_frag ? IG_META_MULTI_FRAG : 0u) | (reason << 24);
+                    my_frags[nf] = fr;
+                }
+                nf++;
+                if (!reason) { tot.chains++; tot.residues += nres; tot.atoms += b - a; }
+            } else overflow = true;
+            r_next += nres;
+        }
+    }
+    if (overflow) { nf = 0; tot = ingest_totals{0, 0, 0, 0}; }
+    if (lane == 0) {
+        if (overflow) file_status[f] = FCZ_INGEST_HOST_FRAGS;
+        // the title every record of this file carries: the parsed one, or the file's stem when there is none or it equals
+        // the file's base name (src/main.cpp:465)
+        const uint32_t tl = title_len[f], nb = name_off[f + 1] - name_off[f];
+        bool stem = tl == 0;
+        if (!stem && tl == nb) { stem = true; for (uint32_t i = 0; i < tl; i++) if (titles[(size_t)f * IG_TITLE_CAP + i] != (uint8_t)names[name_off[f] + i]) { stem = false; break; } }
+        use_stem[f] = stem ? 1u : 0u;
+        tot.title_bytes = tot.chains * (stem ? stem_len[f] : tl);
+        n_frags[f] = nf;
+        totals.chains[f] = tot.chains; totals.residues[f] = tot.residues; totals.atoms[f] = tot.atoms; totals.title_bytes[f] = tot.title_bytes;
+    }
+}
+
+// ---- k_ingest_fill ------------------------------------------------------------------------------------------------------
+struct ingest_out {
+    uint32_t *res_off, *atom_off, *title_off; float *x, *y, *z, *bfac_ca; uint8_t *atom_code, *res_code; int32_t *first_res, *first_atom;
+    char *chain_id, *titles; uint32_t *chain_file, *chain_meta;
+};
+__global__ __launch_bounds__(WAVE) void k_ingest_fill(uint32_t n_files, const uint64_t* __restrict__ abase, ingest_scratch T,
+                                                      const ingest_frag* __restrict__ frags, const uint32_t* __restrict__ n_frags,
+                                                      const uint32_t* __restrict__ c_off, const uint32_t* __restrict__ r_off,
+                                                      const uint32_t* __restrict__ a_off, const uint32_t* __restrict__ t_off,
+                                                      const uint32_t* __restrict__ title_len, const uint32_t* __restrict__ use_stem,
+                                                      const char* __restrict__ names, const uint32_t* __restrict__ name_off,
+                                                      const uint32_t* __restrict__ stem_len, const uint8_t* __restrict__ titles, ingest_out O,
+                                                      uint32_t* __restrict__ refused, uint32_t* __restrict__ n_refused) {
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_files) return;
+    const uint32_t nf = n_frags[f];
+    const size_t A0 = (size_t)abase[f];
+    uint32_t c = c_off[f], r = r_off[f], a = a_off[f], t = t_off[f];
+    const bool stem = use_stem[f] != 0;
+    const uint32_t tl = stem ? stem_len[f] : title_len[f];
+    const uint8_t* tsrc = stem ? (const uint8_t*)names + name_off[f] : titles + (size_t)f * IG_TITLE_CAP;
+    for (uint32_t k = 0; k < nf; k++) {
+        const ingest_frag fr = frags[(size_t)f * IG_MAX_FRAGS + k];
+        if (fr.meta >> 24) {                               // refused: reported (file, meta with the reason), not part of the batch
+            if (lane == 0) { const uint32_t q = atomicAdd(n_refused, 1u); refused[2 * (size_t)q] = f; refused[2 * (size_t)q + 1] = fr.meta; }
+            continue;
+        }
+        const uint32_t na = fr.b - fr.a;
+        for (uint32_t i = lane; i < na; i += WAVE) {
+            const size_t s = A0 + fr.a + i;
+            O.x[a + i] = T.x[s]; O.y[a + i] = T.y[s]; O.z[a + i] = T.z[s]; O.atom_code[a + i] = T.acode[s];
+        }
+        for (uint32_t q = lane; q < fr.nres; q += WAVE) {
+            const size_t s = A0 + fr.r0 + q;
+            O.atom_off[r + q] = a + (T.r_first[s] - fr.a);
+            O.res_code[r + q] = T.r_code[s];
+            O.bfac_ca[r + q] = T.r_bfac[s];
+        }
+        for (uint32_t i = lane; i < tl; i += WAVE) O.titles[t + i] = (char)tsrc[i];
+        if (lane == 0) {
+            O.res_off[c] = r; O.title_off[c] = t;
+            O.first_res[c] = T.resseq[A0 + fr.a]; O.first_atom[c] = T.serial[A0 + fr.a];
+            O.chain_id[c] = (char)T.chain[A0 + fr.a];
+            O.chain_file[c] = f; O.chain_meta[c] = fr.meta;
+        }
+        c++; r += fr.nres; a += na; t += tl;
+    }
+    if (f == n_files - 1 && lane == 0) { O.res_off[c] = r; O.title_off[c] = t; O.atom_off[r] = a; }   // the closing entries
+}
+
+// scratch capacity of a file's atom table: an ATOM record the parser accepts has at least 54 characters
+__global__ void k_ingest_caps(const uint64_t* __restrict__ file_off, uint32_t n_files, uint64_t* __restrict__ cap) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_files) cap[f] = (file_off[f + 1] - file_off[f]) / 54u + 1u;
+}
+
+}  // namespace fcz

@@ -207,6 +207,58 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
                              uint64_t* text_off, int32_t* status);
 int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
 
+/* ---- structure ingest: PDB text -> fcz_chain_batch on the device ------------------------------------ */
+/* What the reference's driver does to every input file before Foldcomp::compress (src/main.cpp:455-508): StructureReader
+ * (src/structure_reader.cpp:31-61; the fixed-column ATOM / HETATM record as foldcomp/foldcomp.cxx:259-278 reads it),
+ * removeAlternativePosition (src/atom_coordinate.cpp:362-370), identifyChains (:469-497), identifyDiscontinousResInd (:506-530),
+ * then per fragment the residue split, residue codes and CA B-factors of Foldcomp::preprocess (src/foldcomp.cpp:450-559).
+ * Input: the bytes of n_files PDB files back to back (file i = text[file_off[i] .. file_off[i+1])), their base names
+ * (names[name_off[i] .. name_off[i+1]); the first stem_len[i] characters are the stem that names the records and replaces an
+ * absent title, src/main.cpp:465). Output: one fcz_chain_batch in HBM holding every fragment the codec can take, file order
+ * then fragment order, ready for fcz_compress_sizes_dev / fcz_compress_batch_dev, plus per chain the file it came from and
+ * how the reference names it:
+ *   chain_meta = chain id | fragment ordinal << 8 | FCZ_INGEST_MULTI_CHAIN (the file holds several chains: the id is appended
+ *                to the name) | FCZ_INGEST_MULTI_FRAG (the chain has gaps: "_<ordinal>" is appended).
+ * file_status[i]: FCZ_OK, FCZ_INGEST_NO_ATOMS, or FCZ_INGEST_HOST_*: something outside the fixed-column layout (a number
+ * field the exact fixed-point rule does not cover, a title beyond 512 bytes, more than 32 fragments) -- nothing of that file is
+ * in the batch and the caller's own parser has to take it. refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the
+ * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order, chain beyond the
+ * header's counts, --skip-discontinuous). mmCIF and gzip stay on the host. */
+enum fcz_ingest_status { FCZ_INGEST_HOST_FIELD = 1, FCZ_INGEST_HOST_TITLE = 2, FCZ_INGEST_HOST_FRAGS = 3, FCZ_INGEST_NO_ATOMS = 4 };
+enum fcz_ingest_reason { FCZ_INGEST_REF_RESNAME = 1, FCZ_INGEST_REF_BACKBONE = 2, FCZ_INGEST_REF_TOO_LONG = 3, FCZ_INGEST_REF_SKIP_DISC = 4 };
+#define FCZ_INGEST_MULTI_CHAIN (1u << 16)
+#define FCZ_INGEST_MULTI_FRAG  (1u << 17)
+#define FCZ_INGEST_SKIP_DISCONTINUOUS 1   /* flags: --skip-discontinuous (src/main.cpp:476-480) */
+typedef struct fcz_ingest_result {        /* device pointers owned by the ctx, valid until its next ingest call */
+    fcz_chain_batch batch;
+    const uint32_t* chain_file;           /* [C] */
+    const uint32_t* chain_meta;           /* [C] */
+    const int32_t*  file_status;          /* [F] */
+    const uint32_t* refused;              /* [2 * n_refused], in no particular order */
+    uint32_t n_files, n_refused;
+} fcz_ingest_result;
+/* Device-resident: text_dev / file_off_dev / names_dev / name_off_dev / stem_len_dev are device pointers; one stream
+ * synchronisation (the totals). */
+int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* file_off_dev, uint32_t n_files, uint64_t text_bytes,
+                       const char* names_dev, const uint32_t* name_off_dev, const uint32_t* stem_len_dev, int anchor_threshold,
+                       int flags, fcz_ingest_result* out);
+/* Host-pointer convenience: copies the text in (true DMA from fcz_pinned_alloc memory) and runs the ingest; the batch stays
+ * in the ctx. counts = {chains, residues, atoms, title bytes, refused fragments}. fetch() copies the batch arrays (every
+ * pointer of host_batch must be caller-allocated for those counts; the struct's const is cast away) and the per-chain /
+ * per-file / refusal arrays (any of them may be NULL) to the host. */
+int fcz_ingest_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* file_off, uint32_t n_files, const char* names,
+                         const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5]);
+int fcz_ingest_pdb_fetch(fcz_ctx* ctx, const fcz_chain_batch* host_batch, uint32_t* chain_file, uint32_t* chain_meta,
+                         int32_t* file_status, uint32_t* refused);
+/* Text in, FCZ records out: ingest + fcz_compress_sizes_dev + fcz_compress_batch_dev on the resident batch.
+ * begin(): counts = {chains, residues, atoms, title bytes, refused fragments}, *fcz_bytes = size of the blob; fetch(): record
+ * offsets out_off[C+1], per-chain status[C] and the arrays of fcz_ingest_pdb_fetch (any may be NULL), then the blob. */
+int fcz_compress_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* file_off, uint32_t n_files, const char* names,
+                           const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5],
+                           uint64_t* fcz_bytes);
+int fcz_compress_pdb_fetch(fcz_ctx* ctx, uint64_t* out_off, int32_t* status, uint32_t* chain_file, uint32_t* chain_meta,
+                           int32_t* file_status, uint32_t* refused, uint8_t* blob);
+
 /* ---- extract ---------------------------------------------------------------------------------- */
 /* Foldcomp::extract (src/foldcomp.cpp:1260-1336) straight from the FCZ bytes, no reconstruction.
  *   mode 0: pLDDT (B-factor) of every residue with `digits` in 1..4 characters ("d", "dd", "dd.d", "dd.dd"; digit rules
@@ -229,7 +281,8 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
  * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
- * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format", "extract_sizes", "extract". */
+ * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format", "extract_sizes", "extract",
+ * "ingest_parse", "ingest_frags", "ingest_fill". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

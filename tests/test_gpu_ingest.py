@@ -1,0 +1,221 @@
+"""Structure ingest on the device (fcz_ingest_pdb_*, foldcomp_amd/csrc/fcz_ingest.h) -- SURVEY.md section 8 row f3.
+
+PDB text in, fcz_chain_batch out, every step on the GPU. Parity:
+  * the reference's own test files (tests/golden/reference_ingest.npz: test.pdb, test_af.pdb, multichain.pdb): the batch equals
+    the batch built from what the REFERENCE's reader (gemmi) + removeAlternativePosition + identifyChains +
+    identifyDiscontinousResInd hand to Foldcomp::compress (src/main.cpp:455-508), bit for bit, names and titles included;
+  * seeded synthetic files, alternative positions, HETATM, chain changes with and without an N, gaps, CRLF line ends, a last
+    line without a line end, TITLE / HEADER records: == the Python host's parser + fragmenting on the same text;
+  * what the device does not decide (fields outside the fixed-column layout) is handed back (file_status), never guessed;
+  * text -> FCZ in one call (fcz_compress_pdb_*) == host parse + fcz_compress_batch, byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+from _cases import golden_batch
+from foldcomp_amd.codec import Codec
+from foldcomp_amd.structure import AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb, remove_alternative_position
+from test_host_cpp import _pdb_text
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def codec():
+    with Codec(0) as c:
+        yield c
+
+
+@pytest.fixture(scope="module")
+def ing():
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
+
+
+def _title_of(text: str) -> str:
+    """gemmi's _entry.id for a PDB file: HEADER id code (columns 63-66), else the TITLE records before the first ATOM"""
+    parts = []
+    for line in text.splitlines():
+        if line.startswith("ATOM"):
+            break
+        if len(line) >= 66 and line.startswith("HEADER") and line[62:66].strip():
+            return line[62:66].strip()
+        if line.startswith("TITLE"):
+            parts.append(line[10:80].strip())
+    return " ".join(parts).strip()
+
+
+def _host_expect(texts, names, brk=25, skip_disc=False):
+    """what the hosts make of the files: (batch, fragment names, chain_file, refused [(file, name)])"""
+    chains, out_names, cfile, refused = [], [], [], []
+    for fi, (text, base) in enumerate(zip(texts, names)):
+        s = text.decode("latin-1")
+        stem = base.rsplit(".", 1)[0] if "." in base else base
+        t = remove_alternative_position(parse_pdb(s, hetatm=True))
+        if len(t) == 0:
+            continue
+        title = _title_of(s)
+        if title == "" or title == base:
+            title = stem
+        cs_all = identify_chains(t)
+        for cs in cs_all:
+            frags = identify_discontinuous(t, cs)
+            for j, sl in enumerate(frags):
+                nm = stem + (t.chain[cs.start] if len(cs_all) > 1 else "") + (f"_{j}" if len(frags) > 1 else "")
+                ch = Chain(title, t.take(sl))
+                try:
+                    if skip_disc and len(frags) > 1:
+                        raise StructureError("skip")
+                    build_batch([ch], brk)
+                except StructureError:
+                    refused.append((fi, nm)); continue
+                chains.append(ch); out_names.append(nm); cfile.append(fi)
+    return (build_batch(chains, brk) if chains else None), out_names, cfile, refused
+
+
+def _name_of(base, meta):
+    stem = base.rsplit(".", 1)[0] if "." in base else base
+    nm = stem
+    if meta & (1 << 16):
+        nm += chr(meta & 0xff)
+    if meta & (1 << 17):
+        nm += f"_{(meta >> 8) & 0xff}"
+    return nm
+
+
+def _same_batch(got, exp):
+    assert got.n_chains == exp.n_chains and got.n_residues == exp.n_residues and got.n_atoms == exp.n_atoms
+    for k in ("res_off", "atom_off", "atom_code", "res_code", "first_res_index", "first_atom_index", "chain_id", "title_off"):
+        assert np.array_equal(np.asarray(getattr(got, k)).astype(np.int64), np.asarray(getattr(exp, k)).astype(np.int64)), k
+    for k in ("x", "y", "z", "bfac_ca"):
+        assert np.array_equal(getattr(got, k).view(np.uint32), getattr(exp, k).view(np.uint32)), k
+    assert bytes(got.titles) == bytes(exp.titles)
+
+
+def _check(codec, texts, names, brk=25, skip_disc=False):
+    exp, exp_names, exp_file, exp_ref = _host_expect(texts, names, brk, skip_disc)
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names, brk, skip_disc)
+    assert set(int(v) for v in fstat) <= {0, 4}, fstat        # nothing here needs the host parser (4 = a file without atoms)
+    if exp is None:
+        assert b.n_chains == 0
+    else:
+        _same_batch(b, exp)
+        assert [_name_of(names[f], m) for f, m in zip(cfile, cmeta)] == exp_names
+        assert list(cfile) == exp_file
+    assert sorted((int(f), _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
+    return b, cfile, cmeta, fstat, refused
+
+
+@pytest.mark.parametrize("fn", ["test.pdb", "test_af.pdb", "multichain.pdb"])
+def test_device_ingest_equals_reference_reader(codec, ing, fn):
+    """the device's batch == the batch built from the REFERENCE reader's atom table and fragments (reference-minted goldens)"""
+    strs = lambda a: [bytes(r).rstrip(b"\0").decode() for r in a]
+    k = f"ingest:{fn}"
+    t = AtomTable(strs(ing[f"{k}/atom"]), strs(ing[f"{k}/residue"]), [chr(c) for c in ing[f"{k}/chain"]], ing[f"{k}/atom_index"],
+                  ing[f"{k}/res_index"], ing[f"{k}/xyz"], ing[f"{k}/bfac"])
+    frag = [tuple(int(v) for v in f) for f in ing[f"{k}/frag"]]
+    n_chains = int(ing[f"{k}/n_chains"][0])
+    ref_title = bytes(ing[f"{k}/title"]).decode("latin-1")
+    stem = fn.rsplit(".", 1)[0]
+    title = stem if ref_title == fn else ref_title
+    names, chains = [], []
+    for (a, b, ci, fj) in frag:
+        n_in = sum(1 for f in frag if f[2] == ci)
+        names.append(stem + (t.chain[a] if n_chains > 1 else "") + (f"_{fj}" if n_in > 1 else ""))
+        chains.append(Chain(title, t.take(slice(a, b))))
+    exp = build_batch(chains, 25)
+    got, cfile, cmeta, fstat, refused = codec.ingest_pdb([ing[f"file:{fn}"].tobytes()], [fn])
+    assert fstat[0] == 0 and len(refused) == 0
+    _same_batch(got, exp)
+    assert [_name_of(fn, int(m)) for m in cmeta] == names
+
+
+def test_device_ingest_many_files_and_the_awkward_ones(codec, golden):
+    z, _ = golden
+    base = {n: _pdb_text(z, n) for n in ("pdb:test_af", "pdb:test", "syn:len350", "syn:len26", "syn:len129", "pdb:multichainA")}
+    b0, b1 = _pdb_text(z, "pdb:multichainB_0"), _pdb_text(z, "pdb:multichainB_1")
+    a = base["pdb:multichainA"]
+    texts, names = [], []
+
+    def add(name, text):
+        names.append(name); texts.append(text.encode("latin-1") if isinstance(text, str) else text)
+    for i, (n, t) in enumerate(base.items()):
+        add(f"f{i}_{n.split(':')[1]}.pdb", t)
+    # alternative positions (every 7th ATOM line doubled, once tripled), HETATM records, a REMARK, three fragments, -b 25
+    la, dup = a.splitlines(), []
+    for i, l in enumerate(la):
+        dup.append(l)
+        if l.startswith("ATOM") and i % 7 == 3:
+            dup.append(l[:30] + "   9.999   9.999   9.999" + l[54:])
+            if i % 21 == 3:
+                dup.append(l[:30] + "  -0.001  -0.000 -99.999" + l[54:])
+    het = "HETATM 9001  O   HOH A 900      11.000  12.000  13.000  1.00 30.00           O  \n"
+    add("multi.pdb", "REMARK test\n" + "\n".join(dup) + "\n" + het + b0 + b1 + "END\n")
+    # CRLF line ends; a last line without a line end; empty lines; a TITLE over two records; a HEADER id that wins over TITLE
+    t_af = base["pdb:test_af"]
+    add("crlf.pdb", t_af.replace("\n", "\r\n"))
+    add("noeol.pdb", t_af.rstrip("\n").rsplit("\nTER", 1)[0])
+    add("blank.pdb", "\n\n" + t_af.replace("\nATOM", "\n\nATOM", 5) + "\n\n\n")
+    add("titled.pdb", "TITLE     A PROTEIN OF SOME KIND                                       \nTITLE    2 CONTINUED HERE\n" + t_af)
+    add("header.pdb", "HEADER    HYDROLASE                               01-JAN-00   1ABC              \nTITLE     IGNORED\n" + t_af)
+    add("title_is_name.pdb", "TITLE     title_is_name.pdb\n" + t_af)
+    # chain id changes at a non-N atom: the atoms up to the next N belong to nobody; and a chain change with no N after it
+    lines = [l for l in base["syn:len26"].splitlines() if l.startswith("ATOM")]
+    k = next(i for i, l in enumerate(lines) if i > 40 and l[12:16].strip() == "CA")
+    mixed = lines[:k] + [l[:21] + "B" + l[22:] for l in lines[k:]]
+    add("chain_at_ca.pdb", "\n".join(mixed) + "\n")
+    tail = lines[:-3] + [l[:21] + "C" + l[22:] for l in lines[-3:] if l[12:16].strip() != "N"]
+    add("chain_no_n.pdb", "\n".join(tail) + "\n")
+    # gaps in the residue numbering; a residue the codec does not know; a residue without its CA; a file without atoms
+    lg = [l for l in base["syn:len129"].splitlines() if l.startswith("ATOM")]
+    gap = [l[:22] + "%4d" % (int(l[22:26]) + (5 if int(l[22:26]) > 40 else 0) + (7 if int(l[22:26]) > 90 else 0)) + l[26:] for l in lg]
+    add("gaps.pdb", "\n".join(gap) + "\n")
+    add("mse.pdb", t_af.replace(" ALA ", " MSE ", 4))
+    add("no_ca.pdb", "\n".join(l for i, l in enumerate(t_af.splitlines()) if not (l.startswith("ATOM") and l[12:16].strip() == "CA" and int(l[22:26]) == 7)) + "\n")
+    add("empty.pdb", "HEADER    nothing to see\nEND\n")
+    add("zero.pdb", "")
+    _check(codec, texts, names)
+    _check(codec, texts, names, brk=10)
+    _check(codec, texts, names, skip_disc=True)
+    # the same files one by one (a batch of one file has its own offsets)
+    for t, n in list(zip(texts, names))[6:12]:
+        _check(codec, [t], [n])
+
+
+def test_device_ingest_hands_back_what_it_does_not_decide(codec, golden):
+    z, _ = golden
+    t_af = _pdb_text(z, "pdb:test_af")
+    lines = t_af.splitlines()
+    i = next(k for k, l in enumerate(lines) if l.startswith("ATOM"))
+    sci = lines[:i] + [lines[i][:30] + " 1.0e+01" + lines[i][38:]] + lines[i + 1:]              # a number outside the fixed layout
+    short = lines[:i] + [lines[i][:50]] + lines[i + 1:]                                          # an ATOM record cut short
+    hyb = lines[:i] + [lines[i][:6] + "A0000" + lines[i][11:]] + lines[i + 1:]                    # hybrid-36 serial
+    long_title = "".join("TITLE   %2d %s\n" % (k + 1, "X" * 60) for k in range(12)) + t_af       # 12 x 60 characters of title
+    texts = [("\n".join(v) + "\n").encode() for v in (sci, short, hyb)] + [long_title.encode(), t_af.encode()]
+    names = ["sci.pdb", "short.pdb", "hyb.pdb", "long_title.pdb", "good.pdb"]
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    assert list(fstat) == [1, 1, 1, 2, 0]
+    assert b.n_chains == 1 and list(cfile) == [4]
+    exp, *_ = _host_expect([texts[4]], [names[4]])
+    _same_batch(b, exp)
+
+
+def test_text_to_fcz_in_one_call(codec, golden):
+    """fcz_compress_pdb_*: the records equal those of host parse + fcz_compress_batch on the same files; and of the goldens"""
+    z, _ = golden
+    cases = ["pdb:test_af", "pdb:test", "syn:len350", "syn:len26", "syn:len129"]
+    texts = [_pdb_text(z, n).encode() for n in cases] * 40
+    names = [f"f{i:03d}.pdb" for i in range(len(texts))]
+    r = codec.compress_pdb(texts, names)
+    assert (r["status"] == 0).all() and (r["file_status"] == 0).all() and len(r["refused"]) == 0
+    exp, exp_names, _, _ = _host_expect(texts, names)
+    blob, off, st = codec.compress_batch(exp)
+    assert np.array_equal(off, r["off"]) and blob.tobytes() == r["blob"].tobytes()
+
+    def no_title(f):
+        na, tl = f[12], int.from_bytes(f[24:28], "little")
+        return f[:24] + f[28:76 + 4 * na] + f[76 + 4 * na + tl:]
+    for i, n in enumerate(cases):
+        rec = r["blob"][int(r["off"][i]):int(r["off"][i + 1])].tobytes()
+        assert no_title(rec) == no_title(z[f"{n}/fcz"].tobytes()), n

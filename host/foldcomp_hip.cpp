@@ -764,6 +764,7 @@ struct Options {
     int brk = 25, digits = 1, ext_mode = 0;
     bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
     bool single = false;        // one structure / FCZ file in, one file out
+    bool host_parse = false;    // --host-parse: compress parses on the host threads even where the device could (A/B, debugging)
     bool check = false;         // --check: decompress skips entries that fail Foldcomp::checkValidity (src/main.cpp:629-636)
     bool merge = true;          // --no-merge: extract writes one file per entry instead of one merged file (src/main.cpp:171-195)
     bool file_input = false;    // -f / --file: <input> is a text file that lists the inputs, one per line (src/main.cpp:304-325)
@@ -784,13 +785,18 @@ struct Fragment {
 // one structure file -> its fragments (src/main.cpp:455-508)
 // (out_stem, ext) = getFileParts of the input's base name, or of the OUTPUT path for a single-file run (src/main.cpp:444-457):
 // they name the fragments and decide the suffix (isCompressible, :498-502)
+void fragments_from_memory(const char* data, size_t size, const std::string& base, const std::string& out_stem, const std::string& ext,
+                           bool to_dir_or_file, const Options& o, std::vector<Fragment>& out);
 void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
                   std::vector<Fragment>& out) {
-    const std::string base = base_name(path);
     static thread_local FileImage image;
     read_file_into(path, image);
+    fragments_from_memory(image.data(), image.n, base_name(path), out_stem, ext, to_dir_or_file, o, out);
+}
+// the same from a file image that is already in memory
+void fragments_from_memory(const char* data, size_t size, const std::string& base, const std::string& out_stem, const std::string& ext,
+                           bool to_dir_or_file, const Options& o, std::vector<Fragment>& out) {
     std::string plain = base, unz;
-    const char* data = image.data(); size_t size = image.n;
     if (ends_with(base, ".gz")) { unz = gunzip(std::string(data, size)); data = unz.data(); size = unz.size(); plain = base.substr(0, base.size() - 3); }
     std::string title;
     AtomTable t;
@@ -894,6 +900,7 @@ void pwrite_all(int fd, const uint8_t* p, uint64_t n, uint64_t off) {
     }
 }
 
+int run_compress_device(const Options& o, const std::vector<std::string>& files, const std::string& output);
 int run_compress(const Options& o) {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
@@ -905,6 +912,8 @@ int run_compress(const Options& o) {
     if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
     const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
     if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
+    // directories and databases of files: the structure ingest runs on the device (the host threads only read)
+    if (!single && !o.host_parse) return run_compress_device(o, files, output);
     const int n_workers = gpus * std::max(1, o.workers_per_gpu);
     pinned_enabled() = true;
     int db_fd = -1;
@@ -1058,6 +1067,265 @@ int run_compress(const Options& o) {
                (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), wall, t_parse, busy,
                *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_parsed, t_joined,
                wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0);
+    }
+    return hard_fail ? 1 : 0;
+}
+
+
+// ---- compress with the structure ingest on the device ---------------------------------------------------------------------
+// The host-parse pipeline above spends its wall time in the parse threads (240 KB of text per 20 us of GPU work). Here the
+// host threads only READ: the files of a job land back to back in a page-locked buffer, one DMA takes them to the GPU, and
+// fcz_compress_pdb_begin / _fetch (parse -> fragments -> batch -> FCZ, all in HBM) return the records. What the device hands
+// back (file_status FCZ_INGEST_HOST_*: a field outside the fixed-column layout) and what it does not read (mmCIF, gzip) goes
+// through the host parser of this file and fcz_compress_batch; the records of a job are merged in file order either way.
+struct TextJob {
+    size_t index = 0;
+    std::vector<std::string> paths;            // the job's files, in input order
+    std::vector<int> slot;                     // position among the text files of the job, -1: a host-parsed file
+    pvec<uint8_t>* text = nullptr;             // page-locked: the text files back to back
+    std::vector<uint64_t> file_off{0};
+    std::string names; std::vector<uint32_t> name_off{0}, stem_len;
+    std::vector<std::vector<Fragment>> host_frags;   // per file of the job: fragments of the host-parsed ones
+};
+
+struct TextPool {                              // the page-locked text buffers go round (pinning memory is expensive)
+    std::mutex m; std::condition_variable cv; std::vector<pvec<uint8_t>*> free_;
+    pvec<uint8_t>* get() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free_.empty(); }); pvec<uint8_t>* b = free_.back(); free_.pop_back(); return b; }
+    void put(pvec<uint8_t>* b) { { std::lock_guard<std::mutex> l(m); free_.push_back(b); } cv.notify_one(); }
+};
+
+bool is_plain_pdb(const std::string& path) { return ends_with(path, ".pdb") || ends_with(path, ".ent"); }
+
+int run_compress_device(const Options& o, const std::vector<std::string>& files, const std::string& output) {
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
+    const int n_dev = fcz_device_count();
+    const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
+    const int n_workers = gpus * std::max(1, o.workers_per_gpu);
+    pinned_enabled() = true;
+    int db_fd = -1;
+    if (o.db) {
+        db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+        if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
+    } else make_dir(output);
+
+    struct Row { size_t job, pos; uint64_t off, len; std::string name; };
+    std::vector<std::vector<Row>> rows(n_workers);
+    JobQueue<TextJob> queue((size_t)n_workers + 1);
+    Sequencer seq;
+    std::atomic<bool> hard_fail{false};
+    std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0}, n_host_files{0};
+    std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);
+    std::vector<std::unique_ptr<pvec<uint8_t>>> text_bufs;
+    TextPool pool;
+    for (int i = 0; i < n_workers + 2; i++) { text_bufs.emplace_back(new pvec<uint8_t>()); pool.put(text_bufs.back().get()); }
+
+    std::vector<std::thread> workers;
+    for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
+        fcz_ctx* ctx = nullptr;
+        if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
+        pvec<uint8_t> blob, blob_host, packed;
+        Batch hb;
+        TextJob job;
+        while (queue.get(job)) {
+            struct Rec { size_t file; uint32_t sub; const uint8_t* p; uint64_t len; std::string out_name, db_name; uint32_t nres, natoms; };
+            std::vector<Rec> recs;
+            bool failed = !ctx;
+            const uint32_t n_text = (uint32_t)job.file_off.size() - 1;
+            std::vector<uint64_t> off; std::vector<int32_t> status, file_status; std::vector<uint32_t> chain_file, chain_meta, refused, counts(5, 0);
+            std::vector<size_t> text_file(n_text);                      // text slot -> file of the job
+            for (size_t i = 0; i < job.paths.size(); i++) if (job.slot[i] >= 0) text_file[(size_t)job.slot[i]] = i;
+            auto stem_of = [&](size_t i) { std::string stem, ext; file_parts(base_name(job.paths[i]), stem, ext); return stem; };
+            if (!failed && n_text) {
+                uint64_t fcz_bytes = 0;
+                const auto t0 = clk::now();
+                int rc = fcz_compress_pdb_begin(ctx, job.text->data(), job.file_off.data(), n_text, job.names.data(), job.name_off.data(), job.stem_len.data(),
+                                                o.brk, o.skip_discontinuous ? FCZ_INGEST_SKIP_DISCONTINUOUS : 0, counts.data(), &fcz_bytes);
+                if (rc == FCZ_OK) {
+                    const uint32_t C = counts[0];
+                    off.assign((size_t)C + 1, 0); status.assign(C, 0); chain_file.assign(C, 0); chain_meta.assign(C, 0);
+                    file_status.assign(n_text, 0); refused.assign(2 * (size_t)counts[4], 0);
+                    blob.resize(fcz_bytes);
+                    rc = fcz_compress_pdb_fetch(ctx, off.data(), status.data(), chain_file.data(), chain_meta.data(), file_status.data(), refused.data(), blob.data());
+                }
+                gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
+                if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s: job of %u files not compressed\n", fcz_status_string(rc), n_text); failed = true; }
+            }
+            if (!failed && n_text) {
+                auto frag_name = [&](size_t file, uint32_t meta) {
+                    std::string nm = stem_of(file);
+                    if (meta & FCZ_INGEST_MULTI_CHAIN) nm.push_back((char)(meta & 0xffu));
+                    if (meta & FCZ_INGEST_MULTI_FRAG) nm += "_" + std::to_string((meta >> 8) & 0xffu);
+                    return nm;
+                };
+                for (uint32_t c = 0; c < counts[0]; c++) {
+                    const size_t file = text_file[chain_file[c]];
+                    const std::string nm = frag_name(file, chain_meta[c]);
+                    if (status[c] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s.fcz\n", nm.c_str()); continue; }
+                    recs.push_back({file, (chain_meta[c] >> 8) & 0xffu, blob.data() + off[c], off[c + 1] - off[c], nm + ".fcz", stem_of(file), 0, 0});
+                    // (sub: the order of a file's records is the order the device emitted them; see the stable sort below)
+                    recs.back().sub = c;
+                }
+                for (size_t k = 0; k + 1 < refused.size(); k += 2) {
+                    static const char* why[] = {"", "residue name is not supported by the codec", "residue without N, CA, C backbone atoms in order",
+                                                "chain does not fit the FCZ header (65535 residues, 255 anchors)", "discontinuous chain skipped"};
+                    const uint32_t reason = refused[k + 1] >> 24;
+                    fprintf(stderr, "[Error] compressing %s.fcz: %s\n", frag_name(text_file[refused[k]], refused[k + 1]).c_str(), why[reason < 5 ? reason : 0]);
+                }
+                // what the device handed back: parsed here from the text that is already in memory
+                for (uint32_t t = 0; t < n_text; t++) {
+                    if (file_status[t] == FCZ_INGEST_NO_ATOMS) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base_name(job.paths[text_file[t]]).c_str()); continue; }
+                    if (file_status[t] == FCZ_OK) continue;
+                    n_host_files++;
+                    const size_t file = text_file[t];
+                    std::string stem, ext; file_parts(base_name(job.paths[file]), stem, ext);
+                    try { fragments_from_memory((const char*)job.text->data() + job.file_off[t], job.file_off[t + 1] - job.file_off[t], base_name(job.paths[file]), stem, ext, !o.db, o, job.host_frags[file]); }
+                    catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(job.paths[file]).c_str(), e.what()); }
+                }
+            }
+            // host-parsed fragments (mmCIF, gzip, and what the device handed back): one fcz_compress_batch for the job
+            std::vector<uint64_t> hoff; std::vector<int32_t> hstatus;
+            if (!failed) {
+                hb.clear();
+                std::vector<std::pair<size_t, size_t>> kept;          // (file, fragment)
+                for (size_t i = 0; i < job.host_frags.size(); i++) for (size_t j = 0; j < job.host_frags[i].size(); j++) {
+                    Fragment& f = job.host_frags[i][j];
+                    try { hb.add(f.atoms, f.title, o.brk); kept.push_back({i, j}); }
+                    catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), e.what()); }
+                }
+                if (!kept.empty()) {
+                    fcz_chain_batch v = hb.view(o.brk);
+                    hoff.assign(v.n_chains + 1, 0);
+                    fcz_compress_sizes(&v, hoff.data());
+                    blob_host.resize(hoff.back());
+                    const int32_t UNSET = INT32_MIN;
+                    hstatus.assign(v.n_chains, UNSET);
+                    const auto t0 = clk::now();
+                    const int rc = fcz_compress_batch(ctx, &v, hoff.data(), blob_host.data(), hstatus.data());
+                    gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
+                    bool call_failed = rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG;
+                    for (uint32_t q = 0; q < v.n_chains && !call_failed; q++) if (hstatus[q] == UNSET) call_failed = true;
+                    if (call_failed) { fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size()); failed = true; }
+                    for (size_t q = 0; q < kept.size() && !failed; q++) {
+                        const Fragment& f = job.host_frags[kept[q].first][kept[q].second];
+                        if (hstatus[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
+                        recs.push_back({kept[q].first, (uint32_t)kept[q].second, blob_host.data() + hoff[q], hoff[q + 1] - hoff[q], f.out_name, f.db_name, 0, 0});
+                    }
+                }
+            }
+            if (failed) { hard_fail = true; if (o.db) seq.claim(job.index, 0); pool.put(job.text); continue; }
+            try {
+                // records of the job in file order (a file's own records keep the order they were emitted in)
+                std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.file != b.file ? a.file < b.file : a.sub < b.sub; });
+                uint64_t total = 0; for (const Rec& r : recs) total += r.len;
+                if (o.db) {
+                    packed.resize(total);
+                    uint64_t pos = 0;
+                    for (const Rec& r : recs) { memcpy(packed.data() + pos, r.p, r.len); pos += r.len; }
+                    const uint64_t at = seq.claim(job.index, total);
+                    if (total) pwrite_all(db_fd, packed.data(), total, at);
+                    pos = 0;
+                    for (size_t q = 0; q < recs.size(); q++) { rows[w].push_back({job.index, q, at + pos, recs[q].len, recs[q].db_name}); pos += recs[q].len; }
+                } else {
+                    for (const Rec& r : recs) write_out(output + "/" + r.out_name, (const char*)r.p, r.len, o.overwrite);
+                }
+                for (const Rec& r : recs) {
+                    n_frag_ok++; n_bytes += r.len;
+                    n_res += (uint32_t)r.p[4] | ((uint32_t)r.p[5] << 8); n_atoms += (uint32_t)r.p[6] | ((uint32_t)r.p[7] << 8);   // header.nResidue, nAtom
+                }
+            } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
+            pool.put(job.text);
+        }
+        if (ctx) fcz_ctx_destroy(ctx);
+    });
+
+    // ---- producer: size, then read, the files of a job side by side on the host threads ----
+    double t_read = 0.0; uint64_t in_bytes = 0;
+    {
+        const size_t JOB = std::max<size_t>(64, std::min<size_t>(2048, files.size() / (4 * (size_t)n_workers) + 1));
+        size_t job_index = 0;
+        for (size_t f0 = 0; f0 < files.size(); f0 += JOB) {
+            const auto t0 = clk::now();
+            const size_t f1 = std::min(files.size(), f0 + JOB), nf = f1 - f0;
+            TextJob j; j.index = job_index++;
+            j.paths.assign(files.begin() + f0, files.begin() + f1);
+            j.slot.assign(nf, -1); j.host_frags.resize(nf);
+            std::vector<uint64_t> size(nf, 0);
+#pragma omp parallel for schedule(dynamic, 16)
+            for (long long i = 0; i < (long long)nf; i++) {
+                if (!is_plain_pdb(j.paths[i])) continue;
+                struct stat st;
+                if (stat(j.paths[i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) size[i] = (uint64_t)st.st_size; else size[i] = UINT64_MAX;
+            }
+            uint32_t n_text = 0;
+            for (size_t i = 0; i < nf; i++) {
+                if (!is_plain_pdb(j.paths[i])) continue;
+                if (size[i] == UINT64_MAX) { fprintf(stderr, "[Error] cannot open %s\n", j.paths[i].c_str()); continue; }
+                j.slot[i] = (int)n_text++;
+                j.file_off.push_back(j.file_off.back() + size[i]);
+                const std::string base = base_name(j.paths[i]);
+                std::string stem, ext; file_parts(base, stem, ext);
+                j.names += base; j.name_off.push_back((uint32_t)j.names.size()); j.stem_len.push_back((uint32_t)stem.size());
+            }
+            j.text = pool.get();
+            if (j.text->size() < j.file_off.back() + 64) j.text->resize(j.file_off.back() + j.file_off.back() / 8 + 64);   // grows, never shrinks: a resize touches (zero-fills) what it adds
+            std::vector<std::string> err(nf);
+#pragma omp parallel for schedule(dynamic, 8)
+            for (long long i = 0; i < (long long)nf; i++) {
+                if (j.slot[i] >= 0) {
+                    // straight into the page-locked buffer; a file that shrank since stat() leaves spaces (an empty line), one that
+                    // grew is cut at its stat size
+                    const uint64_t at = j.file_off[(size_t)j.slot[i]], want = j.file_off[(size_t)j.slot[i] + 1] - at;
+                    uint64_t got = 0;
+                    const int fd = open(j.paths[i].c_str(), O_RDONLY);
+                    if (fd >= 0) {
+                        while (got < want) { const ssize_t k = read(fd, j.text->data() + at + got, want - got); if (k <= 0) break; got += (uint64_t)k; }
+                        close(fd);
+                    }
+                    if (got < want) memset(j.text->data() + at + got, ' ', want - got);
+                    g_bytes_read += got;
+                } else if (!is_plain_pdb(j.paths[i])) {
+                    std::string stem, ext; file_parts(base_name(j.paths[i]), stem, ext);
+                    try { fragments_of(j.paths[i], stem, ext, !o.db, o, j.host_frags[i]); }
+                    catch (const std::exception& e) { err[i] = "[Error] " + base_name(j.paths[i]) + ": " + e.what() + "\n"; }
+                }
+            }
+            for (const std::string& e : err) if (!e.empty()) fputs(e.c_str(), stderr);
+            t_read += std::chrono::duration<double>(clk::now() - t0).count();
+            in_bytes = g_bytes_read.load();
+            queue.put(std::move(j));
+        }
+        queue.close();
+    }
+    const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
+    for (std::thread& t : workers) t.join();
+    const double t_joined = std::chrono::duration<double>(clk::now() - t_start).count();
+    if (o.db && hard_fail) {
+        close(db_fd); unlink(output.c_str());
+        fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
+    } else if (o.db) {
+        close(db_fd);
+        std::vector<Row> all;
+        for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
+        std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.job != b.job ? a.job < b.job : a.pos < b.pos; });
+        std::ofstream fi(output + ".index"), fl(output + ".lookup");
+        long long key = 0;
+        for (const Row& r : all) { fi << key << "\t" << r.off << "\t" << r.len << "\n"; fl << key << "\t" << r.name << "\t0\n"; key++; }
+        std::ofstream t(output + ".dbtype", std::ios::binary);
+        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+    }
+    if (o.json_stats) {
+        const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
+        double busy = 0.0; for (double g : gpu_busy) busy += g;
+        const double ready = *std::max_element(ctx_ready.begin(), ctx_ready.end());
+        printf("{\"mode\": \"compress\", \"ingest\": \"device\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
+               "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"host_parsed_files\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
+               "\"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_parsed_s\": %.4f, \"workers_done_s\": %.4f, \"residues_per_s\": %.1f, "
+               "\"input_MB_per_s\": %.1f, \"pinned_blocks\": %llu}\n",
+               gpus, n_workers, omp_get_max_threads(), files.size(), (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
+               (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), (unsigned long long)n_host_files.load(), wall, t_read, busy,
+               ready, t_queued, t_joined, wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load());
     }
     return hard_fail ? 1 : 0;
 }
@@ -1449,6 +1717,7 @@ int main(int argc, char** argv) {
         else if (a == "--skip-discontinuous") o.skip_discontinuous = true;
         else if (a == "-d" || a == "--db") o.db = true;
         else if (a == "--check") o.check = true;
+        else if (a == "--host-parse") o.host_parse = true;
         else if (a == "--no-merge") o.merge = false;
         else if (a == "-f" || a == "--file") o.file_input = true;
         else if (a == "-l" || a == "--id-list") { if (i + 1 < argc) o.id_list = argv[++i]; }

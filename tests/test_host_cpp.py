@@ -441,3 +441,53 @@ def test_cpp_cli_flags_equal_the_python_cli(tmp_path, golden):
     assert r.returncode == 0, r.stderr
     outd = str(tmp_path / "inputs.txt") + "_pdb"
     assert len(os.listdir(outd)) == len(names) + 1 and "one.pdb" in os.listdir(outd)
+
+
+@pytest.mark.gpu
+def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
+    """`compress -d` with the structure ingest on the device (the default for directories) and with --host-parse: the same
+    database, byte for byte -- also for what the device hands back to the host parser (a number outside the fixed layout), what
+    it never reads (mmCIF, gzip), multi-chain files with gaps, alternative positions, and files the codec refuses"""
+    import gzip, json
+    from foldcomp_amd.database import DatabaseReader
+    z, _ = golden
+    d = tmp_path / "in"
+    d.mkdir()
+    srcs = ["pdb:test_af", "syn:len26", "syn:len129", "pdb:test", "syn:len350", "pdb:multichainA"]
+    texts = {n: _pdb_text(z, n) for n in srcs}
+    for i in range(300):
+        (d / f"f{i:04d}.pdb").write_text(texts[srcs[(i * 5) % len(srcs)]])
+    t_af = texts["pdb:test_af"]
+    lines = t_af.splitlines()
+    k = next(i for i, l in enumerate(lines) if l.startswith("ATOM"))
+    (d / "f0007_sci.pdb").write_text("\n".join(lines[:k] + [lines[k][:30] + " 1.0e+01" + lines[k][38:]] + lines[k + 1:]) + "\n")
+    (d / "f0011.cif").write_text(_cif_text(z, "pdb:test_af"))
+    (d / "f0013.pdb.gz").write_bytes(gzip.compress(texts["pdb:test"].encode()))
+    (d / "f0017_multi.pdb").write_text(texts["pdb:multichainA"] + _pdb_text(z, "pdb:multichainB_0") + _pdb_text(z, "pdb:multichainB_1"))
+    (d / "f0019_mse.pdb").write_text(t_af.replace(" ALA ", " MSE ", 2))
+    (d / "f0023_empty.pdb").write_text("HEADER    nothing\n")
+    (d / "f0029_alt.pdb").write_text("\n".join(l for ln in lines for l in ([ln, ln[:30] + "   1.000   2.000   3.000" + ln[54:]] if ln.startswith("ATOM") and ln[12:16].strip() == "CB" else [ln])) + "\n")
+    outs = {}
+    for tag, extra in (("dev", []), ("host", ["--host-parse"])):
+        r = _run("compress", "-d", "-y", "-t", "8", "--gpus", "1", "--json-stats", *extra, str(d), str(tmp_path / f"db_{tag}"))
+        assert r.returncode == 0, r.stderr
+        st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        outs[tag] = (st, r.stderr)
+    assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 1      # the scientific-notation file
+    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1
+    for ext in ("", ".index", ".lookup", ".dbtype"):
+        assert (tmp_path / f"db_dev{ext}").read_bytes() == (tmp_path / f"db_host{ext}").read_bytes(), ext
+    for tag in ("dev", "host"):
+        assert "f0019_mse" in outs[tag][1] and "No atoms found" in outs[tag][1]
+    rd = DatabaseReader(str(tmp_path / "db_dev"))
+    names = [rd.name(i) for i in range(len(rd))]
+    assert names == sorted(names) and names.count("f0017_multi") == 3 and "f0011" in names and "f0013.pdb" in names
+    rd.close()
+    # directory output: the same files either way
+    for tag, extra in (("dev", []), ("host", ["--host-parse"])):
+        r = _run("compress", "-y", "-t", "8", *extra, str(d), str(tmp_path / f"dir_{tag}"))
+        assert r.returncode == 0, r.stderr
+    a, b = sorted(os.listdir(tmp_path / "dir_dev")), sorted(os.listdir(tmp_path / "dir_host"))
+    assert a == b and "f0017_multiB_1.fcz" in a
+    for f in a:
+        assert (tmp_path / "dir_dev" / f).read_bytes() == (tmp_path / "dir_host" / f).read_bytes(), f

@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--mixed-steps", type=int, default=3)
     ap.add_argument("--e2e-files", type=int, default=8192,
                     help="PDB files of the end_to_end leg (disk -> FCZ database through host/foldcomp-hip, N=1 only; 0 = skip)")
+    ap.add_argument("--e2e-passes", type=int, default=24,
+                    help="times every end_to_end run of the GPU host walks the files (steady state: 24 x 8192 = 196 608 file reads per run; "
+                         "the reference's loops, which have no start-up, walk them min(passes, 4) times)")
     ap.add_argument("--host-chains", type=int, default=65536,
                     help="chains pushed through the host-pointer entry points for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--numerics", choices=("exact", "fast"), default="exact",
@@ -344,15 +347,22 @@ def timed(fn, steps, world, dist, dev):
 
 
 def end_to_end_leg(args, codec, w, dev):
-    """PDB files on local disk -> FCZ database through the C++ host (host/foldcomp-hip compress -d: parse threads -> batch queue ->
-    page-locked staging -> GPU -> pwrite at prefix offsets -> index), next to the reference's own driver loop on the same files
-    (oracle/_ref: StructureReader + Foldcomp::compress under `omp parallel for`, the CPU baseline of this leg). The input files
-    are the first --e2e-files chains of the headline workload, rendered to PDB text by the device formatter. Wall times include
-    reading the files; the GPU is one of several stages here and not the bound."""
+    """Disk to disk through the C++ host, both directions, next to the reference's own driver loops on the same inputs
+    (oracle/_ref, `omp parallel for`, best thread count):
+      compress    PDB files -> FCZ database (`host/foldcomp-hip compress -d`): the structure ingest runs on the device (the host
+                  threads read the files into page-locked buffers, one DMA per job, parse -> fragments -> batch -> FCZ in HBM);
+                  `--host-parse` (round 2's pipeline: parse threads -> SoA batch -> GPU) is timed beside it;
+      decompress  FCZ database -> PDB-text database (`host/foldcomp-hip decompress -d`, BASELINE configs[2] as the reference runs
+                  it: Foldcomp::read + decompress + writeAtomCoordinatesToPDB per entry, src/main.cpp:612-689).
+    The input files are the first --e2e-files chains of the headline workload rendered to PDB text by the device formatter; every
+    run walks them --e2e-passes times (a `-f` list that names the directory that often), so that the wall time is many times the
+    HIP start-up; that start-up (`ctx_ready_s`) is reported and the steady rate excludes it. The GPU is one stage of several
+    here: `gpu_call_share` = time inside the codec calls / (workers x steady wall)."""
     import shutil
     import subprocess
     import tempfile
     n = min(w.C, args.e2e_files)
+    passes = max(1, args.e2e_passes)
     host = os.path.join(ROOT, "host", "foldcomp-hip")
     if not os.path.exists(host):
         return {"skipped": "host/foldcomp-hip not built"}
@@ -379,36 +389,63 @@ def end_to_end_leg(args, codec, w, dev):
             with open(pth, "wb") as fh:
                 fh.write(text[toff[i]:toff[i + 1]].tobytes())
             paths.append(pth)
+        lst = os.path.join(tmp, "inputs.txt")
+        with open(lst, "w") as fh:
+            fh.write((src + "\n") * passes)
         n_res = int(w.res_off_dev[n])
-        out = {"files": n, "input_bytes": int(toff[n]), "residues": n_res, "host_cores": effective_cores(), "hardware_threads": os.cpu_count()}
-        # Both sides are run at several host thread counts and their best is reported: the parse / reference loops of this image
-        # stop scaling well below the visible core count (page-fault and allocator contention), and the right count differs per box
-        cores = os.cpu_count() or 1
-        eff = effective_cores()
-        # thread counts around what the process may use (the CFS quota), plus every hardware thread for the record
-        tcounts = sorted({t for t in (max(1, eff // 2), eff, 2 * eff, 4 * eff, cores) if 1 <= t <= cores})
-        runs = []
-        for t in tcounts:
-            db = os.path.join(tmp, f"db{t}")
+        eff = effective_cores(); cores = os.cpu_count() or 1
+        out = {"files": n, "passes": passes, "input_bytes": int(toff[n]) * passes, "residues": n_res * passes, "host_cores": eff, "hardware_threads": cores}
+        tcounts = sorted({t for t in (max(1, eff // 2), eff, 2 * eff) if 1 <= t <= cores})
+
+        def run_host(cmd, timeout=900):
             t0 = time.perf_counter()
-            r = subprocess.run([host, "compress", "-d", "-y", "-t", str(t), "--gpus", "1", "--json-stats", src, db], capture_output=True, text=True, timeout=600)
+            r = subprocess.run([host, *cmd], capture_output=True, text=True, timeout=timeout)
             wall = time.perf_counter() - t0
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
-                return {"failed": (r.stderr or r.stdout)[-400:]}
+                raise RuntimeError((r.stderr or r.stdout)[-400:])
             st = json.loads(line[-1]); st["process_wall_s"] = round(wall, 4)
-            runs.append(st)
-        best = min(runs, key=lambda x: x["wall_s"])
-        out["gpu_host"] = {"command": "host/foldcomp-hip compress -d -t <threads> --gpus 1 <dir> <db>", "wall_s": best["wall_s"], "process_wall_s": best["process_wall_s"],
-                           "parse_s": best["parse_s"], "codec_call_s_sum": best["codec_call_s_sum"], "workers": best["workers"],
-                           "host_threads": best["host_threads"], "records": best["records"], "residues_per_s": round(best["residues"] / best["wall_s"]),
-                           "input_MB_per_s": round(best["input_bytes"] / best["wall_s"] / 1e6, 1),
-                           # the run's timeline (seconds after its start): the workers' device contexts exist, the last file is
-                           # parsed and queued, the last worker is done. The HIP runtime's start-up is inside this wall time.
-                           "timeline_s": {k: best.get(k) for k in ("ctx_ready_s", "all_parsed_s", "workers_done_s")},
-                           "wall_s_by_threads": {str(r_["host_threads"]): r_["wall_s"] for r_ in runs}}
-        # records of the database == records of the device-resident path (same chains, same titles? titles differ: file stem), so
-        # compare against the reference on the same file instead
+            return st
+
+        def summarise(runs, bytes_key, what):
+            best = min(runs, key=lambda x: x["wall_s"])
+            steady = max(best["wall_s"] - best["ctx_ready_s"], 1e-9)
+            return {"command": what, "wall_s": best["wall_s"], "process_wall_s": best["process_wall_s"], "ctx_ready_s": best["ctx_ready_s"],
+                    "steady_wall_s": round(steady, 4), "workers": best["workers"], "host_threads": best.get("host_threads"),
+                    "records": best["records"], "residues_per_s": round(best["residues"] / best["wall_s"]),
+                    "steady_residues_per_s": round(best["residues"] / steady),
+                    "steady_text_GB_per_s": round(best[bytes_key] / steady / 1e9, 2),
+                    "codec_call_s_sum": best["codec_call_s_sum"], "gpu_call_share": round(best["codec_call_s_sum"] / (best["workers"] * steady), 3),
+                    "read_or_parse_s": best.get("parse_s"), "host_parsed_files": best.get("host_parsed_files"),
+                    "page_locked_blocks": best.get("pinned_blocks"),
+                    "wall_s_by_threads": {str(r_.get("host_threads")): r_["wall_s"] for r_ in runs}}
+
+        # ---- compress: device ingest, and round 2's host-parse pipeline beside it ----
+        comp = {}
+        runs = [run_host(["compress", "-d", "-y", "-t", str(t), "--gpus", "1", "--json-stats", "-f", lst, os.path.join(tmp, f"db{t}")]) for t in tcounts]
+        comp["gpu_host"] = summarise(runs, "input_bytes", "host/foldcomp-hip compress -d -t <threads> --gpus 1 -f <list> <db>   (structure ingest on the device)")
+        comp["gpu_host"]["link_GB_per_s"] = comp["gpu_host"]["steady_text_GB_per_s"]     # every text byte crosses the link once; the FCZ bytes coming back are 2.5 % of it
+        runs_h = [run_host(["compress", "-d", "-y", "-t", str(eff), "--host-parse", "--gpus", "1", "--json-stats", "-f", lst, os.path.join(tmp, "dbh")])]
+        comp["gpu_host_parse"] = summarise(runs_h, "input_bytes", "... --host-parse   (parse threads -> SoA batch -> GPU: round 2's pipeline)")
+        comp["device_ingest_over_host_parse"] = round(comp["gpu_host"]["steady_residues_per_s"] / max(comp["gpu_host_parse"]["steady_residues_per_s"], 1), 2)
+        same = True
+        for ext in ("", ".index"):
+            same = same and open(os.path.join(tmp, f"db{tcounts[0]}") + ext, "rb").read() == open(os.path.join(tmp, "dbh") + ext, "rb").read()
+        comp["databases_identical"] = same
+        out["compress"] = comp
+        # one pass as the decompress leg's input
+        db1 = os.path.join(tmp, "db_one")
+        run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", "--json-stats", src, db1])
+        dlist = os.path.join(tmp, "dbs.txt")
+        dpasses = max(1, passes // 8)
+        with open(dlist, "w") as fh:
+            fh.write((db1 + "\n") * dpasses)
+        dec = {"entries": n * dpasses}
+        runs_d = [run_host(["decompress", "-d", "-y", "-t", str(eff), "--gpus", "1", "--json-stats", "-f", dlist, os.path.join(tmp, "pdbdb")])]
+        dec["gpu_host"] = summarise(runs_d, "text_bytes", "host/foldcomp-hip decompress -d --gpus 1 -f <list> <db>   (decode + PDB text on the device)")
+        dec["gpu_host"]["link_GB_per_s"] = dec["gpu_host"]["steady_text_GB_per_s"]
+        out["decompress"] = dec
+
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _harness as H
         if H.have_ref():
@@ -416,29 +453,53 @@ def end_to_end_leg(args, codec, w, dev):
             rl.ref_compress_files.restype = ctypes.c_int
             rl.ref_compress_files.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
-            blob = b"".join(p_.encode() + b"\0" for p_ in paths)
+            rpasses = min(passes, 4)
+            blob = b"".join(p_.encode() + b"\0" for p_ in paths) * rpasses
             secs = ctypes.c_double(); rres = ctypes.c_ulonglong(); rbytes = ctypes.c_ulonglong(); flen = ctypes.c_long()
             first = ctypes.create_string_buffer(1 << 20)
             ref_runs = {}
             for t in tcounts:
-                fail = rl.ref_compress_files(blob, n, t, args.anchor, ctypes.byref(secs), ctypes.byref(rres), ctypes.byref(rbytes), first, 1 << 20, ctypes.byref(flen))
+                fail = rl.ref_compress_files(blob, n * rpasses, t, args.anchor, ctypes.byref(secs), ctypes.byref(rres), ctypes.byref(rbytes), first, 1 << 20, ctypes.byref(flen))
                 ref_runs[t] = (secs.value, int(fail))
             bt = min(ref_runs, key=lambda k: ref_runs[k][0])
-            out["cpu_reference"] = {"what": "the reference's driver loop on the same files (oracle/_ref: StructureReader + Foldcomp::compress, omp parallel for), best thread count",
-                                    "cores": bt, "wall_s": round(ref_runs[bt][0], 4), "residues_per_s": round(rres.value / ref_runs[bt][0]) if ref_runs[bt][0] else None,
-                                    "failed_files": ref_runs[bt][1], "fcz_bytes": int(rbytes.value),
-                                    "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in ref_runs.items()}}
-            secs.value = ref_runs[bt][0]
-            # parity: first record of the host's database == the reference's bytes for the first file
+            comp["cpu_reference"] = {"what": "the reference's driver loop on the same files (oracle/_ref: StructureReader + Foldcomp::compress, omp parallel for), best thread count",
+                                     "cores": bt, "passes": rpasses, "wall_s": round(ref_runs[bt][0], 4), "residues_per_s": round(rres.value / ref_runs[bt][0]) if ref_runs[bt][0] else None,
+                                     "failed_files": ref_runs[bt][1], "fcz_bytes": int(rbytes.value),
+                                     "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in ref_runs.items()}}
             from foldcomp_amd.database import DatabaseReader
             rd = DatabaseReader(os.path.join(tmp, f"db{tcounts[0]}"))
             e0 = bytearray(rd.data(0)); rd.close()
             for k in (14, 15, 22, 23):
                 e0[k] = 0
-            out["first_record_equals_reference"] = bytes(e0) == first.raw[:flen.value]
-            out["fcz_bytes_equal_reference_total"] = best["fcz_bytes"] == int(rbytes.value)
-            out["speedup_vs_cpu_reference"] = round(secs.value / best["wall_s"], 2) if best["wall_s"] else None
+            comp["first_record_equals_reference"] = bytes(e0) == first.raw[:flen.value]
+            comp["fcz_bytes_equal_reference_total"] = runs[0]["fcz_bytes"] * rpasses == int(rbytes.value) * passes
+            comp["speedup_vs_cpu_reference"] = round(comp["gpu_host"]["residues_per_s"] / comp["cpu_reference"]["residues_per_s"], 2)
+            comp["steady_speedup_vs_cpu_reference"] = round(comp["gpu_host"]["steady_residues_per_s"] / comp["cpu_reference"]["residues_per_s"], 2)
+            # decompress: the reference's loop over the same database
+            rl.ref_decompress_db.restype = ctypes.c_int
+            rl.ref_decompress_db.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+            tb = ctypes.c_ulonglong(); first_t = ctypes.create_string_buffer(1 << 22)
+            dref = {}
+            for t in tcounts:
+                fail = rl.ref_decompress_db(db1.encode(), (db1 + ".index").encode(), t, 0, dpasses, os.path.join(tmp, "refpdbdb").encode(), ctypes.byref(secs),
+                                            ctypes.byref(rres), ctypes.byref(tb), first_t, 1 << 22, ctypes.byref(flen))
+                dref[t] = (secs.value, int(fail))
+            bt = min(dref, key=lambda k: dref[k][0])
+            dec["cpu_reference"] = {"what": "the reference's decompress loop on the same database into a database (oracle/_ref: Foldcomp::read + decompress + writeAtomCoordinatesToPDB, "
+                                            "omp for, writer_append under omp critical, free_writer), best thread count",
+                                    "cores": bt, "wall_s": round(dref[bt][0], 4), "residues_per_s": round(rres.value / dref[bt][0]) if dref[bt][0] else None,
+                                    "text_GB_per_s": round(tb.value / dref[bt][0] / 1e9, 3) if dref[bt][0] else None, "failed_entries": dref[bt][1],
+                                    "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in dref.items()}}
+            rd = DatabaseReader(os.path.join(tmp, "pdbdb"))
+            dec["first_text_equals_reference"] = rd.data(0) == first_t.raw[:flen.value]
+            dec["text_bytes_equal_reference_total"] = runs_d[0]["text_bytes"] + runs_d[0]["records"] == int(tb.value)
+            rd.close()
+            dec["speedup_vs_cpu_reference"] = round(dref[bt][0] / dec["gpu_host"]["wall_s"], 2)
+            dec["steady_speedup_vs_cpu_reference"] = round(dref[bt][0] / dec["gpu_host"]["steady_wall_s"], 2)
         return out
+    except (RuntimeError, subprocess.TimeoutExpired) as e:
+        return {"failed": str(e)[-400:]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -446,9 +507,13 @@ def end_to_end_leg(args, codec, w, dev):
 def host_boundary_leg(args, codec, hb):
     """The PCIe-inclusive rate: the same codec through the HOST-pointer entry points (fcz_compress_batch /
     fcz_decompress_batch, include/fcz_hip.h), page-locked buffers on both sides (fcz_pinned_alloc, what the C++ host
-    stages through), one batch in flight. Every byte crosses the link twice per round trip (objects in, FCZ out; FCZ in,
-    objects out), so this is bounded by PCIe, not by the kernels; it is reported beside the resident `value`, never as it."""
+    stages through). Every byte crosses the link twice per round trip (objects in, FCZ out; FCZ in, objects out), so this is
+    bounded by PCIe, not by the kernels; it is reported beside the resident `value`, never as it. Two figures: one batch in
+    flight on one ctx, and `overlapped`: two ctxs on the GPU, each with its own page-locked buffers, driven by two host
+    threads -- one ctx's transfers run beside the other's kernels and, the link being full duplex, beside its transfers in
+    the other direction (the arrangement of the C++ host's two workers per GPU)."""
     import ctypes
+    import threading
     from foldcomp_amd._lib import CAtomsOut
     from foldcomp_amd.structure import batch_as_c
     lib = codec.lib
@@ -465,59 +530,103 @@ def host_boundary_leg(args, codec, hb):
         view[...] = arr.reshape(-1)
         return view
 
-    try:
+    def make_set(cdc):
+        """page-locked copies of the batch and of every output, and the two calls on ctx `cdc`"""
         import copy
         pb = copy.copy(hb)
         for k in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca", "first_res_index",
                   "first_atom_index", "chain_id", "titles", "title_off"):
             setattr(pb, k, pinned(getattr(hb, k)))
         C, R, M = pb.n_chains, pb.n_residues, pb.n_atoms
-        off = pinned(codec.compress_sizes(pb))
+        off = pinned(cdc.compress_sizes(pb))
         blob = pinned(np.zeros(int(off[-1]), np.uint8))
         st = pinned(np.zeros(C, np.int32))
         cb = batch_as_c(pb)
         x = pinned(np.zeros(M, np.float32)); y = pinned(np.zeros(M, np.float32)); z = pinned(np.zeros(M, np.float32))
         bf = pinned(np.zeros(R, np.float32)); rc = pinned(np.zeros(R, np.uint8)); ac = pinned(np.zeros(M, np.uint8))
         out = CAtomsOut(x.ctypes.data, y.ctypes.data, z.ctypes.data, bf.ctypes.data, rc.ctypes.data, ac.ctypes.data)
-        info, d_res_off, d_atom_off = None, None, None
 
         def compress():
-            r = lib.fcz_compress_batch(codec.ctx, ctypes.byref(cb), off.ctypes.data, blob.ctypes.data, st.ctypes.data)
+            r = lib.fcz_compress_batch(cdc.ctx, ctypes.byref(cb), off.ctypes.data, blob.ctypes.data, st.ctypes.data)
             if r != 0:
                 raise RuntimeError(f"fcz_compress_batch -> {r}")
 
         compress()
-        info, d_res_off, d_atom_off = codec.decompress_sizes(blob, off)
+        info, d_res_off, d_atom_off = cdc.decompress_sizes(blob, off)
 
         def decompress():
-            r = lib.fcz_decompress_batch(codec.ctx, blob.ctypes.data, off.ctypes.data, C, d_res_off.ctypes.data,
+            r = lib.fcz_decompress_batch(cdc.ctx, blob.ctypes.data, off.ctypes.data, C, d_res_off.ctypes.data,
                                          d_atom_off.ctypes.data, 0, ctypes.byref(out))
             if r != 0:
                 raise RuntimeError(f"fcz_decompress_batch -> {r}")
 
         decompress()
+        return dict(pb=pb, off=off, blob=blob, x=x, compress=compress, decompress=decompress, keep=(st, cb, y, z, bf, rc, ac, out, info, d_res_off, d_atom_off))
+
+    second = None
+    try:
+        A = make_set(codec)
+        pb, off, blob, x = A["pb"], A["off"], A["blob"], A["x"]
+        C, R, M = pb.n_chains, pb.n_residues, pb.n_atoms
         reps = 3
         t0 = time.perf_counter()
-        for _ in range(reps): compress()
+        for _ in range(reps): A["compress"]()
         t1 = time.perf_counter()
-        for _ in range(reps): decompress()
+        for _ in range(reps): A["decompress"]()
         t2 = time.perf_counter()
         tc, td = (t1 - t0) / reps, (t2 - t1) / reps
         in_c = sum(getattr(pb, k).nbytes for k in ("res_off", "atom_off", "x", "y", "z", "atom_code", "res_code", "bfac_ca",
                                                    "first_res_index", "first_atom_index", "chain_id", "titles", "title_off"))
         fcz = int(off[-1])
         out_d = 12 * M + 4 * R + R + M
-        # the decoded atoms of the first chains must equal what went in to the codec's own precision: checked bit-exactly
-        # against the resident path by the caller (same blob, same kernels); here only that the call filled the outputs
-        return {"chains": C, "residues": R, "buffers": "page-locked (fcz_pinned_alloc)",
-                "compress_ms": round(tc * 1e3, 3), "decompress_ms": round(td * 1e3, 3),
-                "residues_per_s": round(R / (tc + td)),
-                "compress_link_GBs": round((in_c + fcz + 4 * C) / tc / 1e9, 2),
-                "decompress_link_GBs": round((fcz + out_d) / td / 1e9, 2),
-                "bytes_over_link_per_residue": round((in_c + 2 * fcz + out_d) / R, 1),
-                "fcz_sha": __import__("hashlib").sha1(blob.tobytes()).hexdigest()[:16],
-                "coords_filled": bool(np.isfinite(x).all() and float(np.abs(x).max()) > 0)}
+        res = {"chains": C, "residues": R, "buffers": "page-locked (fcz_pinned_alloc)",
+               "compress_ms": round(tc * 1e3, 3), "decompress_ms": round(td * 1e3, 3),
+               "residues_per_s": round(R / (tc + td)),
+               "compress_link_GBs": round((in_c + fcz + 4 * C) / tc / 1e9, 2),
+               "decompress_link_GBs": round((fcz + out_d) / td / 1e9, 2),
+               "bytes_over_link_per_residue": round((in_c + 2 * fcz + out_d) / R, 1),
+               "fcz_sha": __import__("hashlib").sha1(blob.tobytes()).hexdigest()[:16],
+               "coords_filled": bool(np.isfinite(x).all() and float(np.abs(x).max()) > 0)}
+        # ---- two ctxs, two host threads, alternating page-locked buffers ----
+        second = Codec(codec.device)
+        B = make_set(second)
+        oreps = 4
+        errs = []
+
+        def worker(S, order):
+            try:
+                for _ in range(oreps):
+                    for k in order:
+                        S[k]()
+            except Exception as e:   # noqa: BLE001
+                errs.append(repr(e))
+
+        def both(orders):
+            th = [threading.Thread(target=worker, args=(S_, o_)) for S_, o_ in zip((A, B), orders)]
+            t0_ = time.perf_counter()
+            for t_ in th: t_.start()
+            for t_ in th: t_.join()
+            return time.perf_counter() - t0_
+        w_c = both((("compress",), ("compress",)))                      # both ctxs compress: copies of one beside kernels of the other
+        w_d = both((("decompress",), ("decompress",)))
+        w_rt = both((("compress", "decompress"), ("decompress", "compress")))   # opposite directions at the same time: the link is full duplex
+        if errs:
+            res["overlapped"] = {"failed": errs[0]}
+        else:
+            nb = 2 * oreps                                              # batches per direction and measurement
+            res["overlapped"] = {"ctxs": 2, "host_threads": 2, "batches_per_run": nb,
+                                 "compress_ms_per_batch": round(w_c / nb * 1e3, 3), "decompress_ms_per_batch": round(w_d / nb * 1e3, 3),
+                                 "compress_link_GBs": round((in_c + fcz + 4 * C) * nb / w_c / 1e9, 2),
+                                 "decompress_link_GBs": round((fcz + out_d) * nb / w_d / 1e9, 2),
+                                 "round_trip_ms_per_batch": round(w_rt / nb * 1e3, 3),
+                                 "residues_per_s": round(R * nb / w_rt),
+                                 "round_trip_link_GBs_both_directions": round((in_c + 2 * fcz + out_d + 4 * C) * nb / w_rt / 1e9, 2),
+                                 "fcz_equals_single_ctx": bool(B["blob"].tobytes() == blob.tobytes()),
+                                 "over_one_in_flight": round((tc + td) / (w_rt / nb), 2)}
+        return res
     finally:
+        if second is not None:
+            second.close()
         for p in held:
             lib.fcz_pinned_free(p)
 
@@ -792,6 +901,34 @@ def main():
                "write_GBs": round(tbytes / (ms_f * 1e-3) / 1e9, 1) if ms_f else None,
                "frac_of_hbm_peak": round(tbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_f else None,
                "atoms_per_s": round(n_at / ((ms_s + ms_f) * 1e-3)) if ms_f else None, "first_chain_equals_host_writer": bool(ok_pdb)}
+        # ---- §8 f3 leg: the same text back through the structure ingest on the device (PDB text -> fcz_chain_batch in HBM) ----
+        try:
+            from foldcomp_amd._lib import CIngestResult
+            nm = [f"s{i:07d}.pdb".encode() for i in range(npdb)]
+            name_off = torch.from_numpy(np.arange(npdb + 1, dtype=np.int64) * len(nm[0])).to(torch.int32).to(dev)
+            names_dev = torch.from_numpy(np.frombuffer(b"".join(nm), np.uint8).copy()).to(dev)
+            stem_len = torch.full((npdb,), len(nm[0]) - 4, dtype=torch.int32, device=dev)
+            file_off = text_off.to(torch.int64)
+            res = CIngestResult()
+            torch.cuda.synchronize()
+            codec.reset_timing()
+            reps_i = 3
+            for _ in range(reps_i):
+                _lib.check(lib.fcz_ingest_pdb_dev(codec.ctx, text_dev.data_ptr(), file_off.data_ptr(), npdb, tbytes, names_dev.data_ptr(), name_off.data_ptr(),
+                                                  stem_len.data_ptr(), args.anchor, 0, ctypes.byref(res)), "fcz_ingest_pdb_dev")
+            codec.synchronize()
+            ims = {k: codec.kernel_time(k)[0] / reps_i for k in ("ingest_parse", "ingest_frags", "ingest_fill")}
+            tot_ms = sum(ims.values())
+            n_r = int(res_off_dev[npdb]) & 0xFFFFFFFF
+            ingest = {"files": npdb, "text_bytes": tbytes, "ms": {k: round(v, 4) for k, v in ims.items()},
+                      "text_GBs": round(tbytes / (tot_ms * 1e-3) / 1e9, 1) if tot_ms else None,
+                      "frac_of_hbm_peak": round(tbytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tot_ms else None,
+                      "residues_per_s": round(n_r / (tot_ms * 1e-3)) if tot_ms else None,
+                      "counts_equal_decoded": bool(res.batch.n_chains == npdb and res.batch.n_residues == n_r and res.batch.n_atoms == n_at),
+                      "refused": int(res.n_refused)}
+            pdb["ingest_of_the_same_text"] = ingest
+        except Exception as e:   # noqa: BLE001
+            pdb["ingest_of_the_same_text"] = {"failed": repr(e)[:300]}
         del text_dev
     # ---- §8 f4 leg: `extract --plddt -p 2` of every record straight from the FCZ bytes ----
     ext = None

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 
-from .structure import CAtomsOut, CChainBatch, CEntryInfo
+from .structure import CAtomsOut, CChainBatch, CEntryInfo, CIngestResult
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FCZ_HIP_LIB selects another build of the same library (A/B timing of kernel variants); it is still a HIP build

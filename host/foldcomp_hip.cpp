@@ -27,6 +27,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <omp.h>
@@ -773,6 +774,7 @@ struct Options {
     std::vector<std::string> inputs;   // what <input> expands to (itself, or the lines of the -f file: containers first, then files)
     int gpus = 1;               // --gpus N: devices used by compress (0 = every visible device)
     int workers_per_gpu = 2;    // host threads (each with its own ctx and stream) per device
+    int write_threads = 8;      // threads a decompress worker writes its job's text with (set from -t: threads / workers)
     bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
 };
 
@@ -1059,14 +1061,14 @@ int run_compress(const Options& o) {
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
         double busy = 0.0; for (double g : gpu_busy) busy += g;
-        printf("{\"mode\": \"compress\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
+        printf("{\"mode\": \"compress\", \"ingest\": \"host\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
                "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
                "\"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_parsed_s\": %.4f, \"workers_done_s\": %.4f, \"residues_per_s\": %.1f, "
-               "\"input_MB_per_s\": %.1f}\n",
+               "\"input_MB_per_s\": %.1f, \"pinned_blocks\": %llu}\n",
                gpus, n_workers, omp_get_max_threads(), files.size(), (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
                (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), wall, t_parse, busy,
                *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_parsed, t_joined,
-               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0);
+               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load());
     }
     return hard_fail ? 1 : 0;
 }
@@ -1404,46 +1406,94 @@ int run_decompress(const Options& o) {
     JobQueue<DecompressJob> queue((size_t)n_workers + 2);
     Sequencer seq;
     std::atomic<bool> hard_fail{false};
-    std::atomic<uint64_t> n_ok{0}, n_text{0}, n_fcz{0};
+    std::atomic<uint64_t> n_ok{0}, n_text{0}, n_fcz{0}, n_res{0};
+    std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
         fcz_ctx* ctx = nullptr;
         if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
         pvec<uint8_t> text, packed;
         DecompressJob job;
         while (queue.get(job)) {
             const uint32_t n = job.ents.n();
             std::vector<uint64_t> text_off(n + 1, 0);
             std::vector<int32_t> status(n, 0);
+            const auto t0 = clk::now();
             int rc = ctx ? fcz_decompress_pdb_begin(ctx, job.ents.blob.data(), job.ents.off.data(), n, o.alt ? 1 : 0, text_off.data(), status.data()) : FCZ_E_NO_DEVICE;
+            gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
             uint32_t n_good = 0;
             if (rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) n_good += status[i] == FCZ_OK ? 1u : 0u;
             // PDB text in a database carries the MMseqs terminator (src/main.cpp:659): one NUL per record
             const uint64_t bytes = rc == FCZ_OK ? text_off[n] + (o.db ? n_good : 0) : 0;
             const uint64_t at = o.db ? seq.claim(job.index, bytes) : 0;     // every job claims, also a failed one
-            if (rc == FCZ_OK) { text.resize(text_off[n]); rc = fcz_decompress_pdb_fetch(ctx, text.data()); }
+            if (rc == FCZ_OK) {
+                if (text.size() < text_off[n]) text.resize(text_off[n] + text_off[n] / 8);     // grows, never shrinks (a resize zero-fills what it adds)
+                const auto t1 = clk::now();
+                rc = fcz_decompress_pdb_fetch(ctx, text.data());
+                gpu_busy[w] += std::chrono::duration<double>(clk::now() - t1).count();
+                for (uint32_t i = 0; i < n; i++) if (status[i] == FCZ_OK) { const uint8_t* e = job.ents.blob.data() + job.ents.off[i]; n_res += (uint32_t)e[4] | ((uint32_t)e[5] << 8); }
+            }
             if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s\n", fcz_status_string(rc)); hard_fail = true; continue; }
             try {
                 if (o.db) {
-                    packed.resize(bytes);
-                    uint64_t pos = 0; size_t k = 0;
+                    // entry i of the output database = its text + the MMseqs NUL: written straight from the fetched buffer with
+                    // gathered writes (pwritev: text, NUL, text, NUL ...), the job's range cut into pieces that several threads
+                    // write side by side -- the copy into the page cache is the cost of this direction (the text is 40x the FCZ bytes)
+                    std::vector<uint32_t> good; std::vector<uint64_t> dst;       // entries that decompressed, and where they go
+                    uint64_t pos = 0;
                     for (uint32_t i = 0; i < n; i++) {
                         if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
                         const uint64_t len = text_off[i + 1] - text_off[i];
-                        memcpy(packed.data() + pos, text.data() + text_off[i], len); packed[pos + len] = 0;
                         std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
-                        rows[w].push_back({job.index, k++, at + pos, len + 1, stem});
+                        rows[w].push_back({job.index, good.size(), at + pos, len + 1, stem});
+                        good.push_back(i); dst.push_back(at + pos);
                         pos += len + 1;
                     }
-                    pwrite_all(db_fd, packed.data(), bytes, at);
+                    static const char NUL = 0;
+                    const int pieces = (int)std::min<size_t>(std::max<size_t>(good.size() / 64, 1), (size_t)std::max(1, o.write_threads));
+                    std::atomic<bool> wfail{false};
+                    std::vector<std::thread> wt;
+                    for (int pc = 0; pc < pieces; pc++) wt.emplace_back([&, pc]() {
+                        const size_t g0 = good.size() * (size_t)pc / (size_t)pieces, g1 = good.size() * (size_t)(pc + 1) / (size_t)pieces;
+                        std::vector<iovec> iov;
+                        for (size_t g = g0; g < g1;) {
+                            iov.clear();
+                            const uint64_t start = dst[g]; uint64_t bytes_here = 0;
+                            for (; g < g1 && iov.size() + 2 <= 512; g++) {
+                                const uint32_t i = good[g];
+                                iov.push_back({(void*)(text.data() + text_off[i]), (size_t)(text_off[i + 1] - text_off[i])});
+                                iov.push_back({(void*)&NUL, 1});
+                                bytes_here += text_off[i + 1] - text_off[i] + 1;
+                            }
+                            // a gathered write may come back short: continue from where it stopped
+                            uint64_t done = 0; size_t k = 0;
+                            while (done < bytes_here) {
+                                const ssize_t wr = pwritev(db_fd, iov.data() + k, (int)(iov.size() - k), (off_t)(start + done));
+                                if (wr <= 0) { wfail = true; return; }
+                                done += (uint64_t)wr;
+                                uint64_t left = (uint64_t)wr;
+                                while (k < iov.size() && left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
+                                if (k < iov.size() && left) { iov[k].iov_base = (char*)iov[k].iov_base + left; iov[k].iov_len -= left; }
+                            }
+                        }
+                    });
+                    for (std::thread& t : wt) t.join();
+                    if (wfail) throw std::runtime_error("pwritev failed");
                 } else {
-                    for (uint32_t i = 0; i < n; i++) {
-                        if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
-                        std::string stem, ext;
-                        file_parts(base_name(job.ents.names[i]), stem, ext);
-                        const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
-                        write_out(single ? output : output + "/" + fname, (const char*)text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
-                    }
+                    // one file per entry, written by several threads (open / write / close per file is what takes the time)
+                    const int pieces = (int)std::min<size_t>(std::max<size_t>(n / 64, 1), (size_t)std::max(1, o.write_threads));
+                    std::vector<std::thread> wt;
+                    for (int pc = 0; pc < pieces; pc++) wt.emplace_back([&, pc]() {
+                        for (uint32_t i = (uint32_t)((uint64_t)n * pc / pieces); i < (uint32_t)((uint64_t)n * (pc + 1) / pieces); i++) {
+                            if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
+                            std::string stem, ext;
+                            file_parts(base_name(job.ents.names[i]), stem, ext);
+                            const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
+                            write_out(single ? output : output + "/" + fname, (const char*)text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
+                        }
+                    });
+                    for (std::thread& t : wt) t.join();
                 }
                 n_ok += n_good; n_text += text_off[n]; n_fcz += job.ents.off.back();
             } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
@@ -1475,6 +1525,7 @@ int run_decompress(const Options& o) {
         for_each_entry(o, ents, flush, JOB);
         queue.close();
     }
+    const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
     for (std::thread& t : workers) t.join();
     if (o.db && hard_fail) {
         close(db_fd); unlink(output.c_str());
@@ -1492,9 +1543,12 @@ int run_decompress(const Options& o) {
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
-        printf("{\"mode\": \"decompress\", \"gpus\": %d, \"workers\": %d, \"records\": %llu, \"fcz_bytes\": %llu, \"text_bytes\": %llu, \"wall_s\": %.4f, "
-               "\"text_MB_per_s\": %.1f}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_fcz.load(),
-               (unsigned long long)n_text.load(), wall, wall > 0 ? n_text.load() / wall / 1e6 : 0.0);
+        double busy = 0.0; for (double g : gpu_busy) busy += g;
+        printf("{\"mode\": \"decompress\", \"gpus\": %d, \"workers\": %d, \"records\": %llu, \"residues\": %llu, \"fcz_bytes\": %llu, \"text_bytes\": %llu, "
+               "\"wall_s\": %.4f, \"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_queued_s\": %.4f, \"residues_per_s\": %.1f, \"text_MB_per_s\": %.1f, "
+               "\"pinned_blocks\": %llu}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
+               (unsigned long long)n_text.load(), wall, busy, *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_queued,
+               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? n_text.load() / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load());
     }
     return hard_fail ? 1 : 0;
 }
@@ -1754,6 +1808,7 @@ int main(int argc, char** argv) {
         else o.output = o.input + "_" + suffix;
     }
     if (o.mode == "compress") return run_compress(o);
+    o.write_threads = std::max(1, omp_get_max_threads() / std::max(1, (o.gpus <= 0 ? 1 : o.gpus) * std::max(1, o.workers_per_gpu)));
     if (o.mode == "decompress") return run_decompress(o);
     if (o.mode == "extract") return run_extract(o);
     if (o.mode == "check") return run_check(o);

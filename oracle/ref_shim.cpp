@@ -375,4 +375,54 @@ int ref_compress_files(const char* paths, int n_files, int n_threads, int anchor
     return failed;
 }
 
+// ---- end to end on a database: what the decompress lambda of src/main.cpp:612-689 does per entry under the reference's own
+// `omp for` over the database (DatabaseProcessor::run, src/input_processor.h:237-257): Foldcomp::read, decompress,
+// writeAtomCoordinatesToPDB into a string + the '\0' of the --db output, then -- when out_path is given -- writer_append under
+// `omp critical` into a database made by make_writer and closed by free_writer, exactly as src/main.cpp:571-575,656-664,683-685
+// do (out_path == NULL: the text is counted and dropped). `passes` walks over the database. Wall time of the loop incl.
+// free_writer; returns the number of entries that failed.
+int ref_decompress_db(const char* data_path, const char* index_path, int n_threads, int alt_order, int passes, const char* out_path, double* seconds,
+                      unsigned long long* residues, unsigned long long* text_bytes, char* first_out, long first_cap, long* first_len) {
+    void* r = make_reader(data_path, index_path, DB_READER_USE_DATA | DB_READER_USE_LOOKUP_REVERSE);
+    if (!r) return -1;
+    void* wh = nullptr;
+    unsigned int key = 0;
+    if (out_path) wh = make_writer(out_path, (std::string(out_path) + ".index").c_str());
+    const long n = (long)reader_get_size(r);
+    unsigned long long res = 0, bytes = 0; int failed = 0;
+    *first_len = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int pass = 0; pass < passes; pass++) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : res, bytes, failed)
+        for (long i = 0; i < n; i++) {
+            Foldcomp comp;
+            std::istringstream in(std::string(reader_get_data(r, i), (size_t)reader_get_length(r, i)));
+            if (comp.read(in) != 0) { failed++; continue; }
+            std::vector<AtomCoordinate> atoms;
+            comp.useAltAtomOrder = alt_order != 0;
+            if (comp.decompress(atoms) != 0) { failed++; continue; }
+            std::ostringstream oss;
+            writeAtomCoordinatesToPDB(atoms, comp.strTitle, oss);
+            oss << '\0';
+            const std::string os = oss.str();
+            res += comp.nResidue; bytes += os.size();
+            if (pass == 0 && i == 0 && (long)os.size() <= first_cap) { memcpy(first_out, os.data(), os.size()); *first_len = (long)os.size(); }
+            if (wh) {
+                const char* nm = reader_lookup_name_alloc(r, reader_get_key(r, i));
+#pragma omp critical
+                {
+                    writer_append(wh, os.c_str(), os.size(), key, nm ? nm : "");
+                    key++;
+                }
+                if (nm) free((void*)nm);
+            }
+        }
+    }
+    if (wh) free_writer(wh);
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *residues = res; *text_bytes = bytes;
+    free_reader(r);
+    return failed;
+}
+
 }  // extern "C"

@@ -18,7 +18,7 @@ def line():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--chains", "16384", "--steps", "2", "--warmup", "1",
            "--cpu-sample", "512", "--parity-chains", "512", "--pdb-sample", "1024", "--mixed-chains", "6000", "--mixed-steps", "1",
-           "--e2e-files", "0", "--host-chains", "4096"]
+           "--e2e-files", "384", "--e2e-passes", "8", "--host-chains", "4096"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -58,3 +58,27 @@ def test_host_pointer_leg_matches_the_resident_path(line):
     assert h["residues_per_s"] > 0 and h["compress_link_GBs"] > 0 and h["decompress_link_GBs"] > 0
     # over the link every residue costs its objects twice and its record twice: far above the resident path's time
     assert h["residues_per_s"] < line["value"]
+
+
+def test_overlapped_host_boundary(line):
+    o = line["host_boundary"]["overlapped"]
+    assert o["ctxs"] == 2 and o["fcz_equals_single_ctx"] and o["residues_per_s"] > 0 and o["round_trip_link_GBs_both_directions"] > 0
+
+
+def test_end_to_end_both_directions(line):
+    """disk -> FCZ database with the structure ingest on the device (== the host-parse pipeline's database, first record == the
+    reference's), and FCZ database -> PDB-text database (first text == the reference's); each beside the reference's own loop"""
+    e = line["end_to_end"]
+    assert e["files"] == 384 and e["passes"] == 8
+    c, d = e["compress"], e["decompress"]
+    assert c["databases_identical"] and c["gpu_host"]["records"] == 384 * 8 and c["gpu_host"]["host_parsed_files"] == 0
+    assert c["gpu_host"]["page_locked_blocks"] > 0 and c["gpu_host_parse"]["page_locked_blocks"] > 0
+    assert c["gpu_host"]["steady_residues_per_s"] > 0 and d["gpu_host"]["steady_residues_per_s"] > 0
+    if "cpu_reference" in c:      # oracle/_ref travels to the GPU box
+        assert c["first_record_equals_reference"] and c["fcz_bytes_equal_reference_total"] and c["cpu_reference"]["failed_files"] == 0
+        assert d["first_text_equals_reference"] and d["text_bytes_equal_reference_total"] and d["cpu_reference"]["failed_entries"] == 0
+
+
+def test_resident_ingest_leg(line):
+    i = line["pdb_text"]["ingest_of_the_same_text"]
+    assert i["files"] == 1024 and i["counts_equal_decoded"] and i["refused"] == 0 and i["text_GBs"] > 0

@@ -23,12 +23,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def codec():
-    with Codec(0) as c:
-        yield c
-
-
-@pytest.fixture(scope="module")
 def ing():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
 

@@ -206,6 +206,39 @@ class Sink:
 
 
 # ---- modes ---------------------------------------------------------------------------------------------
+def host_fragments(name: str, data: bytes, a, kind: str, single: bool, output) -> List[Tuple[str, str, Chain]]:
+    """one structure file -> its fragments as (output file name, database name, chain): src/main.cpp:455-508 on the host
+    (parse, removeAlternativePosition, identifyChains, identifyDiscontinousResInd, names and title)"""
+    out: List[Tuple[str, str, Chain]] = []
+    base = os.path.basename(name)
+    stem, ext = file_parts(base)
+    if kind in ("tar", "db"):
+        out_file = stem
+    elif single:
+        out_file, ext = file_parts(output)      # a single-file run names and suffixes by the OUTPUT path (src/main.cpp:449-451)
+    else:
+        out_file = stem
+    t, title = load_structure(name, data)
+    if len(t) == 0:
+        print(f"[Error] No atoms found in the input file: {base}", file=sys.stderr); return out
+    if title == base:
+        title = out_file            # src/main.cpp:465
+    t = remove_alternative_position(t)
+    chains = identify_chains(t)
+    for cs in chains:
+        frags = identify_discontinuous(t, cs)
+        if a.skip_discontinuous and len(frags) > 1:
+            print(f"Skipping discontinuous chain: {base}", file=sys.stderr); continue
+        for j, sl in enumerate(frags):
+            fname = out_file + (t.chain[cs.start] if len(chains) > 1 else "")
+            if len(frags) > 1:
+                fname += f"_{j}"
+            if kind != "db":
+                fname += ".fcz" if is_compressible(out_file, ext) else ("." + ext if ext else "")
+            out.append((fname, out_file, Chain(title, t.take(sl))))
+    return out
+
+
 def run_compress(a, inputs, output, kind, single):
     sink = Sink(output, kind, a.overwrite)
     pending: List[Tuple[str, str, Chain]] = []   # (file name, db name, chain)
@@ -236,35 +269,10 @@ def run_compress(a, inputs, output, kind, single):
 
     for inp in inputs:
         for name, data in iter_entries(inp, a.recursive, None, 1):
-            base = os.path.basename(name)
-            stem, ext = file_parts(base)
-            if kind in ("tar", "db"):
-                out_file = stem
-            elif single:
-                out_file, ext = file_parts(output)      # a single-file run names and suffixes by the OUTPUT path (src/main.cpp:449-451)
-            else:
-                out_file = stem
             try:
-                t, title = load_structure(name, data)
+                pending.extend(host_fragments(name, data, a, kind, single, output))
             except Exception as e:  # noqa: BLE001 - parse errors are reported and skipped like the reference
-                print(f"[Error] {base}: {e}", file=sys.stderr); continue
-            if len(t) == 0:
-                print(f"[Error] No atoms found in the input file: {base}", file=sys.stderr); continue
-            if title == base:
-                title = out_file            # src/main.cpp:465
-            t = remove_alternative_position(t)
-            chains = identify_chains(t)
-            for cs in chains:
-                frags = identify_discontinuous(t, cs)
-                if a.skip_discontinuous and len(frags) > 1:
-                    print(f"Skipping discontinuous chain: {base}", file=sys.stderr); continue
-                for j, sl in enumerate(frags):
-                    fname = out_file + (t.chain[cs.start] if len(chains) > 1 else "")
-                    if len(frags) > 1:
-                        fname += f"_{j}"
-                    if kind != "db":
-                        fname += ".fcz" if is_compressible(out_file, ext) else ("." + ext if ext else "")
-                    pending.append((fname, out_file, Chain(title, t.take(sl))))
+                print(f"[Error] {os.path.basename(name)}: {e}", file=sys.stderr); continue
             if len(pending) >= BATCH_CHAINS:
                 flush()
     flush()
@@ -402,6 +410,10 @@ def main(argv=None):
     ap.add_argument("--use-title", action="store_true")
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--use-cache", action="store_true")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="compress / decompress into a database (-d) sharded over N GPUs of the node, one process per GPU "
+                         "(foldcomp_amd/sharded_cli.py); 1 = the same code in a 1-rank group; 0 = this process only")
+    ap.add_argument("--json-stats", action="store_true")
     ap.add_argument("mode", nargs="?")
     ap.add_argument("input", nargs="?")
     ap.add_argument("output", nargs="?")
@@ -439,6 +451,13 @@ def main(argv=None):
         else:
             output = f"{inp}_{a.suffix}/"
     kind = "db" if a.db else "tar" if a.tar else ("file" if single else "dir")
+    if a.gpus >= 1 and a.mode in ("compress", "decompress"):
+        if kind != "db":
+            print("[Error] --gpus shards a database run: add -d", file=sys.stderr); return 1
+        from . import sharded_cli
+        if a.gpus > 1 and "RANK" not in os.environ:
+            return sharded_cli.launch(list(argv) if argv is not None else sys.argv[1:], a.gpus)
+        return sharded_cli.run(a, inputs, output.rstrip("/"))
     if a.mode == "compress":
         run_compress(a, inputs, output.rstrip("/") if kind != "file" else output, kind, single)
     elif a.mode == "decompress":

@@ -90,3 +90,34 @@ def test_two_rank_sharded_db_equals_single_writer(tmp_path):
     r = DatabaseReader(str(tmp_path / "db"))
     assert len(r) == 24 and r.data(7) == z[f"{names[7]}/fcz"].tobytes()
     r.close()
+
+
+def test_sharded_cli_plan_covers_every_item_once(tmp_path):
+    """the listing + range cut every rank of `python -m foldcomp_amd ... --gpus N` computes for itself: identical on every rank,
+    contiguous, disjoint, complete, balanced by bytes -- for directories (sorted walk) and databases (key order, --id-list)"""
+    from foldcomp_amd import shard, sharded_cli
+    from foldcomp_amd.database import DatabaseWriter
+    d = tmp_path / "files"
+    d.mkdir()
+    rng = np.random.default_rng(5)
+    for i in range(97):
+        (d / f"f{i:03d}.pdb").write_bytes(b"x" * int(rng.integers(1, 5000)))
+    w = DatabaseWriter(str(tmp_path / "db"))
+    for k in reversed(range(40)):
+        w.append(b"y" * int(rng.integers(10, 3000)), k, f"n{k}")
+    w.close()
+    (tmp_path / "ids.txt").write_text("n3\nn17\nmissing\nn5\n")
+    for inputs, id_list, n_exp in (([str(d)], None, 97), ([str(tmp_path / "db")], None, 40), ([str(tmp_path / "db"), str(d)], None, 137),
+                                   ([str(tmp_path / "db")], str(tmp_path / "ids.txt"), 3)):
+        items = sharded_cli.list_items(inputs, False, id_list, 1)
+        assert len(items) == n_exp
+        again = sharded_cli.list_items(inputs, False, id_list, 1)
+        assert [it.name for it in items] == [it.name for it in again]
+        for world in (1, 2, 3, 8):
+            cuts = [shard.shard_range(len(items), [it.size for it in items], r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == len(items) and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+            if world == 2 and n_exp > 20:
+                tot = sum(it.size for it in items); half = sum(it.size for it in items[cuts[0][0]:cuts[0][1]])
+                assert abs(half - tot / 2) <= max(it.size for it in items)
+    if id_list := str(tmp_path / "ids.txt"):
+        assert [it.name for it in sharded_cli.list_items([str(tmp_path / "db")], False, id_list, 1)] == ["n3", "n17", "n5"]

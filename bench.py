@@ -750,13 +750,23 @@ def dry_run(args, world, rank):
     else:
         seen = 1
     if rank == 0:
-        print(json.dumps({"metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs", "value": None,
-                          "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "dry_run": True}))
+        emit_line({"metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs", "value": None,
+                   "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "dry_run": True})
     if world > 1:
         dist.destroy_process_group()
 
 
 _T0 = time.perf_counter()
+_JSON_FD = None
+
+
+def emit_line(obj):
+    """the JSON line, on the process's original stdout (see main)"""
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
 
 
 def note(msg):
@@ -776,19 +786,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE JSON line and nothing else: native libraries (RCCL prints a version banner) write to file
+    # descriptor 1 behind Python's back, so descriptor 1 is pointed at stderr and the line goes to a private copy of the original
+    sys.stdout.flush()
+    global _JSON_FD
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if args.dry_run:
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the FCZ hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+    # One code path for every N: also a single GPU runs in a (1-rank) RCCL process group, so that the step timed at N = 1 --
+    # compress, synchronise, gather of the record lengths for the index, decompress -- is the step timed at N = 2, 4, 8.
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+    group_note = None
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         world = dist.get_world_size()   # what RCCL actually formed; n_gpus below reports this, not the flag
         assert world == args.gpus, (world, args.gpus)
+    except Exception as e:   # noqa: BLE001
+        if world > 1:
+            raise
+        dist = None; group_note = f"no 1-rank RCCL group ({type(e).__name__}): the index exchange of the step is skipped at N = 1"
 
     C, n_res = args.chains, args.residues
     d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C, mixed=args.mixed)
@@ -801,12 +827,12 @@ def main():
     off_dev, blob_dev, status_dev, res_off_dev, atom_off_dev, out_t, cout = (w.off_dev, w.blob_dev, w.status_dev, w.res_off_dev,
                                                                              w.atom_off_dev, w.out_t, w.cout)
     lengths_dev = torch.zeros(C, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(world)] if (dist is not None and rank == 0) else None
     torch.cuda.synchronize()
 
     def step():
         w.compress()
-        if world > 1:
+        if dist is not None:
             # the only exchange of the sharded job: per-record lengths -> rank 0 builds the global index
             codec.synchronize()
             torch.sub(off_dev[1:], off_dev[:-1], out=lengths_dev)
@@ -819,18 +845,18 @@ def main():
     warm_csum = w.checksum() if (rank == 0 and args.warmup and not args.no_parity) else None
     codec.enable_timing(True); codec.reset_timing()
     # the timed region: exactly --steps steps between barrier + synchronize pairs, max over ranks
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     codec.synchronize(); torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -1031,7 +1057,8 @@ def main():
                                     if args.mixed else f"{C} synthetic {n_res}-residue chains per GPU, ")
                                    + f"compress+decompress, anchor -b {args.anchor}",
                        "chains_per_gpu": C, "residues_per_chain": round(R / C, 1) if args.mixed else n_res, "atoms_per_residue": round(A, 3),
-                       "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective"},
+                       "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective",
+                       "index_exchange": group_note or f"record lengths gathered on rank 0 over RCCL inside every step ({world}-rank group)"},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,
@@ -1039,8 +1066,8 @@ def main():
             "decompress_only": legs[0] if legs else None, "mixed": legs[1] if legs else None, "pdb_text": pdb, "extract": ext, "end_to_end": e2e,
             "host_boundary": hostb,
         }
-        print(json.dumps(line))
-    if world > 1:
+        emit_line(line)
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     codec.close()

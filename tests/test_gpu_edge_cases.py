@@ -124,3 +124,32 @@ def test_roundtrip_properties_at_scale(codec):
     bb = same & (b.atom_code < 3)
     errb = np.sqrt((dd["x"] - b.x) ** 2 + (dd["y"] - b.y) ** 2 + (dd["z"] - b.z) ** 2)[bb]
     assert float(np.sqrt(np.mean(errb.astype(np.float64) ** 2))) < 0.15
+
+
+def test_batch_beyond_32_bit_atom_offsets_is_refused(codec):
+    """residue / atom offsets are 32-bit (include/fcz_hip.h): a decompress batch whose atoms reach 2^32 is refused by the sizes pass
+    (FCZ_E_INVALID_ARG), not wrapped. 4 700 copies of one 65 535-residue all-TRP record = 4.3 G atoms."""
+    import ctypes
+    import torch
+    from foldcomp_amd import _lib, synthetic
+    n = 65535
+    b = synthetic.to_chain_batch(synthetic.generate(1, [n], seed=99, anchor_threshold=300, res_code=17))   # 65 535 x TRP, -b 300: 220 anchors
+    blob, off, st = codec.compress_batch(b)
+    assert st[0] == 0
+    per_atoms = int(codec.decompress_sizes(blob, off)[2][-1])
+    copies = (1 << 32) // per_atoms + 2
+    dev = "cuda:0"
+    one = torch.from_numpy(blob).to(dev)
+    big = one.repeat(copies)
+    offs = (torch.arange(copies + 1, dtype=torch.int64, device=dev) * len(blob))
+    res_off = torch.zeros(copies + 1, dtype=torch.int32, device=dev); atom_off = torch.zeros(copies + 1, dtype=torch.int32, device=dev)
+    tr, ta = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    torch.cuda.synchronize()
+    rc = codec.lib.fcz_decompress_sizes_dev(codec.ctx, big.data_ptr(), offs.data_ptr(), copies, res_off.data_ptr(), atom_off.data_ptr(), ctypes.byref(tr), ctypes.byref(ta))
+    assert rc == -1, rc                                   # FCZ_E_INVALID_ARG
+    # one copy fewer than the limit is fine
+    ok = (1 << 32) // per_atoms - 1
+    rc = codec.lib.fcz_decompress_sizes_dev(codec.ctx, big.data_ptr(), offs.data_ptr(), ok, res_off.data_ptr(), atom_off.data_ptr(), ctypes.byref(tr), ctypes.byref(ta))
+    assert rc == 0 and ta.value == ok * per_atoms
+    del big, one
+    torch.cuda.empty_cache()

@@ -1149,3 +1149,14 @@ extern "C" int fcz_debug_bb_timing(unsigned long long* out8) {
     return 0;
 }
 #endif
+
+#ifdef FCZ_IG_TIMING
+// measurement aid: read and clear the phase counters of k_ingest_parse
+extern "C" int fcz_debug_ig_timing(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fcz::g_ig_timing), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fcz::g_ig_timing), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -108,13 +108,105 @@ __device__ __forceinline__ bool ig_int(const uint8_t* f, int n, int32_t* out) {
     return true;
 }
 
+// ---- the same field readers on a line held in registers (17 dwords = columns 1-68), every index a compile-time constant:
+//      no dependent byte loads (the per-byte global loads of the readers above, each waiting for the compare before it, were
+//      what the parse kernel spent its time on) ----
+struct ig_line { uint32_t w[17]; };
+template <int I> __device__ __forceinline__ uint32_t ig_b(const ig_line& L) { return (L.w[I >> 2] >> (8 * (I & 3))) & 0xffu; }
+// right-aligned integer part of a fixed field, characters [A, A + N): spaces, one optional '-', at least one digit
+template <int A, int N>
+__device__ __forceinline__ bool ig_intpart(const ig_line& L, uint32_t* val, bool* neg) {
+    uint32_t v = 0, mult = 1; bool ok = true, ng = false; int state = 0;   // 0: digits, 1: only spaces may follow (to the left)
+    auto step = [&](uint32_t c, bool rightmost) {
+        const uint32_t d = c - '0';
+        if (state == 0) {
+            if (d <= 9u) { v += d * mult; mult *= 10u; }
+            else if (rightmost) ok = false;                      // no digit before the point
+            else if (c == '-') { ng = true; state = 1; }
+            else if (c == ' ') state = 1;
+            else ok = false;
+        } else if (c != ' ') ok = false;
+    };
+    if (N >= 1) step(ig_b<A + N - 1>(L), true);
+    if (N >= 2) step(ig_b<A + (N >= 2 ? N - 2 : 0)>(L), false);
+    if (N >= 3) step(ig_b<A + (N >= 3 ? N - 3 : 0)>(L), false);
+    if (N >= 4) step(ig_b<A + (N >= 4 ? N - 4 : 0)>(L), false);
+    *val = v; *neg = ng;
+    return ok;
+}
+// fixed_field<8, 3> at column A (coordinates) / fixed_field<6, 2> (B-factor)
+template <int A>
+__device__ __forceinline__ bool ig_fixed83(const ig_line& L, float* out) {
+    const uint32_t d0 = ig_b<A + 5>(L) - '0', d1 = ig_b<A + 6>(L) - '0', d2 = ig_b<A + 7>(L) - '0';
+    uint32_t ip; bool neg;
+    const bool ok = ig_intpart<A, 4>(L, &ip, &neg) && ig_b<A + 4>(L) == '.' && d0 <= 9u && d1 <= 9u && d2 <= 9u;
+    const float v = (float)((double)(ip * 1000u + d0 * 100u + d1 * 10u + d2) * 0.001);
+    *out = neg ? -v : v;
+    return ok;
+}
+template <int A>
+__device__ __forceinline__ bool ig_fixed62(const ig_line& L, float* out) {
+    const uint32_t d0 = ig_b<A + 4>(L) - '0', d1 = ig_b<A + 5>(L) - '0';
+    uint32_t ip; bool neg;
+    const bool ok = ig_intpart<A, 3>(L, &ip, &neg) && ig_b<A + 3>(L) == '.' && d0 <= 9u && d1 <= 9u;
+    const float v = (float)((double)(ip * 100u + d0 * 10u + d1) * 0.01);
+    *out = neg ? -v : v;
+    return ok;
+}
+// field_int on characters [A, A + N), N <= 5: spaces on both sides, optional sign, digits
+template <int A, int N>
+__device__ __forceinline__ bool ig_int_reg(const ig_line& L, int32_t* out) {
+    uint32_t c[5] = {ig_b<A>(L), ig_b<A + (N > 1 ? 1 : 0)>(L), ig_b<A + (N > 2 ? 2 : 0)>(L), ig_b<A + (N > 3 ? 3 : 0)>(L), ig_b<A + (N > 4 ? 4 : 0)>(L)};
+    int a = 0, e = N;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (a == i && c[i] == ' ') a = i + 1;
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) if (e == i + 1 && e > a && (c[i] == ' ' || c[i] == '\r')) e = i;
+    bool neg = false, ok = true;
+    int32_t v = 0; int nd = 0; bool sign_seen = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (i < a || i >= e) continue;
+        const uint32_t d = c[i] - '0';
+        if (i == a && (c[i] == '-' || c[i] == '+')) { neg = c[i] == '-'; sign_seen = true; }
+        else if (d <= 9u) { v = v * 10 + (int32_t)d; nd++; }
+        else ok = false;
+    }
+    (void)sign_seen;
+    *out = neg ? -v : v;
+    return ok && nd > 0;
+}
+template <int A, int N>
+__device__ __forceinline__ uint32_t ig_pack_reg(const ig_line& L) {      // field_pack of N <= 4 characters at column A
+    const uint32_t c[4] = {ig_b<A>(L), ig_b<A + (N > 1 ? 1 : 0)>(L), ig_b<A + (N > 2 ? 2 : 0)>(L), ig_b<A + (N > 3 ? 3 : 0)>(L)};
+    int a = 0, e = N;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (a == i && ig_is_space(c[i])) a = i + 1;
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) if (e == i + 1 && e > a && ig_is_space(c[i])) e = i;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (i >= a && i < e) v |= c[i] << (8 * (i - a));     // (i - a): a is a run-time shift of 0, 8, 16 or 24
+    return v;
+}
+
+constexpr int IG_BACK = 256;                      // bytes of the previous chunk kept in front of the staged one (a line that ends in a
+                                                  // chunk starts at most this far back, or is read from global memory)
 struct ingest_lds {
+    alignas(16) uint8_t buf[IG_BACK + IG_CHUNK + 80];   // the staged text: every global byte is loaded once, coalesced
     uint32_t line_end[IG_LINES];          // chunk-relative position of every '\n' of the chunk, in order
     uint32_t akey[64], rkey[32];          // open-addressed name -> code tables (packed name, 0 = empty)
     uint8_t aval[64], rval[32];
 };
 __device__ __forceinline__ uint32_t ig_hash(uint32_t k) { return (k * 0x9E3779B1u) >> 24; }
 
+#ifdef FCZ_IG_TIMING
+// measurement aid (not built into the product): wavefront-cycles in the parts of k_ingest_parse
+__device__ unsigned long long g_ig_timing[8];
+#define IG_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define IG_STAMP(i)
+#endif
 // ---- k_ingest_parse --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict__ text, const uint64_t* __restrict__ file_off, uint32_t n_files,
                                                        uint64_t text_bytes, const uint64_t* __restrict__ abase, ingest_scratch T,
@@ -149,6 +241,9 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         return -1;
     };
 
+#ifdef FCZ_IG_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     const uint64_t f0 = file_off[f], f1 = file_off[f + 1];
     const uint8_t* base = text + f0;
     const uint64_t flen = f1 - f0;
@@ -162,20 +257,31 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     uint64_t line_start = 0;               // file-relative start of the line that is open at the chunk's beginning (uniform)
 
     // one line [ls, le) (file-relative, le excludes the newline) per lane; `on` = this lane has a line
-    auto do_lines = [&](bool on, uint64_t ls, uint64_t le) {
+    // lo = offset of the line's first byte in S.buf, or -1 when it is not staged (it started more than IG_BACK before the chunk)
+    auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo) {
         uint32_t len = on ? (uint32_t)(le - ls) : 0u;
         const uint8_t* p = base + ls;
-        if (on && len && p[len - 1] == '\r') len--;
+        // the staged copy serves every read of the usual line (no global load the parse has to wait for)
+        const bool staged = on && lo >= 0 && (uint32_t)lo + len <= (uint32_t)sizeof(S.buf);
+        if (on && len && (staged ? S.buf[lo + len - 1] : p[len - 1]) == '\r') len--;
+        ig_line L;
+        if (staged) {
+#pragma unroll
+            for (int i = 0; i < 17; i++) __builtin_memcpy(&L.w[i], &S.buf[lo + 4 * i], 4);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 17; i++) L.w[i] = 0;
+        }
         uint32_t w0 = 0, w1 = 0;
-        if (on && len >= 4) w0 = ld_u32(p);
-        if (on && len >= 6) w1 = ld_u16(p + 4);
+        if (on && len >= 4) w0 = staged ? L.w[0] : ld_u32(p);
+        if (on && len >= 6) w1 = staged ? (L.w[1] & 0xffffu) : ld_u16(p + 4);
         const bool is_atom = on && len >= 4 && w0 == 0x4d4f5441u;                             // "ATOM"
         const bool is_het = on && len >= 6 && w0 == 0x41544548u && w1 == 0x4d54u;             // "HETATM"
         const bool rec = is_atom || is_het;
         // ---- title records before the first ATOM (gemmi: HEADER id code, else the TITLE records joined) ----
         if (!seen_atom && !have_header) {
             const unsigned long long m_atom = __ballot(is_atom);
-            const bool is_title = on && !rec && len >= 5 && w0 == 0x4c544954u && p[4] == 'E';   // "TITLE"
+            const bool is_title = on && !rec && len >= 5 && w0 == 0x4c544954u && (staged ? (L.w[1] & 0xffu) : (uint32_t)p[4]) == 'E';   // "TITLE"
             bool is_hdr = false;
             if (on && !rec && len >= 66 && w0 == 0x44414548u && w1 == 0x5245u) {              // "HEADER" with an id code in columns 63-66
                 for (int i = 62; i < 66; i++) if (!ig_is_space(p[i])) is_hdr = true;
@@ -208,7 +314,26 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         bool bad = false;
         if (rec) {
             if (len < 54) bad = true;      // the coordinate columns are not all there: the host parser decides what that means
-            else {
+            else if (staged || f0 + ls + 68 <= text_bytes) {
+                // the line's first 68 bytes in registers (they may reach into the next line: only [0, len) is looked at)
+                if (!staged) {
+#pragma unroll
+                    for (int i = 0; i < 17; i++) L.w[i] = ld_u32(p + 4 * i);
+                }
+                an = ig_pack_reg<12, 4>(L);
+                rn = ig_pack_reg<17, 3>(L);
+                ch = ig_b<21>(L);
+                if (!ig_int_reg<6, 5>(L, &serial) || !ig_int_reg<22, 4>(L, &resseq)) bad = true;
+                if (!ig_fixed83<30>(L, &x) || !ig_fixed83<38>(L, &y) || !ig_fixed83<46>(L, &z)) bad = true;
+                // columns 61-66: all there and in the fixed layout, or blank (to the end of the line), else the host's business
+                const uint32_t cb[6] = {ig_b<60>(L), ig_b<61>(L), ig_b<62>(L), ig_b<63>(L), ig_b<64>(L), ig_b<65>(L)};
+                bool blank = true;
+#pragma unroll
+                for (int i = 0; i < 6; i++) if (60u + (uint32_t)i < len && !ig_is_space(cb[i])) blank = false;
+                if (len >= 66 && ig_fixed62<60>(L, &bf)) {}
+                else if (blank) bf = 0.f;
+                else bad = true;
+            } else {
                 an = ig_pack4(ld_u32(p + 12), 4);
                 rn = ig_pack4(ld_u32(p + 16) >> 8, 3);
                 ch = p[21];
@@ -250,28 +375,60 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         }
     };
 
+    uint64_t c0_staged = 0;
+    // a chunk's dwords, dword (d * 64 + lane) in pre[d]: 256 contiguous bytes per load instruction; zero past the end of the file
+    uint32_t pre[16];
+    auto load_chunk = [&](uint64_t cc) {
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            const uint64_t q = cc + 4ull * (uint64_t)(d * WAVE + lane);
+            uint32_t v = 0;
+            if (q + 4 <= flen) v = ld_u32(base + q);
+            else for (int b = 0; b < 4; b++) if (q + b < flen) v |= (uint32_t)base[q + b] << (8 * b);
+            pre[d] = v;
+        }
+    };
+    load_chunk(0);
+    IG_STAMP(0)
     for (uint64_t c0 = 0; c0 < flen; c0 += IG_CHUNK) {
-        // ---- line ends of the chunk ----
+        // ---- stage the chunk: the tail of the previous window moves to the front, then the chunk's 16 coalesced dwords per lane,
+        //      which were requested while the previous chunk was being parsed ----
+        {
+            uint32_t tail;
+            __builtin_memcpy(&tail, &S.buf[IG_CHUNK + 4 * lane], 4);          // = window bytes [IG_BACK + IG_CHUNK - 256 ...)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_memcpy(&S.buf[4 * lane], &tail, 4);
+#pragma unroll
+            for (int d = 0; d < 16; d++) __builtin_memcpy(&S.buf[IG_BACK + 4 * (d * WAVE + lane)], &pre[d], 4);
+            __builtin_amdgcn_wave_barrier();
+            c0_staged = c0;
+            load_chunk(c0 + IG_CHUNK);                                         // the next chunk is on its way
+        }
+        IG_STAMP(1)
+        // ---- line ends of the chunk: every lane looks at its 64 staged bytes ----
         const uint64_t my = c0 + 64ull * (uint64_t)lane;     // file-relative start of this lane's 64 bytes
         uint32_t t[16];
         uint32_t cnt = 0;
-        if (my < flen) {
-            const bool full = my + 64 <= flen;
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(&S.buf[IG_BACK + 64 * lane]);
 #pragma unroll
-            for (int d = 0; d < 16; d++) {
-                uint32_t v;
-                if (full) v = ld_u32(base + my + 4 * d);
-                else { v = 0; for (int b = 0; b < 4; b++) { const uint64_t q = my + 4 * d + b; if (q < flen) v |= (uint32_t)base[q] << (8 * b); } }
-                const uint32_t xz = v ^ 0x0a0a0a0au;
-                t[d] = ~(((xz & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xz | 0x7f7f7f7fu);     // 0x80 in every byte that is '\n'
-                cnt += (uint32_t)__builtin_popcount(t[d]);
+            for (int q4 = 0; q4 < 4; q4++) {
+                const uint4 v4 = src[q4];
+                const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int d = 4 * q4 + k;
+                    const uint32_t xz = vv[k] ^ 0x0a0a0a0au;
+                    uint32_t m = ~(((xz & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xz | 0x7f7f7f7fu);     // 0x80 in every byte that is '\n'
+                    // bytes past the end of the file were staged as zero: never a line end
+                    t[d] = (my + 4 * d < flen) ? m : 0u;
+                    cnt += (uint32_t)__builtin_popcount(t[d]);
+                }
             }
-        } else {
-#pragma unroll
-            for (int d = 0; d < 16; d++) t[d] = 0;
         }
         uint32_t total;
         uint32_t ord = wave_excl_scan_dpp(cnt, &total);
+        IG_STAMP(2)
         // chunks with more line ends than the table holds (blank-line runs) go through it in rounds
         for (uint32_t r0 = 0; r0 < total || r0 == 0; r0 += IG_LINES) {
             uint32_t o = ord;
@@ -285,20 +442,26 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            IG_STAMP(3)
             const uint32_t n_here = total - r0 < (uint32_t)IG_LINES ? total - r0 : (uint32_t)IG_LINES;
             for (uint32_t k0 = 0; k0 < n_here; k0 += WAVE) {
                 const uint32_t k = k0 + (uint32_t)lane;
                 const bool on = k < n_here;
                 const uint64_t le = on ? c0 + S.line_end[k] : 0;
                 const uint64_t ls = on ? (k == 0 ? line_start : c0 + S.line_end[k - 1] + 1) : 0;
-                do_lines(on, ls, le);
+                const long long rel = (long long)ls - (long long)c0;                 // >= -IG_BACK: the line's start is staged
+                do_lines(on, ls, le, (on && rel >= -(long long)IG_BACK) ? (int)(IG_BACK + rel) : -1);
             }
             if (n_here) line_start = c0 + S.line_end[n_here - 1] + 1;
             __builtin_amdgcn_wave_barrier();
+            IG_STAMP(4)
             if (total == 0) break;
         }
     }
-    if (line_start < flen) do_lines(lane == 0, line_start, flen);     // a last line without a line end
+    if (line_start < flen) {     // a last line without a line end
+        const long long rel = (long long)line_start - (long long)c0_staged;
+        do_lines(lane == 0, line_start, flen, rel >= -(long long)IG_BACK ? (int)(IG_BACK + rel) : -1);
+    }
     if (lane == 0) {
         // title = HEADER id, else the TITLE parts joined and stripped (the parts were stripped one by one; joined with ' ')
         uint32_t a = 0, e = tlen;
@@ -311,6 +474,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         n_kept[f] = status == FCZ_OK ? kept : 0u;
         file_status[f] = status;
     }
+#ifdef FCZ_IG_TIMING
+    IG_STAMP(5)
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_ig_timing[i], tacc[i]);
+#endif
 }
 
 // ---- k_ingest_frags -----------------------------------------------------------------------------------------------------

@@ -1018,6 +1018,9 @@ def main():
         traffic, traffic_src = measured_traffic(dom, R, -1 if args.mixed else n_res)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_note": "FETCH_SIZE / WRITE_SIZE count requests that leave the L2 towards the fabric, hits in the 256 MB Infinity Cache "
+                                    "included (MI355X_MICROARCH.md); k_backbone's per-group ring (~190 MB live) fits that cache, so for it this is an "
+                                    "upper bound on HBM bytes, not a measurement of them",
                     "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
                     "kernel_ms": {k: round(v, 4) for k, v in ktime.items()},
                     "per_kernel_GBs": {k: round(b / (t * 1e-3) / 1e9, 1) if t else None for k, (b, t) in kern.items()},

@@ -1016,11 +1016,28 @@ def main():
         by, ms = kern[dom]
         ach = by / (ms * 1e-3) / 1e9 if ms else 0.0
         traffic, traffic_src = measured_traffic(dom, R, -1 if args.mixed else n_res)
+        # the bound that actually holds (SURVEY.md section 8d "secondary bound to report honestly"): VALU issue. Instruction counts per
+        # residue and the VALU-active share of a wavefront's cycles come from the committed PMC passes (they cannot be collected
+        # inside the timed region); the SIMD-cycles per VALU wave-instruction use this run's own kernel time.
+        valu = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                tk = json.load(fh)["kernels"][dom]
+            occ = {"k_backbone": 2, "k_compress_angles_w": 3, "k_compress_pack": 3, "k_sidechain": 4}.get(dom)
+            n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            valu = {"bound": "VALU issue", "valu_wave_insts_per_residue": tk["valu_wave_insts_per_residue"],
+                    "simd_cycles_per_valu_wave_inst": round(ms * 1e-3 * 2.4e9 * n_simd / (tk["valu_wave_insts_per_residue"] * R), 2) if ms else None,
+                    "issue_cost_of_the_mix_cycles": "2.9 (f32 add/mul/fma) ... 4.6 (f64, compares, 3-operand integer) ... 16 (f64 rsq): profiles/r3_valu_rates.txt",
+                    "valu_active_share_of_simd_cycles": round(tk["valu_active_share_of_wave_cycles"] * occ, 3) if occ else None,
+                    "resident_wavefronts_per_simd": occ, "source": "profiles/traffic.json (r3_v1 PMC passes) + this run's HIP-event time; 2.4 GHz"}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_note": "FETCH_SIZE / WRITE_SIZE count requests that leave the L2 towards the fabric, hits in the 256 MB Infinity Cache "
                                     "included (MI355X_MICROARCH.md); k_backbone's per-group ring (~190 MB live) fits that cache, so for it this is an "
                                     "upper bound on HBM bytes, not a measurement of them",
+                    "secondary_bound": valu,
                     "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
                     "kernel_ms": {k: round(v, 4) for k, v in ktime.items()},
                     "per_kernel_GBs": {k: round(b / (t * 1e-3) / 1e9, 1) if t else None for k, (b, t) in kern.items()},

@@ -48,5 +48,10 @@ for k, v in d.items():
     if "fcz::k_" not in k or "FETCH_SIZE" not in v: continue
     out["kernels"][short(k)] = {"fetch_bytes_per_residue": round(2 * v["FETCH_SIZE"] * 1024 / R, 2),
                                         "write_bytes_per_residue": round(v.get("WRITE_SIZE", 0.0) * 1024 / R, 2)}
+    if "SQ_WAVE_CYCLES" in v:
+        # the other bound: VALU issue. Share of its lifetime a wavefront spends issuing VALU instructions, and the
+        # VALU wave-instructions per residue (x resident wavefronts per SIMD = share of the SIMD's cycles that issue VALU work)
+        out["kernels"][short(k)]["valu_active_share_of_wave_cycles"] = round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+        out["kernels"][short(k)]["valu_wave_insts_per_residue"] = round(v.get("SQ_INSTS_VALU", 0.0) / R, 3)
 if out["kernels"]:
     json.dump(out, open(os.path.join("gpurun_out", "prof_" + tag, "traffic.json"), "w"), indent=1)

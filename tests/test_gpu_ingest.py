@@ -213,3 +213,55 @@ def test_text_to_fcz_in_one_call(codec, golden):
     for i, n in enumerate(cases):
         rec = r["blob"][int(r["off"][i]):int(r["off"][i + 1])].tobytes()
         assert no_title(rec) == no_title(z[f"{n}/fcz"].tobytes()), n
+
+
+def test_device_ingest_fuzz_never_parses_differently(codec, golden):
+    """seeded mutations of a PDB file (characters replaced anywhere in ATOM records, lines cut, duplicated, swapped, tabs and
+    lower case, HETATM / ANISOU / junk lines spliced in): whenever the device takes a file (file_status 0) its batch, names and
+    refusals equal the host parser's; everything else it hands back or reports as atom-free -- it never parses differently"""
+    z, _ = golden
+    base = _pdb_text(z, "syn:len26").splitlines()
+    rng = np.random.default_rng(20260927)
+    alphabet = list("0123456789 .-+ANCOHETMabcxyz\t*")
+    texts, names = [], []
+    for i in range(400):
+        lines = list(base)
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 8))
+            j = int(rng.integers(0, len(lines)))
+            l = lines[j]
+            if kind == 0 and l:                       # one character replaced
+                k = int(rng.integers(0, len(l))); lines[j] = l[:k] + alphabet[int(rng.integers(0, len(alphabet)))] + l[k + 1:]
+            elif kind == 1:                           # line cut short
+                lines[j] = l[:int(rng.integers(0, len(l) + 1))]
+            elif kind == 2:                           # duplicated (an alternative position when it is an ATOM)
+                lines.insert(j, l)
+            elif kind == 3 and j + 1 < len(lines):    # swapped with its neighbour
+                lines[j], lines[j + 1] = lines[j + 1], lines[j]
+            elif kind == 4:                           # chain id changed from here on
+                ch = "BCD"[int(rng.integers(0, 3))]
+                lines[j:] = [x[:21] + ch + x[22:] if x.startswith("ATOM") and len(x) > 22 else x for x in lines[j:]]
+            elif kind == 5:                           # residue numbers shifted from here on (a gap)
+                lines[j:] = [x[:22] + "%4d" % (int(x[22:26]) + 3) + x[26:] if x.startswith("ATOM") and x[22:26].strip().lstrip("-").isdigit() else x for x in lines[j:]]
+            elif kind == 6:                           # foreign records
+                lines.insert(j, ["HETATM 9001  O   HOH A 900      11.000  12.000  13.000  1.00 30.00           O  ",
+                                 "ANISOU    1  N   MET A   1     2406   1892   1614    198    519   -328       N  ",
+                                 "TITLE     SOMETHING", "junk", ""][int(rng.integers(0, 5))])
+            else:                                     # line removed
+                del lines[j]
+        texts.append(("\n".join(lines) + ("\n" if rng.integers(0, 4) else "")).encode("latin-1"))
+        names.append(f"fz{i:03d}.pdb")
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    ok = [i for i in range(len(texts)) if fstat[i] == 0]
+    assert len(ok) > 200, "the fuzz should leave most files in the fixed layout"
+    remap = {f: k for k, f in enumerate(ok)}
+    exp, exp_names, exp_file, exp_ref = _host_expect([texts[i] for i in ok], [names[i] for i in ok])
+    got_names = [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)]
+    assert got_names == exp_names
+    assert [remap[int(f)] for f in cfile] == exp_file
+    _same_batch(b, exp)
+    assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
+    # files reported as atom-free really have no ATOM / HETATM record the host parser would keep
+    for i in range(len(texts)):
+        if fstat[i] == 4:
+            assert len(parse_pdb(texts[i].decode("latin-1"), hetatm=True)) == 0, names[i]

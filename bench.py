@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--e2e-passes", type=int, default=24,
                     help="times every end_to_end run of the GPU host walks the files (steady state: 24 x 8192 = 196 608 file reads per run; "
                          "the reference's loops, which have no start-up, walk them min(passes, 4) times)")
+    ap.add_argument("--e2e-workers", type=int, default=0, help="--workers-per-gpu of the end_to_end compress runs (0 = the host's default, 2)")
     ap.add_argument("--host-chains", type=int, default=65536,
                     help="chains pushed through the host-pointer entry points for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--numerics", choices=("exact", "fast"), default="exact",
@@ -422,7 +423,8 @@ def end_to_end_leg(args, codec, w, dev):
 
         # ---- compress: device ingest, and round 2's host-parse pipeline beside it ----
         comp = {}
-        runs = [run_host(["compress", "-d", "-y", "-t", str(t), "--gpus", "1", "--json-stats", "-f", lst, os.path.join(tmp, f"db{t}")]) for t in tcounts]
+        wpg = ["--workers-per-gpu", str(args.e2e_workers)] if args.e2e_workers else []
+        runs = [run_host(["compress", "-d", "-y", "-t", str(t), "--gpus", "1", *wpg, "--json-stats", "-f", lst, os.path.join(tmp, f"db{t}")]) for t in tcounts]
         comp["gpu_host"] = summarise(runs, "input_bytes", "host/foldcomp-hip compress -d -t <threads> --gpus 1 -f <list> <db>   (structure ingest on the device)")
         comp["gpu_host"]["link_GB_per_s"] = comp["gpu_host"]["steady_text_GB_per_s"]     # every text byte crosses the link once; the FCZ bytes coming back are 2.5 % of it
         runs_h = [run_host(["compress", "-d", "-y", "-t", str(eff), "--host-parse", "--gpus", "1", "--json-stats", "-f", lst, os.path.join(tmp, "dbh")])]

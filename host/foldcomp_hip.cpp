@@ -886,11 +886,40 @@ template <class T> struct JobQueue {           // bounded hand-over between the 
     void close() { std::lock_guard<std::mutex> l(m); closed = true; cv_get.notify_all(); }
 };
 
-struct Sequencer {                             // byte offset of a job's slice = total size of all earlier jobs
-    std::mutex m; std::condition_variable cv; size_t next = 0; uint64_t pos = 0;
-    uint64_t claim(size_t job, uint64_t bytes) {
+// Jobs take their turn in job order: a job's byte range in the data file = the total size of all earlier jobs, its keys = the
+// records of all earlier jobs, and -- because the turns come in order -- its .index / .lookup lines are appended right there
+// (free_writer's formats, src/database_writer.cpp:59-73). Nothing per record is kept in memory: an index of 214 M entries is
+// streamed, not collected and sorted at the end.
+struct Sequencer {
+    std::mutex m; std::condition_variable cv; size_t next = 0; uint64_t pos = 0; long long key = 0;
+    FILE* fi = nullptr; FILE* fl = nullptr;
+    bool open_index(const std::string& db) {
+        fi = fopen((db + ".index").c_str(), "w"); fl = fopen((db + ".lookup").c_str(), "w");
+        return fi && fl;
+    }
+    // lens / names: the job's records in the order they lie in its byte range (both null: a job without records)
+    uint64_t claim(size_t job, uint64_t bytes, const std::vector<uint64_t>* lens = nullptr, const std::vector<std::string>* names = nullptr) {
         std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return next == job; });
-        const uint64_t at = pos; pos += bytes; next++; cv.notify_all(); return at;
+        const uint64_t at = pos;
+        if (lens && names && fi && fl) {
+            uint64_t o = at;
+            for (size_t q = 0; q < lens->size(); q++) {
+                fprintf(fi, "%lld\t%llu\t%llu\n", key, (unsigned long long)o, (unsigned long long)(*lens)[q]);
+                fprintf(fl, "%lld\t%s\t0\n", key, (*names)[q].c_str());
+                key++; o += (*lens)[q];
+            }
+        }
+        pos += bytes; next++; cv.notify_all(); return at;
+    }
+    // closes the index files; `keep` false (a failed run): they and the data file are removed -- a database without its index
+    // is unusable and one with a partial index looks complete
+    void finish(const std::string& db, bool keep) {
+        if (fi) fclose(fi);
+        if (fl) fclose(fl);
+        fi = fl = nullptr;
+        if (!keep) { unlink(db.c_str()); unlink((db + ".index").c_str()); unlink((db + ".lookup").c_str()); unlink((db + ".dbtype").c_str()); return; }
+        std::ofstream t(db + ".dbtype", std::ios::binary);
+        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
     }
 };
 
@@ -924,10 +953,9 @@ int run_compress(const Options& o) {
         if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
     } else if (!single) make_dir(output);
 
-    struct Row { size_t job, pos; uint64_t off, len; std::string name; };
-    std::vector<std::vector<Row>> rows(n_workers);
     JobQueue<CompressJob> queue((size_t)n_workers + 2);
     Sequencer seq;
+    if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
     std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0};
     std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);   // ctx_ready: seconds after the start until the worker had its ctx
@@ -983,22 +1011,22 @@ int run_compress(const Options& o) {
             }
             try {
                 uint64_t packed = 0;                                      // bytes of the records that compressed
-                std::vector<uint64_t> at_rel(kept.size(), 0);
+                std::vector<uint64_t> lens; std::vector<std::string> names;
                 for (size_t q = 0; q < kept.size(); q++) {
                     if (status[q] != FCZ_OK) continue;
                     const uint64_t len = off[q + 1] - off[q];
                     if (o.db && packed != off[q]) memmove(blob.data() + packed, blob.data() + off[q], len);
-                    at_rel[q] = o.db ? packed : off[q];
+                    if (o.db) { lens.push_back(len); names.push_back(job.frags[kept[q]].db_name); }
                     packed += len;
                 }
-                const uint64_t at = o.db ? seq.claim(job.index, packed) : 0;
+                const uint64_t at = o.db ? seq.claim(job.index, packed, &lens, &names) : 0;
                 if (o.db && packed) pwrite_all(db_fd, blob.data(), packed, at);
                 for (size_t q = 0; q < kept.size(); q++) {
                     const Fragment& f = job.frags[kept[q]];
                     if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
                     n_frag_ok++; n_res += v.res_off[q + 1] - v.res_off[q]; n_bytes += off[q + 1] - off[q];
                     n_atoms += v.atom_off[v.res_off[q + 1]] - v.atom_off[v.res_off[q]];
-                    if (o.db) { rows[w].push_back({job.index, q, at + at_rel[q], off[q + 1] - off[q], f.db_name}); continue; }
+                    if (o.db) continue;
                     const std::string path = single ? output : output + "/" + f.out_name;
                     write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
                 }
@@ -1043,20 +1071,10 @@ int run_compress(const Options& o) {
     const double t_joined = std::chrono::duration<double>(clk::now() - t_start).count();
 
     // ---- index: rows of all workers in job order, keys numbered over the records that made it ----
-    if (o.db && hard_fail) {
-        // a database without its index is unusable and one with a partial index looks complete: leave neither behind
-        close(db_fd); unlink(output.c_str());
-        fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
-    } else if (o.db) {
+    if (o.db) {
         close(db_fd);
-        std::vector<Row> all;
-        for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
-        std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.job != b.job ? a.job < b.job : a.pos < b.pos; });
-        std::ofstream fi(output + ".index"), fl(output + ".lookup");
-        long long key = 0;
-        for (const Row& r : all) { fi << key << "\t" << r.off << "\t" << r.len << "\n"; fl << key << "\t" << r.name << "\t0\n"; key++; }
-        std::ofstream t(output + ".dbtype", std::ios::binary);
-        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+        seq.finish(output, !hard_fail);
+        if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -1111,10 +1129,9 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
         if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
     } else make_dir(output);
 
-    struct Row { size_t job, pos; uint64_t off, len; std::string name; };
-    std::vector<std::vector<Row>> rows(n_workers);
     JobQueue<TextJob> queue((size_t)n_workers + 1);
     Sequencer seq;
+    if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
     std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0}, n_host_files{0};
     std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);
@@ -1225,10 +1242,10 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
                     packed.resize(total);
                     uint64_t pos = 0;
                     for (const Rec& r : recs) { memcpy(packed.data() + pos, r.p, r.len); pos += r.len; }
-                    const uint64_t at = seq.claim(job.index, total);
+                    std::vector<uint64_t> lens(recs.size()); std::vector<std::string> names(recs.size());
+                    for (size_t q = 0; q < recs.size(); q++) { lens[q] = recs[q].len; names[q] = recs[q].db_name; }
+                    const uint64_t at = seq.claim(job.index, total, &lens, &names);
                     if (total) pwrite_all(db_fd, packed.data(), total, at);
-                    pos = 0;
-                    for (size_t q = 0; q < recs.size(); q++) { rows[w].push_back({job.index, q, at + pos, recs[q].len, recs[q].db_name}); pos += recs[q].len; }
                 } else {
                     for (const Rec& r : recs) write_out(output + "/" + r.out_name, (const char*)r.p, r.len, o.overwrite);
                 }
@@ -1303,19 +1320,10 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
     const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
     for (std::thread& t : workers) t.join();
     const double t_joined = std::chrono::duration<double>(clk::now() - t_start).count();
-    if (o.db && hard_fail) {
-        close(db_fd); unlink(output.c_str());
-        fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
-    } else if (o.db) {
+    if (o.db) {
         close(db_fd);
-        std::vector<Row> all;
-        for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
-        std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.job != b.job ? a.job < b.job : a.pos < b.pos; });
-        std::ofstream fi(output + ".index"), fl(output + ".lookup");
-        long long key = 0;
-        for (const Row& r : all) { fi << key << "\t" << r.off << "\t" << r.len << "\n"; fl << key << "\t" << r.name << "\t0\n"; key++; }
-        std::ofstream t(output + ".dbtype", std::ios::binary);
-        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+        seq.finish(output, !hard_fail);
+        if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -1401,10 +1409,9 @@ int run_decompress(const Options& o) {
         if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
     } else if (!single) make_dir(output);
 
-    struct Row { size_t job, pos; uint64_t off, len; std::string name; };
-    std::vector<std::vector<Row>> rows(n_workers);
     JobQueue<DecompressJob> queue((size_t)n_workers + 2);
     Sequencer seq;
+    if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
     std::atomic<uint64_t> n_ok{0}, n_text{0}, n_fcz{0}, n_res{0};
     std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);
@@ -1426,7 +1433,13 @@ int run_decompress(const Options& o) {
             if (rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) n_good += status[i] == FCZ_OK ? 1u : 0u;
             // PDB text in a database carries the MMseqs terminator (src/main.cpp:659): one NUL per record
             const uint64_t bytes = rc == FCZ_OK ? text_off[n] + (o.db ? n_good : 0) : 0;
-            const uint64_t at = o.db ? seq.claim(job.index, bytes) : 0;     // every job claims, also a failed one
+            std::vector<uint64_t> lens; std::vector<std::string> dbnames;
+            if (o.db && rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) {
+                if (status[i] != FCZ_OK) continue;
+                std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
+                lens.push_back(text_off[i + 1] - text_off[i] + 1); dbnames.push_back(stem);
+            }
+            const uint64_t at = o.db ? seq.claim(job.index, bytes, &lens, &dbnames) : 0;     // every job claims, also a failed one
             if (rc == FCZ_OK) {
                 if (text.size() < text_off[n]) text.resize(text_off[n] + text_off[n] / 8);     // grows, never shrinks (a resize zero-fills what it adds)
                 const auto t1 = clk::now();
@@ -1445,8 +1458,6 @@ int run_decompress(const Options& o) {
                     for (uint32_t i = 0; i < n; i++) {
                         if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
                         const uint64_t len = text_off[i + 1] - text_off[i];
-                        std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
-                        rows[w].push_back({job.index, good.size(), at + pos, len + 1, stem});
                         good.push_back(i); dst.push_back(at + pos);
                         pos += len + 1;
                     }
@@ -1527,19 +1538,10 @@ int run_decompress(const Options& o) {
     }
     const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
     for (std::thread& t : workers) t.join();
-    if (o.db && hard_fail) {
-        close(db_fd); unlink(output.c_str());
-        fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
-    } else if (o.db) {
+    if (o.db) {
         close(db_fd);
-        std::vector<Row> all;
-        for (auto& r : rows) for (Row& x : r) all.push_back(std::move(x));
-        std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.job != b.job ? a.job < b.job : a.pos < b.pos; });
-        std::ofstream fi(output + ".index"), fl(output + ".lookup");
-        long long key = 0;
-        for (const Row& r : all) { fi << key << "\t" << r.off << "\t" << r.len << "\n"; fl << key << "\t" << r.name << "\t0\n"; key++; }
-        std::ofstream t(output + ".dbtype", std::ios::binary);
-        const int32_t twelve = 12; t.write((const char*)&twelve, 4);
+        seq.finish(output, !hard_fail);
+        if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();

@@ -26,7 +26,7 @@ import numpy as np
 from . import fczfile
 from .api import decompress_many, default_codec
 from .database import DatabaseReader, DatabaseWriter
-from .structure import (AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb,
+from .structure import (AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb, parse_pdb_gemmi,
                         remove_alternative_position)
 
 VERSION = "0.1.0"
@@ -121,11 +121,10 @@ def load_structure(name: str, data: bytes) -> Tuple[AtomTable, str]:
         data = gzip.decompress(data); base_nogz = base[:-3]
     else:
         base_nogz = base
-    text = data.decode("latin-1")
     if base_nogz.endswith(".cif"):
-        t, title = _parse_cif(text)
+        t, title = _parse_cif(data.decode("latin-1"))
     else:
-        t, title = parse_pdb(text, hetatm=True), _pdb_title(text)
+        t, title = parse_pdb_gemmi(data)       # the command line reads PDB text the way the reference's does: through gemmi's rules
     return t, (title if title else base)
 
 

@@ -111,7 +111,8 @@ __device__ __forceinline__ bool ig_int(const uint8_t* f, int n, int32_t* out) {
 // ---- the same field readers on a line held in registers (17 dwords = columns 1-68), every index a compile-time constant:
 //      no dependent byte loads (the per-byte global loads of the readers above, each waiting for the compare before it, were
 //      what the parse kernel spent its time on) ----
-struct ig_line { uint32_t w[17]; };
+constexpr int IG_LINE_DW = 19;                   // columns 1-76
+struct ig_line { uint32_t w[IG_LINE_DW]; };
 template <int I> __device__ __forceinline__ uint32_t ig_b(const ig_line& L) { return (L.w[I >> 2] >> (8 * (I & 3))) & 0xffu; }
 // right-aligned integer part of a fixed field, characters [A, A + N): spaces, one optional '-', at least one digit
 template <int A, int N>
@@ -250,116 +251,159 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     const uint64_t A0 = abase[f];
     uint8_t* tbuf = titles + (size_t)f * IG_TITLE_CAP;
     uint32_t kept = 0;                     // atoms written so far (uniform)
-    uint32_t last_name = 0; bool have_last = false;       // name of the last ATOM / HETATM record seen (uniform)
-    bool seen_atom = false, have_header = false;          // title state (uniform)
-    uint32_t tlen = 0; bool first_part = true;
+    uint32_t last_name = 0; bool have_last = false;       // the last ATOM / HETATM record seen (uniform): its atom name,
+    int32_t last_seq = 0; uint32_t last_rn = 0, last_seg = 0, last_icch = 0;   // its residue (number, name, segment, insertion code | chain << 8)
+    uint32_t tlen = 0, hdr_id = 0, hdr_n = 0;             // title state (uniform): TITLE text so far, the last HEADER id code
+    bool ended = false;                                   // an END record was read
+    bool seen_model = false, seen_endm = false;           // MODEL / ENDMDL records read
     int32_t status = FCZ_OK;
     uint64_t line_start = 0;               // file-relative start of the line that is open at the chunk's beginning (uniform)
 
     // one line [ls, le) (file-relative, le excludes the newline) per lane; `on` = this lane has a line
-    // lo = offset of the line's first byte in S.buf, or -1 when it is not staged (it started more than IG_BACK before the chunk)
-    auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo) {
-        uint32_t len = on ? (uint32_t)(le - ls) : 0u;
+    // One line [ls, le) (file-relative, le excludes the line end) per lane; `on` = this lane has a line; lo = offset of its first
+    // byte in S.buf, or -1 when it is not staged (it started more than IG_BACK before the chunk); has_nl = a line end follows it.
+    // The rules are gemmi's (lib/gemmi/pdb.hpp:262-365, restated in foldcomp_amd/structure.py parse_pdb_gemmi): records are
+    // matched on four letters case-insensitively, END stops the reading, `len` below is the reader's line length (line end
+    // included, at most 120). What the fixed-column fast path cannot promise to read as that reader would -- a field outside the
+    // fixed layout, a two-character chain name, ANISOU / MODEL records, a residue whose lines are apart (the reader regroups them)
+    // -- marks the file for the host, which implements every rule.
+    auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo, bool has_nl) {
+        if (ended) return;
+        const bool seen_endm_before = seen_endm;
+        const uint32_t raw = on ? (uint32_t)(le - ls) : 0u;
+        const uint32_t glen = raw + (has_nl ? 1u : 0u) < 120u ? raw + (has_nl ? 1u : 0u) : 120u;       // gemmi's len
         const uint8_t* p = base + ls;
         // the staged copy serves every read of the usual line (no global load the parse has to wait for)
-        const bool staged = on && lo >= 0 && (uint32_t)lo + len <= (uint32_t)sizeof(S.buf);
+        const bool staged = on && lo >= 0 && (uint32_t)lo + 80u <= (uint32_t)sizeof(S.buf) && (uint32_t)lo + raw <= (uint32_t)sizeof(S.buf);
+        uint32_t len = raw;
         if (on && len && (staged ? S.buf[lo + len - 1] : p[len - 1]) == '\r') len--;
         ig_line L;
         if (staged) {
 #pragma unroll
-            for (int i = 0; i < 17; i++) __builtin_memcpy(&L.w[i], &S.buf[lo + 4 * i], 4);
+            for (int i = 0; i < IG_LINE_DW; i++) __builtin_memcpy(&L.w[i], &S.buf[lo + 4 * i], 4);
         } else {
 #pragma unroll
-            for (int i = 0; i < 17; i++) L.w[i] = 0;
+            for (int i = 0; i < IG_LINE_DW; i++) L.w[i] = 0;
+            if (on && raw >= 4) L.w[0] = ld_u32(p);
+            if (on && raw >= 8) L.w[1] = ld_u32(p + 4);
         }
-        uint32_t w0 = 0, w1 = 0;
-        if (on && len >= 4) w0 = staged ? L.w[0] : ld_u32(p);
-        if (on && len >= 6) w1 = staged ? (L.w[1] & 0xffffu) : ld_u16(p + 4);
-        const bool is_atom = on && len >= 4 && w0 == 0x4d4f5441u;                             // "ATOM"
-        const bool is_het = on && len >= 6 && w0 == 0x41544548u && w1 == 0x4d54u;             // "HETATM"
-        const bool rec = is_atom || is_het;
-        // ---- title records before the first ATOM (gemmi: HEADER id code, else the TITLE records joined) ----
-        if (!seen_atom && !have_header) {
-            const unsigned long long m_atom = __ballot(is_atom);
-            const bool is_title = on && !rec && len >= 5 && w0 == 0x4c544954u && (staged ? (L.w[1] & 0xffu) : (uint32_t)p[4]) == 'E';   // "TITLE"
-            bool is_hdr = false;
-            if (on && !rec && len >= 66 && w0 == 0x44414548u && w1 == 0x5245u) {              // "HEADER" with an id code in columns 63-66
-                for (int i = 62; i < 66; i++) if (!ig_is_space(p[i])) is_hdr = true;
+        // the record name as the reader compares it: four characters, case folded, nothing beyond the line (a short last line)
+        const uint32_t nvis = raw + (has_nl ? 1u : 0u);
+        const uint32_t w0 = on ? (nvis >= 4 ? L.w[0] : (L.w[0] & ((1u << (8 * nvis)) - 1u))) : 0u;
+        const uint32_t up4 = w0 & ~0x20202020u;
+        const bool rec = on && (up4 == (0x4d4f5441u & ~0x20202020u) || up4 == (0x41544548u & ~0x20202020u));     // ATOM, HETA(TM)
+        const bool is_end = on && !rec && (up4 & 0x00ffffffu) == 0x00444e45u && ((up4 >> 24) & 0xf0u) == 0u;          // END, not ENDMDL
+        // records this path does not model: ANISOU (attached to atoms, can fail the file), data_
+        const bool foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_'));
+        // MODEL / ENDMDL: one MODEL record before the first atom and ENDMDL records after the last one (the single-model file every
+        // predicted structure is) change nothing; atoms after an ENDMDL or a second MODEL start new models, with rules of their own
+        const bool is_model = on && !rec && up4 == (0x45444f4du & ~0x20202020u);
+        const bool is_endm = on && !rec && up4 == (0x4d444e45u & ~0x20202020u);
+        const unsigned long long m_end = __ballot(is_end);
+        const int end_lane = m_end ? __builtin_ctzll(m_end) : 64;
+        const bool live = on && lane < end_lane;                 // what follows an END record is not read
+        if (__any(live && foreign)) status = FCZ_INGEST_HOST_FIELD;
+        const unsigned long long m_model = __ballot(live && is_model), m_endm = __ballot(live && is_endm);
+        // ---- title: the last HEADER record's id code (columns 63-66, right-trimmed), else the TITLE records' text concatenated ----
+        {
+            const bool is_title = live && !rec && up4 == (0x4c544954u & ~0x20202020u) && glen > 10;
+            bool is_hdr = false; uint32_t hid = 0, hn = 0;
+            if (live && !rec && up4 == (0x44414548u & ~0x20202020u) && glen > 66) {
+                if (staged) {
+                    uint32_t c[4] = {ig_b<62>(L), ig_b<63>(L), ig_b<64>(L), ig_b<65>(L)};
+                    hn = 4; while (hn && (c[hn - 1] == ' ' || c[hn - 1] == '\r' || c[hn - 1] == '\n' || c[hn - 1] == '\t')) hn--;
+                    for (uint32_t i = 0; i < hn; i++) hid |= c[i] << (8 * i);
+                    is_hdr = hn != 0;
+                } else status = FCZ_INGEST_HOST_TITLE;
             }
             unsigned long long m_t = __ballot(is_title || is_hdr);
-            const int first_atom_lane = m_atom ? __builtin_ctzll(m_atom) : 64;
             while (m_t) {
                 const int l = __builtin_ctzll(m_t); m_t &= m_t - 1;
-                if (l > first_atom_lane || have_header) break;
                 const bool hdr = __shfl((int)is_hdr, l, WAVE) != 0;
+                if (hdr) { hdr_id = (uint32_t)__shfl((int)hid, l, WAVE); hdr_n = (uint32_t)__shfl((int)hn, l, WAVE); continue; }
                 uint32_t add = 0;
                 if (lane == l) {
-                    int a = hdr ? 62 : 10, e = hdr ? 66 : (len < 80u ? (int)len : 80);
-                    if (a > e) a = e;
-                    while (a < e && ig_is_space(p[a])) a++;
-                    while (e > a && ig_is_space(p[e - 1])) e--;
-                    uint32_t at = hdr ? 0u : tlen;
-                    if (!hdr && !first_part) { if (at < (uint32_t)IG_TITLE_CAP) tbuf[at] = ' '; at++; }
-                    for (int i = a; i < e; i++, at++) if (at < (uint32_t)IG_TITLE_CAP) tbuf[at] = p[i];
+                    int e = (int)glen - 1;                        // the reader drops the line's last character (its line end)
+                    auto at_ = [&](int i) -> uint32_t { return staged ? (uint32_t)S.buf[lo + i] : (uint32_t)p[i]; };
+                    while (e > 10) { const uint32_t c = at_(e - 1); if (c == ' ' || c == '\r' || c == '\n' || c == '\t') e--; else break; }
+                    uint32_t at = tlen;
+                    for (int i = 10; i < e; i++, at++) if (at < (uint32_t)IG_TITLE_CAP) tbuf[at] = (uint8_t)at_(i);
                     add = at;
                 }
                 tlen = (uint32_t)__shfl((int)add, l, WAVE);
-                first_part = false;
-                if (hdr) have_header = true;
             }
-            if (m_atom) seen_atom = true;
         }
         // ---- ATOM / HETATM records ----
-        uint32_t an = 0, rn = 0; int32_t serial = 0, resseq = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; uint32_t ch = ' ';
+        const bool arec = rec && live;
+        uint32_t an = 0, rn = 0, seg = 0, icode = 0; int32_t serial = 0, resseq = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; uint32_t ch = ' ';
         bool bad = false;
-        if (rec) {
-            if (len < 54) bad = true;      // the coordinate columns are not all there: the host parser decides what that means
-            else if (staged || f0 + ls + 68 <= text_bytes) {
-                // the line's first 68 bytes in registers (they may reach into the next line: only [0, len) is looked at)
-                if (!staged) {
-#pragma unroll
-                    for (int i = 0; i < 17; i++) L.w[i] = ld_u32(p + 4 * i);
-                }
+        if (arec) {
+            // the coordinate columns must all be there (the reader fails a file with a shorter record: the host reports it)
+            if (!staged || len < 54 || glen < 55) bad = true;
+            else {
                 an = ig_pack_reg<12, 4>(L);
                 rn = ig_pack_reg<17, 3>(L);
                 ch = ig_b<21>(L);
+                if (ig_b<20>(L) != ' ' || (ch != ' ' && ig_is_space(ch))) bad = true;        // a two-character chain name
+                icode = ig_b<26>(L);
                 if (!ig_int_reg<6, 5>(L, &serial) || !ig_int_reg<22, 4>(L, &resseq)) bad = true;
                 if (!ig_fixed83<30>(L, &x) || !ig_fixed83<38>(L, &y) || !ig_fixed83<46>(L, &z)) bad = true;
-                // columns 61-66: all there and in the fixed layout, or blank (to the end of the line), else the host's business
-                const uint32_t cb[6] = {ig_b<60>(L), ig_b<61>(L), ig_b<62>(L), ig_b<63>(L), ig_b<64>(L), ig_b<65>(L)};
-                bool blank = true;
+                // B-factor: 20 when the line ends before column 65 (the reader's default); the fixed layout; six blanks = 0
+                if (glen <= 64) bf = 20.0f;
+                else if (len >= 66 && ig_fixed62<60>(L, &bf)) {}
+                else {
+                    bool blank = len >= 66;
 #pragma unroll
-                for (int i = 0; i < 6; i++) if (60u + (uint32_t)i < len && !ig_is_space(cb[i])) blank = false;
-                if (len >= 66 && ig_fixed62<60>(L, &bf)) {}
-                else if (blank) bf = 0.f;
-                else bad = true;
-            } else {
-                an = ig_pack4(ld_u32(p + 12), 4);
-                rn = ig_pack4(ld_u32(p + 16) >> 8, 3);
-                ch = p[21];
-                if (!ig_int(p + 6, 5, &serial) || !ig_int(p + 22, 4, &resseq)) bad = true;
-                if (!ig_fixed<8, 3>(p + 30, &x) || !ig_fixed<8, 3>(p + 38, &y) || !ig_fixed<8, 3>(p + 46, &z)) bad = true;
-                if (len >= 66) {
-                    if (!ig_fixed<6, 2>(p + 60, &bf)) {
-                        bool blank = true; for (int i = 60; i < 66; i++) if (!ig_is_space(p[i])) blank = false;
-                        if (blank) bf = 0.f; else bad = true;
-                    }
-                } else {
-                    for (uint32_t i = 60; i < len; i++) if (!ig_is_space(p[i])) bad = true;   // a partial field: host
-                    bf = 0.f;
+                    for (int i = 0; i < 6; i++) if (!ig_is_space(i == 0 ? ig_b<60>(L) : i == 1 ? ig_b<61>(L) : i == 2 ? ig_b<62>(L) : i == 3 ? ig_b<63>(L) : i == 4 ? ig_b<64>(L) : ig_b<65>(L))) blank = false;
+                    if (blank) bf = 0.f; else bad = true;
                 }
+                // segment id (columns 73-76) is part of the residue's identity when the line reaches it
+                if (glen > 72) {
+                    const uint32_t c[4] = {ig_b<72>(L), ig_b<73>(L), ig_b<74>(L), ig_b<75>(L)};
+                    uint32_t nv = raw > 72u ? (raw - 72u < 4u ? raw - 72u : 4u) : 0u;       // characters of the field inside the line
+                    for (uint32_t i = 0; i < nv; i++) if (c[i] == '\r' || c[i] == '\0') { nv = i; break; }
+                    uint32_t a_ = 0; while (a_ < nv && ig_is_space(c[a_])) a_++;
+                    while (nv > a_ && ig_is_space(c[nv - 1])) nv--;
+                    for (uint32_t i = a_; i < nv; i++) seg |= c[i] << (8 * (i - a_));
+                }
+            }
+        }
+        // the reader gathers the atoms of a residue (number, insertion code, name, segment) wherever their lines stand inside a run
+        // of lines with one chain name. File order is its order as long as every new residue of a run has a larger (number, insertion
+        // code) than the one before it; anything else goes to the host, which regroups.
+        const unsigned long long m_rec = __ballot(arec);
+        const uint32_t pl = ig_prev_lane(m_rec, lane);
+        if (m_model | m_endm) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (live && is_model && (have_last || seen_model || ((m_rec | m_model) & below))) bad = true;
+            if (arec && (m_endm & below)) bad = true;
+            seen_model = seen_model || m_model != 0; seen_endm = seen_endm || m_endm != 0;
+        }
+        if (arec && seen_endm_before) bad = true;
+        {
+            const int src = pl < 64u ? (int)pl : 0;
+            // (the shuffles stand outside every condition: a lane that sits one out would hand its neighbour nothing)
+            const int32_t s_seq = __shfl(resseq, src, WAVE);
+            const uint32_t s_rn = (uint32_t)__shfl((int)rn, src, WAVE), s_seg = (uint32_t)__shfl((int)seg, src, WAVE);
+            const uint32_t s_ic = (uint32_t)__shfl((int)(icode | (ch << 8)), src, WAVE);
+            const int32_t p_seq = pl < 64u ? s_seq : last_seq;
+            const uint32_t p_rn = pl < 64u ? s_rn : last_rn;
+            const uint32_t p_seg = pl < 64u ? s_seg : last_seg;
+            const uint32_t p_ic = pl < 64u ? s_ic : last_icch;
+            const bool has_p = pl < 64u ? true : have_last;
+            if (arec && !bad && has_p && (p_ic >> 8) == ch) {
+                const bool same_res = p_seq == resseq && p_rn == rn && p_seg == seg && (p_ic & 0xffu) == icode;
+                if (!same_res && !(resseq > p_seq || (resseq == p_seq && icode > (p_ic & 0xffu)))) bad = true;
             }
         }
         if (__any(bad)) status = FCZ_INGEST_HOST_FIELD;
         // keep rule. removeAlternativePosition drops an atom whose name equals the name of the last atom KEPT; that is the
         // same as "equals the name of the record right before it": if that record was kept it is the comparison itself, if it
         // was dropped it carried the kept atom's name.
-        const unsigned long long m_rec = __ballot(rec);
-        const uint32_t pl = ig_prev_lane(m_rec, lane);
         const uint32_t pname = (uint32_t)__shfl((int)an, pl < 64u ? (int)pl : 0, WAVE);
         const bool has_prev = pl < 64u ? true : have_last;
         const uint32_t prev_name = pl < 64u ? pname : last_name;
-        const bool keep = rec && !bad && !(has_prev && prev_name == an);   // (a bad record marks the file for the host: nothing of it is used)
+        const bool keep = arec && !bad && !(has_prev && prev_name == an);   // (a bad record marks the file for the host: nothing of it is used)
         const unsigned long long m_keep = __ballot(keep);
         if (keep) {
             const size_t o = (size_t)A0 + kept + (uint32_t)__builtin_popcountll(m_keep & ((1ull << lane) - 1ull));
@@ -372,7 +416,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         if (m_rec) {
             const int hl = 63 - __builtin_clzll(m_rec);
             last_name = (uint32_t)__shfl((int)an, hl, WAVE); have_last = true;
+            last_seq = __shfl(resseq, hl, WAVE); last_rn = (uint32_t)__shfl((int)rn, hl, WAVE); last_seg = (uint32_t)__shfl((int)seg, hl, WAVE);
+            last_icch = (uint32_t)__shfl((int)(icode | (ch << 8)), hl, WAVE);
         }
+        if (m_end) ended = true;
     };
 
     uint64_t c0_staged = 0;
@@ -390,7 +437,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     };
     load_chunk(0);
     IG_STAMP(0)
-    for (uint64_t c0 = 0; c0 < flen; c0 += IG_CHUNK) {
+    for (uint64_t c0 = 0; c0 < flen && !ended; c0 += IG_CHUNK) {
         // ---- stage the chunk: the tail of the previous window moves to the front, then the chunk's 16 coalesced dwords per lane,
         //      which were requested while the previous chunk was being parsed ----
         {
@@ -408,7 +455,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         // ---- line ends of the chunk: every lane looks at its 64 staged bytes ----
         const uint64_t my = c0 + 64ull * (uint64_t)lane;     // file-relative start of this lane's 64 bytes
         uint32_t t[16];
-        uint32_t cnt = 0;
+        uint32_t cnt = 0, nul = 0;
         {
             const uint4* src = reinterpret_cast<const uint4*>(&S.buf[IG_BACK + 64 * lane]);
 #pragma unroll
@@ -423,9 +470,14 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
                     // bytes past the end of the file were staged as zero: never a line end
                     t[d] = (my + 4 * d < flen) ? m : 0u;
                     cnt += (uint32_t)__builtin_popcount(t[d]);
+                    // a NUL inside the file ends the reader's line there (C strings): not this path's business
+                    const uint32_t zz = ~(((vv[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | vv[k] | 0x7f7f7f7fu);
+                    const uint64_t w_at = my + 4 * d;
+                    nul |= w_at + 4 <= flen ? zz : (w_at < flen ? zz & ((1u << (8 * (uint32_t)(flen - w_at))) - 1u) : 0u);
                 }
             }
         }
+        if (__any(nul != 0u)) status = FCZ_INGEST_HOST_FIELD;
         uint32_t total;
         uint32_t ord = wave_excl_scan_dpp(cnt, &total);
         IG_STAMP(2)
@@ -450,7 +502,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
                 const uint64_t le = on ? c0 + S.line_end[k] : 0;
                 const uint64_t ls = on ? (k == 0 ? line_start : c0 + S.line_end[k - 1] + 1) : 0;
                 const long long rel = (long long)ls - (long long)c0;                 // >= -IG_BACK: the line's start is staged
-                do_lines(on, ls, le, (on && rel >= -(long long)IG_BACK) ? (int)(IG_BACK + rel) : -1);
+                do_lines(on, ls, le, (on && rel >= -(long long)IG_BACK) ? (int)(IG_BACK + rel) : -1, true);
             }
             if (n_here) line_start = c0 + S.line_end[n_here - 1] + 1;
             __builtin_amdgcn_wave_barrier();
@@ -458,18 +510,15 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
             if (total == 0) break;
         }
     }
-    if (line_start < flen) {     // a last line without a line end
+    if (line_start < flen && !ended) {     // a last line without a line end
         const long long rel = (long long)line_start - (long long)c0_staged;
-        do_lines(lane == 0, line_start, flen, rel >= -(long long)IG_BACK ? (int)(IG_BACK + rel) : -1);
+        do_lines(lane == 0, line_start, flen, rel >= -(long long)IG_BACK ? (int)(IG_BACK + rel) : -1, false);
     }
     if (lane == 0) {
-        // title = HEADER id, else the TITLE parts joined and stripped (the parts were stripped one by one; joined with ' ')
-        uint32_t a = 0, e = tlen;
-        if (tlen > (uint32_t)IG_TITLE_CAP) { if (status == FCZ_OK) status = FCZ_INGEST_HOST_TITLE; e = 0; }
-        while (a < e && ig_is_space(tbuf[a])) a++;
-        while (e > a && ig_is_space(tbuf[e - 1])) e--;
-        if (a) for (uint32_t i = a; i < e; i++) tbuf[i - a] = tbuf[i];
-        title_len[f] = e - a;
+        // title = the HEADER id code, else the concatenated TITLE text (as the reader leaves it: nothing stripped)
+        if (tlen > (uint32_t)IG_TITLE_CAP) { if (status == FCZ_OK) status = FCZ_INGEST_HOST_TITLE; tlen = 0; }
+        if (hdr_n) { for (uint32_t i = 0; i < hdr_n; i++) tbuf[i] = (uint8_t)(hdr_id >> (8 * i)); tlen = hdr_n; }
+        title_len[f] = tlen;
         if (status == FCZ_OK && kept == 0) status = FCZ_INGEST_NO_ATOMS;
         n_kept[f] = status == FCZ_OK ? kept : 0u;
         file_status[f] = status;

@@ -83,6 +83,184 @@ def parse_pdb(text: str, *, hetatm: bool = False, single_chain: bool = False) ->
                      np.asarray(bf, np.float64).astype(np.float32))
 
 
+# ---- the command line's reader: gemmi's read_pdb as StructureReader uses it ---------------------------------------------------
+# `foldcomp compress` does not read PDB text with the binding's fixed-column parser above but with gemmi 0.5.1
+# (src/structure_reader.cpp:31-61 -> lib/gemmi/pdb.hpp:262-365). What that reader does beyond taking columns, restated here
+# (and checked against the live reference on mutated files, tests/test_ingest_vs_reference.py):
+#   * records are matched on their first four letters, case-insensitively (ATOM, HETA..., TITL..., HEAD..., MODE..., ENDM...,
+#     END stops the reading); a line is at most 120 characters, the rest is dropped;
+#   * an ATOM / HETATM line shorter than 54 characters (+ its line end) fails the whole file;
+#   * numbers are the longest valid prefix of their field (fast_float::from_chars after blanks and one '+'), 0 when there is
+#     none; integers likewise (hybrid-36 when the field starts with a letter); the B-factor is 20.0 when the line ends before
+#     column 65, the residue number field carries the insertion code, columns 21-22 are the chain name, 73-76 the segment;
+#   * atoms are grouped: inside one run of lines with the same chain name (MODEL / ENDMDL end a run) an atom whose residue
+#     (number, insertion code, name, segment) was seen before joins THAT residue, wherever its line stands;
+#   * the title is the HEADER id code (columns 63-66 of the last HEADER record long enough to hold it, right-trimmed), else the
+#     TITLE records' columns 11.. right-trimmed and concatenated.
+import re
+
+_NUM_PREFIX = re.compile(rb"-?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?")
+_SPACES = b" \t\n\v\f\r"
+
+
+def _g_double(f: bytes) -> float:
+    """gemmi read_double: fast_float::from_chars on the field after blanks and one '+'; 0.0 when nothing parses"""
+    f = f.split(b"\0", 1)[0].lstrip(_SPACES)
+    if f[:1] == b"+":
+        f = f[1:]
+    m = _NUM_PREFIX.match(f)
+    if m:
+        return float(m.group(0))
+    low = f[:9].lower()
+    neg = low[:1] == b"-"
+    body = low[1:] if neg else low
+    for word, val in ((b"infinity", float("inf")), (b"inf", float("inf")), (b"nan", float("nan"))):
+        if body.startswith(word):
+            return -val if neg else val
+    return 0.0
+
+
+def _g_int(f: bytes) -> int:
+    """gemmi read_int (string_to_int, unchecked): blanks, a sign, the digits that follow; 0 when there are none"""
+    i = 0
+    while i < len(f) and f[i:i + 1] in (b" ", b"\t", b"\n", b"\v", b"\f", b"\r"):
+        i += 1
+    neg = f[i:i + 1] == b"-"
+    if f[i:i + 1] in (b"-", b"+"):
+        i += 1
+    n = 0
+    while i < len(f) and f[i:i + 1].isdigit():
+        n = n * 10 + (f[i] - 48); i += 1
+    n = -n if neg else n
+    return ((n + 2 ** 31) % 2 ** 32) - 2 ** 31        # int arithmetic of the reader wraps
+
+
+def _g_base36(f: bytes) -> int:
+    z = f.split(b"\0", 1)[0].lstrip(_SPACES)
+    m = re.match(rb"[+-]?[0-9a-zA-Z]*", z)
+    txt = m.group(0).decode() if m else ""
+    try:
+        return int(txt, 36) if txt.strip("+-") else 0
+    except ValueError:
+        return 0
+
+
+def _g_string(f: bytes) -> str:
+    """gemmi read_string: left trim, stop at the end of the line, right trim"""
+    f = f.lstrip(_SPACES)
+    for stop in (b"\n", b"\r", b"\0"):
+        k = f.find(stop)
+        if k >= 0:
+            f = f[:k]
+    return f.rstrip(_SPACES).decode("latin-1")
+
+
+def _g_id4(line: bytes) -> bytes:
+    return bytes(c & ~0x20 & 0xff for c in (line + b"\0\0\0\0")[:4])
+
+
+def parse_pdb_gemmi(data: bytes):
+    """PDB text -> (AtomTable in the order StructureReader hands the atoms on, title or "") as gemmi + updateStructure make it
+    (lib/gemmi/pdb.hpp:262-365, src/structure_reader.cpp:31-61). Raises StructureError where the reader fails the file."""
+    if isinstance(data, str):
+        data = data.encode("latin-1")
+    ID = {k: _g_id4(k) for k in (b"ATOM", b"HETA", b"HEAD", b"TITL", b"MODE", b"ENDM", b"ANIS", b"data")}
+    models: list = []          # [name, chains]; chain = [name, residues (list of [rid, atoms]), resmap]; atom = [..., u11 set]
+    model = chain = resi = None
+    entry_id = None; title = ""
+    pos, n = 0, len(data)
+    while pos < n:
+        nl = data.find(b"\n", pos)
+        end = n if nl < 0 else nl + 1
+        line = data[pos:end][:120]                      # at most 120 characters; what follows on the line is dropped
+        pos = end
+        k = line.find(b"\0")
+        if k >= 0:
+            line = line[:k]                              # the reader works on C strings
+            if not line:
+                break                                    # gets() returns an empty string: the reading stops
+        ln = len(line)
+        buf = line + b"\0" * 8                          # reads past the end of the line see the terminator
+        rid4 = _g_id4(line)
+        if rid4 == ID[b"ATOM"] or rid4 == ID[b"HETA"]:
+            if ln < 55:
+                raise StructureError("The line is too short to be correct")
+            chain_name = _g_string(buf[20:22])
+            icode = buf[26:27] if buf[26:27] not in (b"\r", b"\n") else b"\0"
+            if buf[22] < 65:
+                f = buf[22:26]; i = 0
+                seq = 0
+                while i < 4:
+                    if f[i:i + 1] not in (b" ", b"\t", b"\n", b"\v", b"\f", b"\r"):
+                        seq = _g_int(f[i:]); break
+                    i += 1
+                else:
+                    seq = None                           # a blank field leaves the number unset (INT_MIN in gemmi)
+            else:
+                seq = _g_base36(buf[22:26]) - 466560 + 10000
+            resname = _g_string(buf[17:20])
+            segment = _g_string(buf[72:76]) if ln > 72 else ""
+            rid = (seq, icode, resname, segment)
+            if chain is None or chain_name != chain[0]:
+                if model is None:
+                    name = str(len(models) + 1)
+                    if any(m[0] == name for m in models):
+                        raise StructureError("ATOM/HETATM between models")
+                    model = [name, []]; models.append(model)
+                chain = [chain_name, [], {}]; model[1].append(chain); resi = None
+            if resi is None or resi[0] != rid:
+                j = chain[2].get(rid)
+                if j is None:
+                    chain[2][rid] = len(chain[1]); resi = [rid, []]; chain[1].append(resi)
+                else:
+                    resi = chain[1][j]
+            serial = _g_int(buf[6:11]) if buf[6] < 65 else _g_base36(buf[6:11]) - 16796160 + 100000
+            b_iso = np.float32(_g_double(buf[60:66])) if ln > 64 else np.float32(20.0)
+            resi[1].append([_g_string(buf[12:16]), serial, _g_double(buf[30:38]), _g_double(buf[38:46]), _g_double(buf[46:54]), b_iso, False])
+        elif rid4 == ID[b"ANIS"]:
+            # the reader attaches the record to the last atom read and fails the file when there is none or it has one already
+            if model is None or chain is None or resi is None or not resi[1]:
+                raise StructureError("ANISOU record not directly after ATOM/HETATM.")
+            if resi[1][-1][6]:
+                raise StructureError("Duplicated ANISOU record or not directly after ATOM/HETATM.")
+            resi[1][-1][6] = np.float32(_g_int(buf[28:35])) * np.float32(1e-4) != 0
+        elif rid4 == ID[b"HEAD"]:
+            if ln > 66:
+                e = buf[62:66].split(b"\0", 1)[0].decode("latin-1").rstrip(" \r\n\t")
+                if e:
+                    entry_id = e
+        elif rid4 == ID[b"TITL"]:
+            if ln > 10:
+                title += line[10:ln - 1].decode("latin-1").rstrip(" \r\n\t")
+        elif rid4 == ID[b"MODE"]:
+            if model is not None and chain is not None:
+                raise StructureError("MODEL without ENDMDL?")
+            name = str(_g_int(buf[10:14]))
+            model = next((m for m in models if m[0] == name), None)
+            if model is None:
+                model = [name, []]; models.append(model)
+            if model[1]:
+                raise StructureError("duplicate MODEL number: " + name)
+            chain = None
+        elif rid4 == ID[b"ENDM"]:
+            model = None; chain = None
+        elif rid4[:3] == b"END" and (rid4[3] & ~0xf) == 0:
+            break
+        elif rid4 == ID[b"data"] and buf[4:5] == b"_" and model is None:
+            raise StructureError("Incorrect file format (perhaps it is cif not pdb?)")
+    atom, residue, chains, ai, ri, xyz, bf = [], [], [], [], [], [], []
+    for mdl in models:
+        for ch in mdl[1]:
+            for rid, atoms in ch[1]:
+                for (an, serial, x, y, z, b, _aniso) in atoms:
+                    atom.append(an); residue.append(rid[2]); chains.append(ch[0])
+                    ai.append(serial); ri.append(rid[0] if rid[0] is not None else -2 ** 31)
+                    xyz.append((x, y, z)); bf.append(b)
+    t = AtomTable(atom, residue, chains, np.asarray(ai, np.int64).astype(np.int32), np.asarray(ri, np.int64).astype(np.int32),
+                  np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3), np.asarray(bf, np.float32))
+    return t, (entry_id if entry_id else title)
+
+
 def remove_alternative_position(t: AtomTable) -> AtomTable:
     """Drop an atom whose name equals the previous (kept) atom's name (atom_coordinate.cpp:362-370)."""
     keep = np.ones(len(t), bool)

@@ -29,6 +29,8 @@
 #include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
+#include <climits>
+#include <unordered_map>
 #include <zlib.h>
 #include <omp.h>
 
@@ -70,6 +72,8 @@ struct AtomTable {
     std::vector<uint32_t> atom, residue;          // packed names
     std::vector<std::string> long_names;          // names of more than four characters
     std::vector<char> chain;
+    std::vector<uint16_t> chain_key;               // the chain NAME (columns 21-22 trimmed, up to two characters packed) where the reader
+                                                   // that filled the table knows it; empty = `chain` is the whole name
     std::vector<int> atom_index, res_index;
     std::vector<float> x, y, z, bfac;
     // filled by the parse threads (name -> code once per atom, in parallel): atom code (fcz_atom_code_from_name) and the
@@ -84,6 +88,11 @@ struct AtomTable {
         return 0xff000000u | (uint32_t)(long_names.size() - 1);
     }
     uint32_t intern(const std::string& s) { return intern(s.data(), s.size()); }
+    bool same_chain(size_t i, size_t j) const { return chain_key.size() == size() ? chain_key[i] == chain_key[j] : chain[i] == chain[j]; }
+    std::string chain_name(size_t i) const {       // what the reference appends to a record's name (src/main.cpp:489-491)
+        if (chain_key.size() != size()) return std::string(1, chain[i]);
+        std::string o; if (chain_key[i] & 0xff) o.push_back((char)(chain_key[i] & 0xff)); if (chain_key[i] >> 8) o.push_back((char)(chain_key[i] >> 8)); return o;
+    }
     std::string name(uint32_t pk) const {
         if ((pk >> 24) == 0xffu) return long_names[pk & 0xffffffu];
         std::string o;
@@ -91,7 +100,7 @@ struct AtomTable {
         return o;
     }
     void clear() {   // keeps every capacity (TablePool)
-        atom.clear(); residue.clear(); long_names.clear(); chain.clear(); atom_index.clear(); res_index.clear();
+        atom.clear(); residue.clear(); long_names.clear(); chain.clear(); chain_key.clear(); atom_index.clear(); res_index.clear();
         x.clear(); y.clear(); z.clear(); bfac.clear(); atom_code.clear(); res_code.clear();
     }
     void reserve(size_t n) {
@@ -103,6 +112,7 @@ struct AtomTable {
         t.long_names = long_names;
         t.atom.assign(atom.begin() + a, atom.begin() + b); t.residue.assign(residue.begin() + a, residue.begin() + b);
         t.chain.assign(chain.begin() + a, chain.begin() + b);
+        if (chain_key.size() == size()) t.chain_key.assign(chain_key.begin() + a, chain_key.begin() + b);
         t.atom_index.assign(atom_index.begin() + a, atom_index.begin() + b); t.res_index.assign(res_index.begin() + a, res_index.begin() + b);
         t.x.assign(x.begin() + a, x.begin() + b); t.y.assign(y.begin() + a, y.begin() + b); t.z.assign(z.begin() + a, z.begin() + b);
         t.bfac.assign(bfac.begin() + a, bfac.begin() + b);
@@ -111,6 +121,7 @@ struct AtomTable {
     }
     void push_from(const AtomTable& o, size_t i) {   // o shares this table's long_names (remove_alternative_position copies them first)
         atom.push_back(o.atom[i]); residue.push_back(o.residue[i]); chain.push_back(o.chain[i]);
+        if (o.chain_key.size() == o.size()) chain_key.push_back(o.chain_key[i]);
         atom_index.push_back(o.atom_index[i]); res_index.push_back(o.res_index[i]);
         x.push_back(o.x[i]); y.push_back(o.y[i]); z.push_back(o.z[i]); bfac.push_back(o.bfac[i]);
         if (o.atom_code.size() == o.size()) { atom_code.push_back(o.atom_code[i]); res_code.push_back(o.res_code[i]); }
@@ -142,7 +153,6 @@ std::string strip(const std::string& s) {
     while (b > a && isspace((unsigned char)s[b - 1])) b--;
     return s.substr(a, b - a);
 }
-std::string field(const std::string& line, size_t a, size_t b) { return a < line.size() ? line.substr(a, std::min(b, line.size()) - a) : std::string(); }
 bool starts_with(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
 bool ends_with(const std::string& s, const std::string& p) { return s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0; }
 
@@ -291,67 +301,167 @@ void fill_codes(AtomTable& t) {
     }
 }
 
-// drop_alt: removeAlternativePosition (an atom whose name equals that of the atom kept before it is dropped, reference
-// src/atom_coordinate.cpp) applied while parsing instead of as a second pass over a copy
-AtomTable parse_pdb_raw(const char* data, size_t size, bool hetatm, std::string& title, bool drop_alt = false) {
+// ---- the reference's reader for PDB text: gemmi 0.5.1 read_pdb as StructureReader uses it -------------------------------------
+// (src/structure_reader.cpp:31-61, lib/gemmi/pdb.hpp:262-365; restated rule by rule in foldcomp_amd/structure.py parse_pdb_gemmi,
+// which tests/test_ingest_vs_reference.py checks against the live reference on mutated files, and this function against that):
+// records matched on their first four letters case-insensitively, END stops the reading, MODEL / ENDMDL end a chain run, a line
+// is at most 120 characters, an ATOM / HETATM line shorter than 54 characters + line end fails the file, numbers = the longest
+// valid prefix of their field (0 when there is none), B-factor 20 when the line ends before column 65, atoms grouped by residue
+// (number, insertion code, name, segment) inside a run of lines with one chain name, title = HEADER id code else the TITLE texts.
+inline bool g_space(unsigned char c) { return c == ' ' || (unsigned)(c - 9) < 5u; }
+inline double g_double(const char* p, size_t n) {          // fast_float::from_chars after blanks and one '+'
+    const char* e = p + n;
+    while (p < e && g_space((unsigned char)*p)) p++;
+    if (p < e && *p == '+') p++;
+    const char* q = p;
+    if (q < e && *q == '-') q++;
+    const char* d0 = q;
+    while (q < e && *q >= '0' && *q <= '9') q++;
+    size_t nd = (size_t)(q - d0);
+    if (q < e && *q == '.') { q++; const char* f0 = q; while (q < e && *q >= '0' && *q <= '9') q++; nd += (size_t)(q - f0); }
+    if (nd == 0) {                                          // no digits: inf / infinity / nan (any case), else nothing
+        const char* w = p; bool neg = false;
+        if (w < e && *w == '-') { neg = true; w++; }
+        auto is = [&](const char* word) { size_t k = strlen(word); if ((size_t)(e - w) < k) return false; for (size_t i = 0; i < k; i++) if (((unsigned char)w[i] | 0x20) != (unsigned char)word[i]) return false; return true; };
+        if (is("inf")) return neg ? -HUGE_VAL : HUGE_VAL;
+        if (is("nan")) return neg ? -NAN : NAN;
+        return 0.0;
+    }
+    if (q < e && (*q == 'e' || *q == 'E')) {
+        const char* x = q + 1;
+        if (x < e && (*x == '+' || *x == '-')) x++;
+        if (x < e && *x >= '0' && *x <= '9') { while (x < e && *x >= '0' && *x <= '9') x++; q = x; }
+    }
+    char tmp[64]; const size_t len = std::min<size_t>((size_t)(q - p), sizeof tmp - 1);
+    memcpy(tmp, p, len); tmp[len] = 0;
+    return strtod(tmp, nullptr);
+}
+inline int g_int(const char* p, size_t n) {                 // string_to_int(p, false, n): blanks, sign, digits; wraps like int
+    size_t i = 0;
+    while (i < n && g_space((unsigned char)p[i])) i++;
+    bool neg = false;
+    if (i < n && p[i] == '-') { neg = true; i++; } else if (i < n && p[i] == '+') i++;
+    uint32_t v = 0;
+    for (; i < n && p[i] >= '0' && p[i] <= '9'; i++) v = v * 10u + (uint32_t)(p[i] - '0');
+    return (int)(neg ? 0u - v : v);
+}
+inline long g_base36(const char* p, size_t n) { char z[8] = {0}; memcpy(z, p, std::min<size_t>(n, 7)); return strtol(z, nullptr, 36); }
+inline uint32_t g_pack(const char* p, size_t n, AtomTable* t = nullptr) {   // read_string: left trim, stop at the line end, right trim
+    size_t a = 0;
+    while (a < n && g_space((unsigned char)p[a])) a++;
+    size_t b = a;
+    while (b < n && p[b] != '\n' && p[b] != '\r' && p[b] != '\0') b++;
+    while (b > a && g_space((unsigned char)p[b - 1])) b--;
+    (void)t;
+    return pack_name(p + a, b - a);
+}
+inline uint32_t g_id4(const char* s) { return (((uint32_t)(unsigned char)s[0] << 24) | ((uint32_t)(unsigned char)s[1] << 16) | ((uint32_t)(unsigned char)s[2] << 8) | (uint32_t)(unsigned char)s[3]) & ~0x20202020u; }
+
+AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
     AtomTable t = table_pool().get();
-    t.reserve(size / 78 + 8);                                         // an ATOM line is 80 or 81 bytes with its line end
+    t.reserve(size / 78 + 8);
     const NameCodes& nc = name_codes();
+    struct Rid { int seq; char icode; uint32_t resn, seg; bool operator==(const Rid& o) const { return seq == o.seq && icode == o.icode && resn == o.resn && seg == o.seg; } };
+    struct RidHash { size_t operator()(const Rid& r) const { return (size_t)((uint32_t)r.seq * 0x9E3779B1u) ^ ((size_t)r.resn << 7) ^ ((size_t)r.seg << 17) ^ (size_t)(unsigned char)r.icode; } };
+    std::vector<uint64_t> order;                       // (run << 32 | residue ordinal inside the run) of every atom
+    std::vector<uint8_t> aniso;                        // the atom has an ANISOU record with u11 != 0
+    std::unordered_map<Rid, uint32_t, RidHash> resmap;
+    std::vector<std::string> model_names; std::vector<bool> model_has_chains;
+    int model = -1; bool have_chain = false; uint16_t chain_key = 0; uint32_t run = 0, n_res_in_run = 0;
+    bool have_resi = false; Rid cur{}; uint32_t cur_ord = 0; long last_atom_of_cur = -1; bool regroup = false;
+    std::vector<long> last_atom_of;                    // last atom read of every residue of the run (for ANISOU)
+    std::string entry_id; title.clear();
     uint32_t last_res = 0xfffffffeu; int8_t last_rc = -1;
-    std::vector<std::string> title_parts; std::string header_id; bool seen_atom = false, have_header = false;
-    const char* p = data; const char* end = p + size;
+    const char* p = data; const char* end = data + size;
+    char line[128];
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* le = nl ? nl : end;
-        size_t len = (size_t)(le - p);
-        if (len && p[len - 1] == '\r') len--;
-        const bool is_atom = len >= 4 && memcmp(p, "ATOM", 4) == 0;
-        if (is_atom || (hetatm && len >= 6 && memcmp(p, "HETATM", 6) == 0)) {
-            const uint32_t an = field_pack(p, len, 12, 16), rn = field_pack(p, len, 17, 20);
-            if (is_atom) seen_atom = true;
-            if (drop_alt && !t.atom.empty() && t.atom.back() == an) { if (!nl) break; p = nl + 1; continue; }
-            t.atom.push_back(an); t.residue.push_back(rn);
-            t.atom_code.push_back((uint8_t)nc.atom(an));
-            if (rn != last_res) { last_res = rn; last_rc = (int8_t)nc.residue(rn); }
-            t.res_code.push_back(last_rc);
-            t.chain.push_back(len > 21 ? p[21] : ' ');
-            t.atom_index.push_back(field_int(p, len, 6, 11));
-            t.res_index.push_back(field_int(p, len, 22, 26));
-            float fx, fy, fz, fb;
-            if (len >= 54 && fixed_field<8, 3>(p + 30, fx) && fixed_field<8, 3>(p + 38, fy) && fixed_field<8, 3>(p + 46, fz)) {
-                t.x.push_back(fx); t.y.push_back(fy); t.z.push_back(fz);
-            } else {
-                t.x.push_back(field_float(p, len, 30, 38)); t.y.push_back(field_float(p, len, 38, 46)); t.z.push_back(field_float(p, len, 46, 54));
+        const char* le = nl ? nl + 1 : end;
+        size_t len = std::min<size_t>((size_t)(le - p), 120);
+        memcpy(line, p, len); memset(line + len, 0, sizeof line - len);
+        p = le;
+        const size_t sl = strnlen(line, len);
+        if (sl < len) { len = sl; memset(line + len, 0, sizeof line - len); if (!len) break; }
+        const uint32_t id = g_id4(line);
+        if (id == g_id4("ATOM") || id == g_id4("HETA")) {
+            if (len < 55) throw std::runtime_error("The line is too short to be correct");
+            const uint32_t cn = g_pack(line + 20, 2);
+            Rid rid;
+            rid.icode = (line[26] != '\r' && line[26] != '\n') ? line[26] : '\0';
+            if ((unsigned char)line[22] < 'A') {
+                rid.seq = INT_MIN;
+                for (int i = 0; i < 4; i++) if (!g_space((unsigned char)line[22 + i])) { rid.seq = g_int(line + 22 + i, (size_t)(4 - i)); break; }
+            } else rid.seq = (int)(g_base36(line + 22, 4) - 466560 + 10000);
+            rid.resn = g_pack(line + 17, 3);
+            rid.seg = len > 72 ? g_pack(line + 72, 4) : 0u;
+            if (!have_chain || (uint16_t)cn != chain_key) {
+                if (model < 0) {
+                    const std::string name = std::to_string(model_names.size() + 1);
+                    for (const std::string& m : model_names) if (m == name) throw std::runtime_error("ATOM/HETATM between models");
+                    model_names.push_back(name); model_has_chains.push_back(false); model = (int)model_names.size() - 1;
+                }
+                model_has_chains[(size_t)model] = true;
+                have_chain = true; chain_key = (uint16_t)cn; run++; n_res_in_run = 0; resmap.clear(); last_atom_of.clear(); have_resi = false;
             }
-            if (len >= 66 && fixed_field<6, 2>(p + 60, fb)) t.bfac.push_back(fb);
-            else t.bfac.push_back(field_blank(p, len, 60, 66) ? 0.0f : field_float(p, len, 60, 66));
-            if (is_atom) seen_atom = true;
-        } else if (!seen_atom && !have_header) {          // gemmi: _entry.id = HEADER id code (cols 63-66), else the TITLE records
-            if (len >= 66 && memcmp(p, "HEADER", 6) == 0 && !field_strip(p, len, 62, 66).empty()) { header_id = field_strip(p, len, 62, 66); have_header = true; }
-            else if (len >= 5 && memcmp(p, "TITLE", 5) == 0) title_parts.push_back(field_strip(p, len, 10, 80));
+            if (!have_resi || !(cur == rid)) {
+                auto it = resmap.find(rid);
+                if (it == resmap.end()) { cur_ord = n_res_in_run++; resmap.emplace(rid, cur_ord); last_atom_of.push_back(-1); }
+                else { cur_ord = it->second; if (cur_ord + 1 != n_res_in_run) regroup = true; }
+                cur = rid; have_resi = true;
+            }
+            const uint32_t an = g_pack(line + 12, 4);
+            t.atom.push_back(an); t.residue.push_back(rid.resn);
+            t.atom_code.push_back((uint8_t)nc.atom(an));
+            if (rid.resn != last_res) { last_res = rid.resn; last_rc = (int8_t)nc.residue(rid.resn); }
+            t.res_code.push_back(last_rc);
+            t.chain.push_back((cn & 0xff) ? (char)(cn & 0xff) : ' '); t.chain_key.push_back((uint16_t)cn);
+            t.atom_index.push_back((unsigned char)line[6] < 'A' ? g_int(line + 6, 5) : (int)(g_base36(line + 6, 5) - 16796160 + 100000));
+            t.res_index.push_back(rid.seq);
+            float fx, fy, fz, fb;
+            if (fixed_field<8, 3>(line + 30, fx) && fixed_field<8, 3>(line + 38, fy) && fixed_field<8, 3>(line + 46, fz)) { t.x.push_back(fx); t.y.push_back(fy); t.z.push_back(fz); }
+            else { t.x.push_back((float)g_double(line + 30, 8)); t.y.push_back((float)g_double(line + 38, 8)); t.z.push_back((float)g_double(line + 46, 8)); }
+            if (len > 64) { if (len >= 67 && fixed_field<6, 2>(line + 60, fb)) t.bfac.push_back(fb); else t.bfac.push_back((float)g_double(line + 60, 6)); }
+            else t.bfac.push_back(20.0f);                       // gemmi's default B-factor: the line ends before the field
+            order.push_back(((uint64_t)run << 32) | cur_ord); aniso.push_back(0);
+            last_atom_of[cur_ord] = (long)t.atom.size() - 1; last_atom_of_cur = (long)t.atom.size() - 1;
+        } else if (id == g_id4("ANIS")) {
+            if (model < 0 || !have_chain || !have_resi || last_atom_of[cur_ord] < 0) throw std::runtime_error("ANISOU record not directly after ATOM/HETATM.");
+            uint8_t& a = aniso[(size_t)last_atom_of[cur_ord]];
+            if (a) throw std::runtime_error("Duplicated ANISOU record or not directly after ATOM/HETATM.");
+            a = ((float)g_int(line + 28, 7) * 1e-4f) != 0.f;
+        } else if (id == g_id4("HEAD")) {
+            if (len > 66) { size_t b = 66; while (b > 62 && (line[b - 1] == ' ' || line[b - 1] == '\r' || line[b - 1] == '\n' || line[b - 1] == '\t')) b--; if (b > 62) entry_id.assign(line + 62, b - 62); }
+        } else if (id == g_id4("TITL")) {
+            if (len > 10) { size_t b = len - 1; while (b > 10 && (line[b - 1] == ' ' || line[b - 1] == '\r' || line[b - 1] == '\n' || line[b - 1] == '\t')) b--; title.append(line + 10, b - 10); }
+        } else if (id == g_id4("MODE")) {
+            if (model >= 0 && have_chain) throw std::runtime_error("MODEL without ENDMDL?");
+            const std::string name = std::to_string(g_int(line + 10, 4));
+            model = -1;
+            for (size_t m = 0; m < model_names.size(); m++) if (model_names[m] == name) model = (int)m;
+            if (model < 0) { model_names.push_back(name); model_has_chains.push_back(false); model = (int)model_names.size() - 1; }
+            if (model_has_chains[(size_t)model]) throw std::runtime_error("duplicate MODEL number: " + name);
+            have_chain = false;
+        } else if (id == g_id4("ENDM")) {
+            model = -1; have_chain = false;
+        } else if ((id & ~0xfu) == (g_id4("END") & ~0xfu) && (id >> 8) == (g_id4("END") >> 8)) {
+            break;
+        } else if (id == g_id4("data") && line[4] == '_' && model < 0) {
+            throw std::runtime_error("Incorrect file format (perhaps it is cif not pdb?)");
         }
-        if (!nl) break;
-        p = nl + 1;
     }
-    if (have_header) title = header_id;
-    else { title.clear(); for (size_t i = 0; i < title_parts.size(); i++) title += (i ? " " : "") + title_parts[i]; title = strip(title); }
-    return t;
-}
-
-AtomTable parse_pdb(const std::vector<std::string>& lines, bool hetatm) {
-    AtomTable t;
-    for (const std::string& line : lines) {
-        if (!(starts_with(line, "ATOM") || (hetatm && starts_with(line, "HETATM")))) continue;
-        t.atom.push_back(t.intern(strip(field(line, 12, 16))));
-        t.residue.push_back(t.intern(strip(field(line, 17, 20))));
-        const std::string ch = field(line, 21, 22);
-        t.chain.push_back(ch.empty() ? ' ' : ch[0]);
-        t.atom_index.push_back(parse_int(field(line, 6, 11)));
-        t.res_index.push_back(parse_int(field(line, 22, 26)));
-        t.x.push_back(parse_float(field(line, 30, 38))); t.y.push_back(parse_float(field(line, 38, 46))); t.z.push_back(parse_float(field(line, 46, 54)));
-        const std::string b = strip(field(line, 60, 66));
-        t.bfac.push_back(b.empty() ? 0.0f : parse_float(b));
+    (void)last_atom_of_cur;
+    if (regroup) {
+        // atoms of a residue whose lines were apart: the reader hands them on residue by residue
+        std::vector<size_t> idx(t.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return order[a] < order[b]; });
+        AtomTable o = table_pool().get();
+        o.reserve(t.size());
+        for (size_t i : idx) o.push_from(t, i);
+        table_pool().put(std::move(t));
+        t = std::move(o);
     }
+    if (!entry_id.empty()) title = entry_id;
     return t;
 }
 
@@ -460,7 +570,7 @@ std::vector<Range> identify_chains(const AtomTable& t) {
     const size_t n = t.size();
     size_t start = 0, i = 1;
     while (i < n) {
-        if (t.chain[i] != t.chain[i - 1]) {
+        if (!t.same_chain(i, i - 1)) {
             if (t.atom[i] == PK_N) { out.push_back({start, i}); start = i; }
             else {
                 size_t j = i;
@@ -803,7 +913,7 @@ void fragments_from_memory(const char* data, size_t size, const std::string& bas
     std::string title;
     AtomTable t;
     if (ends_with(plain, ".cif")) { t = parse_cif(split_lines(std::string(data, size)), title); fill_codes(t); t = remove_alternative_position(t); }
-    else t = parse_pdb_raw(data, size, true, title, true);           // names -> codes and removeAlternativePosition in the same pass
+    else { t = parse_pdb_gemmi(data, size, title); AtomTable k = remove_alternative_position(t); table_pool().put(std::move(t)); t = std::move(k); }   // the reference's reader rules, then removeAlternativePosition
     if (t.size() == 0) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base.c_str()); return; }
     if (title.empty() || title == base) title = out_stem;            // src/main.cpp:465
     const std::vector<Range> chains = identify_chains(t);
@@ -812,7 +922,7 @@ void fragments_from_memory(const char* data, size_t size, const std::string& bas
         if (o.skip_discontinuous && frags.size() > 1) { fprintf(stderr, "Skipping discontinuous chain: %s\n", base.c_str()); continue; }
         for (size_t j = 0; j < frags.size(); j++) {
             std::string fname = out_stem;
-            if (chains.size() > 1) fname += t.chain[cs.a];
+            if (chains.size() > 1) fname += t.chain_name(cs.a);
             if (frags.size() > 1) fname += "_" + std::to_string(j);
             if (to_dir_or_file) fname += is_compressible(out_stem, ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
             // the usual file is one chain in one piece: its table moves into the fragment instead of being copied
@@ -1696,8 +1806,8 @@ AtomTable load_table(const std::string& path) {
     const std::string base = base_name(path);
     std::string raw = read_file(path), plain = base, title;
     if (ends_with(base, ".gz")) { raw = gunzip(raw); plain = base.substr(0, base.size() - 3); }
-    const std::vector<std::string> lines = split_lines(raw);
-    return ends_with(plain, ".cif") ? parse_cif(lines, title) : parse_pdb(lines, true);
+    if (ends_with(plain, ".cif")) return parse_cif(split_lines(raw), title);
+    return parse_pdb_gemmi(raw.data(), raw.size(), title);
 }
 int run_rmsd(const Options& o) {
     if (o.output.empty()) { fprintf(stderr, "[Error] rmsd needs two structure files.\n"); return 1; }

@@ -254,6 +254,8 @@ long ref_load_structure(const char* buf, long len, const char* name, long cap_at
     const long n = (long)atoms.size();
     *title_len = (int)reader.title.size();
     if (title_cap > 0) { const int t = std::min<int>(*title_len, title_cap); memcpy(title, reader.title.data(), t); }
+    *n_frag = 0; *n_chains = 0;
+    if (atoms.empty()) return 0;      // src/main.cpp:459-462 stops here ("No atoms found"): identifyChains is never given an empty vector
     std::vector<std::pair<size_t, size_t>> chains = identifyChains(atoms);
     *n_chains = (int)chains.size();
     int nf = 0;

@@ -41,3 +41,54 @@ def entries_blob(entries):
     off[1:] = np.cumsum([len(e) for e in entries])
     blob = np.frombuffer(b"".join(entries), np.uint8).copy() if entries else np.zeros(0, np.uint8)
     return blob, off
+
+
+# records a mutated PDB file may get spliced in (what gemmi's reader reacts to beyond ATOM lines)
+_FOREIGN = ["ANISOU    2  CA  MET A   1     2406   1892   1614    198    519   -328       C  ",
+            "ANISOU    3  C   MET A   1        0   1892   1614    198    519   -328       C  ", "MODEL        1", "MODEL        2", "ENDMDL", "data_x",
+            "REMARK 465 junk", "HETATM 9001  O   HOH A 900      11.000  12.000  13.000  1.00 30.00           O  ", "TITLE     SOMETHING", "TITLE    2 MORE OF IT  ",
+            "HEADER    HYDROLASE                               01-JAN-00   1ABC              ", "junk", "", "END", "TER",
+            "atom      1  N   MET A   1      27.340  24.430   2.614  1.00  9.67           N"]
+
+
+def mutated_pdb(base_lines, rng, max_edits=5):
+    """one seeded mutation of a PDB file: characters replaced anywhere, lines cut, duplicated elsewhere, swapped, removed, given a
+    CR, chain ids and residue numbers changed from some line on, foreign records spliced in -- what tests of the readers feed them"""
+    alphabet = list("0123456789 .-+ANCOHETMabcxyz\t*")
+    lines = list(base_lines)
+    for _ in range(int(rng.integers(1, max_edits + 1))):
+        kind = int(rng.integers(0, 9)); j = int(rng.integers(0, len(lines))); l = lines[j]
+        if kind == 0 and l:
+            k = int(rng.integers(0, len(l))); lines[j] = l[:k] + alphabet[int(rng.integers(0, len(alphabet)))] + l[k + 1:]
+        elif kind == 1:
+            lines[j] = l[:int(rng.integers(0, len(l) + 1))]
+        elif kind == 2:
+            lines.insert(int(rng.integers(0, len(lines))), l)
+        elif kind == 3 and j + 1 < len(lines):
+            lines[j], lines[j + 1] = lines[j + 1], lines[j]
+        elif kind == 4:
+            ch = "BCD"[int(rng.integers(0, 3))]
+            lines[j:] = [x[:21] + ch + x[22:] if x.startswith("ATOM") and len(x) > 22 else x for x in lines[j:]]
+        elif kind == 5:
+            lines[j:] = [x[:22] + "%4d" % (int(x[22:26]) + 3) + x[26:] if x.startswith("ATOM") and x[22:26].strip().lstrip("-").isdigit() else x for x in lines[j:]]
+        elif kind == 6:
+            lines.insert(j, _FOREIGN[int(rng.integers(0, len(_FOREIGN)))])
+        elif kind == 7:
+            lines[j] = l + "\r"
+        else:
+            del lines[j]
+    return ("\n".join(lines) + ("\n" if rng.integers(0, 4) else "")).encode("latin-1")
+
+
+def reference_would_spin(t) -> bool:
+    """identifyChains of the reference (src/atom_coordinate.cpp:469-497) never returns when a chain id changes at an atom that is
+    not an N and no N follows: such inputs cannot be put to the live reference"""
+    n = len(t); i = 1
+    while i < n:
+        if t.chain[i] != t.chain[i - 1] and t.atom[i] != "N":
+            j = next((j for j in range(i, n) if t.atom[j] == "N"), None)
+            if j is None:
+                return True
+            i = j
+        i += 1
+    return False

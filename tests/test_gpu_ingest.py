@@ -13,9 +13,9 @@ import os
 import numpy as np
 import pytest
 
-from _cases import golden_batch
+from _cases import golden_batch, mutated_pdb
 from foldcomp_amd.codec import Codec
-from foldcomp_amd.structure import AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb, remove_alternative_position
+from foldcomp_amd.structure import AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb_gemmi, remove_alternative_position
 from test_host_cpp import _pdb_text
 
 pytestmark = pytest.mark.gpu
@@ -27,29 +27,19 @@ def ing():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
 
 
-def _title_of(text: str) -> str:
-    """gemmi's _entry.id for a PDB file: HEADER id code (columns 63-66), else the TITLE records before the first ATOM"""
-    parts = []
-    for line in text.splitlines():
-        if line.startswith("ATOM"):
-            break
-        if len(line) >= 66 and line.startswith("HEADER") and line[62:66].strip():
-            return line[62:66].strip()
-        if line.startswith("TITLE"):
-            parts.append(line[10:80].strip())
-    return " ".join(parts).strip()
-
-
 def _host_expect(texts, names, brk=25, skip_disc=False):
-    """what the hosts make of the files: (batch, fragment names, chain_file, refused [(file, name)])"""
-    chains, out_names, cfile, refused = [], [], [], []
+    """what the host reader (gemmi's rules, checked against the live reference in test_ingest_vs_reference.py) makes of the files:
+    (batch, fragment names, chain_file, refused [(file, name)], files the reader fails)"""
+    chains, out_names, cfile, refused, failed = [], [], [], [], set()
     for fi, (text, base) in enumerate(zip(texts, names)):
-        s = text.decode("latin-1")
         stem = base.rsplit(".", 1)[0] if "." in base else base
-        t = remove_alternative_position(parse_pdb(s, hetatm=True))
+        try:
+            t, title = parse_pdb_gemmi(text)
+        except StructureError:
+            failed.add(fi); continue
+        t = remove_alternative_position(t)
         if len(t) == 0:
             continue
-        title = _title_of(s)
         if title == "" or title == base:
             title = stem
         cs_all = identify_chains(t)
@@ -65,7 +55,7 @@ def _host_expect(texts, names, brk=25, skip_disc=False):
                 except StructureError:
                     refused.append((fi, nm)); continue
                 chains.append(ch); out_names.append(nm); cfile.append(fi)
-    return (build_batch(chains, brk) if chains else None), out_names, cfile, refused
+    return (build_batch(chains, brk) if chains else None), out_names, cfile, refused, failed
 
 
 def _name_of(base, meta):
@@ -88,7 +78,8 @@ def _same_batch(got, exp):
 
 
 def _check(codec, texts, names, brk=25, skip_disc=False):
-    exp, exp_names, exp_file, exp_ref = _host_expect(texts, names, brk, skip_disc)
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect(texts, names, brk, skip_disc)
+    assert not failed
     b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names, brk, skip_disc)
     assert set(int(v) for v in fstat) <= {0, 4}, fstat        # nothing here needs the host parser (4 = a file without atoms)
     if exp is None:
@@ -165,7 +156,11 @@ def test_device_ingest_many_files_and_the_awkward_ones(codec, golden):
     lg = [l for l in base["syn:len129"].splitlines() if l.startswith("ATOM")]
     gap = [l[:22] + "%4d" % (int(l[22:26]) + (5 if int(l[22:26]) > 40 else 0) + (7 if int(l[22:26]) > 90 else 0)) + l[26:] for l in lg]
     add("gaps.pdb", "\n".join(gap) + "\n")
-    add("mse.pdb", t_af.replace(" ALA ", " MSE ", 4))
+    ala = next(l[22:26] for l in t_af.splitlines() if l.startswith("ATOM") and l[17:20] == "ALA")
+    add("mse.pdb", "\n".join(l[:17] + "MSE" + l[20:] if l.startswith("ATOM") and l[22:26] == ala else l for l in t_af.splitlines()) + "\n")
+    # insertion codes (52, 52A, 52B): the reader keeps file order
+    ins = [l[:22] + ("%4d%s" % (52, " AB"[int(l[22:26]) - 52]) if 52 <= int(l[22:26]) <= 54 else "%4d " % (int(l[22:26]) - (2 if int(l[22:26]) > 54 else 0))) + l[27:] for l in lg]
+    add("icode.pdb", "\n".join(ins) + "\n")
     add("no_ca.pdb", "\n".join(l for i, l in enumerate(t_af.splitlines()) if not (l.startswith("ATOM") and l[12:16].strip() == "CA" and int(l[22:26]) == 7)) + "\n")
     add("empty.pdb", "HEADER    nothing to see\nEND\n")
     add("zero.pdb", "")
@@ -203,7 +198,7 @@ def test_text_to_fcz_in_one_call(codec, golden):
     names = [f"f{i:03d}.pdb" for i in range(len(texts))]
     r = codec.compress_pdb(texts, names)
     assert (r["status"] == 0).all() and (r["file_status"] == 0).all() and len(r["refused"]) == 0
-    exp, exp_names, _, _ = _host_expect(texts, names)
+    exp, exp_names, *_ = _host_expect(texts, names)
     blob, off, st = codec.compress_batch(exp)
     assert np.array_equal(off, r["off"]) and blob.tobytes() == r["blob"].tobytes()
 
@@ -216,52 +211,28 @@ def test_text_to_fcz_in_one_call(codec, golden):
 
 
 def test_device_ingest_fuzz_never_parses_differently(codec, golden):
-    """seeded mutations of a PDB file (characters replaced anywhere in ATOM records, lines cut, duplicated, swapped, tabs and
-    lower case, HETATM / ANISOU / junk lines spliced in): whenever the device takes a file (file_status 0) its batch, names and
-    refusals equal the host parser's; everything else it hands back or reports as atom-free -- it never parses differently"""
+    """seeded mutations of PDB files (characters replaced anywhere, lines cut, moved, duplicated, swapped, CR, tabs and lower case,
+    HETATM / ANISOU / MODEL / END / junk lines spliced in; _cases.mutated_pdb, the mutations test_ingest_vs_reference.py puts to
+    the live reference): whenever the device takes a file (file_status 0) its batch, names and refusals equal the host reader's;
+    everything else it hands back or reports as atom-free -- it never parses differently, and never takes a file the reader fails"""
     z, _ = golden
-    base = _pdb_text(z, "syn:len26").splitlines()
+    bases = [_pdb_text(z, "syn:len26").splitlines(), _pdb_text(z, "pdb:multichainA").splitlines()[:300] + _pdb_text(z, "pdb:multichainB_0").splitlines()[:200]]
     rng = np.random.default_rng(20260927)
-    alphabet = list("0123456789 .-+ANCOHETMabcxyz\t*")
     texts, names = [], []
-    for i in range(400):
-        lines = list(base)
-        for _ in range(int(rng.integers(1, 6))):
-            kind = int(rng.integers(0, 8))
-            j = int(rng.integers(0, len(lines)))
-            l = lines[j]
-            if kind == 0 and l:                       # one character replaced
-                k = int(rng.integers(0, len(l))); lines[j] = l[:k] + alphabet[int(rng.integers(0, len(alphabet)))] + l[k + 1:]
-            elif kind == 1:                           # line cut short
-                lines[j] = l[:int(rng.integers(0, len(l) + 1))]
-            elif kind == 2:                           # duplicated (an alternative position when it is an ATOM)
-                lines.insert(j, l)
-            elif kind == 3 and j + 1 < len(lines):    # swapped with its neighbour
-                lines[j], lines[j + 1] = lines[j + 1], lines[j]
-            elif kind == 4:                           # chain id changed from here on
-                ch = "BCD"[int(rng.integers(0, 3))]
-                lines[j:] = [x[:21] + ch + x[22:] if x.startswith("ATOM") and len(x) > 22 else x for x in lines[j:]]
-            elif kind == 5:                           # residue numbers shifted from here on (a gap)
-                lines[j:] = [x[:22] + "%4d" % (int(x[22:26]) + 3) + x[26:] if x.startswith("ATOM") and x[22:26].strip().lstrip("-").isdigit() else x for x in lines[j:]]
-            elif kind == 6:                           # foreign records
-                lines.insert(j, ["HETATM 9001  O   HOH A 900      11.000  12.000  13.000  1.00 30.00           O  ",
-                                 "ANISOU    1  N   MET A   1     2406   1892   1614    198    519   -328       N  ",
-                                 "TITLE     SOMETHING", "junk", ""][int(rng.integers(0, 5))])
-            else:                                     # line removed
-                del lines[j]
-        texts.append(("\n".join(lines) + ("\n" if rng.integers(0, 4) else "")).encode("latin-1"))
-        names.append(f"fz{i:03d}.pdb")
+    for i in range(1200):
+        texts.append(mutated_pdb(bases[i % 2], rng)); names.append(f"fz{i:04d}.pdb")
     b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
     ok = [i for i in range(len(texts)) if fstat[i] == 0]
-    assert len(ok) > 200, "the fuzz should leave most files in the fixed layout"
+    assert len(ok) > 300, "the fuzz should leave many files in the fixed layout"
     remap = {f: k for k, f in enumerate(ok)}
-    exp, exp_names, exp_file, exp_ref = _host_expect([texts[i] for i in ok], [names[i] for i in ok])
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok])
+    assert not failed, [names[ok[k]] for k in failed]
     got_names = [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)]
     assert got_names == exp_names
     assert [remap[int(f)] for f in cfile] == exp_file
     _same_batch(b, exp)
     assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
-    # files reported as atom-free really have no ATOM / HETATM record the host parser would keep
+    # files reported as atom-free really have no ATOM / HETATM record the reader would keep
     for i in range(len(texts)):
         if fstat[i] == 4:
-            assert len(parse_pdb(texts[i].decode("latin-1"), hetatm=True)) == 0, names[i]
+            assert len(parse_pdb_gemmi(texts[i])[0]) == 0, names[i]

@@ -45,7 +45,8 @@ def _dump(path, brk=25):
 
 
 def _python_batch(text, stem, brk=25):
-    t = remove_alternative_position(parse_pdb(text, hetatm=True))
+    from foldcomp_amd.structure import parse_pdb_gemmi
+    t = remove_alternative_position(parse_pdb_gemmi(text.encode("latin-1") if isinstance(text, str) else text)[0])
     chains = identify_chains(t)
     names, cs_list = [], []
     for cs in chains:
@@ -237,9 +238,10 @@ def test_cpp_host_directory_is_parsed_in_file_order(tmp_path, golden):
         nm, b1 = _python_batch(texts[stem], stem)
         names += nm
     # one Python batch over everything, in the same order
+    from foldcomp_amd.structure import parse_pdb_gemmi
     all_chains = []
     for stem in sorted(texts):
-        t = remove_alternative_position(parse_pdb(texts[stem], hetatm=True))
+        t = remove_alternative_position(parse_pdb_gemmi(texts[stem].encode("latin-1"))[0])
         for cs in identify_chains(t):
             for sl in identify_discontinuous(t, cs):
                 all_chains.append(Chain(stem, t.take(sl)))
@@ -464,7 +466,8 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
     (d / "f0011.cif").write_text(_cif_text(z, "pdb:test_af"))
     (d / "f0013.pdb.gz").write_bytes(gzip.compress(texts["pdb:test"].encode()))
     (d / "f0017_multi.pdb").write_text(texts["pdb:multichainA"] + _pdb_text(z, "pdb:multichainB_0") + _pdb_text(z, "pdb:multichainB_1"))
-    (d / "f0019_mse.pdb").write_text(t_af.replace(" ALA ", " MSE ", 2))
+    ala = next(l[22:26] for l in lines if l.startswith("ATOM") and l[17:20] == "ALA")
+    (d / "f0019_mse.pdb").write_text("\n".join(l[:17] + "MSE" + l[20:] if l.startswith("ATOM") and l[22:26] == ala else l for l in lines) + "\n")
     (d / "f0023_empty.pdb").write_text("HEADER    nothing\n")
     (d / "f0029_alt.pdb").write_text("\n".join(l for ln in lines for l in ([ln, ln[:30] + "   1.000   2.000   3.000" + ln[54:]] if ln.startswith("ATOM") and ln[12:16].strip() == "CB" else [ln])) + "\n")
     outs = {}

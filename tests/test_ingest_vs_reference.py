@@ -163,3 +163,124 @@ def test_reference_reader_reads_our_writers(ing, golden, tmp_path):
     assert [(r[0], r[3]) for r in rows] == [(2, names[2]), (5, names[5]), (9, names[9])]
     assert rows[1][4] == z["db:05/fcz"].tobytes()
     assert H.ref_db_lookup(str(tmp_path / "w"), names[9]) == 2
+
+
+def _mutation_bases(ing):
+    """test_af.pdb, and the head of multichain.pdb: some header records, the first 300 coordinate records (two chains, HETATM)"""
+    mc = ing["file:multichain.pdb"].tobytes().decode("latin-1").splitlines()
+    coord = [l for l in mc if l.startswith(("ATOM", "HETATM", "TER", "ANISOU"))]
+    cut = [l for l in coord if l[21:22] == "A"][:200] + [l for l in coord if l[21:22] == "B"][:100]
+    return [ing["file:test_af.pdb"].tobytes().decode("latin-1").splitlines(), mc[:6] + cut + ["END"]]
+
+
+class _RefWorker:
+    """the live reference in a child process: on some mutated inputs the reference itself crashes or never returns (identifyChains
+    spins when a chain id changes at a non-N atom with no N after it); such inputs are skipped, they have no reference answer"""
+
+    def __init__(self):
+        import multiprocessing as mp
+        self.mp = mp.get_context("fork")
+        self.pool = None
+
+    @staticmethod
+    def _call(data, name):
+        import faulthandler
+        faulthandler.disable()          # a crash of the reference in this child is an answer ("crash"), not a report to print
+        try:
+            return ("ok",) + tuple(H.ref_load_structure(data, name))
+        except RuntimeError:
+            return ("fail",)
+
+    def load(self, data, name):
+        if self.pool is None:
+            self.pool = self.mp.Pool(1)
+        try:
+            return self.pool.apply_async(self._call, (data, name)).get(timeout=10)
+        except Exception:   # noqa: BLE001 - the worker died or hangs
+            self.pool.terminate(); self.pool = None
+            return ("crash",)
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+
+
+def test_python_pdb_reader_equals_live_reference_on_mutated_files(ing):
+    """the command line's PDB reader (foldcomp_amd.structure.parse_pdb_gemmi = gemmi's read_pdb + StructureReader::updateStructure
+    restated) against the LIVE reference (oracle/_ref: gemmi 0.5.1 itself) on 1 500 seeded mutations of two files: same atoms in
+    the same order -- residues regrouped, END / MODEL / ANISOU rules, lenient number fields, default B-factor 20 --, same title,
+    same fragments, and the same verdict on the files the reader fails."""
+    if not H.have_ref():
+        pytest.skip("oracle/_ref is not built (it only exists where /root/reference does)")
+    from _cases import mutated_pdb, reference_would_spin
+    from foldcomp_amd.structure import StructureError, parse_pdb_gemmi
+    bases = _mutation_bases(ing)
+    rng = np.random.default_rng(20260927)
+    same = failed = crashed = 0
+    ref = _RefWorker()
+    for i in range(1500):
+        data = mutated_pdb(bases[i % 2], rng)
+        name = f"fz{i}.pdb"
+        try:
+            t, title = parse_pdb_gemmi(data)
+            t = remove_alternative_position(t)
+        except StructureError:
+            t = None
+        if t is not None and reference_would_spin(t):
+            continue
+        r = ref.load(data, name)
+        if r[0] == "crash":
+            crashed += 1; continue
+        rt, rtitle, rfrag, rnch = r[1:] if r[0] == "ok" else (None, None, None, None)
+        assert (t is None) == (rt is None), (i, "only one of the two readers fails the file")
+        if t is None:
+            failed += 1; continue
+        assert len(t) == len(rt), i
+        assert t.atom == rt.atom and t.residue == rt.residue and [c[:1] or " " for c in t.chain] == rt.chain, i
+        assert np.array_equal(t.atom_index, rt.atom_index) and np.array_equal(t.res_index, rt.res_index), i
+        assert np.array_equal(t.xyz.view(np.uint32), rt.xyz.view(np.uint32)) and np.array_equal(t.bfac.view(np.uint32), rt.bfac.view(np.uint32)), i
+        assert (title if title else name) == rtitle, i
+        if len(t):
+            chains = identify_chains(t)
+            frag = [(sl.start, sl.stop, ci, j) for ci, cs in enumerate(chains) for j, sl in enumerate(identify_discontinuous(t, cs))]
+            assert frag == rfrag and len(chains) == rnch, i
+        same += 1
+    ref.close()
+    assert same > 900 and failed > 100 and crashed < 100, (same, failed, crashed)
+
+
+def test_cpp_pdb_reader_equals_python_reader_on_mutated_files(ing, tmp_path):
+    """the C++ host's reader (parse_pdb_gemmi in host/foldcomp_hip.cpp, through dump-batch on a directory) == the Python one on
+    300 mutated files: fragments, names, every array of the batch; files the reader fails and fragments the codec refuses drop out
+    of both"""
+    from _cases import mutated_pdb
+    from foldcomp_amd.structure import StructureError, parse_pdb_gemmi
+    bases = _mutation_bases(ing)
+    rng = np.random.default_rng(7)
+    d = tmp_path / "fz"
+    d.mkdir()
+    names, chains = [], []
+    for i in range(300):
+        data = mutated_pdb(bases[i % 2], rng)
+        stem = f"f{i:03d}"
+        (d / (stem + ".pdb")).write_bytes(data)
+        try:
+            t, title = parse_pdb_gemmi(data)
+        except StructureError:
+            continue
+        if len(t) == 0:
+            continue
+        title = stem if (not title or title == stem + ".pdb") else title
+        t = remove_alternative_position(t)
+        cs_all = identify_chains(t)
+        for cs in cs_all:
+            frags = identify_discontinuous(t, cs)
+            for j, sl in enumerate(frags):
+                ch = Chain(title, t.take(sl))
+                try:
+                    build_batch([ch], 25)
+                except Exception:
+                    continue
+                names.append(stem + (t.chain[cs.start] if len(cs_all) > 1 else "") + (f"_{j}" if len(frags) > 1 else "") + ".fcz")
+                chains.append(ch)
+    _same(_dump(d), names, build_batch(chains, 25))

@@ -365,7 +365,7 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
     struct RidHash { size_t operator()(const Rid& r) const { return (size_t)((uint32_t)r.seq * 0x9E3779B1u) ^ ((size_t)r.resn << 7) ^ ((size_t)r.seg << 17) ^ (size_t)(unsigned char)r.icode; } };
     std::vector<uint64_t> order;                       // (run << 32 | residue ordinal inside the run) of every atom
     std::vector<uint8_t> aniso;                        // the atom has an ANISOU record with u11 != 0
-    std::unordered_map<Rid, uint32_t, RidHash> resmap;
+    std::unordered_map<Rid, uint32_t, RidHash> resmap; std::vector<Rid> run_rids; bool map_built = false; long long max_key = 0;
     std::vector<std::string> model_names; std::vector<bool> model_has_chains;
     int model = -1; bool have_chain = false; uint16_t chain_key = 0; uint32_t run = 0, n_res_in_run = 0;
     bool have_resi = false; Rid cur{}; uint32_t cur_ord = 0; long last_atom_of_cur = -1; bool regroup = false;
@@ -378,10 +378,9 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
         const char* le = nl ? nl + 1 : end;
         size_t len = std::min<size_t>((size_t)(le - p), 120);
-        memcpy(line, p, len); memset(line + len, 0, sizeof line - len);
+        memcpy(line, p, len); memset(line + len, 0, 8);               // (reads past the end of a line see its terminator)
         p = le;
-        const size_t sl = strnlen(line, len);
-        if (sl < len) { len = sl; memset(line + len, 0, sizeof line - len); if (!len) break; }
+        if (memchr(line, 0, len)) { len = strnlen(line, len); memset(line + len, 0, sizeof line - len); if (!len) break; }
         const uint32_t id = g_id4(line);
         if (id == g_id4("ATOM") || id == g_id4("HETA")) {
             if (len < 55) throw std::runtime_error("The line is too short to be correct");
@@ -401,12 +400,19 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
                     model_names.push_back(name); model_has_chains.push_back(false); model = (int)model_names.size() - 1;
                 }
                 model_has_chains[(size_t)model] = true;
-                have_chain = true; chain_key = (uint16_t)cn; run++; n_res_in_run = 0; resmap.clear(); last_atom_of.clear(); have_resi = false;
+                have_chain = true; chain_key = (uint16_t)cn; run++; n_res_in_run = 0; run_rids.clear(); map_built = false; last_atom_of.clear(); have_resi = false;
             }
             if (!have_resi || !(cur == rid)) {
-                auto it = resmap.find(rid);
-                if (it == resmap.end()) { cur_ord = n_res_in_run++; resmap.emplace(rid, cur_ord); last_atom_of.push_back(-1); }
-                else { cur_ord = it->second; if (cur_ord + 1 != n_res_in_run) regroup = true; }
+                // a residue whose (number, insertion code) is beyond every one of the run so far is new: the usual file never
+                // needs the map, which is only built (from the run's list) when a residue could be an earlier one coming back
+                const long long key = ((long long)rid.seq << 8) | (unsigned char)rid.icode;
+                if (run_rids.empty() || key > max_key) { cur_ord = n_res_in_run++; run_rids.push_back(rid); if (map_built) resmap.emplace(rid, cur_ord); last_atom_of.push_back(-1); max_key = key; }
+                else {
+                    if (!map_built) { resmap.clear(); for (uint32_t k = 0; k < (uint32_t)run_rids.size(); k++) resmap.emplace(run_rids[k], k); map_built = true; }
+                    auto it = resmap.find(rid);
+                    if (it == resmap.end()) { cur_ord = n_res_in_run++; resmap.emplace(rid, cur_ord); run_rids.push_back(rid); last_atom_of.push_back(-1); if (key > max_key) max_key = key; }
+                    else { cur_ord = it->second; if (cur_ord + 1 != n_res_in_run) regroup = true; }
+                }
                 cur = rid; have_resi = true;
             }
             const uint32_t an = g_pack(line + 12, 4);
@@ -428,7 +434,7 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
             if (model < 0 || !have_chain || !have_resi || last_atom_of[cur_ord] < 0) throw std::runtime_error("ANISOU record not directly after ATOM/HETATM.");
             uint8_t& a = aniso[(size_t)last_atom_of[cur_ord]];
             if (a) throw std::runtime_error("Duplicated ANISOU record or not directly after ATOM/HETATM.");
-            a = ((float)g_int(line + 28, 7) * 1e-4f) != 0.f;
+            a = len > 28 && ((float)g_int(line + 28, 7) * 1e-4f) != 0.f;
         } else if (id == g_id4("HEAD")) {
             if (len > 66) { size_t b = 66; while (b > 62 && (line[b - 1] == ' ' || line[b - 1] == '\r' || line[b - 1] == '\n' || line[b - 1] == '\t')) b--; if (b > 62) entry_id.assign(line + 62, b - 62); }
         } else if (id == g_id4("TITL")) {

@@ -419,6 +419,8 @@ def end_to_end_leg(args, codec, w, dev):
                     "codec_call_s_sum": best["codec_call_s_sum"], "gpu_call_share": round(best["codec_call_s_sum"] / (best["workers"] * steady), 3),
                     "read_or_parse_s": best.get("parse_s"), "host_parsed_files": best.get("host_parsed_files"),
                     "page_locked_blocks": best.get("pinned_blocks"),
+                    **({"queue_wait_s_sum": best["queue_wait_s_sum"], "write_s_sum": best["write_s_sum"], "buffer_alloc_s_sum": best.get("buffer_alloc_s_sum"),
+                        "all_queued_s": best.get("all_queued_s")} if "write_s_sum" in best else {}),
                     "wall_s_by_threads": {str(r_.get("host_threads")): r_["wall_s"] for r_ in runs}}
 
         # ---- compress: device ingest, and round 2's host-parse pipeline beside it ----
@@ -439,11 +441,16 @@ def end_to_end_leg(args, codec, w, dev):
         db1 = os.path.join(tmp, "db_one")
         run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", "--json-stats", src, db1])
         dlist = os.path.join(tmp, "dbs.txt")
-        dpasses = max(1, passes // 8)
+        dpasses = max(1, passes // 4)
         with open(dlist, "w") as fh:
             fh.write((db1 + "\n") * dpasses)
         dec = {"entries": n * dpasses}
-        runs_d = [run_host(["decompress", "-d", "-y", "-t", str(eff), "--gpus", "1", "--json-stats", "-f", dlist, os.path.join(tmp, "pdbdb")])]
+        runs_d = []
+        for t in tcounts:
+            for ext in ("", ".index", ".lookup", ".dbtype"):       # (a run does not pay for the truncation of the previous run's output)
+                if os.path.exists(os.path.join(tmp, "pdbdb") + ext):
+                    os.remove(os.path.join(tmp, "pdbdb") + ext)
+            runs_d.append(run_host(["decompress", "-d", "-y", "-t", str(t), "--gpus", "1", *wpg, "--json-stats", "-f", dlist, os.path.join(tmp, "pdbdb")]))
         dec["gpu_host"] = summarise(runs_d, "text_bytes", "host/foldcomp-hip decompress -d --gpus 1 -f <list> <db>   (decode + PDB text on the device)")
         dec["gpu_host"]["link_GB_per_s"] = dec["gpu_host"]["steady_text_GB_per_s"]
         out["decompress"] = dec

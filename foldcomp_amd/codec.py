@@ -108,14 +108,15 @@ class Codec:
                        "fcz_decompress_batch")
         return dict(x=x, y=y, z=z, bfac_res=bf, res_code=rc, atom_code=ac, res_off=res_off, atom_off=atom_off, info=info)
 
-    def decompress_pdb(self, blob: np.ndarray, off: np.ndarray, alt_order: bool = False):
-        """FCZ entries -> (list of PDB texts as bytes, per-entry status); decoding and text formatting both on the GPU"""
+    def decompress_pdb(self, blob: np.ndarray, off: np.ndarray, alt_order: bool = False, nul_terminated: bool = False):
+        """FCZ entries -> (list of PDB texts as bytes, per-entry status); decoding and text formatting both on the GPU.
+        nul_terminated: every text that decodes ends in the NUL a database record carries (FCZ_PDB_NUL_TERMINATED)"""
         blob = np.ascontiguousarray(blob, np.uint8)
         off = np.ascontiguousarray(off, np.uint64)
         n = len(off) - 1
         text_off = np.zeros(n + 1, np.uint64)
         status = np.zeros(max(n, 1), np.int32)
-        _lib.check(self.lib.fcz_decompress_pdb_begin(self.ctx, blob.ctypes.data, off.ctypes.data, n, int(alt_order),
+        _lib.check(self.lib.fcz_decompress_pdb_begin(self.ctx, blob.ctypes.data, off.ctypes.data, n, int(bool(alt_order)) | (0x100 if nul_terminated else 0),
                                                      text_off.ctypes.data, status.ctypes.data), "fcz_decompress_pdb_begin")
         text = np.zeros(int(text_off[-1]), np.uint8)
         _lib.check(self.lib.fcz_decompress_pdb_fetch(self.ctx, text.ctypes.data if len(text) else None), "fcz_decompress_pdb_fetch")

@@ -251,18 +251,22 @@ int fcz_ctx_synchronize(fcz_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // PDB text of decompressed chains (writeAtomCoordinatesToPDB, reference src/atom_coordinate.cpp:220-291)
 // ------------------------------------------------------------------------------------------------
-int fcz_pdb_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, const uint32_t* res_off_dev,
-                      const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev, uint64_t* text_off_dev) {
+static int pdb_sizes_impl(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, const uint32_t* res_off_dev,
+                          const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev, uint32_t pad, uint64_t* text_off_dev) {
     if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev || !atoms_dev || !text_off_dev) return FCZ_E_INVALID_ARG;
     if (!atoms_dev->x || !atoms_dev->y || !atoms_dev->z || !atoms_dev->bfac_res || !atoms_dev->res_code) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ctx->pdb_size.ensure(sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
     span_guard g(ctx, "pdb_sizes");
     if (n) hipLaunchKernelGGL(k_pdb_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
-                              res_off_dev, atom_off_dev, *atoms_dev, ctx->pdb_size.as<uint64_t>());
+                              res_off_dev, atom_off_dev, *atoms_dev, pad, ctx->pdb_size.as<uint64_t>());
     if ((rc = device_scan<uint64_t>(ctx, ctx->pdb_size.as<uint64_t>(), text_off_dev, n))) return rc;
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
+}
+int fcz_pdb_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, const uint32_t* res_off_dev,
+                      const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev, uint64_t* text_off_dev) {
+    return pdb_sizes_impl(ctx, blob_dev, off_dev, n, res_off_dev, atom_off_dev, atoms_dev, 0, text_off_dev);
 }
 
 int fcz_pdb_format_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, const uint32_t* res_off_dev,
@@ -285,6 +289,8 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
                              int32_t* status) {
     if (!ctx || !blob || !off || !text_off) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t pad = (alt_order & FCZ_PDB_NUL_TERMINATED) ? 1u : 0u;   // every entry followed by one NUL (a database record)
+    alt_order &= FCZ_PDB_ALT_ORDER;
     ctx->pdb_bytes = 0;
     ctx->sizes_fresh = false;   // the staging buffers the cache is keyed on are about to be rewritten
     if (n == 0) { text_off[0] = 0; return FCZ_OK; }
@@ -316,13 +322,14 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
         if (rc) return rc;
     }
     ctx->sizes_fresh = false;
-    rc = fcz_pdb_sizes_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
-                           ctx->stage[3].as<uint32_t>(), &dv, ctx->pdb_off.as<uint64_t>());
+    rc = pdb_sizes_impl(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
+                        ctx->stage[3].as<uint32_t>(), &dv, pad, ctx->pdb_off.as<uint64_t>());
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(text_off, ctx->pdb_off.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pdb_bytes = text_off[n];
     if ((rc = ctx->pdb_text.ensure(std::max<uint64_t>(ctx->pdb_bytes, 16)))) return rc;
+    if (pad && ctx->pdb_bytes) HIP_TRY(hipMemsetAsync(ctx->pdb_text.p, 0, ctx->pdb_bytes, ctx->stream));   // the terminators: the format pass writes the text around them
     return fcz_pdb_format_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
                               ctx->stage[3].as<uint32_t>(), &dv, alt_order, ctx->pdb_off.as<uint64_t>(), ctx->pdb_text.as<uint8_t>());
 }

@@ -81,7 +81,7 @@ struct pdb_atom_ctx { uint32_t n_atoms; bool has_oxt; };
 
 __global__ __launch_bounds__(BLOCK) void k_pdb_sizes(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries,
                                                      const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ atom_off,
-                                                     fcz_atoms_out at, uint64_t* __restrict__ text_size) {
+                                                     fcz_atoms_out at, uint32_t pad, uint64_t* __restrict__ text_size) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= n_entries) return;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(BLOCK) void k_pdb_sizes(const uint8_t* __restrict__
     }
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) bytes += __shfl_xor(bytes, d, WAVE);
-    if (lane == 0) text_size[c] = bytes;
+    if (lane == 0) text_size[c] = bytes + pad;      // pad: the terminator a database entry carries (left zero by the caller)
 }
 
 // ---- byte emitter into the wave's LDS staging buffer ----

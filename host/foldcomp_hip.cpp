@@ -1530,7 +1530,7 @@ int run_decompress(const Options& o) {
     if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
     std::atomic<uint64_t> n_ok{0}, n_text{0}, n_fcz{0}, n_res{0};
-    std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);
+    std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0), wait_s(n_workers, 0.0), write_s(n_workers, 0.0), alloc_s(n_workers, 0.0);
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
         fcz_ctx* ctx = nullptr;
@@ -1538,75 +1538,49 @@ int run_decompress(const Options& o) {
         ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
         pvec<uint8_t> text, packed;
         DecompressJob job;
-        while (queue.get(job)) {
+        for (;;) {
+            const auto tw = clk::now();
+            const bool more = queue.get(job);
+            wait_s[w] += std::chrono::duration<double>(clk::now() - tw).count();
+            if (!more) break;
             const uint32_t n = job.ents.n();
             std::vector<uint64_t> text_off(n + 1, 0);
             std::vector<int32_t> status(n, 0);
             const auto t0 = clk::now();
-            int rc = ctx ? fcz_decompress_pdb_begin(ctx, job.ents.blob.data(), job.ents.off.data(), n, o.alt ? 1 : 0, text_off.data(), status.data()) : FCZ_E_NO_DEVICE;
+            // a database record is the text + the MMseqs terminator (src/main.cpp:659): the device leaves the NULs in place, so a job's
+            // records are one contiguous range of the data file
+            const int flags = (o.alt ? FCZ_PDB_ALT_ORDER : 0) | (o.db ? FCZ_PDB_NUL_TERMINATED : 0);
+            int rc = ctx ? fcz_decompress_pdb_begin(ctx, job.ents.blob.data(), job.ents.off.data(), n, flags, text_off.data(), status.data()) : FCZ_E_NO_DEVICE;
             gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
             uint32_t n_good = 0;
             if (rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) n_good += status[i] == FCZ_OK ? 1u : 0u;
-            // PDB text in a database carries the MMseqs terminator (src/main.cpp:659): one NUL per record
-            const uint64_t bytes = rc == FCZ_OK ? text_off[n] + (o.db ? n_good : 0) : 0;
+            const uint64_t bytes = rc == FCZ_OK ? text_off[n] : 0;
             std::vector<uint64_t> lens; std::vector<std::string> dbnames;
             if (o.db && rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) {
                 if (status[i] != FCZ_OK) continue;
                 std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
-                lens.push_back(text_off[i + 1] - text_off[i] + 1); dbnames.push_back(stem);
+                lens.push_back(text_off[i + 1] - text_off[i]); dbnames.push_back(stem);
             }
             const uint64_t at = o.db ? seq.claim(job.index, bytes, &lens, &dbnames) : 0;     // every job claims, also a failed one
             if (rc == FCZ_OK) {
+                const auto ta = clk::now();
                 if (text.size() < text_off[n]) text.resize(text_off[n] + text_off[n] / 8);     // grows, never shrinks (a resize zero-fills what it adds)
+                alloc_s[w] += std::chrono::duration<double>(clk::now() - ta).count();
                 const auto t1 = clk::now();
                 rc = fcz_decompress_pdb_fetch(ctx, text.data());
                 gpu_busy[w] += std::chrono::duration<double>(clk::now() - t1).count();
                 for (uint32_t i = 0; i < n; i++) if (status[i] == FCZ_OK) { const uint8_t* e = job.ents.blob.data() + job.ents.off[i]; n_res += (uint32_t)e[4] | ((uint32_t)e[5] << 8); }
             }
             if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s\n", fcz_status_string(rc)); hard_fail = true; continue; }
+            const auto t_write = clk::now();
             try {
                 if (o.db) {
-                    // entry i of the output database = its text + the MMseqs NUL: written straight from the fetched buffer with
-                    // gathered writes (pwritev: text, NUL, text, NUL ...), the job's range cut into pieces that several threads
-                    // write side by side -- the copy into the page cache is the cost of this direction (the text is 40x the FCZ bytes)
-                    std::vector<uint32_t> good; std::vector<uint64_t> dst;       // entries that decompressed, and where they go
-                    uint64_t pos = 0;
-                    for (uint32_t i = 0; i < n; i++) {
-                        if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
-                        const uint64_t len = text_off[i + 1] - text_off[i];
-                        good.push_back(i); dst.push_back(at + pos);
-                        pos += len + 1;
-                    }
-                    static const char NUL = 0;
-                    const int pieces = (int)std::min<size_t>(std::max<size_t>(good.size() / 64, 1), (size_t)std::max(1, o.write_threads));
-                    std::atomic<bool> wfail{false};
-                    std::vector<std::thread> wt;
-                    for (int pc = 0; pc < pieces; pc++) wt.emplace_back([&, pc]() {
-                        const size_t g0 = good.size() * (size_t)pc / (size_t)pieces, g1 = good.size() * (size_t)(pc + 1) / (size_t)pieces;
-                        std::vector<iovec> iov;
-                        for (size_t g = g0; g < g1;) {
-                            iov.clear();
-                            const uint64_t start = dst[g]; uint64_t bytes_here = 0;
-                            for (; g < g1 && iov.size() + 2 <= 512; g++) {
-                                const uint32_t i = good[g];
-                                iov.push_back({(void*)(text.data() + text_off[i]), (size_t)(text_off[i + 1] - text_off[i])});
-                                iov.push_back({(void*)&NUL, 1});
-                                bytes_here += text_off[i + 1] - text_off[i] + 1;
-                            }
-                            // a gathered write may come back short: continue from where it stopped
-                            uint64_t done = 0; size_t k = 0;
-                            while (done < bytes_here) {
-                                const ssize_t wr = pwritev(db_fd, iov.data() + k, (int)(iov.size() - k), (off_t)(start + done));
-                                if (wr <= 0) { wfail = true; return; }
-                                done += (uint64_t)wr;
-                                uint64_t left = (uint64_t)wr;
-                                while (k < iov.size() && left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
-                                if (k < iov.size() && left) { iov[k].iov_base = (char*)iov[k].iov_base + left; iov[k].iov_len -= left; }
-                            }
-                        }
-                    });
-                    for (std::thread& t : wt) t.join();
-                    if (wfail) throw std::runtime_error("pwritev failed");
+                    // the job's records lie in the fetched buffer exactly as in the data file: one run of large writes. (The copy into
+                    // the page cache is the cost of this direction -- the text is 40x the FCZ bytes -- and writes to ONE file
+                    // serialise on its inode lock: large writes from one thread reach what the file system gives,
+                    // tools/dbg/write_bench.cpp; more writer threads only add contention.)
+                    for (uint32_t i = 0; i < n; i++) if (status[i] != FCZ_OK) fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str());
+                    pwrite_all(db_fd, text.data(), bytes, at);
                 } else {
                     // one file per entry, written by several threads (open / write / close per file is what takes the time)
                     const int pieces = (int)std::min<size_t>(std::max<size_t>(n / 64, 1), (size_t)std::max(1, o.write_threads));
@@ -1622,13 +1596,14 @@ int run_decompress(const Options& o) {
                     });
                     for (std::thread& t : wt) t.join();
                 }
-                n_ok += n_good; n_text += text_off[n]; n_fcz += job.ents.off.back();
+                n_ok += n_good; n_text += text_off[n] - (o.db ? n_good : 0); n_fcz += job.ents.off.back();
             } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
+            write_s[w] += std::chrono::duration<double>(clk::now() - t_write).count();
         }
         if (ctx) fcz_ctx_destroy(ctx);
     });
     {
-        const size_t JOB = 4096;
+        const size_t JOB = 2048;            // ~0.5 GB of text per job: page-locked buffers of that size, several jobs in flight
         size_t job_index = 0;
         Entries ents;
         auto flush = [&]() {
@@ -1661,12 +1636,16 @@ int run_decompress(const Options& o) {
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
-        double busy = 0.0; for (double g : gpu_busy) busy += g;
+        double busy = 0.0, waited = 0.0, wrote = 0.0, alloc = 0.0;
+        for (double g : alloc_s) alloc += g;
+        for (double g : gpu_busy) busy += g;
+        for (double g : wait_s) waited += g;
+        for (double g : write_s) wrote += g;
         printf("{\"mode\": \"decompress\", \"gpus\": %d, \"workers\": %d, \"records\": %llu, \"residues\": %llu, \"fcz_bytes\": %llu, \"text_bytes\": %llu, "
                "\"wall_s\": %.4f, \"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_queued_s\": %.4f, \"residues_per_s\": %.1f, \"text_MB_per_s\": %.1f, "
-               "\"pinned_blocks\": %llu}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
+               "\"pinned_blocks\": %llu, \"queue_wait_s_sum\": %.4f, \"write_s_sum\": %.4f, \"buffer_alloc_s_sum\": %.4f, \"host_threads\": %d}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
                (unsigned long long)n_text.load(), wall, busy, *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_queued,
-               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? n_text.load() / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load());
+               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? n_text.load() / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load(), waited, wrote, alloc, o.write_threads * n_workers);
     }
     return hard_fail ? 1 : 0;
 }

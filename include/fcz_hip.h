@@ -202,7 +202,12 @@ int fcz_pdb_format_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* of
                        const uint32_t* res_off_dev, const uint32_t* atom_off_dev, const fcz_atoms_out* atoms_dev,
                        int alt_order, const uint64_t* text_off_dev, uint8_t* text_dev);
 /* Host-pointer convenience: FCZ entries -> PDB text with every stage on the device. begin() fills text_off[n+1]
- * (host) and status[n] (may be NULL) and keeps the text in the ctx; fetch() copies text_off[n] bytes out. */
+ * (host) and status[n] (may be NULL) and keeps the text in the ctx; fetch() copies text_off[n] bytes out.
+ * alt_order here is a set of flags: FCZ_PDB_ALT_ORDER (--use-alt-order), FCZ_PDB_NUL_TERMINATED (every entry that decodes
+ * is followed by one NUL, counted in text_off: the record `foldcomp decompress` appends to a database, src/main.cpp:656-664,
+ * so that a job's records are one contiguous byte range of the data file). */
+#define FCZ_PDB_ALT_ORDER      1
+#define FCZ_PDB_NUL_TERMINATED 0x100
 int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order,
                              uint64_t* text_off, int32_t* status);
 int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);

@@ -74,6 +74,23 @@ def test_pdb_text_skips_bad_entries(codec, golden):
     assert texts[1] == b"" and texts[2] == b"" and texts[0] == texts[3] == z["pdb:test_af/pdb0"].tobytes()
 
 
+def test_pdb_text_with_database_terminators(codec, golden):
+    """FCZ_PDB_NUL_TERMINATED: every text that decodes is followed by the NUL of a database record (src/main.cpp:656-664), the
+    entries that do not decode take no byte; twice in a row on one ctx (the second call's buffer held the first call's text)"""
+    z, index = golden
+    names = [n for n in index if f"{n}/pdb0" in z.files and f"{n}/fcz" in z.files]
+    entries = [z[f"{n}/fcz"].tobytes() for n in names]
+    bad = b"NOPE" + entries[0][4:]
+    for order in (entries[:7] + [bad] + entries[7:], [bad] + entries[::-1] + [bad]):
+        blob, off = _blob(order)
+        plain, st0 = codec.decompress_pdb(blob, off)
+        term, st1 = codec.decompress_pdb(blob, off, nul_terminated=True)
+        assert np.array_equal(st0, st1)
+        for e, a, b, s in zip(order, plain, term, st0):
+            assert b == (a + b"\0" if s == 0 else b""), (len(a), len(b), s)
+        assert sum(len(t) for t in term) == sum(len(t) for t in plain) + int((st0 == 0).sum())
+
+
 def test_extract_equals_reference_for_every_golden(codec, golden):
     """k_extract (pLDDT digits 1..4, sequence) against the reference's `foldcomp extract` strings"""
     z, index = golden

@@ -224,9 +224,15 @@ int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
  * how the reference names it:
  *   chain_meta = chain id | fragment ordinal << 8 | FCZ_INGEST_MULTI_CHAIN (the file holds several chains: the id is appended
  *                to the name) | FCZ_INGEST_MULTI_FRAG (the chain has gaps: "_<ordinal>" is appended).
- * file_status[i]: FCZ_OK, FCZ_INGEST_NO_ATOMS, or FCZ_INGEST_HOST_*: something outside the fixed-column layout (a number
- * field the exact fixed-point rule does not cover, a title beyond 512 bytes, more than 32 fragments) -- nothing of that file is
- * in the batch and the caller's own parser has to take it. refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the
+ * The reading rules are those of the reference's reader (gemmi 0.5.1 read_pdb, lib/gemmi/pdb.hpp:262-365): record names on
+ * four letters case-insensitively, END stops the reading, B-factor 20 on a line that ends before column 65, title = last
+ * HEADER id code else the TITLE texts concatenated, one leading MODEL / trailing ENDMDL ignored.
+ * file_status[i]: FCZ_OK, FCZ_INGEST_NO_ATOMS, or FCZ_INGEST_HOST_*: something this path does not decide the way that reader
+ * would on its own (a number field the exact fixed-point rule does not cover, a blank or hybrid-36 number, a two-character chain
+ * name, an ATOM record shorter than its coordinates, ANISOU records, several models, a NUL byte, a residue whose (number,
+ * insertion code) does not grow inside its run of one chain name -- the reader regroups such lines --, a title beyond 512 bytes,
+ * more than 32 fragments) -- nothing of that file is in the batch and the caller's own reader has to take it (the hosts of this
+ * repository restate every rule: foldcomp_amd/structure.py parse_pdb_gemmi, host/foldcomp_hip.cpp parse_pdb_gemmi). refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the
  * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order, chain beyond the
  * header's counts, --skip-discontinuous). mmCIF and gzip stay on the host. */
 enum fcz_ingest_status { FCZ_INGEST_HOST_FIELD = 1, FCZ_INGEST_HOST_TITLE = 2, FCZ_INGEST_HOST_FRAGS = 3, FCZ_INGEST_NO_ATOMS = 4 };

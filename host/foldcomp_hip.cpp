@@ -904,7 +904,7 @@ struct Fragment {
 // (out_stem, ext) = getFileParts of the input's base name, or of the OUTPUT path for a single-file run (src/main.cpp:444-457):
 // they name the fragments and decide the suffix (isCompressible, :498-502)
 void fragments_from_memory(const char* data, size_t size, const std::string& base, const std::string& out_stem, const std::string& ext,
-                           bool to_dir_or_file, const Options& o, std::vector<Fragment>& out);
+                           bool to_dir_or_file, const Options& o, std::vector<Fragment>& out, bool inflated = false);   // inflated: the bytes of a .gz file after gunzip
 void fragments_of(const std::string& path, const std::string& out_stem, const std::string& ext, bool to_dir_or_file, const Options& o,
                   std::vector<Fragment>& out) {
     static thread_local FileImage image;
@@ -913,9 +913,12 @@ void fragments_of(const std::string& path, const std::string& out_stem, const st
 }
 // the same from a file image that is already in memory
 void fragments_from_memory(const char* data, size_t size, const std::string& base, const std::string& out_stem, const std::string& ext,
-                           bool to_dir_or_file, const Options& o, std::vector<Fragment>& out) {
+                           bool to_dir_or_file, const Options& o, std::vector<Fragment>& out, bool inflated) {
     std::string plain = base, unz;
-    if (ends_with(base, ".gz")) { unz = gunzip(std::string(data, size)); data = unz.data(); size = unz.size(); plain = base.substr(0, base.size() - 3); }
+    if (ends_with(base, ".gz")) {
+        plain = base.substr(0, base.size() - 3);
+        if (!inflated) { unz = gunzip(std::string(data, size)); data = unz.data(); size = unz.size(); }
+    }
     std::string title;
     AtomTable t;
     if (ends_with(plain, ".cif")) { t = parse_cif(split_lines(std::string(data, size)), title); fill_codes(t); t = remove_alternative_position(t); }
@@ -1231,6 +1234,10 @@ struct TextPool {                              // the page-locked text buffers g
 };
 
 bool is_plain_pdb(const std::string& path) { return ends_with(path, ".pdb") || ends_with(path, ".ent"); }
+bool is_gz_pdb(const std::string& path) { return ends_with(path, ".pdb.gz") || ends_with(path, ".ent.gz"); }
+// PDB text the device ingest takes: plain files are read straight into the page-locked buffer, gzipped ones are inflated by
+// the reader threads first (their parse still happens on the device)
+bool is_device_text(const std::string& path) { return is_plain_pdb(path) || is_gz_pdb(path); }
 
 int run_compress_device(const Options& o, const std::vector<std::string>& files, const std::string& output) {
     using clk = std::chrono::steady_clock;
@@ -1272,6 +1279,8 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
             std::vector<size_t> text_file(n_text);                      // text slot -> file of the job
             for (size_t i = 0; i < job.paths.size(); i++) if (job.slot[i] >= 0) text_file[(size_t)job.slot[i]] = i;
             auto stem_of = [&](size_t i) { std::string stem, ext; file_parts(base_name(job.paths[i]), stem, ext); return stem; };
+            // the suffix of a fragment's file (src/main.cpp:498-502): ".fcz" for what isCompressible knows, else the input's own
+            auto suffix_of = [&](size_t i) { std::string stem, ext; file_parts(base_name(job.paths[i]), stem, ext); return is_compressible(stem, ext) ? std::string(".fcz") : (ext.empty() ? std::string() : "." + ext); };
             if (!failed && n_text) {
                 uint64_t fcz_bytes = 0;
                 const auto t0 = clk::now();
@@ -1298,7 +1307,7 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
                     const size_t file = text_file[chain_file[c]];
                     const std::string nm = frag_name(file, chain_meta[c]);
                     if (status[c] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s.fcz\n", nm.c_str()); continue; }
-                    recs.push_back({file, (chain_meta[c] >> 8) & 0xffu, blob.data() + off[c], off[c + 1] - off[c], nm + ".fcz", stem_of(file), 0, 0});
+                    recs.push_back({file, (chain_meta[c] >> 8) & 0xffu, blob.data() + off[c], off[c + 1] - off[c], nm + suffix_of(file), stem_of(file), 0, 0});
                     // (sub: the order of a file's records is the order the device emitted them; see the stable sort below)
                     recs.back().sub = c;
                 }
@@ -1315,7 +1324,7 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
                     n_host_files++;
                     const size_t file = text_file[t];
                     std::string stem, ext; file_parts(base_name(job.paths[file]), stem, ext);
-                    try { fragments_from_memory((const char*)job.text->data() + job.file_off[t], job.file_off[t + 1] - job.file_off[t], base_name(job.paths[file]), stem, ext, !o.db, o, job.host_frags[file]); }
+                    try { fragments_from_memory((const char*)job.text->data() + job.file_off[t], job.file_off[t + 1] - job.file_off[t], base_name(job.paths[file]), stem, ext, !o.db, o, job.host_frags[file], /*inflated=*/true); }
                     catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(job.paths[file]).c_str(), e.what()); }
                 }
             }
@@ -1387,15 +1396,23 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
             j.paths.assign(files.begin() + f0, files.begin() + f1);
             j.slot.assign(nf, -1); j.host_frags.resize(nf);
             std::vector<uint64_t> size(nf, 0);
+            std::vector<std::string> unz(nf);                         // the inflated text of the gzipped PDB files
+            std::vector<std::string> err(nf);
 #pragma omp parallel for schedule(dynamic, 16)
             for (long long i = 0; i < (long long)nf; i++) {
+                if (is_gz_pdb(j.paths[i])) {
+                    try { const std::string z = read_file(j.paths[i]); g_bytes_read += z.size(); unz[i] = gunzip(z); size[i] = unz[i].size(); }
+                    catch (const std::exception& e) { err[i] = "[Error] " + base_name(j.paths[i]) + ": " + e.what() + "\n"; size[i] = UINT64_MAX - 1; }
+                    continue;
+                }
                 if (!is_plain_pdb(j.paths[i])) continue;
                 struct stat st;
                 if (stat(j.paths[i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) size[i] = (uint64_t)st.st_size; else size[i] = UINT64_MAX;
             }
             uint32_t n_text = 0;
             for (size_t i = 0; i < nf; i++) {
-                if (!is_plain_pdb(j.paths[i])) continue;
+                if (!is_device_text(j.paths[i])) continue;
+                if (size[i] == UINT64_MAX - 1) continue;               // a gzip stream that does not inflate (reported below)
                 if (size[i] == UINT64_MAX) { fprintf(stderr, "[Error] cannot open %s\n", j.paths[i].c_str()); continue; }
                 j.slot[i] = (int)n_text++;
                 j.file_off.push_back(j.file_off.back() + size[i]);
@@ -1405,10 +1422,12 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
             }
             j.text = pool.get();
             if (j.text->size() < j.file_off.back() + 64) j.text->resize(j.file_off.back() + j.file_off.back() / 8 + 64);   // grows, never shrinks: a resize touches (zero-fills) what it adds
-            std::vector<std::string> err(nf);
 #pragma omp parallel for schedule(dynamic, 8)
             for (long long i = 0; i < (long long)nf; i++) {
-                if (j.slot[i] >= 0) {
+                if (j.slot[i] >= 0 && is_gz_pdb(j.paths[i])) {
+                    memcpy(j.text->data() + j.file_off[(size_t)j.slot[i]], unz[i].data(), unz[i].size());
+                    std::string().swap(unz[i]);
+                } else if (j.slot[i] >= 0) {
                     // straight into the page-locked buffer; a file that shrank since stat() leaves spaces (an empty line), one that
                     // grew is cut at its stat size
                     const uint64_t at = j.file_off[(size_t)j.slot[i]], want = j.file_off[(size_t)j.slot[i] + 1] - at;
@@ -1420,7 +1439,7 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
                     }
                     if (got < want) memset(j.text->data() + at + got, ' ', want - got);
                     g_bytes_read += got;
-                } else if (!is_plain_pdb(j.paths[i])) {
+                } else if (!is_device_text(j.paths[i])) {
                     std::string stem, ext; file_parts(base_name(j.paths[i]), stem, ext);
                     try { fragments_of(j.paths[i], stem, ext, !o.db, o, j.host_frags[i]); }
                     catch (const std::exception& e) { err[i] = "[Error] " + base_name(j.paths[i]) + ": " + e.what() + "\n"; }

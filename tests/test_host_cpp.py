@@ -470,21 +470,26 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
     (d / "f0019_mse.pdb").write_text("\n".join(l[:17] + "MSE" + l[20:] if l.startswith("ATOM") and l[22:26] == ala else l for l in lines) + "\n")
     (d / "f0023_empty.pdb").write_text("HEADER    nothing\n")
     (d / "f0029_alt.pdb").write_text("\n".join(l for ln in lines for l in ([ln, ln[:30] + "   1.000   2.000   3.000" + ln[54:]] if ln.startswith("ATOM") and ln[12:16].strip() == "CB" else [ln])) + "\n")
+    # gzipped PDB text: inflated by the reader threads, parsed on the device; one of them holds a record the device hands back
+    (d / "f0331.ent.gz").write_bytes(gzip.compress(texts["syn:len129"].encode()))
+    (d / "f0337_sci.pdb.gz").write_bytes(gzip.compress(("\n".join(lines[:k] + [lines[k][:30] + " 1.0e+01" + lines[k][38:]] + lines[k + 1:]) + "\n").encode()))
+    (d / "f0341_bad.pdb.gz").write_bytes(b"not a gzip stream")
     outs = {}
     for tag, extra in (("dev", []), ("host", ["--host-parse"])):
         r = _run("compress", "-d", "-y", "-t", "8", "--gpus", "1", "--json-stats", *extra, str(d), str(tmp_path / f"db_{tag}"))
         assert r.returncode == 0, r.stderr
         st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         outs[tag] = (st, r.stderr)
-    assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 1      # the scientific-notation file
-    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1
+    assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 2      # the scientific-notation files
+    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1 + 2
+    assert all("f0341_bad" in outs[tag][1] for tag in ("dev", "host"))
     for ext in ("", ".index", ".lookup", ".dbtype"):
         assert (tmp_path / f"db_dev{ext}").read_bytes() == (tmp_path / f"db_host{ext}").read_bytes(), ext
     for tag in ("dev", "host"):
         assert "f0019_mse" in outs[tag][1] and "No atoms found" in outs[tag][1]
     rd = DatabaseReader(str(tmp_path / "db_dev"))
     names = [rd.name(i) for i in range(len(rd))]
-    assert names == sorted(names) and names.count("f0017_multi") == 3 and "f0011" in names and "f0013.pdb" in names
+    assert names == sorted(names) and names.count("f0017_multi") == 3 and "f0011" in names and "f0013.pdb" in names and "f0331.ent" in names and "f0337_sci.pdb" in names
     rd.close()
     # directory output: the same files either way
     for tag, extra in (("dev", []), ("host", ["--host-parse"])):

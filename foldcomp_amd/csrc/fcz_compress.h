@@ -955,8 +955,12 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
         st_u64(rec + RL.o_words + 8 * (size_t)k, word);
         rec[RL.o_tbytes + k] = (uint8_t)quant_round(v6, qmin[6], qdisc[6]);
     };
-    auto finish_q = [&](int q, float lo, float hi, const float* src, uint32_t cntq, int mode) {
+    // first = element 0 of the array (wave-uniform). std::min_element / max_element start from it and replace it only when a
+    // comparison says so: a NaN there stays (nothing compares below or above it), a NaN anywhere else is never picked -- which is
+    // what the fminf / fmaxf reductions give
+    auto finish_q = [&](int q, float first, float lo, float hi, const float* src, uint32_t cntq, int mode) {
         if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
+        if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
     };
     if (small) {
@@ -971,7 +975,8 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
                 lo = __builtin_fminf(lo, on ? va[q][u] : kInf);
                 hi = __builtin_fmaxf(hi, on ? va[q][u] : -kInf);
             }
-            finish_q(q, wave_min_f32(lo), wave_max_f32(hi), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), cntq, q < 3 ? 1 : (q < 6 ? 2 : 0));
+            const float first = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(va[q][0])));
+            finish_q(q, first, wave_min_f32(lo), wave_max_f32(hi), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), cntq, q < 3 ? 1 : (q < 6 ? 2 : 0));
         }
         if (keep_first_angle) {
             // fcz_compress_angles reads the scratch back: leave the finished angles there
@@ -991,9 +996,9 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     } else {
         // longer chains: all seven arrays advance together, 128 residues per memory round trip (clamped, unconditional
         // loads), first for the extrema, then again (from the L2) for the words
-        float lo[7], hi[7];
+        float lo[7], hi[7], first[7];
 #pragma unroll
-        for (int q = 0; q < 7; q++) { lo[q] = kInf; hi[q] = -kInf; }
+        for (int q = 0; q < 7; q++) { lo[q] = kInf; hi[q] = -kInf; first[q] = 0.f; }
         for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
             float tv[7][2];
 #pragma unroll
@@ -1011,6 +1016,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
                 tv[3][u] = dec_angle<3>(tv[3][u]); tv[4][u] = dec_angle<4>(tv[4][u]); tv[5][u] = dec_angle<5>(tv[5][u]);
 #pragma unroll
                 for (int q = 0; q < 7; q++) {
+                    if (k0 == 0 && u == 0) first[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tv[q][0])));
                     const bool on = k < ((q < 6) ? m : n);
                     if (q < 6 && on) a_arr[(size_t)q * R + k] = tv[q][u];
                     lo[q] = __builtin_fminf(lo[q], on ? tv[q][u] : kInf); hi[q] = __builtin_fmaxf(hi[q], on ? tv[q][u] : -kInf);
@@ -1019,7 +1025,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
         }
 #pragma unroll
         for (int q = 0; q < 7; q++)
-            finish_q(q, wave_min_f32(lo[q]), wave_max_f32(hi[q]), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), (q < 6) ? m : n, 0);
+            finish_q(q, first[q], wave_min_f32(lo[q]), wave_max_f32(hi[q]), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), (q < 6) ? m : n, 0);
         for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
             float tv[7][2]; uint32_t rc2[2];
 #pragma unroll
@@ -1056,8 +1062,12 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
         h[17] = (uint8_t)fcz_res1[h_rc_last];
         h[18] = 0; h[19] = 0;
         st_u32(h + 20, title_len);
+        // a NaN among the angle parameters (a zero-length bond at the first window: 0 / 0 in getCosineTheta) is one the arithmetic
+        // made, and the reference's x86-64 arithmetic makes the negative quiet NaN (the "real indefinite", 0xFFC00000) and carries
+        // it unchanged through acos, the degree conversion and the quantiser's subtraction and division; gfx950 makes 0x7FC00000
+        auto x86_nan = [](float v) { return v != v ? __uint_as_float(0xFFC00000u) : v; };
 #pragma unroll
-        for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, qmin[q]); st_f32(h + 48 + 4 * q, qcont[q]); }
+        for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, x86_nan(qmin[q])); st_f32(h + 48 + 4 * q, x86_nan(qcont[q])); }
         // OXT (src/foldcomp.cpp:474-482): the last atom of the span
         const uint32_t la = a_end - 1;
         const bool has_oxt = a_end > a_first && in.atom_code[la] == FCZ_ATOM_OXT;

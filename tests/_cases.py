@@ -92,3 +92,80 @@ def reference_would_spin(t) -> bool:
             i = j
         i += 1
     return False
+
+
+# ---- coordinates no structure has: what the angle code makes of zero-length bonds, straight lines, coinciding atoms ----------
+def _first_atom(b, chain, res):
+    return int(b.atom_off[int(b.res_off[chain]) + res])
+
+
+def degenerate_cases():
+    """[(name, mutate(batch, x, y, z))]: in-place edits of a synthetic batch's coordinates. NaN angles (a zero-length bond gives
+    0 / 0 in getCosineTheta), the NaN guard of the dihedrals, min / max over arrays that hold NaN (std::min_element keeps what it
+    holds when a comparison with NaN is false), overflow to infinity, every value equal (a quantiser with max == min)."""
+    def ca_on_n(res):
+        def f(b, x, y, z):
+            for ch in range(b.n_chains):
+                a = _first_atom(b, ch, res); x[a + 1], y[a + 1], z[a + 1] = x[a], y[a], z[a]
+        return f
+
+    def c_on_ca(b, x, y, z):
+        for ch in range(b.n_chains):
+            a = _first_atom(b, ch, 0); x[a + 2], y[a + 2], z[a + 2] = x[a + 1], y[a + 1], z[a + 1]
+
+    def straight(b, x, y, z):
+        for ch in range(b.n_chains):
+            a = _first_atom(b, ch, 7)
+            x[a + 1], y[a + 1], z[a + 1] = x[a] + 1.0, y[a], z[a]
+            x[a + 2], y[a + 2], z[a + 2] = x[a] + 2.0, y[a], z[a]
+
+    def residue_at_origin(b, x, y, z):
+        for ch in range(b.n_chains):
+            a0, a1 = _first_atom(b, ch, 3), _first_atom(b, ch, 4)
+            x[a0:a1] = 0; y[a0:a1] = 0; z[a0:a1] = 0
+
+    def far_away(b, x, y, z):
+        for ch in range(b.n_chains):
+            x[_first_atom(b, ch, 9) + 1] = 1e30
+
+    def noise(b, x, y, z):
+        rng = np.random.default_rng(1)
+        for v in (x, y, z):
+            v[:] = rng.normal(0, 10, len(v)).astype(np.float32).round(3)
+
+    def lattice(b, x, y, z):
+        rng = np.random.default_rng(2)
+        for v in (x, y, z):
+            v[:] = rng.integers(-3, 4, len(v)).astype(np.float32)
+
+    def one_point(b, x, y, z):
+        x[:] = 1.0; y[:] = 2.0; z[:] = 3.0
+
+    def n1_on_c0(b, x, y, z):
+        for ch in range(b.n_chains):
+            a, a1 = _first_atom(b, ch, 0), _first_atom(b, ch, 1); x[a1], y[a1], z[a1] = x[a + 2], y[a + 2], z[a + 2]
+
+    def coincidences(seed):
+        def f(b, x, y, z):
+            rng = np.random.default_rng(seed)
+            for ch in range(b.n_chains):
+                n = int(b.res_off[ch + 1] - b.res_off[ch])
+                for _ in range(int(rng.integers(1, 6))):
+                    r = int(rng.integers(0, n)) if rng.random() < 0.6 else (0 if rng.random() < 0.5 else n - 1)
+                    a = _first_atom(b, ch, r); na = _first_atom(b, ch, r + 1) - a if r + 1 < n else 4
+                    i, j = int(rng.integers(0, min(na, 5))), int(rng.integers(0, min(na, 5)))
+                    x[a + i], y[a + i], z[a + i] = x[a + j], y[a + j], z[a + j]
+        return f
+
+    return [("N of residue 1 on C of residue 0", n1_on_c0)] + [(f"random coincidences {k}", coincidences(k)) for k in range(6)] + [("CA on N, residue 5", ca_on_n(5)), ("CA on N, first residue", ca_on_n(0)), ("C on CA, first residue", c_on_ca),
+            ("three atoms in a line", straight), ("a residue at the origin", residue_at_origin), ("an atom 1e30 away", far_away),
+            ("noise", noise), ("integer lattice", lattice), ("every atom at one point", one_point)]
+
+
+def degenerate_batch(mutate, lens=(40, 350, 90), seed=3):
+    from foldcomp_amd import synthetic
+    b = synthetic.to_chain_batch(synthetic.generate(len(lens), list(lens), seed=seed))
+    x, y, z = b.x.copy(), b.y.copy(), b.z.copy()
+    mutate(b, x, y, z)
+    b.x, b.y, b.z = x, y, z
+    return b

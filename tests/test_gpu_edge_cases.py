@@ -153,3 +153,21 @@ def test_batch_beyond_32_bit_atom_offsets_is_refused(codec):
     assert rc == 0 and ta.value == ok * per_atoms
     del big, one
     torch.cuda.empty_cache()
+
+
+def test_degenerate_coordinates(codec):
+    """zero-length bonds, straight lines, coinciding atoms, overflow, every atom at one point (_cases.degenerate_cases; the oracle
+    is pinned to the live reference on the same inputs in test_oracle_vs_golden.py): records bit-exact, decoded coordinates
+    bit-exact where they are numbers and NaN where the oracle's are NaN"""
+    from _cases import degenerate_batch, degenerate_cases
+    for name, mutate in degenerate_cases():
+        b = degenerate_batch(mutate)
+        blob, off, st = codec.compress_batch(b)
+        oblob, ooff, ost = H.oracle_compress(b, n_threads=4)
+        assert (st == 0).all() and (ost == 0).all(), name
+        assert np.array_equal(off, ooff) and blob.tobytes() == oblob.tobytes(), name
+        for alt in (False, True):
+            d = codec.decompress_batch(blob, off, alt_order=alt)
+            o = H.oracle_decompress(oblob, ooff, alt_order=alt, n_threads=4)
+            for k in ("x", "y", "z", "bfac_res"):
+                assert np.all((_bits(d[k]) == _bits(o[k])) | (np.isnan(d[k]) & np.isnan(o[k]))), (name, alt, k)

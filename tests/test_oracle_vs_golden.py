@@ -98,3 +98,25 @@ def test_oracle_vs_live_reference_on_fresh_synthetic():
         a0, a1 = d["atom_off"][c], d["atom_off"][c + 1]
         for k in "xyz":
             assert np.array_equal(_bits(r[k]), _bits(d[k][a0:a1]))
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_vs_live_reference_on_degenerate_coordinates():
+    """zero-length bonds, straight lines, coinciding atoms, overflow, every atom at one point: NaN angles and what the quantisers
+    make of them. The oracle's records and its decode of them == the real reference's (NaN for NaN where coordinates are NaN)"""
+    from _cases import degenerate_batch, degenerate_cases
+    from tools_chain_table import chain_table
+    for name, mutate in degenerate_cases():
+        b = degenerate_batch(mutate)
+        blob, off, st = H.oracle_compress(b)
+        assert (st == 0).all(), name
+        d = H.oracle_decompress(blob, off)
+        for c in range(b.n_chains):
+            title = bytes(b.titles[b.title_off[c]:b.title_off[c + 1]]).decode()
+            ref = H.mask_pad(H.ref_compress(chain_table(b, c), title, b.anchor_threshold))
+            assert ref == blob[off[c]:off[c + 1]].tobytes(), (name, c)
+            r = H.ref_decompress(ref)
+            a0, a1 = d["atom_off"][c], d["atom_off"][c + 1]
+            for k in "xyz":
+                got, exp = d[k][a0:a1], np.asarray(r[k], np.float32)
+                assert np.all((_bits(got) == _bits(exp)) | (np.isnan(got) & np.isnan(exp))), (name, c, k)

@@ -26,20 +26,25 @@ __device__ __forceinline__ uint32_t dec_len(int v) {
     return d + (v < 0 ? 1u : 0u);
 }
 
-// fast_ftoa<T,P> (reference src/atom_coordinate.cpp:185-218): r = n +- 0.5/T in float, I = (int)r, D = (int)((r - I) * T)
-struct ftoa_parts { uint32_t I, D; bool neg; };
+// fast_ftoa<T,P> (reference src/atom_coordinate.cpp:185-218): r = n +- 0.5/T in float, I = (int)r, D = (int)((r - I) * T).
+// odd: r is a NaN, infinite or beyond the int range. (int) of such a float is INT_MIN on x86-64 (cvttss2si's "integer indefinite"),
+// for I and then for D as well, std::abs leaves it INT_MIN, and itoa_pos_only (:172-183) ends after ONE character for a negative
+// number: '0' + INT_MIN % 10 = '('. The number reads "(.00(" ("-(.00(" for a negative infinity); what a decoded NaN looks like in
+// the reference's text (a record whose quantiser parameters are NaN).
+struct ftoa_parts { uint32_t I, D; bool neg, odd; };
 __device__ __forceinline__ ftoa_parts fast_ftoa_parts(float v, float T) {
     const float half = 0.5f / T;
     ftoa_parts p;
     p.neg = v < 0.0f;
     const float r = v + (p.neg ? -half : half);
-    const int I = (int)r;
-    const int D = (int)((r - (float)I) * T);
+    p.odd = !(__builtin_fabsf(r) < 2147483648.0f);
+    const int I = p.odd ? 0 : (int)r;
+    const int D = p.odd ? 0 : (int)((r - (float)I) * T);
     p.I = (uint32_t)(I < 0 ? -I : I);
     p.D = (uint32_t)(D < 0 ? -D : D);
     return p;
 }
-__device__ __forceinline__ uint32_t ftoa_len(const ftoa_parts& p, uint32_t P) { return dec_len((int)p.I) + 1u + P + (p.neg ? 1u : 0u); }
+__device__ __forceinline__ uint32_t ftoa_len(const ftoa_parts& p, uint32_t P) { return (p.odd ? 1u : dec_len((int)p.I)) + 1u + P + (p.neg ? 1u : 0u); }
 
 // per-chain facts from the FCZ header
 struct pdb_chain {
@@ -151,6 +156,7 @@ struct line_writer {
         const uint32_t l = ftoa_len(f, P);
         if (l < width) spaces(width - l);
         if (f.neg) ch('-');
+        if (f.odd) { ch('('); ch('.'); for (uint32_t i = 1; i < P; i++) ch('0'); ch('('); return; }
         const uint32_t nd = dec_len((int)f.I);
         uint32_t a = f.I, p = pos + nd;
         for (uint32_t i = 0; i < nd; i++) { buf[--p] = (uint8_t)('0' + a % 10u); a /= 10u; }
@@ -229,6 +235,16 @@ __device__ __forceinline__ void put_int(line81& L, uint32_t a, bool neg) {
 // "%*s" of fast_ftoa<T,P>(v) known to fit: WI columns for sign + integer digits, '.', P decimals
 template <int COL, int WI, int P>
 __device__ __forceinline__ void put_num(line81& L, const ftoa_parts& f) {
+    if (__builtin_expect(f.odd, 0)) {
+        L.put<COL + WI - 1>('('); L.put<COL + WI - 2>(f.neg ? '-' : ' ');
+        if constexpr (WI > 2) L.put<COL + WI - 3>(' ');
+        if constexpr (WI > 3) L.put<COL + WI - 4>(' ');
+        L.put<COL + WI>('.');
+        if constexpr (P > 1) L.put<COL + WI + 1>('0');
+        if constexpr (P > 2) L.put<COL + WI + 2>('0');
+        L.put<COL + WI + P>('(');
+        return;
+    }
     put_int<COL, WI>(L, f.I, f.neg);
     L.put<COL + WI>('.');
     uint32_t d = f.D;

@@ -24,10 +24,15 @@ def fast_ftoa(values: np.ndarray, T: int, P: int):
     half = np.float32(0.5) / np.float32(T)
     neg = v < 0
     r = v + np.where(neg, -half, half).astype(np.float32)
-    I = r.astype(np.int32)                                  # C truncation
-    D = ((r - I.astype(np.float32)) * np.float32(T)).astype(np.int32)
+    # (int) of a NaN, an infinity or a float beyond int is INT_MIN on x86-64, for the integer and then for the decimals; std::abs
+    # leaves it, and itoa_pos_only (:172-183) stops after one character for a negative number: '0' + INT_MIN % 10 = '('
+    odd = ~(np.abs(r) < np.float32(2147483648.0))
+    rs = np.where(odd, np.float32(0), r)
+    I = rs.astype(np.int32)                                 # C truncation
+    D = ((rs - I.astype(np.float32)) * np.float32(T)).astype(np.int32)
     I = np.abs(I); D = np.abs(D)
-    return ["%s%d.%0*d" % ("-" if ng else "", i, P, d) for ng, i, d in zip(neg.tolist(), I.tolist(), D.tolist())]
+    return [("%s(.%s(" % ("-" if ng else "", "0" * (P - 1))) if od else "%s%d.%0*d" % ("-" if ng else "", i, P, d)
+            for ng, i, d, od in zip(neg.tolist(), I.tolist(), D.tolist(), odd.tolist())]
 
 
 def title_lines(title: str) -> str:

@@ -91,6 +91,29 @@ def test_pdb_text_with_database_terminators(codec, golden):
         assert sum(len(t) for t in term) == sum(len(t) for t in plain) + int((st0 == 0).sum())
 
 
+def test_pdb_text_of_degenerate_records(codec):
+    """NaN coordinates in the text ("(.00(": what the reference prints for them, test_host_formats.py pins the restatement to the
+    live reference on the same records): device text == restatement, both atom orders"""
+    import _harness as H
+    from _cases import degenerate_batch, degenerate_cases
+    seen_nan = False
+    for name, mutate in degenerate_cases():
+        b = degenerate_batch(mutate)
+        blob, off, st = codec.compress_batch(b)
+        assert (st == 0).all()
+        entries = [blob[off[i]:off[i + 1]].tobytes() for i in range(b.n_chains)]
+        for alt in (False, True):
+            texts, status = codec.decompress_pdb(blob, off, alt_order=alt)
+            assert (status == 0).all()
+            o = H.oracle_decompress(blob, off, alt_order=alt)
+            from host_text import pdb_from_result
+            for i, (t, e) in enumerate(zip(texts, entries)):
+                exp = pdb_from_result(fczfile.parse(e), o, i, alt).encode("latin-1")
+                assert t == exp, (name, alt, i, next((k for k in range(min(len(t), len(exp))) if t[k] != exp[k]), None))
+                seen_nan = seen_nan or b"(.00(" in t
+    assert seen_nan
+
+
 def test_extract_equals_reference_for_every_golden(codec, golden):
     """k_extract (pLDDT digits 1..4, sequence) against the reference's `foldcomp extract` strings"""
     z, index = golden

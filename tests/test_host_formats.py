@@ -158,3 +158,27 @@ def test_pdb_writer_restatement_equals_reference_on_column_overflows():
             assert mine == ref, (alt, i)
             if i < 3:
                 assert any(len(line) > 80 for line in ref.split("\n")), "the case must really overflow a column"
+
+
+def test_pdb_text_of_degenerate_records_equals_live_reference():
+    """records whose decoded coordinates are NaN (quantiser parameters that are NaN: _cases.degenerate_cases): the reference prints
+    "(.00(" for such a number -- (int)NaN is INT_MIN on x86-64 and itoa_pos_only stops after one character for a negative number.
+    The text restatement (oracle/host_text.py, the checker of the device's text) == the live reference's text on every case"""
+    import _harness as H
+    if not H.have_ref():
+        pytest.skip("oracle/_ref (the reference built from its own sources) is not available")
+    from _cases import degenerate_batch, degenerate_cases
+    from foldcomp_amd import fczfile
+    from host_text import pdb_from_result as _pdb_from_result
+    seen_nan = False
+    for name, mutate in degenerate_cases():
+        b = degenerate_batch(mutate)
+        blob, off, st = H.oracle_compress(b)
+        for alt in (False, True):
+            o = H.oracle_decompress(blob, off, alt_order=alt)
+            for i in range(b.n_chains):
+                e = blob[off[i]:off[i + 1]].tobytes()
+                ref = H.ref_decompress_pdb(e, alt_order=alt)
+                assert _pdb_from_result(fczfile.parse(e), o, i, alt) == ref, (name, alt, i)
+                seen_nan = seen_nan or "(.00(" in ref
+    assert seen_nan, "the cases must reach the NaN text"

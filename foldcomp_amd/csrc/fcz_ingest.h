@@ -38,7 +38,7 @@ constexpr int IG_TITLE_CAP = 512;                 // bytes of title per file
 constexpr int IG_MAX_FRAGS = 32;                  // fragments per file
 
 // fragment refusal reasons (what Batch::prepare of the host throws), chain_meta of a refused fragment carries them << 24
-constexpr uint32_t IG_REF_NONE = 0, IG_REF_RESNAME = 1, IG_REF_BACKBONE = 2, IG_REF_TOO_LONG = 3, IG_REF_SKIP_DISC = 4;
+constexpr uint32_t IG_REF_NONE = 0, IG_REF_RESNAME = 1, IG_REF_BACKBONE = 2, IG_REF_TOO_LONG = 3, IG_REF_SKIP_DISC = 4, IG_REF_BACKBONE_TWICE = 5, IG_REF_LAST_NAME = 6;
 constexpr uint32_t IG_META_MULTI_CHAIN = 1u << 16, IG_META_MULTI_FRAG = 1u << 17;
 
 struct ingest_scratch {       // per-atom table of the kept atoms, file f at [abase[f], abase[f] + n_kept[f])
@@ -643,7 +643,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
             // the FCZ header holds nResidue in 16 bits and nAnchor in 8 (src/foldcomp.h:120-125): refused, not wrapped
             if (nres > 65535u || (anchor_threshold > 0 && nres / (uint32_t)anchor_threshold + 2u > 255u)) { if (!reason) reason = IG_REF_TOO_LONG; }
             // lane = residue: code of the residue name, first N / CA / C in order, the CA B-factor
-            bool bad_name = false, bad_bb = false;
+            // (a second N, CA or C in a residue: the reference counts residues on the flat list of those atoms, it would shift all
+            // that follows; the last atom's residue name: it is header.lastResidue, src/foldcomp.cpp:469 -- both refused, see the
+            // hosts' build_batch / Batch::prepare)
+            bool bad_name = false, bad_bb = false, bad_twice = false;
             for (uint32_t q0 = 0; q0 < nres; q0 += WAVE) {
                 const uint32_t q = q0 + (uint32_t)lane;
                 if (q < nres) {
@@ -651,9 +654,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
                     const uint32_t s1 = q + 1 < nres ? ig_ld_coherent(&T.r_first[A0 + r_next + q + 1]) : b;
                     const int code = T.rcode[A0 + s0];
                     if (code < 0) bad_name = true;
-                    int pos[3] = {-1, -1, -1};
-                    for (uint32_t i = s0; i < s1; i++) { const uint32_t ac = T.acode[A0 + i]; if (ac < 3u && pos[ac] < 0) pos[ac] = (int)i; }
+                    int pos[3] = {-1, -1, -1}; uint32_t cnt = 0;
+                    for (uint32_t i = s0; i < s1; i++) { const uint32_t ac = T.acode[A0 + i]; if (ac < 3u) { cnt++; if (pos[ac] < 0) pos[ac] = (int)i; } }
                     if (pos[0] < 0 || pos[1] < 0 || pos[2] < 0 || !(pos[0] < pos[1] && pos[1] < pos[2])) bad_bb = true;
+                    else if (cnt != 3u) bad_twice = true;
                     T.r_code[A0 + r_next + q] = (uint8_t)(code < 0 ? 23 : code);
                     T.r_bfac[A0 + r_next + q] = pos[1] >= 0 ? T.b[A0 + (uint32_t)pos[1]] : 0.f;
                 }
@@ -661,6 +665,11 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
             // the host reports the first problem it meets walking the residues; a fragment with either is refused all the same
             if (!reason && __any(bad_name)) reason = IG_REF_RESNAME;
             if (!reason && __any(bad_bb)) reason = IG_REF_BACKBONE;
+            if (!reason && __any(bad_twice)) reason = IG_REF_BACKBONE_TWICE;
+            if (!reason && nres) {
+                const uint32_t s_last = ig_ld_coherent(&T.r_first[A0 + r_next + nres - 1]);
+                if (T.resn[A0 + b - 1] != T.resn[A0 + s_last]) reason = IG_REF_LAST_NAME;
+            }
             if (nf < (uint32_t)IG_MAX_FRAGS) {
                 if (lane == 0) {
                     ingest_frag fr;

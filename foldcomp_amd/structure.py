@@ -396,7 +396,18 @@ def build_batch(chains: Sequence[Chain], anchor_threshold: int = 25) -> ChainBat
             pos = [np.nonzero(seg == k)[0] for k in (0, 1, 2)]
             if any(len(p) == 0 for p in pos) or not (pos[0][0] < pos[1][0] < pos[2][0]):
                 raise StructureError("residue without N, CA, C backbone atoms in order")
+            # The reference works on the FLAT list of every atom named N, CA or C (filterBackbone, src/atom_coordinate.cpp:135-143;
+            # nResidue = their number / 3, src/foldcomp.cpp:462) and on every CA's B-factor (:543-547); this codec on the first N,
+            # CA, C of each residue. The two agree exactly when a residue has one of each -- a second one (a line that strayed into
+            # the residue) shifts every later residue of the reference's record: such a chain is refused, not compressed differently
+            if any(len(p) != 1 for p in pos):
+                raise StructureError("residue with a second N, CA or C atom")
             bf[r] = t.bfac[ro[r] + pos[1][0]]
+        # header.lastResidue is the residue name of the chain's LAST ATOM (src/foldcomp.cpp:469), the residue codes are those of
+        # each residue's first atom (getResidueNameVector, src/atom_coordinate.cpp:330-345): one value in the batch serves both
+        # only when they agree (splitAtomByResidue, :304-328, always puts the last atom into the last residue, whatever it says)
+        if t.residue[len(t) - 1] != t.residue[ro[nres - 1]]:
+            raise StructureError("the chain's last atom carries another residue name than its residue")
         atom_off_parts.append(ro[:-1] + abase)
         abase += len(t)
         res_off.append(res_off[-1] + nres)

@@ -672,12 +672,20 @@ struct Batch {
             const int code = coded ? (int)t.res_code[ro[r]] : fcz_res_code_from_name(t.name(t.residue[ro[r]]).c_str());
             if (code < 0) throw std::runtime_error("residue name '" + t.name(t.residue[ro[r]]) + "' is not supported by the codec");
             p.rc[r] = (uint8_t)code;
-            long pos[3] = {-1, -1, -1};
-            for (uint32_t i = ro[r]; i < ro[r + 1]; i++) if (p.ac[i] < 3 && pos[p.ac[i]] < 0) pos[p.ac[i]] = i;
+            long pos[3] = {-1, -1, -1}; int cnt[3] = {0, 0, 0};
+            for (uint32_t i = ro[r]; i < ro[r + 1]; i++) if (p.ac[i] < 3) { cnt[p.ac[i]]++; if (pos[p.ac[i]] < 0) pos[p.ac[i]] = i; }
             if (pos[0] < 0 || pos[1] < 0 || pos[2] < 0 || !(pos[0] < pos[1] && pos[1] < pos[2]))
                 throw std::runtime_error("residue without N, CA, C backbone atoms in order");
+            // the reference works on the flat list of every N / CA / C atom (filterBackbone; nResidue = their number / 3), this
+            // codec on the first of each per residue: they agree when a residue has one of each. A second one would shift every
+            // later residue of the reference's record: refused, not compressed differently
+            if (cnt[0] != 1 || cnt[1] != 1 || cnt[2] != 1) throw std::runtime_error("residue with a second N, CA or C atom");
             p.bf[r] = t.bfac[pos[1]];
         }
+        // header.lastResidue is the residue name of the chain's last ATOM (src/foldcomp.cpp:469), the residue codes those of each
+        // residue's first atom: one value serves both only when they agree
+        if (t.residue[t.size() - 1] != t.residue[ro[nres - 1]])
+            throw std::runtime_error("the chain's last atom carries another residue name than its residue");
         return p;
     }
     // appends one prepared fragment (copies only)
@@ -1313,9 +1321,10 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
                 }
                 for (size_t k = 0; k + 1 < refused.size(); k += 2) {
                     static const char* why[] = {"", "residue name is not supported by the codec", "residue without N, CA, C backbone atoms in order",
-                                                "chain does not fit the FCZ header (65535 residues, 255 anchors)", "discontinuous chain skipped"};
+                                                "chain does not fit the FCZ header (65535 residues, 255 anchors)", "discontinuous chain skipped",
+                                                "residue with a second N, CA or C atom", "the chain's last atom carries another residue name than its residue"};
                     const uint32_t reason = refused[k + 1] >> 24;
-                    fprintf(stderr, "[Error] compressing %s.fcz: %s\n", frag_name(text_file[refused[k]], refused[k + 1]).c_str(), why[reason < 5 ? reason : 0]);
+                    fprintf(stderr, "[Error] compressing %s.fcz: %s\n", frag_name(text_file[refused[k]], refused[k + 1]).c_str(), why[reason < 7 ? reason : 0]);
                 }
                 // what the device handed back: parsed here from the text that is already in memory
                 for (uint32_t t = 0; t < n_text; t++) {

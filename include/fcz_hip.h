@@ -55,8 +55,12 @@ enum fcz_status {
 
 /* Compress input: C chains, R residues in total, M atoms in total. Caller-owned.
  * Replaces the tcb::span<AtomCoordinate> handed to Foldcomp::compress (src/main.cpp:485-488).
- * Preconditions (the reference's input domain): every residue holds atoms
- * named N, CA, C; residues of a chain are gap-free; residue names are the 20 standard ones or UNK. */
+ * Preconditions (the reference's input domain): every residue holds exactly one atom
+ * named N, one CA and one C, in that order (the reference counts residues on the flat list of every N / CA / C
+ * atom, src/atom_coordinate.cpp:135-143, src/foldcomp.cpp:462: with one of each per residue that list is this
+ * batch's residues); residues of a chain are gap-free; residue names are the 20 standard ones or UNK; the
+ * chain's last atom belongs to its last residue by name as well (its residue name is header.lastResidue,
+ * src/foldcomp.cpp:469). The structure ingest and the hosts of this repository refuse what does not comply. */
 typedef struct fcz_chain_batch {
     uint32_t n_chains;              /* C */
     uint32_t n_residues;            /* R */
@@ -233,10 +237,12 @@ int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
  * insertion code) does not grow inside its run of one chain name -- the reader regroups such lines --, a title beyond 512 bytes,
  * more than 32 fragments) -- nothing of that file is in the batch and the caller's own reader has to take it (the hosts of this
  * repository restate every rule: foldcomp_amd/structure.py parse_pdb_gemmi, host/foldcomp_hip.cpp parse_pdb_gemmi). refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the
- * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order, chain beyond the
- * header's counts, --skip-discontinuous). mmCIF and gzip stay on the host. */
+ * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order or with a second one
+ * of them, a last atom that carries another residue name than its residue, chain beyond the header's counts,
+ * --skip-discontinuous). mmCIF and gzip stay on the host. */
 enum fcz_ingest_status { FCZ_INGEST_HOST_FIELD = 1, FCZ_INGEST_HOST_TITLE = 2, FCZ_INGEST_HOST_FRAGS = 3, FCZ_INGEST_NO_ATOMS = 4 };
-enum fcz_ingest_reason { FCZ_INGEST_REF_RESNAME = 1, FCZ_INGEST_REF_BACKBONE = 2, FCZ_INGEST_REF_TOO_LONG = 3, FCZ_INGEST_REF_SKIP_DISC = 4 };
+enum fcz_ingest_reason { FCZ_INGEST_REF_RESNAME = 1, FCZ_INGEST_REF_BACKBONE = 2, FCZ_INGEST_REF_TOO_LONG = 3, FCZ_INGEST_REF_SKIP_DISC = 4,
+                         FCZ_INGEST_REF_BACKBONE_TWICE = 5, FCZ_INGEST_REF_LAST_NAME = 6 };
 #define FCZ_INGEST_MULTI_CHAIN (1u << 16)
 #define FCZ_INGEST_MULTI_FRAG  (1u << 17)
 #define FCZ_INGEST_SKIP_DISCONTINUOUS 1   /* flags: --skip-discontinuous (src/main.cpp:476-480) */

@@ -173,36 +173,64 @@ def _mutation_bases(ing):
     return [ing["file:test_af.pdb"].tobytes().decode("latin-1").splitlines(), mc[:6] + cut + ["END"]]
 
 
+def _ref_child(conn):
+    import faulthandler
+    faulthandler.disable()          # a crash of the reference in this child is an answer ("crash"), not a report to print
+    while True:
+        try:
+            what, args = conn.recv()
+        except EOFError:
+            return
+        try:
+            if what == "load":
+                conn.send(("ok",) + tuple(H.ref_load_structure(*args)))
+            else:
+                conn.send(("ok", H.mask_pad(H.ref_compress(*args))))
+        except RuntimeError:
+            conn.send(("fail",))
+
+
 class _RefWorker:
     """the live reference in a child process: on some mutated inputs the reference itself crashes or never returns (identifyChains
-    spins when a chain id changes at a non-N atom with no N after it); such inputs are skipped, they have no reference answer"""
+    spins when a chain id changes at a non-N atom with no N after it); such inputs have no reference answer. A dead child is
+    noticed at once (its sentinel), a spinning one after `timeout` seconds"""
 
-    def __init__(self):
+    def __init__(self, timeout=10.0):
         import multiprocessing as mp
         self.mp = mp.get_context("fork")
-        self.pool = None
+        self.timeout = timeout
+        self.proc = self.conn = None
 
-    @staticmethod
-    def _call(data, name):
-        import faulthandler
-        faulthandler.disable()          # a crash of the reference in this child is an answer ("crash"), not a report to print
-        try:
-            return ("ok",) + tuple(H.ref_load_structure(data, name))
-        except RuntimeError:
-            return ("fail",)
+    def _start(self):
+        self.conn, child = self.mp.Pipe()
+        self.proc = self.mp.Process(target=_ref_child, args=(child,), daemon=True)
+        self.proc.start()
+        child.close()
+
+    def run(self, what, *args):
+        from multiprocessing.connection import wait
+        if self.proc is None:
+            self._start()
+        self.conn.send((what, args))
+        ready = wait([self.conn, self.proc.sentinel], self.timeout)
+        if self.conn in ready:
+            try:
+                return self.conn.recv()
+            except EOFError:
+                pass
+        self.close()
+        return ("crash",)
 
     def load(self, data, name):
-        if self.pool is None:
-            self.pool = self.mp.Pool(1)
-        try:
-            return self.pool.apply_async(self._call, (data, name)).get(timeout=10)
-        except Exception:   # noqa: BLE001 - the worker died or hangs
-            self.pool.terminate(); self.pool = None
-            return ("crash",)
+        return self.run("load", data, name)
+
+    def compress(self, t, title, thr=25):
+        return self.run("compress", t, title, thr)
 
     def close(self):
-        if self.pool is not None:
-            self.pool.terminate()
+        if self.proc is not None:
+            self.proc.kill(); self.proc.join(); self.conn.close()
+        self.proc = self.conn = None
 
 
 def test_python_pdb_reader_equals_live_reference_on_mutated_files(ing):
@@ -247,6 +275,54 @@ def test_python_pdb_reader_equals_live_reference_on_mutated_files(ing):
         same += 1
     ref.close()
     assert same > 900 and failed > 100 and crashed < 100, (same, failed, crashed)
+
+
+def test_oracle_compress_equals_live_reference_on_mutated_files(ing):
+    """what the codec is handed after the reader: the fragments of 500 mutated files (atoms out of order, doubled, missing, foreign
+    records, cut lines ...). Every fragment the host accepts (build_batch) is compressed by the oracle and by the LIVE reference
+    (Foldcomp::compress on the same atoms): same bytes. What the reference compresses and the host refuses are chains whose residues
+    the reference counts differently (it works on the flat list of all N / CA / C atoms: a residue with a missing, a second or an
+    out-of-order backbone atom shifts everything behind it) and one-residue fragments; the device's ingest is held to the host's
+    verdicts and batches on such files in tests/test_gpu_ingest.py."""
+    if not H.have_ref():
+        pytest.skip("oracle/_ref is not built (it only exists where /root/reference does)")
+    from _cases import mutated_pdb
+    from foldcomp_amd.structure import StructureError, parse_pdb_gemmi
+    bases = _mutation_bases(ing)
+    rng = np.random.default_rng(99)
+    ref = _RefWorker()
+    same = refused = ref_failed = crashed = 0
+    for i in range(400):
+        data = mutated_pdb(bases[i % 2], rng)
+        try:
+            t, title = parse_pdb_gemmi(data)
+        except StructureError:
+            continue
+        t = remove_alternative_position(t)
+        if len(t) == 0:
+            continue
+        title = title or f"fz{i}"
+        for cs in identify_chains(t):
+            for sl in identify_discontinuous(t, cs):
+                ft = t.take(sl)
+                try:
+                    b = build_batch([Chain(title, ft)], 25)
+                except StructureError:
+                    refused += 1; continue
+                blob, off, st = H.oracle_compress(b)
+                r = ref.compress(ft, title)
+                if r[0] == "crash":
+                    crashed += 1; continue
+                if st[0] != 0:
+                    assert st[0] == -7 or r[0] == "fail", (i, st[0], "the codec refuses a chain the reference compresses")   # -7: fewer than two residues
+                    ref_failed += 1; continue
+                if r[0] == "fail":
+                    raise AssertionError((i, sl, "the reference refuses a chain the codec compresses"))
+                assert r[0] == "ok", (i, sl)
+                assert r[1] == blob.tobytes(), (i, sl, next(k for k in range(min(len(r[1]), len(blob))) if r[1][k] != blob[k]))
+                same += 1
+    ref.close()
+    assert same > 300 and crashed < 60, (same, refused, ref_failed, crashed)
 
 
 def test_cpp_pdb_reader_equals_python_reader_on_mutated_files(ing, tmp_path):

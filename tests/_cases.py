@@ -169,3 +169,53 @@ def degenerate_batch(mutate, lens=(40, 350, 90), seed=3):
     mutate(b, x, y, z)
     b.x, b.y, b.z = x, y, z
     return b
+
+
+# ---- FCZ records with random payloads (the header, the residue codes and the anchors stay) ----------------------------------
+def payload_mutations(records, per_record=10, seed=20260927, temp_params=False):
+    """random angle words (every one / a tenth / all bits set or clear / one residue / bond-angle bytes only), side-chain torsion
+    bytes and B-factor bytes; temp_params: also the B-factor quantiser's two floats (what `extract` prints from)"""
+    from foldcomp_amd import fczfile
+    rng = np.random.default_rng(seed)
+    out = []
+    for e in records:
+        r = fczfile.parse(e)
+        for v in range(per_record):
+            b = bytearray(e)
+            w = np.frombuffer(e, np.uint8, 8 * r.n_residues, r.o_words).reshape(-1, 8).copy()
+            rnd = rng.integers(0, 256, w.shape, dtype=np.uint8)
+            how = v % 5
+            if how == 0:
+                sel = np.ones(len(w), bool)
+            elif how == 1:
+                sel = rng.random(len(w)) < 0.1
+            elif how == 2:
+                sel = np.ones(len(w), bool); rnd[:] = np.where(rng.random(w.shape) < 0.5, 0, 255).astype(np.uint8)
+            elif how == 3:
+                sel = np.zeros(len(w), bool); sel[int(rng.integers(0, len(w)))] = True
+            else:
+                sel = np.ones(len(w), bool); rnd[:, :5] = w[:, :5]
+            rnd[:, 0] = (w[:, 0] & 0xf8) | (rnd[:, 0] & 0x07)         # the residue code stays (it decides the atom counts)
+            w[sel] = rnd[sel]
+            b[r.o_words:r.o_words + 8 * r.n_residues] = w.tobytes()
+            if v >= per_record // 2:
+                b[r.o_sc:r.o_sc + r.n_sidechain] = rng.integers(0, 256, r.n_sidechain, dtype=np.uint8).tobytes()
+                o_t = r.o_sc + r.n_sidechain + 8
+                b[o_t:o_t + r.n_residues] = rng.integers(0, 256, r.n_residues, dtype=np.uint8).tobytes()
+            if temp_params and v % 3 == 0:
+                mn = np.float32(rng.normal(0, 1) * 10.0 ** int(rng.integers(-2, 4)))
+                cf = np.float32(abs(rng.normal(0, 1)) * 10.0 ** int(rng.integers(-3, 2)))
+                b[r.o_tmp:r.o_tmp + 8] = mn.tobytes() + cf.tobytes()
+            out.append(bytes(b))
+    return out
+
+
+def golden_records(golden):
+    """the FCZ records of the goldens, cut to their own size (the database entries end in a NUL)"""
+    from foldcomp_amd import fczfile
+    z, index = golden
+    recs = []
+    for n in compress_cases(index) + db_cases(index):
+        e = z[f"{n}/fcz"].tobytes()
+        recs.append(e[:fczfile.record_size(e)])
+    return recs

@@ -271,3 +271,70 @@ def mask_pad(fcz: bytes) -> bytes:
         if o < len(b):
             b[o] = 0
     return bytes(b)
+
+
+# ---- the live reference in a child process ---------------------------------------------------
+def _ref_child(conn):
+    import faulthandler
+    faulthandler.disable()          # a crash of the reference in this child is an answer ("crash"), not a report to print
+    while True:
+        try:
+            what, args = conn.recv()
+        except EOFError:
+            return
+        try:
+            if what == "load":
+                conn.send(("ok",) + tuple(ref_load_structure(*args)))
+            elif what == "compress":
+                conn.send(("ok", mask_pad(ref_compress(*args))))
+            else:
+                conn.send(("ok", globals()[what](*args)))
+        except RuntimeError:
+            conn.send(("fail",))
+
+
+class RefWorker:
+    """the live reference in a child process: on some mutated inputs the reference itself crashes or never returns (identifyChains
+    spins when a chain id changes at a non-N atom with no N after it); such inputs have no reference answer. A dead child is
+    noticed at once (its sentinel), a spinning one after `timeout` seconds"""
+
+    def __init__(self, timeout=10.0):
+        import multiprocessing as mp
+        self.mp = mp.get_context("fork")
+        self.timeout = timeout
+        self.proc = self.conn = None
+
+    def _start(self):
+        self.conn, child = self.mp.Pipe()
+        self.proc = self.mp.Process(target=_ref_child, args=(child,), daemon=True)
+        self.proc.start()
+        child.close()
+
+    def run(self, what, *args):
+        from multiprocessing.connection import wait
+        if self.proc is None:
+            self._start()
+        self.conn.send((what, args))
+        ready = wait([self.conn, self.proc.sentinel], self.timeout)
+        if self.conn in ready:
+            try:
+                return self.conn.recv()
+            except EOFError:
+                pass
+        self.close()
+        return ("crash",)
+
+    def load(self, data, name):
+        return self.run("load", data, name)
+
+    def compress(self, t, title, thr=25):
+        return self.run("compress", t, title, thr)
+
+    def close(self):
+        if self.proc is not None:
+            self.proc.kill(); self.proc.join(); self.conn.close()
+        self.proc = self.conn = None
+
+    def call(self, fn_name, *args):
+        """any ref_* function of this module by name -> ("ok", result) | ("fail",) | ("crash",)"""
+        return self.run(fn_name, *args)

@@ -44,33 +44,8 @@ def _compare(codec, entries, alt):
 
 
 def test_payload_mutations_decode_like_the_oracle(codec, golden):
-    rng = np.random.default_rng(20260927)
-    entries = []
-    for e in _records(golden):
-        r = fczfile.parse(e)
-        for v in range(10):
-            b = bytearray(e)
-            w = np.frombuffer(e, np.uint8, 8 * r.n_residues, r.o_words).reshape(-1, 8).copy()
-            rnd = rng.integers(0, 256, w.shape, dtype=np.uint8)
-            how = v % 5
-            if how == 0:                                # every angle of every residue
-                sel = np.ones(len(w), bool)
-            elif how == 1:                              # a tenth of the residues
-                sel = rng.random(len(w)) < 0.1
-            elif how == 2:                              # extreme words: all bits set / clear
-                sel = np.ones(len(w), bool); rnd[:] = np.where(rng.random(w.shape) < 0.5, 0, 255).astype(np.uint8)
-            elif how == 3:                              # one residue
-                sel = np.zeros(len(w), bool); sel[int(rng.integers(0, len(w)))] = True
-            else:                                       # bond angles only (bytes 5..7)
-                sel = np.ones(len(w), bool); rnd[:, :5] = w[:, :5]
-            rnd[:, 0] = (w[:, 0] & 0xf8) | (rnd[:, 0] & 0x07)         # the residue code stays (it decides the atom counts)
-            w[sel] = rnd[sel]
-            b[r.o_words:r.o_words + 8 * r.n_residues] = w.tobytes()
-            if v >= 5:
-                b[r.o_sc:r.o_sc + r.n_sidechain] = rng.integers(0, 256, r.n_sidechain, dtype=np.uint8).tobytes()
-                o_t = r.o_sc + r.n_sidechain + 8
-                b[o_t:o_t + r.n_residues] = rng.integers(0, 256, r.n_residues, dtype=np.uint8).tobytes()
-            entries.append(bytes(b))
+    from _cases import golden_records, payload_mutations
+    entries = payload_mutations(golden_records(golden))        # the records test_oracle_vs_golden.py puts to the live reference
     assert len(entries) >= 250
     for alt in (False, True):
         d = _compare(codec, entries, alt)

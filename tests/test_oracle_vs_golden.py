@@ -120,3 +120,45 @@ def test_oracle_vs_live_reference_on_degenerate_coordinates():
             for k in "xyz":
                 got, exp = d[k][a0:a1], np.asarray(r[k], np.float32)
                 assert np.all((_bits(got) == _bits(exp)) | (np.isnan(got) & np.isnan(exp))), (name, c, k)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_decode_of_mutated_records_equals_live_reference(golden):
+    """random angle words, side-chain torsion bytes and B-factor bytes (_cases.payload_mutations: conformations no structure has):
+    coordinates and B-factors of the oracle's decode == Foldcomp::decompress of the live reference, both atom orders; the PDB text
+    restatement == the reference's text; `extract` (pLDDT with 1..4 digits, from random quantiser parameters too) == the reference's.
+    The reference runs in a child process (on a few of these records it crashes; they have no reference answer). The device is held
+    to the oracle on the same records in tests/test_gpu_fcz_fuzz.py"""
+    from _cases import golden_records, payload_mutations
+    from foldcomp_amd import fczfile
+    from host_text import extract_plddt, pdb_from_result
+    ref = H.RefWorker()
+    recs = payload_mutations(golden_records(golden), per_record=4)
+    blob, off = entries_blob(recs)
+    same = crashed = 0
+    for alt in (False, True):
+        o = H.oracle_decompress(blob, off, alt_order=alt, n_threads=4)
+        for i, e in enumerate(recs):
+            assert o["info"][i].status == 0
+            got_r = ref.call("ref_decompress", e, alt)
+            if got_r[0] == "crash":
+                crashed += 1; continue
+            assert got_r[0] == "ok", (i, alt)
+            r = got_r[1]
+            a0, a1 = o["atom_off"][i], o["atom_off"][i + 1]
+            assert a1 - a0 == len(r["x"]), i
+            for k in "xyz":
+                got, exp = o[k][a0:a1], np.asarray(r[k], np.float32)
+                assert np.all((_bits(got) == _bits(exp)) | (np.isnan(got) & np.isnan(exp))), (i, alt, k)
+            if i % 3 == 0:
+                t = ref.call("ref_decompress_pdb", e, alt)
+                assert t[0] == "ok" and pdb_from_result(fczfile.parse(e), o, i, alt) == t[1], (i, alt)
+            same += 1
+    for i, e in enumerate(payload_mutations(golden_records(golden), per_record=3, seed=5, temp_params=True)):
+        for digits in (1, 2, 3, 4):
+            t = ref.call("ref_extract", e, 0, digits)
+            if t[0] == "crash":
+                crashed += 1; continue
+            assert t[0] == "ok" and extract_plddt(fczfile.parse(e), digits) == t[1], (i, digits)
+    ref.close()
+    assert same > 150 and crashed < same // 4, (same, crashed)

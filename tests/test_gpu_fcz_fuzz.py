@@ -52,6 +52,19 @@ def test_payload_mutations_decode_like_the_oracle(codec, golden):
         assert all(d["info"][i].status == 0 for i in range(len(entries)))
 
 
+def test_extract_of_mutated_records(codec, golden):
+    """pLDDT strings from random B-factor bytes and random quantiser parameters (negative, tiny, huge): the device's `extract` ==
+    the restatement that test_oracle_vs_golden.py pins to the live reference on the same records"""
+    from _cases import golden_records, payload_mutations
+    from host_text import extract_plddt
+    entries = payload_mutations(golden_records(golden), per_record=3, seed=5, temp_params=True)
+    blob, off = entries_blob(entries)
+    for digits in (1, 2, 3, 4):
+        got = codec.extract(blob, off, mode=0, digits=digits)
+        for i, e in enumerate(entries):
+            assert got[i].decode("latin-1") == extract_plddt(fczfile.parse(e), digits), (i, digits)
+
+
 def test_header_mutations_are_refused_or_decode_like_the_oracle(codec, golden):
     rng = np.random.default_rng(7)
     recs = _records(golden)

@@ -26,7 +26,7 @@ import numpy as np
 from . import fczfile
 from .api import decompress_many, default_codec
 from .database import DatabaseReader, DatabaseWriter
-from .structure import (AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb, parse_pdb_gemmi,
+from .structure import (AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb, parse_structure_gemmi,
                         remove_alternative_position)
 
 VERSION = "0.1.0"
@@ -34,97 +34,14 @@ BATCH_CHAINS = 16384
 
 
 # ---- structure files -----------------------------------------------------------------------------------
-def _parse_cif(text: str) -> Tuple[AtomTable, str]:
-    """minimal mmCIF reader: the _atom_site loop (what gemmi hands to StructureReader::updateStructure,
-    src/structure_reader.cpp:31-61) and _entry.id"""
-    title = ""
-    cols: List[str] = []
-    rows: List[List[str]] = []
-    in_loop = False
-    in_site = False
-    for line in text.splitlines():
-        s = line.strip()
-        if s.startswith("_entry.id"):
-            title = s.split(None, 1)[1].strip().strip("'\"") if len(s.split(None, 1)) > 1 else ""
-        if s == "loop_":
-            in_loop, in_site, cols = True, False, []
-            continue
-        if in_loop and s.startswith("_atom_site."):
-            cols.append(s.split(".", 1)[1].split()[0]); in_site = True
-            continue
-        if in_loop and s.startswith("_"):
-            in_site = False
-            continue
-        if in_site and cols:
-            if not s or s.startswith("#"):
-                in_loop = in_site = False
-                continue
-            rows.append(_cif_split(s))
-    ix = {c: i for i, c in enumerate(cols)}
-    def col(*names):
-        for n in names:
-            if n in ix:
-                return ix[n]
-        return None
-    c_atom, c_res = col("label_atom_id", "auth_atom_id"), col("label_comp_id", "auth_comp_id")
-    c_chain, c_seq = col("auth_asym_id", "label_asym_id"), col("auth_seq_id", "label_seq_id")
-    c_id, c_b = col("id"), col("B_iso_or_equiv")
-    cx, cy, cz = col("Cartn_x"), col("Cartn_y"), col("Cartn_z")
-    atom, res, chain, ai, ri, xyz, bf = [], [], [], [], [], [], []
-    for r in rows:
-        if len(r) < len(cols):
-            continue
-        atom.append(r[c_atom].strip('"')); res.append(r[c_res]); chain.append(r[c_chain])
-        ai.append(int(r[c_id]) if c_id is not None else len(ai) + 1)
-        ri.append(int(r[c_seq]) if r[c_seq] not in (".", "?") else 0)
-        xyz.append((float(r[cx]), float(r[cy]), float(r[cz])))
-        bf.append(float(r[c_b]) if c_b is not None and r[c_b] not in (".", "?") else 0.0)
-    t = AtomTable(atom, res, chain, np.asarray(ai, np.int32), np.asarray(ri, np.int32),
-                  np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3), np.asarray(bf, np.float64).astype(np.float32))
-    return t, title
-
-
-def _cif_split(s: str) -> List[str]:
-    out, i, n = [], 0, len(s)
-    while i < n:
-        if s[i].isspace():
-            i += 1; continue
-        if s[i] in "'\"":
-            q = s[i]; j = i + 1
-            while j < n and not (s[j] == q and (j + 1 == n or s[j + 1].isspace())):
-                j += 1
-            out.append(s[i + 1:j]); i = j + 1
-        else:
-            j = i
-            while j < n and not s[j].isspace():
-                j += 1
-            out.append(s[i:j]); i = j
-    return out
-
-
-def _pdb_title(text: str) -> str:
-    """gemmi: _entry.id = HEADER id code (cols 63-66), else _struct.title = TITLE records"""
-    title_parts = []
-    for line in text.splitlines():
-        if line.startswith("HEADER") and len(line) >= 66 and line[62:66].strip():
-            return line[62:66].strip()
-        if line.startswith("TITLE"):
-            title_parts.append(line[10:80].rstrip() if len(title_parts) == 0 else line[10:80].rstrip())
-        if line.startswith("ATOM"):
-            break
-    return " ".join(p.strip() for p in title_parts).strip() if title_parts else ""
-
-
 def load_structure(name: str, data: bytes) -> Tuple[AtomTable, str]:
+    """StructureReader::loadFromBuffer (src/structure_reader.cpp:74-97), the reader of every `compress` input (src/main.cpp:457):
+    the NAME only says whether the bytes are gzipped; whether they are PDB or mmCIF text is read off the content
+    (gemmi::coor_format_from_content), and either is read by gemmi's rules (structure.parse_pdb_gemmi / parse_cif_gemmi)"""
     base = os.path.basename(name)
     if base.endswith(".gz"):
-        data = gzip.decompress(data); base_nogz = base[:-3]
-    else:
-        base_nogz = base
-    if base_nogz.endswith(".cif"):
-        t, title = _parse_cif(data.decode("latin-1"))
-    else:
-        t, title = parse_pdb_gemmi(data)       # the command line reads PDB text the way the reference's does: through gemmi's rules
+        data = gzip.decompress(data)
+    t, title = parse_structure_gemmi(data)
     return t, (title if title else base)
 
 

@@ -111,7 +111,7 @@ __device__ __forceinline__ bool ig_int(const uint8_t* f, int n, int32_t* out) {
 // ---- the same field readers on a line held in registers (17 dwords = columns 1-68), every index a compile-time constant:
 //      no dependent byte loads (the per-byte global loads of the readers above, each waiting for the compare before it, were
 //      what the parse kernel spent its time on) ----
-constexpr int IG_LINE_DW = 19;                   // columns 1-76
+constexpr int IG_LINE_DW = 20;                   // columns 1-80
 struct ig_line { uint32_t w[IG_LINE_DW]; };
 template <int I> __device__ __forceinline__ uint32_t ig_b(const ig_line& L) { return (L.w[I >> 2] >> (8 * (I & 3))) & 0xffu; }
 // right-aligned integer part of a fixed field, characters [A, A + N): spaces, one optional '-', at least one digit
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         const bool rec = on && (up4 == (0x4d4f5441u & ~0x20202020u) || up4 == (0x41544548u & ~0x20202020u));     // ATOM, HETA(TM)
         const bool is_end = on && !rec && (up4 & 0x00ffffffu) == 0x00444e45u && ((up4 >> 24) & 0xf0u) == 0u;          // END, not ENDMDL
         // records this path does not model: ANISOU (attached to atoms, can fail the file), data_
-        const bool foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_'));
+        const bool foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_') ||
+                                            (up4 == (0x6164227bu & ~0x20202020u) && ((L.w[1] & 0x00ffffffu) & ~0x00202020u) == (0x005f6174u & ~0x00202020u)));   // ANISOU, data_, {"data_
         // MODEL / ENDMDL: one MODEL record before the first atom and ENDMDL records after the last one (the single-model file every
         // predicted structure is) change nothing; atoms after an ENDMDL or a second MODEL start new models, with rules of their own
         const bool is_model = on && !rec && up4 == (0x45444f4du & ~0x20202020u);
@@ -356,6 +357,15 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
 #pragma unroll
                     for (int i = 0; i < 6; i++) if (!ig_is_space(i == 0 ? ig_b<60>(L) : i == 1 ? ig_b<61>(L) : i == 2 ? ig_b<62>(L) : i == 3 ? ig_b<63>(L) : i == 4 ? ig_b<64>(L) : ig_b<65>(L))) blank = false;
                     if (blank) bf = 0.f; else bad = true;
+                }
+                // charge (columns 79-80, read_charge lib/gemmi/pdb.hpp:85-98): a digit there needs a sign (or nothing) beside it,
+                // the reader fails the file otherwise
+                if (glen > 78) {
+                    uint32_t dg = raw > 78u ? ig_b<78>(L) : (uint32_t)'\n', sg = raw > 79u ? ig_b<79>(L) : (raw == 79u && has_nl ? (uint32_t)'\n' : 0u);
+                    if (!(dg == ' ' && sg == ' ')) {
+                        if (sg - '0' < 10u) { const uint32_t t_ = dg; dg = sg; sg = t_; }
+                        if (dg - '0' < 10u && !(sg == '+' || sg == '-' || sg == 0u || ig_is_space(sg))) bad = true;
+                    }
                 }
                 // segment id (columns 73-76) is part of the residue's identity when the line reaches it
                 if (glen > 72) {

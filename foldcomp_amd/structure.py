@@ -216,6 +216,14 @@ def parse_pdb_gemmi(data: bytes):
                     resi = chain[1][j]
             serial = _g_int(buf[6:11]) if buf[6] < 65 else _g_base36(buf[6:11]) - 16796160 + 100000
             b_iso = np.float32(_g_double(buf[60:66])) if ln > 64 else np.float32(20.0)
+            if ln > 78:
+                # read_charge (lib/gemmi/pdb.hpp:85-98): a digit in columns 79-80 needs a sign (or nothing) beside it
+                digit, sign = buf[78], buf[79]
+                if not (digit == 0x20 and sign == 0x20):
+                    if 0x30 <= sign <= 0x39:
+                        digit, sign = sign, digit
+                    if 0x30 <= digit <= 0x39 and sign not in b"+-\0 \t\n\v\f\r":
+                        raise StructureError("Wrong format for charge")
             resi[1].append([_g_string(buf[12:16]), serial, _g_double(buf[30:38]), _g_double(buf[38:46]), _g_double(buf[46:54]), b_iso, False])
         elif rid4 == ID[b"ANIS"]:
             # the reader attaches the record to the last atom read and fails the file when there is none or it has one already
@@ -232,6 +240,11 @@ def parse_pdb_gemmi(data: bytes):
         elif rid4 == ID[b"TITL"]:
             if ln > 10:
                 title += line[10:ln - 1].decode("latin-1").rstrip(" \r\n\t")
+        elif rid4 == _g_id4(b"CRYS"):
+            # UnitCell::set -> calculate_properties (lib/gemmi/unitcell.hpp:155-165, 249-260): a cell whose gamma is given and
+            # whose alpha or beta is exactly zero fails the file ("Impossible angle")
+            if ln > 54 and _g_double(buf[47:54]) != 0.0 and (_g_double(buf[33:40]) == 0.0 or _g_double(buf[40:47]) == 0.0):
+                raise StructureError("Impossible angle - N*180deg.")
         elif rid4 == ID[b"MODE"]:
             if model is not None and chain is not None:
                 raise StructureError("MODEL without ENDMDL?")
@@ -248,6 +261,8 @@ def parse_pdb_gemmi(data: bytes):
             break
         elif rid4 == ID[b"data"] and buf[4:5] == b"_" and model is None:
             raise StructureError("Incorrect file format (perhaps it is cif not pdb?)")
+        elif rid4 == _g_id4(b'{"da') and bytes(c & ~0x20 for c in buf[4:7]) == bytes(c & ~0x20 for c in b"ta_") and model is None:
+            raise StructureError("Incorrect file format (perhaps it is mmJSON not pdb?)")
     atom, residue, chains, ai, ri, xyz, bf = [], [], [], [], [], [], []
     for mdl in models:
         for ch in mdl[1]:
@@ -259,6 +274,448 @@ def parse_pdb_gemmi(data: bytes):
     t = AtomTable(atom, residue, chains, np.asarray(ai, np.int64).astype(np.int32), np.asarray(ri, np.int64).astype(np.int32),
                   np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3), np.asarray(bf, np.float32))
     return t, (entry_id if entry_id else title)
+
+
+# ---- mmCIF as the reference's reader takes it (gemmi 0.5.1: cif.hpp grammar, cifdoc.hpp tables, mmcif.hpp atoms) --------------
+_CIF_ORD = frozenset(b"!%&()*+,-./0123456789:<=>?@ABCDEFGHIJKLMNOPQRSTUVWXYZ\\^`abcdefghijklmnopqrstuvwxyz{|}~")   # char_table == 1
+_CIF_WS = frozenset(b" \t\n\r")
+_CIF_KEYWORDS = (b"data_", b"loop_", b"global_", b"save_", b"stop_")
+_CIF_NUM = re.compile(rb"-?(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?")
+
+
+class _CifScanner:
+    """lib/gemmi/cif.hpp:37-148 restated: whitespace and comments, reserved words, the five kinds of value"""
+
+    def __init__(self, data: bytes):
+        self.d, self.n, self.i = data, len(data), 0
+
+    def ws(self) -> bool:
+        """whitespace = plus<ws_char | comment>; -> whether anything was consumed"""
+        d, n, i0 = self.d, self.n, self.i
+        i = i0
+        while i < n:
+            c = d[i]
+            if c in _CIF_WS:
+                i += 1
+            elif c == 0x23:                                # '#': a comment runs to the end of the line
+                j = d.find(b"\n", i)
+                i = n if j < 0 else j + 1
+            else:
+                break
+        self.i = i
+        return i > i0
+
+    def ws_or_eof(self) -> bool:
+        return self.ws() or self.i >= self.n
+
+    def keyword_at(self, i=None):
+        i = self.i if i is None else i
+        head = self.d[i:i + 7].lower()
+        for k in _CIF_KEYWORDS:
+            if head.startswith(k):
+                return k
+        return None
+
+    def nonblank_run(self, i):
+        d, n = self.d, self.n
+        j = i
+        while j < n and 0x21 <= d[j] <= 0x7e:
+            j += 1
+        return j
+
+    def tag(self):
+        if self.i < self.n and self.d[self.i] == 0x5f:
+            j = self.nonblank_run(self.i + 1)
+            if j > self.i + 1:
+                t = self.d[self.i:j]; self.i = j
+                return t
+        return None
+
+    def value(self):
+        """-> the raw value (quotes / semicolons included) or None; raises on an unterminated string or text field"""
+        d, n, i = self.d, self.n, self.i
+        if i >= n:
+            return None
+        c = d[i]
+        j = i
+        while j < n and d[j] in _CIF_ORD:
+            j += 1
+        if j > i and j < n and d[j] in _CIF_WS:             # simunq
+            self.i = j
+            return d[i:j]
+        if c in (0x27, 0x22):                              # quoted: closes at the quote that blank, '#' or the end follows
+            j = i + 1
+            while True:
+                if j >= n or d[j] == 0x0a:
+                    raise StructureError("unterminated string")
+                if d[j] == c and (j + 1 >= n or d[j + 1] in b" \n\r\t#"):
+                    self.i = j + 1
+                    return d[i:j + 1]
+                j += 1
+        if c == 0x3b and (i == 0 or d[i - 1] == 0x0a):      # text field: from ';' in the first column to the next one
+            j = d.find(b"\n;", i)
+            if j < 0:
+                raise StructureError("unterminated text field")
+            self.i = j + 2
+            return d[i:j + 2]
+        if self.keyword_at(i) is not None or c in (0x5f, 0x24, 0x23):
+            return None
+        j = self.nonblank_run(i)
+        if j > i:
+            self.i = j
+            return d[i:j]
+        return None
+
+
+def _cif_items(sc: _CifScanner, in_frame: bool):
+    """star<dataitem | loop | frame> -> list of ("pair", tag, value) | ("loop", tags, values) | ("frame", name, items)"""
+    items = []
+    while True:
+        t = sc.tag()
+        if t is not None:
+            if not sc.ws():
+                raise StructureError("parse error")
+            v = sc.value()
+            if v is None or not sc.ws_or_eof():
+                raise StructureError(t.decode("latin-1") + " has no value")        # (missing_value, or junk glued to the value)
+            items.append(("pair", t, v))
+            continue
+        k = sc.keyword_at()
+        if k == b"loop_":
+            sc.i += 5
+            if not sc.ws():
+                raise StructureError("parse error")
+            tags = []
+            while True:
+                t = sc.tag()
+                if t is None:
+                    break
+                if not sc.ws():
+                    raise StructureError("parse error")
+                tags.append(t)
+            if not tags:
+                raise StructureError("parse error")
+            values = []
+            while True:
+                at = sc.i
+                v = sc.value()
+                if v is None:
+                    break
+                if not sc.ws_or_eof():
+                    sc.i = at                              # plus<...> ends before a value nothing separates from what follows
+                    break
+                values.append(v)
+            if not values and not (sc.i >= sc.n or sc.keyword_at() is not None):
+                raise StructureError("parse error")
+            if sc.keyword_at() == b"stop_":
+                at = sc.i; sc.i += 5
+                if not sc.ws_or_eof():
+                    sc.i = at
+            if len(values) % len(tags) != 0:
+                raise StructureError("Wrong number of values in the loop")
+            items.append(("loop", tags, values))
+            continue
+        if k == b"save_" and not in_frame:
+            j = sc.nonblank_run(sc.i + 5)
+            if j == sc.i + 5:
+                return items                               # a bare save_ outside a frame: nothing here takes it
+            name = sc.d[sc.i + 5:j]; sc.i = j
+            if not sc.ws():
+                raise StructureError("parse error")
+            inner = _cif_items(sc, True)
+            if sc.keyword_at() != b"save_":
+                raise StructureError("parse error")
+            sc.i += 5
+            if not sc.ws_or_eof():
+                raise StructureError("parse error")
+            items.append(("frame", name, inner))
+            continue
+        return items
+
+
+def _cif_document(data: bytes):
+    """cif::read_memory: the grammar, then check_for_missing_values / check_for_duplicates (cifdoc.hpp:971-1020)"""
+    sc = _CifScanner(data)
+    sc.ws()
+    blocks = []
+    if sc.i >= sc.n:
+        return blocks
+    while True:
+        k = sc.keyword_at()
+        if k == b"data_":
+            j = sc.nonblank_run(sc.i + 5)
+            name = sc.d[sc.i + 5:j] or b"#"; sc.i = j
+        elif k == b"global_":
+            name = b""; sc.i += 7
+        else:
+            break
+        if not sc.ws_or_eof():
+            raise StructureError("parse error")
+        blocks.append((name, _cif_items(sc, False)))
+    if not blocks:
+        raise StructureError("expected block header (data_)")
+    if sc.i < sc.n:
+        raise StructureError("parse error")
+    seen = set()
+    for name, items in blocks:
+        low = name.lower()
+        if low in seen and name:
+            raise StructureError("duplicate block name")
+        seen.add(low)
+    for name, items in blocks:
+        tags, frames = set(), set()
+        for it in items:
+            for t in ([it[1]] if it[0] == "pair" else it[1] if it[0] == "loop" else []):
+                if t.lower() in tags:
+                    raise StructureError("duplicate tag " + t.decode("latin-1"))
+                tags.add(t.lower())
+            if it[0] == "frame":
+                if it[1].lower() in frames:
+                    raise StructureError("duplicate save_" + it[1].decode("latin-1"))
+                frames.add(it[1].lower())
+    return blocks
+
+
+def _cif_null(v: bytes) -> bool:
+    return v in (b"?", b".")
+
+
+def _cif_string(v: bytes) -> bytes:
+    """cif::as_string (cifdoc.hpp:82-92)"""
+    if not v or _cif_null(v):
+        return b""
+    if v[0] in (0x22, 0x27):
+        return v[1:-1]
+    if v[0] == 0x3b and len(v) > 2 and v[-2] == 0x0a:
+        return v[1:-3] if v[-3] == 0x0d else v[1:-2]
+    return v
+
+
+def _cif_number(v: bytes, default: float) -> float:
+    """cif::as_number (numb.hpp:19-41): the whole value must be a number (an uncertainty in brackets may follow)"""
+    s = v[1:] if v[:1] == b"+" else v
+    m = _CIF_NUM.match(s)
+    if not m:
+        return default
+    rest = s[m.end():]
+    if rest[:1] == b"(":
+        k = 1
+        while k < len(rest) and 0x30 <= rest[k] <= 0x39:
+            k += 1
+        if rest[k:k + 1] == b")":
+            rest = rest[k + 1:]
+    return float(m.group()) if not rest else default
+
+
+def _cif_int_checked(v: bytes) -> int:
+    """string_to_int(str, true) (atox.hpp:72-98); what it throws is not a std::runtime_error: the reference does not survive it"""
+    m = re.fullmatch(rb"[ \t\n\v\f\r]*([+-]?)([0-9]+)[ \t\n\v\f\r]*", v)
+    if not m:
+        raise StructureError("not an integer: " + v.decode("latin-1"))
+    return _wrap_i32(int(m.group(1) + m.group(2)))
+
+
+def _wrap_i32(n: int) -> int:
+    return ((n + 2 ** 31) % 2 ** 32) - 2 ** 31
+
+
+def parse_cif_gemmi(data: bytes):
+    """mmCIF text -> (AtomTable in the order StructureReader hands the atoms on, title or "") as gemmi's make_structure
+    (lib/gemmi/mmcif.hpp:560-680, 788-797) + updateStructure (src/structure_reader.cpp:31-61) make it. Raises StructureError
+    where the reader fails the file."""
+    if isinstance(data, str):
+        data = data.encode("latin-1")
+    k = data.find(b"\0")
+    blocks = _cif_document(data if k < 0 else data)       # (a NUL is not a blank: the grammar fails on it by itself)
+    if not blocks:
+        raise StructureError("empty file")
+
+    def find_values(items, tag):
+        """Block::find_values: the first loop that has the tag (any case) or the first pair that is the tag (this case)"""
+        low = tag.lower()
+        for it in items:
+            if it[0] == "loop":
+                for c, t in enumerate(it[1]):
+                    if t.lower() == low:
+                        return it, c
+            elif it[0] == "pair" and it[1] == tag:
+                return it, 0
+        return None, 0
+
+    # make_structure_from_doc(doc, possible_chemcomp = true): monomer-library and CCD files take another route in gemmi
+    # (chemcomp_xyz.hpp:106-120); no protein chain comes out of those
+    if (len(blocks) == 2 and blocks[0][0] == b"comp_list") or (len(blocks) == 3 and blocks[0][0] == b"" and blocks[1][0] == b"comp_list") or \
+            (len(blocks) == 1 and find_values(blocks[0][1], b"_atom_site.id")[0] is None and find_values(blocks[0][1], b"_chem_comp_atom.atom_id")[0] is not None):
+        raise StructureError("a chemical-component dictionary, not a structure")
+    for name, items in blocks[1:]:
+        if find_values(items, b"_atom_site.id")[0] is not None:
+            raise StructureError("2+ blocks are ok if only the first one has coordinates")
+    items = blocks[0][1]
+
+    def info(tag):
+        it, c = find_values(items, tag)
+        if it is None:
+            return ""
+        vals = [it[2]] if it[0] == "pair" else it[2][c::len(it[1])]
+        return "; ".join(_cif_string(v).decode("latin-1") for v in vals if not _cif_null(v))
+
+    # set_cell_from_mmcif (lib/gemmi/mmcif_impl.hpp:17-29): the six _cell. values as ONE row; UnitCell::set fails on a zero angle
+    cell_tags = [b"_cell.length_a", b"_cell.length_b", b"_cell.length_c", b"_cell.angle_alpha", b"_cell.angle_beta", b"_cell.angle_gamma"]
+    it0, _ = find_values(items, cell_tags[0])
+    cell = None
+    if it0 is not None and it0[0] == "loop":
+        lows = [t.lower() for t in it0[1]]
+        if all(t.lower() in lows for t in cell_tags):
+            if len(it0[2]) // len(it0[1]) != 1:
+                raise StructureError("Expected one value, found " + str(len(it0[2]) // len(it0[1])))
+            cell = [it0[2][lows.index(t.lower())] for t in cell_tags]
+    else:
+        pairs = {it[1]: it[2] for it in items if it[0] == "pair"}
+        if all(t in pairs for t in cell_tags):
+            cell = [pairs[t] for t in cell_tags]
+    if cell is not None and not any(_cif_null(v) for v in cell[:3]):
+        al, be, ga = (_cif_number(v, float("nan")) for v in cell[3:])
+        if ga != 0.0 and (al == 0.0 or be == 0.0):
+            raise StructureError("Impossible angle - N*180deg.")
+    title = info(b"_entry.id") or info(b"_struct.title")
+    want = [b"id", b"?group_PDB", b"type_symbol", b"?label_atom_id", b"label_alt_id", b"?label_comp_id", b"label_asym_id", b"?label_entity_id",
+            b"?label_seq_id", b"?pdbx_PDB_ins_code", b"Cartn_x", b"Cartn_y", b"Cartn_z", b"occupancy", b"B_iso_or_equiv", b"?pdbx_formal_charge",
+            b"auth_seq_id", b"?auth_comp_id", b"?auth_asym_id", b"?auth_atom_id", b"?pdbx_PDB_model_num", b"?calc_flag", b"?pdbx_tls_group_id"]
+    (kId, kGroup, kSymbol, kLabelAtom, kAlt, kLabelComp, kLabelAsym, kLabelEntity, kLabelSeq, kIns, kX, kY, kZ, kOcc, kB, kCharge, kAuthSeq,
+     kAuthComp, kAuthAsym, kAuthAtom, kModel, kCalc, kTls) = range(23)
+    loop, _ = find_values(items, b"_atom_site.id")
+    pos = []
+    rows = []
+    if loop is not None and loop[0] == "loop":
+        lows = [t.lower() for t in loop[1]]
+        for w in want:
+            full = b"_atom_site." + w.lstrip(b"?")
+            c = lows.index(full.lower()) if full.lower() in lows else -1
+            if c < 0 and not w.startswith(b"?"):
+                pos = []; break
+            pos.append(c)
+        if pos:
+            width = len(loop[1])
+            rows = [loop[2][r * width:(r + 1) * width] for r in range(len(loop[2]) // width)]
+    else:
+        pairs = {it[1]: it[2] for it in items if it[0] == "pair"}
+        one = []
+        for w in want:
+            full = b"_atom_site." + w.lstrip(b"?")
+            if full in pairs:
+                pos.append(len(one)); one.append(pairs[full])
+            elif w.startswith(b"?"):
+                pos.append(-1)
+            else:
+                pos = []; break
+        if pos:
+            rows = [one]
+    models: list = []            # [name, chains]; chain = [name, residues]; residue = [(seq, icode, name), atoms]
+    if rows:
+        kAsym = kAuthAsym if pos[kAuthAsym] >= 0 else kLabelAsym
+        kComp = kAuthComp if pos[kAuthComp] >= 0 else kLabelComp
+        kAtom = kAuthAtom if pos[kAuthAtom] >= 0 else kLabelAtom
+        if pos[kComp] < 0:
+            raise StructureError("Neither _atom_site.label_comp_id nor auth_comp_id found")
+        if pos[kAtom] < 0:
+            raise StructureError("Neither _atom_site.label_atom_id nor auth_atom_id found")
+
+        def model_named(nm):
+            for m in models:
+                if m[0] == nm:
+                    return m
+            models.append([nm, []])
+            return models[-1]
+        model = model_named(_cif_string(rows[0][pos[kModel]]) if pos[kModel] >= 0 else b"1")
+        chain = resi = None
+        for row in rows:
+            if pos[kModel] >= 0 and row[pos[kModel]] != model[0]:
+                model = model_named(_cif_string(row[pos[kModel]])); chain = None
+            asym = _cif_string(row[pos[kAsym]])
+            if chain is None or asym != chain[0]:
+                chain = [asym, []]; model[1].append(chain); resi = None
+            seqs = _cif_string(row[pos[kAuthSeq]])
+            icode = " "
+            if pos[kIns] >= 0:
+                v = row[pos[kIns]]
+                if _cif_null(v):
+                    icode = " "
+                elif len(v) < 2:
+                    icode = chr(v[0])
+                else:
+                    sv = _cif_string(v)
+                    if len(sv) >= 2:
+                        raise StructureError("Not a single character")
+                    icode = chr(sv[0]) if sv else "\0"
+            num = -999                                     # SeqId::OptionalNum::None
+            if seqs:
+                if seqs[-1] >= 0x41:
+                    if icode == " ":
+                        icode = chr(seqs[-1])
+                    elif icode != chr(seqs[-1]):
+                        raise StructureError("Inconsistent insertion code in " + seqs.decode("latin-1"))
+                    num = _cif_int_checked(seqs[:-1])
+                else:
+                    num = _cif_int_checked(seqs)           # (as_int(seqid, None): a null value cannot get here, it is "" already)
+            rid = (num, icode, _cif_string(row[pos[kComp]]))
+            if resi is None or not (resi[0][0] == rid[0] and (ord(resi[0][1]) | 0x20) == (ord(rid[1]) | 0x20) and resi[0][2] == rid[2]):
+                resi = next((r for r in chain[1] if r[0][0] == rid[0] and (ord(r[0][1]) | 0x20) == (ord(rid[1]) | 0x20) and r[0][2] == rid[2]), None)
+                if resi is None:
+                    resi = [rid, []]; chain[1].append(resi)
+                if not resi[1]:
+                    if pos[kLabelSeq] >= 0 and not _cif_null(row[pos[kLabelSeq]]):
+                        _cif_int_checked(row[pos[kLabelSeq]])
+            alt = row[pos[kAlt]]
+            if not _cif_null(alt) and len(alt) >= 2 and len(_cif_string(alt)) >= 2:
+                raise StructureError("Not a single character")
+            if pos[kCharge] >= 0 and not _cif_null(row[pos[kCharge]]):
+                _cif_int_checked(row[pos[kCharge]])
+            m = re.match(rb"[ \t\n\v\f\r]*([+-]?)([0-9]*)", row[pos[kId]])
+            serial = _wrap_i32(int(m.group(1) + m.group(2))) if m.group(2) else 0
+            resi[1].append((_cif_string(row[pos[kAtom]]), serial, _cif_number(row[pos[kX]], float("nan")), _cif_number(row[pos[kY]], float("nan")),
+                            _cif_number(row[pos[kZ]], float("nan")), np.float32(_cif_number(row[pos[kB]], 50.0))))
+    atom, residue, chains, ai, ri, xyz, bf = [], [], [], [], [], [], []
+    for mdl in models:
+        for ch in mdl[1]:
+            for rid, atoms in ch[1]:
+                for (an, serial, x, y, z, b) in atoms:
+                    atom.append(an.decode("latin-1")); residue.append(rid[2].decode("latin-1")); chains.append(ch[0].decode("latin-1"))
+                    ai.append(serial); ri.append(rid[0]); xyz.append((x, y, z)); bf.append(b)
+    t = AtomTable(atom, residue, chains, np.asarray(ai, np.int64).astype(np.int32), np.asarray(ri, np.int64).astype(np.int32),
+                  np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3), np.asarray(bf, np.float32))
+    return t, title
+
+
+def coor_format_from_content(data: bytes) -> str:
+    """gemmi::coor_format_from_content (lib/gemmi/mmread.hpp:31-47): what StructureReader::loadFromBuffer -- the reader of every
+    `compress` input, src/main.cpp:457 -- goes by; the file's extension only says whether it is gzipped"""
+    i, end = 0, len(data) - 8
+    while i < end:
+        c = data[i]
+        if c in b" \t\n\v\f\r":
+            i += 1
+        elif c == 0x23:
+            while i < end and data[i] != 0x0a:
+                i += 1
+        elif c == 0x7b:
+            return "mmjson"
+        elif bytes(x & ~0x20 for x in data[i:i + 4]) == bytes(x & ~0x20 for x in b"data") and data[i + 4] == 0x5f:
+            return "mmcif"
+        else:
+            return "pdb"
+    return "unknown"
+
+
+def parse_structure_gemmi(data: bytes):
+    """the bytes of a structure file (already inflated) -> (AtomTable, title or "") as gemmi::read_structure_from_char_array +
+    StructureReader::updateStructure make them; StructureError where the reader fails the file (mmJSON and chemical-component
+    dictionaries, which gemmi would read, are failed here: no protein chain comes in them)"""
+    fmt = coor_format_from_content(data)
+    if fmt == "pdb":
+        return parse_pdb_gemmi(data)
+    if fmt == "mmcif":
+        return parse_cif_gemmi(data)
+    raise StructureError("wrong format of coordinate file" if fmt == "unknown" else "mmJSON input is not supported")
 
 
 def remove_alternative_position(t: AtomTable) -> AtomTable:

@@ -31,6 +31,8 @@
 #include <unistd.h>
 #include <climits>
 #include <unordered_map>
+#include <unordered_set>
+#include <string_view>
 #include <zlib.h>
 #include <omp.h>
 
@@ -74,6 +76,7 @@ struct AtomTable {
     std::vector<char> chain;
     std::vector<uint16_t> chain_key;               // the chain NAME (columns 21-22 trimmed, up to two characters packed) where the reader
                                                    // that filled the table knows it; empty = `chain` is the whole name
+    std::vector<std::string> chain_names;          // mmCIF: chain names of any length; chain_key then indexes this list
     std::vector<int> atom_index, res_index;
     std::vector<float> x, y, z, bfac;
     // filled by the parse threads (name -> code once per atom, in parallel): atom code (fcz_atom_code_from_name) and the
@@ -89,8 +92,14 @@ struct AtomTable {
     }
     uint32_t intern(const std::string& s) { return intern(s.data(), s.size()); }
     bool same_chain(size_t i, size_t j) const { return chain_key.size() == size() ? chain_key[i] == chain_key[j] : chain[i] == chain[j]; }
+    uint16_t intern_chain(const std::string& nm) {
+        for (size_t i = 0; i < chain_names.size(); i++) if (chain_names[i] == nm) return (uint16_t)i;
+        chain_names.push_back(nm);
+        return (uint16_t)(chain_names.size() - 1);
+    }
     std::string chain_name(size_t i) const {       // what the reference appends to a record's name (src/main.cpp:489-491)
         if (chain_key.size() != size()) return std::string(1, chain[i]);
+        if (!chain_names.empty()) return chain_names[chain_key[i]];
         std::string o; if (chain_key[i] & 0xff) o.push_back((char)(chain_key[i] & 0xff)); if (chain_key[i] >> 8) o.push_back((char)(chain_key[i] >> 8)); return o;
     }
     std::string name(uint32_t pk) const {
@@ -100,7 +109,7 @@ struct AtomTable {
         return o;
     }
     void clear() {   // keeps every capacity (TablePool)
-        atom.clear(); residue.clear(); long_names.clear(); chain.clear(); chain_key.clear(); atom_index.clear(); res_index.clear();
+        atom.clear(); residue.clear(); long_names.clear(); chain.clear(); chain_key.clear(); chain_names.clear(); atom_index.clear(); res_index.clear();
         x.clear(); y.clear(); z.clear(); bfac.clear(); atom_code.clear(); res_code.clear();
     }
     void reserve(size_t n) {
@@ -109,7 +118,7 @@ struct AtomTable {
     }
     AtomTable slice(size_t a, size_t b) const {
         AtomTable t;
-        t.long_names = long_names;
+        t.long_names = long_names; t.chain_names = chain_names;
         t.atom.assign(atom.begin() + a, atom.begin() + b); t.residue.assign(residue.begin() + a, residue.begin() + b);
         t.chain.assign(chain.begin() + a, chain.begin() + b);
         if (chain_key.size() == size()) t.chain_key.assign(chain_key.begin() + a, chain_key.begin() + b);
@@ -153,7 +162,6 @@ std::string strip(const std::string& s) {
     while (b > a && isspace((unsigned char)s[b - 1])) b--;
     return s.substr(a, b - a);
 }
-bool starts_with(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
 bool ends_with(const std::string& s, const std::string& p) { return s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0; }
 
 int parse_int(const std::string& f) {
@@ -171,19 +179,6 @@ float parse_float(const std::string& f) {   // text -> double -> float, as gemmi
     return (float)v;
 }
 
-std::vector<std::string> split_lines(const std::string& text) {
-    std::vector<std::string> lines;
-    size_t a = 0;
-    while (a <= text.size()) {
-        size_t b = text.find('\n', a);
-        if (b == std::string::npos) b = text.size();
-        std::string l = text.substr(a, b - a);
-        if (!l.empty() && l.back() == '\r') l.pop_back();
-        if (b > a || b < text.size()) lines.push_back(l);
-        a = b + 1;
-    }
-    return lines;
-}
 
 // ---- the same parser over the raw file image, without a string per line or per field (the parse threads are what bounds a
 //      disk -> database run: 240 KB of text per 350-residue chain against 20 us of GPU time). Number fields take the exact
@@ -292,14 +287,6 @@ struct NameCodes {
     int residue(uint32_t pk) const { return get(residues, 127, pk, -1); }
 };
 const NameCodes& name_codes() { static const NameCodes c; return c; }
-void fill_codes(AtomTable& t) {
-    const NameCodes& nc = name_codes();
-    t.atom_code.resize(t.size()); t.res_code.resize(t.size());
-    for (size_t i = 0; i < t.size(); i++) {
-        t.atom_code[i] = (uint8_t)nc.atom(t.atom[i]);
-        t.res_code[i] = (i > 0 && t.residue[i] == t.residue[i - 1]) ? t.res_code[i - 1] : (int8_t)nc.residue(t.residue[i]);
-    }
-}
 
 // ---- the reference's reader for PDB text: gemmi 0.5.1 read_pdb as StructureReader uses it -------------------------------------
 // (src/structure_reader.cpp:31-61, lib/gemmi/pdb.hpp:262-365; restated rule by rule in foldcomp_amd/structure.py parse_pdb_gemmi,
@@ -428,6 +415,15 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
             else { t.x.push_back((float)g_double(line + 30, 8)); t.y.push_back((float)g_double(line + 38, 8)); t.z.push_back((float)g_double(line + 46, 8)); }
             if (len > 64) { if (len >= 67 && fixed_field<6, 2>(line + 60, fb)) t.bfac.push_back(fb); else t.bfac.push_back((float)g_double(line + 60, 6)); }
             else t.bfac.push_back(20.0f);                       // gemmi's default B-factor: the line ends before the field
+            if (len > 78) {
+                // read_charge (lib/gemmi/pdb.hpp:85-98): a digit in columns 79-80 needs a sign (or nothing) beside it
+                char digit = line[78], sign = line[79];
+                if (!(digit == ' ' && sign == ' ')) {
+                    if (sign >= '0' && sign <= '9') std::swap(digit, sign);
+                    if (digit >= '0' && digit <= '9' && sign != '+' && sign != '-' && sign != '\0' && !g_space((unsigned char)sign))
+                        throw std::runtime_error("Wrong format for charge");
+                }
+            }
             order.push_back(((uint64_t)run << 32) | cur_ord); aniso.push_back(0);
             last_atom_of[cur_ord] = (long)t.atom.size() - 1; last_atom_of_cur = (long)t.atom.size() - 1;
         } else if (id == g_id4("ANIS")) {
@@ -439,6 +435,10 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
             if (len > 66) { size_t b = 66; while (b > 62 && (line[b - 1] == ' ' || line[b - 1] == '\r' || line[b - 1] == '\n' || line[b - 1] == '\t')) b--; if (b > 62) entry_id.assign(line + 62, b - 62); }
         } else if (id == g_id4("TITL")) {
             if (len > 10) { size_t b = len - 1; while (b > 10 && (line[b - 1] == ' ' || line[b - 1] == '\r' || line[b - 1] == '\n' || line[b - 1] == '\t')) b--; title.append(line + 10, b - 10); }
+        } else if (id == g_id4("CRYS")) {
+            // UnitCell::set -> calculate_properties: a cell whose gamma is given and whose alpha or beta is exactly zero fails the file
+            if (len > 54 && g_double(line + 47, 7) != 0.0 && (g_double(line + 33, 7) == 0.0 || g_double(line + 40, 7) == 0.0))
+                throw std::runtime_error("Impossible angle - N*180deg.");
         } else if (id == g_id4("MODE")) {
             if (model >= 0 && have_chain) throw std::runtime_error("MODEL without ENDMDL?");
             const std::string name = std::to_string(g_int(line + 10, 4));
@@ -453,6 +453,8 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
             break;
         } else if (id == g_id4("data") && line[4] == '_' && model < 0) {
             throw std::runtime_error("Incorrect file format (perhaps it is cif not pdb?)");
+        } else if (id == g_id4("{\"da") && ((line[4] & ~0x20) == ('t' & ~0x20)) && ((line[5] & ~0x20) == ('a' & ~0x20)) && ((line[6] & ~0x20) == ('_' & ~0x20)) && model < 0) {
+            throw std::runtime_error("Incorrect file format (perhaps it is mmJSON not pdb?)");
         }
     }
     (void)last_atom_of_cur;
@@ -473,7 +475,7 @@ AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title) {
 
 AtomTable remove_alternative_position(const AtomTable& t) {
     AtomTable o;
-    o.long_names = t.long_names;
+    o.long_names = t.long_names; o.chain_names = t.chain_names;
     o.reserve(t.size());
     bool have = false; uint32_t prev = 0;
     for (size_t i = 0; i < t.size(); i++) {
@@ -503,70 +505,382 @@ std::string gunzip(const std::string& z) {
 
 // ---- minimal mmCIF reader: the _atom_site loop (what gemmi hands to StructureReader::updateStructure, reference
 //      src/structure_reader.cpp:31-61) and _entry.id ----
-std::vector<std::string> cif_split(const std::string& s) {
-    std::vector<std::string> out;
-    size_t i = 0, n = s.size();
-    while (i < n) {
-        if (isspace((unsigned char)s[i])) { i++; continue; }
-        if (s[i] == '\'' || s[i] == '"') {
-            const char q = s[i]; size_t j = i + 1;
-            while (j < n && !(s[j] == q && (j + 1 == n || isspace((unsigned char)s[j + 1])))) j++;
-            out.push_back(s.substr(i + 1, j - i - 1)); i = j + 1;
-        } else {
-            size_t j = i;
-            while (j < n && !isspace((unsigned char)s[j])) j++;
-            out.push_back(s.substr(i, j - i)); i = j;
-        }
-    }
-    return out;
+// ---- mmCIF as the reference's reader takes it: gemmi 0.5.1's grammar (lib/gemmi/cif.hpp:37-148), its table look-ups
+//      (cifdoc.hpp Block::find / find_values) and make_structure_from_block's atoms (mmcif.hpp:560-680). Restated rule by rule in
+//      foldcomp_amd/structure.py (parse_cif_gemmi), where the rules are checked against the live reference on mutated files ----
+using sv = std::string_view;
+struct CifItem { int type = 0; sv tag, value; std::vector<sv> tags, values; sv name; std::vector<CifItem> items; };   // 0 pair, 1 loop, 2 frame
+struct CifBlock { sv name; bool global = false; std::vector<CifItem> items; };
+inline bool cif_ordinary(unsigned char c) {           // char_table(c) == 1
+    static const char* ord = "!%&()*+,-./0123456789:<=>?@ABCDEFGHIJKLMNOPQRSTUVWXYZ\\^`abcdefghijklmnopqrstuvwxyz{|}~";
+    static bool tab[256], init = false;
+    if (!init) { for (const char* p = ord; *p; p++) tab[(unsigned char)*p] = true; init = true; }
+    return tab[c];
 }
-AtomTable parse_cif(const std::vector<std::string>& lines, std::string& title) {
-    std::vector<std::string> cols;
-    std::vector<std::vector<std::string>> rows;
-    bool in_loop = false, in_site = false;
-    for (const std::string& line : lines) {
-        const std::string s = strip(line);
-        if (starts_with(s, "_entry.id")) {
-            const size_t sp = s.find_first_of(" \t");
-            std::string v = sp == std::string::npos ? "" : strip(s.substr(sp));
-            while (!v.empty() && (v.front() == '\'' || v.front() == '"')) v.erase(v.begin());
-            while (!v.empty() && (v.back() == '\'' || v.back() == '"')) v.pop_back();
-            title = v;
+inline bool cif_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+struct CifScanner {
+    const char* d; size_t n, i = 0;
+    bool ws() {
+        const size_t i0 = i;
+        while (i < n) {
+            if (cif_ws((unsigned char)d[i])) i++;
+            else if (d[i] == '#') { const void* q = memchr(d + i, '\n', n - i); i = q ? (size_t)((const char*)q - d) + 1 : n; }
+            else break;
         }
-        if (s == "loop_") { in_loop = true; in_site = false; cols.clear(); continue; }
-        if (in_loop && starts_with(s, "_atom_site.")) {
-            std::string c = s.substr(11);
-            const size_t sp = c.find_first_of(" \t");
-            if (sp != std::string::npos) c = c.substr(0, sp);
-            cols.push_back(c); in_site = true; continue;
+        return i > i0;
+    }
+    bool ws_or_eof() { return ws() || i >= n; }
+    int keyword_at(size_t at) const {                  // 1 data_ 2 loop_ 3 global_ 4 save_ 5 stop_
+        static const char* kw[] = {"data_", "loop_", "global_", "save_", "stop_"};
+        for (int k = 0; k < 5; k++) {
+            const size_t l = strlen(kw[k]);
+            if (at + l > n) continue;
+            bool eq = true;
+            for (size_t q = 0; q < l && eq; q++) eq = tolower((unsigned char)d[at + q]) == kw[k][q];
+            if (eq) return k + 1;
         }
-        if (in_loop && starts_with(s, "_")) { in_site = false; continue; }
-        if (in_site && !cols.empty()) {
-            if (s.empty() || s[0] == '#') { in_loop = in_site = false; continue; }
-            rows.push_back(cif_split(s));
+        return 0;
+    }
+    size_t nonblank_run(size_t at) const { while (at < n && (unsigned char)d[at] >= 0x21 && (unsigned char)d[at] <= 0x7e) at++; return at; }
+    bool tag(sv& out) {
+        if (i < n && d[i] == '_') { const size_t j = nonblank_run(i + 1); if (j > i + 1) { out = sv(d + i, j - i); i = j; return true; } }
+        return false;
+    }
+    bool value(sv& out) {                              // throws on an unterminated string / text field
+        if (i >= n) return false;
+        const char c = d[i];
+        size_t j = i;
+        while (j < n && cif_ordinary((unsigned char)d[j])) j++;
+        if (j > i && j < n && cif_ws((unsigned char)d[j])) { out = sv(d + i, j - i); i = j; return true; }
+        if (c == '\'' || c == '"') {
+            for (j = i + 1;; j++) {
+                if (j >= n || d[j] == '\n') throw std::runtime_error("unterminated string");
+                if (d[j] == c && (j + 1 >= n || d[j + 1] == ' ' || d[j + 1] == '\n' || d[j + 1] == '\r' || d[j + 1] == '\t' || d[j + 1] == '#')) { out = sv(d + i, j + 1 - i); i = j + 1; return true; }
+            }
+        }
+        if (c == ';' && (i == 0 || d[i - 1] == '\n')) {
+            const sv rest(d + i, n - i);
+            const size_t k = rest.find("\n;");
+            if (k == sv::npos) throw std::runtime_error("unterminated text field");
+            out = sv(d + i, k + 2); i += k + 2; return true;
+        }
+        if (keyword_at(i) || c == '_' || c == '$' || c == '#') return false;
+        j = nonblank_run(i);
+        if (j > i) { out = sv(d + i, j - i); i = j; return true; }
+        return false;
+    }
+};
+void cif_items(CifScanner& sc, bool in_frame, std::vector<CifItem>& items) {
+    for (;;) {
+        sv t;
+        if (sc.tag(t)) {
+            if (!sc.ws()) throw std::runtime_error("parse error");
+            CifItem it; it.type = 0; it.tag = t;
+            if (!sc.value(it.value) || !sc.ws_or_eof()) throw std::runtime_error(std::string(t) + " has no value");
+            items.push_back(std::move(it));
+            continue;
+        }
+        const int k = sc.keyword_at(sc.i);
+        if (k == 2) {
+            sc.i += 5;
+            if (!sc.ws()) throw std::runtime_error("parse error");
+            CifItem it; it.type = 1;
+            while (sc.tag(t)) { if (!sc.ws()) throw std::runtime_error("parse error"); it.tags.push_back(t); }
+            if (it.tags.empty()) throw std::runtime_error("parse error");
+            for (;;) {
+                const size_t at = sc.i; sv v;
+                if (!sc.value(v)) break;
+                if (!sc.ws_or_eof()) { sc.i = at; break; }
+                it.values.push_back(v);
+            }
+            if (it.values.empty() && !(sc.i >= sc.n || sc.keyword_at(sc.i))) throw std::runtime_error("parse error");
+            if (sc.keyword_at(sc.i) == 5) { const size_t at = sc.i; sc.i += 5; if (!sc.ws_or_eof()) sc.i = at; }
+            if (it.values.size() % it.tags.size() != 0) throw std::runtime_error("Wrong number of values in the loop");
+            items.push_back(std::move(it));
+            continue;
+        }
+        if (k == 4 && !in_frame) {
+            const size_t j = sc.nonblank_run(sc.i + 5);
+            if (j == sc.i + 5) return;
+            CifItem it; it.type = 2; it.name = sv(sc.d + sc.i + 5, j - sc.i - 5); sc.i = j;
+            if (!sc.ws()) throw std::runtime_error("parse error");
+            cif_items(sc, true, it.items);
+            if (sc.keyword_at(sc.i) != 4) throw std::runtime_error("parse error");
+            sc.i += 5;
+            if (!sc.ws_or_eof()) throw std::runtime_error("parse error");
+            items.push_back(std::move(it));
+            continue;
+        }
+        return;
+    }
+}
+std::string cif_lower(sv s) { std::string o(s); for (char& c : o) c = (char)tolower((unsigned char)c); return o; }
+std::vector<CifBlock> cif_document(const char* data, size_t size) {
+    CifScanner sc{data, size};
+    sc.ws();
+    std::vector<CifBlock> blocks;
+    if (sc.i >= sc.n) return blocks;
+    for (;;) {
+        const int k = sc.keyword_at(sc.i);
+        CifBlock b;
+        if (k == 1) { const size_t j = sc.nonblank_run(sc.i + 5); b.name = j > sc.i + 5 ? sv(sc.d + sc.i + 5, j - sc.i - 5) : sv("#"); sc.i = j; }
+        else if (k == 3) { b.global = true; sc.i += 7; }
+        else break;
+        if (!sc.ws_or_eof()) throw std::runtime_error("parse error");
+        cif_items(sc, false, b.items);
+        blocks.push_back(std::move(b));
+    }
+    if (blocks.empty()) throw std::runtime_error("expected block header (data_)");
+    if (sc.i < sc.n) throw std::runtime_error("parse error");
+    std::unordered_set<std::string> seen;
+    for (const CifBlock& b : blocks) { if (!seen.insert(cif_lower(b.name)).second && !b.name.empty()) throw std::runtime_error("duplicate block name"); }
+    for (const CifBlock& b : blocks) {
+        std::unordered_set<std::string> tags, frames;
+        for (const CifItem& it : b.items) {
+            if (it.type == 0) { if (!tags.insert(cif_lower(it.tag)).second) throw std::runtime_error("duplicate tag " + std::string(it.tag)); }
+            else if (it.type == 1) { for (sv t : it.tags) if (!tags.insert(cif_lower(t)).second) throw std::runtime_error("duplicate tag " + std::string(t)); }
+            else if (!frames.insert(cif_lower(it.name)).second) throw std::runtime_error("duplicate save_" + std::string(it.name));
         }
     }
-    auto col = [&](std::initializer_list<const char*> names) -> int {
-        for (const char* nm : names) for (size_t i = 0; i < cols.size(); i++) if (cols[i] == nm) return (int)i;
-        return -1;
+    return blocks;
+}
+inline bool cif_null(sv v) { return v.size() == 1 && (v[0] == '?' || v[0] == '.'); }
+sv cif_string(sv v) {                                  // cif::as_string
+    if (v.empty() || cif_null(v)) return sv();
+    if (v[0] == '"' || v[0] == '\'') return v.substr(1, v.size() - 2);
+    if (v[0] == ';' && v.size() > 2 && v[v.size() - 2] == '\n') return v.substr(1, v.size() - (v[v.size() - 3] == '\r' ? 4 : 3));
+    return v;
+}
+double cif_number(sv v, double dflt) {                 // cif::as_number: the whole value is a number (+ an uncertainty in brackets)
+    if (!v.empty() && v[0] == '+') v.remove_prefix(1);
+    size_t i = 0; const size_t n = v.size();
+    if (i < n && v[i] == '-') i++;
+    size_t d0 = i; while (i < n && isdigit((unsigned char)v[i])) i++;
+    size_t nd = i - d0;
+    if (i < n && v[i] == '.') { i++; const size_t f0 = i; while (i < n && isdigit((unsigned char)v[i])) i++; nd += i - f0; }
+    if (nd == 0) return dflt;
+    if (i < n && (v[i] == 'e' || v[i] == 'E')) {
+        size_t j = i + 1; if (j < n && (v[j] == '+' || v[j] == '-')) j++;
+        const size_t e0 = j; while (j < n && isdigit((unsigned char)v[j])) j++;
+        if (j > e0) i = j;
+    }
+    const size_t num_end = i;
+    if (i < n && v[i] == '(') { size_t j = i + 1; while (j < n && isdigit((unsigned char)v[j])) j++; if (j < n && v[j] == ')') i = j + 1; }
+    if (i != n) return dflt;
+    return strtod(std::string(v.substr(0, num_end)).c_str(), nullptr);
+}
+int cif_int_checked(sv v) {                            // string_to_int(str, true): what it throws the reference does not survive
+    size_t i = 0; const size_t n = v.size();
+    auto sp = [](char c) { return c == ' ' || (c >= 9 && c <= 13); };
+    while (i < n && sp(v[i])) i++;
+    bool neg = false;
+    if (i < n && (v[i] == '-' || v[i] == '+')) { neg = v[i] == '-'; i++; }
+    const size_t d0 = i; int64_t acc = 0;
+    while (i < n && isdigit((unsigned char)v[i])) { acc = (acc * 10 + (v[i] - '0')) & 0xffffffffll; i++; }
+    const bool has = i > d0;
+    while (i < n && sp(v[i])) i++;
+    if (!has || i != n) throw std::runtime_error("not an integer: " + std::string(v));
+    const uint32_t u = (uint32_t)acc;
+    return neg ? (int)(0u - u) : (int)u;
+}
+// Block::find_values: the first loop that has the tag (any case) or the first pair that IS the tag (this case)
+const CifItem* cif_find(const std::vector<CifItem>& items, sv tag, size_t& col) {
+    const std::string low = cif_lower(tag);
+    for (const CifItem& it : items) {
+        if (it.type == 1) { for (size_t c = 0; c < it.tags.size(); c++) if (cif_lower(it.tags[c]) == low) { col = c; return &it; } }
+        else if (it.type == 0 && it.tag == tag) { col = 0; return &it; }
+    }
+    return nullptr;
+}
+
+AtomTable parse_cif_gemmi(const char* data, size_t size, std::string& title) {
+    std::vector<CifBlock> blocks = cif_document(data, size);
+    if (blocks.empty()) throw std::runtime_error("empty file");
+    size_t c0 = 0;
+    auto has_tag = [&](const CifBlock& b, sv tag) { size_t c; return cif_find(b.items, tag, c) != nullptr; };
+    // monomer-library and CCD files take another route in gemmi (chemcomp_xyz.hpp:106-120): no protein chain comes out of those
+    if ((blocks.size() == 2 && blocks[0].name == "comp_list" && !blocks[0].global) || (blocks.size() == 3 && blocks[0].global && blocks[1].name == "comp_list") ||
+        (blocks.size() == 1 && !has_tag(blocks[0], "_atom_site.id") && has_tag(blocks[0], "_chem_comp_atom.atom_id")))
+        throw std::runtime_error("a chemical-component dictionary, not a structure");
+    for (size_t b = 1; b < blocks.size(); b++) if (has_tag(blocks[b], "_atom_site.id")) throw std::runtime_error("2+ blocks are ok if only the first one has coordinates");
+    const std::vector<CifItem>& items = blocks[0].items;
+    auto pair_value = [&](sv tag, sv& out) { for (const CifItem& it : items) if (it.type == 0 && it.tag == tag) { out = it.value; return true; } return false; };
+    // the cell: six values as ONE row; a zero alpha or beta beside a gamma fails (UnitCell::set -> calculate_properties)
+    {
+        static const char* ct[6] = {"_cell.length_a", "_cell.length_b", "_cell.length_c", "_cell.angle_alpha", "_cell.angle_beta", "_cell.angle_gamma"};
+        const CifItem* it0 = cif_find(items, ct[0], c0);
+        sv cell[6]; bool have = false;
+        if (it0 && it0->type == 1) {
+            bool all = true; size_t cc[6];
+            for (int k = 0; k < 6 && all; k++) { all = false; for (size_t c = 0; c < it0->tags.size(); c++) if (cif_lower(it0->tags[c]) == cif_lower(ct[k])) { cc[k] = c; all = true; break; } }
+            if (all) {
+                const size_t rows = it0->values.size() / it0->tags.size();
+                if (rows != 1) throw std::runtime_error("Expected one value, found " + std::to_string(rows));
+                for (int k = 0; k < 6; k++) cell[k] = it0->values[cc[k]];
+                have = true;
+            }
+        } else {
+            have = true;
+            for (int k = 0; k < 6 && have; k++) have = pair_value(ct[k], cell[k]);
+        }
+        if (have && !cif_null(cell[0]) && !cif_null(cell[1]) && !cif_null(cell[2])) {
+            const double al = cif_number(cell[3], NAN), be = cif_number(cell[4], NAN), ga = cif_number(cell[5], NAN);
+            if (ga != 0.0 && (al == 0.0 || be == 0.0)) throw std::runtime_error("Impossible angle - N*180deg.");
+        }
+    }
+    auto info = [&](sv tag) {
+        std::string out; size_t c;
+        const CifItem* it = cif_find(items, tag, c);
+        if (!it) return out;
+        bool first = true;
+        auto add = [&](sv v) { if (cif_null(v)) return; if (!first) out += "; "; out += std::string(cif_string(v)); first = false; };
+        if (it->type == 0) add(it->value); else for (size_t r = c; r < it->values.size(); r += it->tags.size()) add(it->values[r]);
+        return out;
     };
-    const int c_atom = col({"label_atom_id", "auth_atom_id"}), c_res = col({"label_comp_id", "auth_comp_id"});
-    const int c_chain = col({"auth_asym_id", "label_asym_id"}), c_seq = col({"auth_seq_id", "label_seq_id"});
-    const int c_id = col({"id"}), c_b = col({"B_iso_or_equiv"}), cx = col({"Cartn_x"}), cy = col({"Cartn_y"}), cz = col({"Cartn_z"});
-    AtomTable t;
-    if (c_atom < 0 || c_res < 0 || c_chain < 0 || c_seq < 0 || cx < 0 || cy < 0 || cz < 0) return t;
-    for (const auto& r : rows) {
-        if (r.size() < cols.size()) continue;
-        std::string an = r[c_atom];
-        while (!an.empty() && an.front() == '"') an.erase(an.begin());
-        while (!an.empty() && an.back() == '"') an.pop_back();
-        t.atom.push_back(t.intern(an)); t.residue.push_back(t.intern(r[c_res])); t.chain.push_back(r[c_chain].empty() ? ' ' : r[c_chain][0]);
-        t.atom_index.push_back(c_id >= 0 ? parse_int(r[c_id]) : (int)t.atom.size());
-        t.res_index.push_back((r[c_seq] == "." || r[c_seq] == "?") ? 0 : parse_int(r[c_seq]));
-        t.x.push_back(parse_float(r[cx])); t.y.push_back(parse_float(r[cy])); t.z.push_back(parse_float(r[cz]));
-        t.bfac.push_back((c_b >= 0 && r[c_b] != "." && r[c_b] != "?") ? parse_float(r[c_b]) : 0.0f);
+    title = info("_entry.id");
+    if (title.empty()) title = info("_struct.title");
+    static const char* want[23] = {"id", "?group_PDB", "type_symbol", "?label_atom_id", "label_alt_id", "?label_comp_id", "label_asym_id", "?label_entity_id",
+        "?label_seq_id", "?pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "?pdbx_formal_charge", "auth_seq_id", "?auth_comp_id",
+        "?auth_asym_id", "?auth_atom_id", "?pdbx_PDB_model_num", "?calc_flag", "?pdbx_tls_group_id"};
+    enum { kId, kGroup, kSymbol, kLabelAtom, kAlt, kLabelComp, kLabelAsym, kLabelEntity, kLabelSeq, kIns, kX, kY, kZ, kOcc, kB, kCharge, kAuthSeq, kAuthComp, kAuthAsym,
+           kAuthAtom, kModel, kCalc, kTls };
+    const CifItem* loop = cif_find(items, "_atom_site.id", c0);
+    int pos[23]; bool ok = false; size_t n_rows = 0; size_t width = 0;
+    std::vector<sv> one;
+    if (loop && loop->type == 1) {
+        ok = true;
+        for (int k = 0; k < 23 && ok; k++) {
+            const bool opt = want[k][0] == '?';
+            const std::string full = cif_lower(std::string("_atom_site.") + (want[k] + (opt ? 1 : 0)));
+            pos[k] = -1;
+            for (size_t c = 0; c < loop->tags.size(); c++) if (cif_lower(loop->tags[c]) == full) { pos[k] = (int)c; break; }
+            if (pos[k] < 0 && !opt) ok = false;
+        }
+        if (ok) { width = loop->tags.size(); n_rows = loop->values.size() / width; }
+    } else {
+        ok = true;
+        for (int k = 0; k < 23 && ok; k++) {
+            const bool opt = want[k][0] == '?';
+            const std::string full = std::string("_atom_site.") + (want[k] + (opt ? 1 : 0));
+            sv v;
+            if (pair_value(full, v)) { pos[k] = (int)one.size(); one.push_back(v); }
+            else if (opt) pos[k] = -1;
+            else ok = false;
+        }
+        if (ok) { width = one.size(); n_rows = 1; }
+    }
+    AtomTable t = table_pool().get();
+    if (!ok || n_rows == 0) return t;
+    const std::vector<sv>& vals = (loop && loop->type == 1) ? loop->values : one;
+    const int kAsym = pos[kAuthAsym] >= 0 ? kAuthAsym : kLabelAsym, kComp = pos[kAuthComp] >= 0 ? kAuthComp : kLabelComp, kAtom = pos[kAuthAtom] >= 0 ? kAuthAtom : kLabelAtom;
+    if (pos[kComp] < 0) throw std::runtime_error("Neither _atom_site.label_comp_id nor auth_comp_id found");
+    if (pos[kAtom] < 0) throw std::runtime_error("Neither _atom_site.label_atom_id nor auth_atom_id found");
+    // models / chains / residues in the order they are made; every atom gets (model, chain, residue) ordinals and is sorted by them
+    struct Res { int num; char icode; sv name; };
+    struct Ch { sv name; std::vector<Res> res; uint32_t ord; };
+    struct Mo { std::string name; std::vector<Ch> chains; };
+    std::vector<Mo> models;
+    auto model_named = [&](sv nm) -> size_t { for (size_t m = 0; m < models.size(); m++) if (models[m].name == nm) return m; models.push_back(Mo{std::string(nm), {}}); return models.size() - 1; };
+    size_t model = model_named(pos[kModel] >= 0 ? cif_string(vals[(size_t)pos[kModel]]) : sv("1"));
+    long chain = -1, resi = -1;
+    std::vector<uint64_t> order; order.reserve(n_rows);
+    std::vector<uint32_t> chain_ord_of_model;             // running count of chains, for the sort key
+    uint32_t n_chain_total = 0;
+    bool sorted = true; uint64_t last_key = 0;
+    t.reserve(n_rows);
+    const NameCodes& nc = name_codes();
+    for (size_t r = 0; r < n_rows; r++) {
+        const sv* row = vals.data() + r * width;
+        if (pos[kModel] >= 0 && row[pos[kModel]] != sv(models[model].name)) { model = model_named(cif_string(row[pos[kModel]])); chain = -1; }
+        const sv asym = cif_string(row[pos[kAsym]]);
+        if (chain < 0 || asym != models[model].chains[(size_t)chain].name) {
+            models[model].chains.push_back(Ch{asym, {}, n_chain_total++}); chain = (long)models[model].chains.size() - 1; resi = -1;
+        }
+        Ch& ch = models[model].chains[(size_t)chain];
+        const sv seqs = cif_string(row[pos[kAuthSeq]]);
+        char icode = ' ';
+        if (pos[kIns] >= 0) {
+            const sv v = row[pos[kIns]];
+            if (cif_null(v)) icode = ' ';
+            else if (v.size() < 2) icode = v[0];
+            else { const sv s2 = cif_string(v); if (s2.size() >= 2) throw std::runtime_error("Not a single character"); icode = s2.empty() ? '\0' : s2[0]; }
+        }
+        int num = -999;                                    // SeqId::OptionalNum::None
+        if (!seqs.empty()) {
+            if ((unsigned char)seqs.back() >= 'A') {
+                if (icode == ' ') icode = seqs.back();
+                else if (icode != seqs.back()) throw std::runtime_error("Inconsistent insertion code in " + std::string(seqs));
+                num = cif_int_checked(seqs.substr(0, seqs.size() - 1));
+            } else num = cif_int_checked(seqs);
+        }
+        const sv comp = cif_string(row[pos[kComp]]);
+        auto matches = [&](const Res& q) { return q.num == num && (q.icode | 0x20) == (icode | 0x20) && q.name == comp; };
+        if (resi < 0 || !matches(ch.res[(size_t)resi])) {
+            resi = -1;
+            for (size_t q = 0; q < ch.res.size(); q++) if (matches(ch.res[q])) { resi = (long)q; break; }
+            const bool fresh = resi < 0;
+            if (fresh) { ch.res.push_back(Res{num, icode, comp}); resi = (long)ch.res.size() - 1; }
+            // (label_seq_id is read when the residue gets its first atom: a residue found again has atoms already)
+            if (fresh && pos[kLabelSeq] >= 0 && !cif_null(row[pos[kLabelSeq]])) (void)cif_int_checked(row[pos[kLabelSeq]]);
+        }
+        const sv alt = row[pos[kAlt]];
+        if (!cif_null(alt) && alt.size() >= 2 && cif_string(alt).size() >= 2) throw std::runtime_error("Not a single character");
+        if (pos[kCharge] >= 0 && !cif_null(row[pos[kCharge]])) (void)cif_int_checked(row[pos[kCharge]]);
+        int serial = 0;
+        {
+            const sv v = row[pos[kId]]; size_t i = 0; const size_t n = v.size();
+            while (i < n && (v[i] == ' ' || (v[i] >= 9 && v[i] <= 13))) i++;
+            bool neg = false; if (i < n && (v[i] == '-' || v[i] == '+')) { neg = v[i] == '-'; i++; }
+            uint32_t u = 0; while (i < n && isdigit((unsigned char)v[i])) { u = u * 10u + (uint32_t)(v[i] - '0'); i++; }
+            serial = neg ? (int)(0u - u) : (int)u;
+        }
+        const sv an = cif_string(row[pos[kAtom]]);
+        const uint32_t a_id = t.intern(an.data(), an.size()), r_id = t.intern(comp.data(), comp.size());
+        t.atom.push_back(a_id); t.residue.push_back(r_id);
+        t.atom_code.push_back((uint8_t)nc.atom(a_id)); t.res_code.push_back((int8_t)nc.residue(r_id));
+        t.chain.push_back(asym.empty() ? ' ' : asym[0]); t.chain_key.push_back(t.intern_chain(std::string(asym)));
+        t.atom_index.push_back(serial); t.res_index.push_back(num);
+        t.x.push_back((float)cif_number(row[pos[kX]], NAN)); t.y.push_back((float)cif_number(row[pos[kY]], NAN)); t.z.push_back((float)cif_number(row[pos[kZ]], NAN));
+        t.bfac.push_back((float)cif_number(row[pos[kB]], 50.0));
+        const uint64_t key = ((uint64_t)model << 48) | ((uint64_t)ch.ord << 24) | (uint64_t)resi;
+        if (!order.empty() && key < last_key) sorted = false;
+        if (order.empty() || key >= last_key) last_key = key;
+        order.push_back(key);
+    }
+    if (!sorted) {
+        std::vector<size_t> idx(t.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return order[a] < order[b]; });
+        AtomTable o = table_pool().get();
+        o.long_names = t.long_names; o.chain_names = t.chain_names;
+        o.reserve(t.size());
+        for (size_t i : idx) o.push_from(t, i);
+        table_pool().put(std::move(t));
+        t = std::move(o);
     }
     return t;
+}
+
+// gemmi::coor_format_from_content (lib/gemmi/mmread.hpp:31-47): what StructureReader::loadFromBuffer -- the reader of every
+// `compress` input, src/main.cpp:457 -- goes by; the file's name only says whether it is gzipped. 0 unknown, 1 pdb, 2 mmcif, 3 mmjson
+int coor_format_from_content(const char* d, size_t size) {
+    size_t i = 0; const long end = (long)size - 8;
+    while ((long)i < end) {
+        const unsigned char c = (unsigned char)d[i];
+        if (c == ' ' || (c >= 9 && c <= 13)) i++;
+        else if (c == '#') { while ((long)i < end && d[i] != '\n') i++; }
+        else if (c == '{') return 3;
+        else if ((d[i] & ~0x20) == 'D' && (d[i + 1] & ~0x20) == 'A' && (d[i + 2] & ~0x20) == 'T' && (d[i + 3] & ~0x20) == 'A' && d[i + 4] == '_') return 2;
+        else return 1;
+    }
+    return 0;
+}
+AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title);
+AtomTable parse_structure_gemmi(const char* data, size_t size, std::string& title) {
+    const int fmt = coor_format_from_content(data, size);
+    if (fmt == 1) return parse_pdb_gemmi(data, size, title);
+    if (fmt == 2) return parse_cif_gemmi(data, size, title);
+    throw std::runtime_error(fmt == 0 ? "wrong format of coordinate file" : "mmJSON input is not supported");
 }
 
 struct Range { size_t a, b; };
@@ -929,8 +1243,9 @@ void fragments_from_memory(const char* data, size_t size, const std::string& bas
     }
     std::string title;
     AtomTable t;
-    if (ends_with(plain, ".cif")) { t = parse_cif(split_lines(std::string(data, size)), title); fill_codes(t); t = remove_alternative_position(t); }
-    else { t = parse_pdb_gemmi(data, size, title); AtomTable k = remove_alternative_position(t); table_pool().put(std::move(t)); t = std::move(k); }   // the reference's reader rules, then removeAlternativePosition
+    // PDB or mmCIF by what the bytes say, not by the name (StructureReader::loadFromBuffer); the reference's reader rules for
+    // either, then removeAlternativePosition
+    { t = parse_structure_gemmi(data, size, title); AtomTable k = remove_alternative_position(t); table_pool().put(std::move(t)); t = std::move(k); }
     if (t.size() == 0) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base.c_str()); return; }
     if (title.empty() || title == base) title = out_stem;            // src/main.cpp:465
     const std::vector<Range> chains = identify_chains(t);
@@ -1819,7 +2134,8 @@ AtomTable load_table(const std::string& path) {
     const std::string base = base_name(path);
     std::string raw = read_file(path), plain = base, title;
     if (ends_with(base, ".gz")) { raw = gunzip(raw); plain = base.substr(0, base.size() - 3); }
-    if (ends_with(plain, ".cif")) return parse_cif(split_lines(raw), title);
+    // rmsd reads through StructureReader::load (src/main.cpp:108-111): the format by the name's extension, anything unknown as PDB
+    if (ends_with(plain, ".cif") || ends_with(plain, ".mmcif")) return parse_cif_gemmi(raw.data(), raw.size(), title);
     return parse_pdb_gemmi(raw.data(), raw.size(), title);
 }
 int run_rmsd(const Options& o) {

@@ -57,7 +57,7 @@ def mutated_pdb(base_lines, rng, max_edits=5):
     alphabet = list("0123456789 .-+ANCOHETMabcxyz\t*")
     lines = list(base_lines)
     for _ in range(int(rng.integers(1, max_edits + 1))):
-        kind = int(rng.integers(0, 9)); j = int(rng.integers(0, len(lines))); l = lines[j]
+        kind = int(rng.integers(0, 10)); j = int(rng.integers(0, len(lines))); l = lines[j]
         if kind == 0 and l:
             k = int(rng.integers(0, len(l))); lines[j] = l[:k] + alphabet[int(rng.integers(0, len(alphabet)))] + l[k + 1:]
         elif kind == 1:
@@ -75,6 +75,8 @@ def mutated_pdb(base_lines, rng, max_edits=5):
             lines.insert(j, _FOREIGN[int(rng.integers(0, len(_FOREIGN)))])
         elif kind == 7:
             lines[j] = l + "\r"
+        elif kind == 9:                                     # the charge columns (79-80): the reader fails a digit beside a non-sign
+            lines[j] = l[:78].ljust(78) + ["1+", "2-", "1A", "A1", "+1", "9 ", " 9", "x5", "5", "7\t"][int(rng.integers(0, 10))]
         else:
             del lines[j]
     return ("\n".join(lines) + ("\n" if rng.integers(0, 4) else "")).encode("latin-1")
@@ -219,3 +221,98 @@ def golden_records(golden):
         e = z[f"{n}/fcz"].tobytes()
         recs.append(e[:fczfile.record_size(e)])
     return recs
+
+
+# ---- mutated mmCIF files --------------------------------------------------------------------------------------------------
+def mutated_cif(text: str, rng, max_edits=4) -> bytes:
+    """one seeded mutation of an mmCIF file: values of _atom_site rows replaced (null, quoted, lower case, letters glued to numbers,
+    uncertainties, junk), rows moved / doubled / dropped / swapped, model / chain / alt / insertion-code columns changed from some
+    row on, and the file around the loop disturbed (tags removed, doubled or re-cased, blocks, comments, text fields, stray reserved
+    words, a cut, random bytes)"""
+    lines = text.split("\n")
+    cols = [l.strip() for l in lines if l.startswith("_atom_site.")]
+    rows = [i for i, l in enumerate(lines) if l.startswith(("ATOM", "HETATM"))]
+    col = {c.split(".", 1)[1]: k for k, c in enumerate(cols)}
+
+    def set_tok(i, name, val):
+        p = lines[i].split()
+        if name in col and col[name] < len(p):
+            p[col[name]] = val; lines[i] = " ".join(p)
+
+    for _ in range(int(rng.integers(1, max_edits + 1))):
+        kind = int(rng.integers(0, 16))
+        rows = [i for i, l in enumerate(lines) if l.startswith(("ATOM", "HETATM", "atom", "hetatm"))]
+        if not rows:
+            break
+        i = rows[int(rng.integers(0, len(rows)))]
+        if kind == 0:                                       # one value of one row
+            name = list(col)[int(rng.integers(0, len(col)))]
+            p = lines[i].split()
+            old = p[col[name]] if col[name] < len(p) else "x"
+            val = ["?", ".", "'" + old + "'", '"' + old + '"', old.lower(), old + "A", old + "(3)", "+" + old, "-" + old, "1e2", "x y", "''", old + "'",
+                   ";", "#c", "_t", "$v", "loop_", "1.5.2", "", "0x10", " ".join([old, old])][int(rng.integers(0, 22))]
+            set_tok(i, name, val)
+        elif kind == 1:                                     # a row moved
+            l = lines.pop(i); lines.insert(rows[int(rng.integers(0, len(rows)))], l)
+        elif kind == 2:
+            lines.insert(i, lines[i])
+        elif kind == 3:
+            del lines[i]
+        elif kind == 4 and i + 1 < len(lines):
+            lines[i], lines[i + 1] = lines[i + 1], lines[i]
+        elif kind == 5:                                     # a column changed from this row on
+            name, val = [("pdbx_PDB_model_num", "2"), ("auth_asym_id", "B"), ("label_asym_id", "B"), ("label_alt_id", "A"), ("pdbx_PDB_ins_code", "A"),
+                         ("auth_comp_id", "ALA"), ("label_comp_id", "GLY"), ("auth_atom_id", "CA"), ("B_iso_or_equiv", "?"), ("occupancy", "."),
+                         ("pdbx_PDB_model_num", "1"), ("auth_seq_id", "7"), ("label_seq_id", "x")][int(rng.integers(0, 13))]
+            stop = rows.index(i) + int(rng.integers(1, 40))
+            for j in rows[rows.index(i):stop]:
+                set_tok(j, name, val)
+        elif kind == 6:                                     # residue numbers shifted from here on (both columns)
+            for j in rows[rows.index(i):]:
+                p = lines[j].split()
+                for name in ("auth_seq_id", "label_seq_id"):
+                    if name in col and col[name] < len(p) and p[col[name]].lstrip("-").isdigit():
+                        p[col[name]] = str(int(p[col[name]]) + 3)
+                lines[j] = " ".join(p)
+        elif kind == 7:                                     # a tag line removed, doubled or re-cased
+            tl = [k for k, l in enumerate(lines) if l.startswith("_")]
+            k = tl[int(rng.integers(0, len(tl)))]
+            how = int(rng.integers(0, 4))
+            if how == 0:
+                del lines[k]
+            elif how == 1:
+                lines.insert(k, lines[k])
+            elif how == 2:
+                lines[k] = lines[k].upper()
+            else:
+                lines[k] = lines[k].split()[0]
+        elif kind == 8:                                     # the atom_site tags
+            tl = [k for k, l in enumerate(lines) if l.startswith("_atom_site.")]
+            k = tl[int(rng.integers(0, len(tl)))]
+            how = int(rng.integers(0, 3))
+            if how == 0:
+                del lines[k]
+            elif how == 1:
+                lines[k] = lines[k].replace("_atom_site.", "_ATOM_SITE.")
+            else:
+                lines[k], lines[tl[0]] = lines[tl[0]], lines[k]
+        elif kind == 9:                                     # something between the rows
+            lines.insert(i, ["# a comment", "", ";text\n;", "loop_", "stop_", "data_second", "save_x", "global_", "_new.tag 1", "'quoted value'", "\t"][int(rng.integers(0, 11))])
+        elif kind == 10:                                    # another block at the end
+            lines += ["data_more", "_atom_site.id 1"] if rng.random() < 0.5 else ["data_more", "_x.y z"]
+        elif kind == 11:                                    # cut
+            t = "\n".join(lines); lines = t[:int(rng.integers(0, len(t)))].split("\n")
+        elif kind == 12:                                    # a random byte
+            t = bytearray("\n".join(lines).encode("latin-1")); t[int(rng.integers(0, len(t)))] = int(rng.integers(0, 256)); lines = t.decode("latin-1").split("\n")
+        elif kind == 13:                                    # the loop as pairs: one atom
+            tl = [k for k, l in enumerate(lines) if l.startswith("_atom_site.")]
+            p = lines[rows[0]].split()
+            if len(p) == len(tl):
+                for k, v in zip(tl, p):
+                    lines[k] = lines[k].strip() + " " + v
+                lines = [l for k, l in enumerate(lines) if k not in set(rows) and not (k == tl[0] - 1 and l.strip() == "loop_")]
+        elif kind == 14:                                    # CR LF
+            lines = [l + "\r" for l in lines]
+        else:                                               # the head of the file
+            lines[0] = ["data_", "DATA_x", "global_", "# no block", "data_x y", "loop_"][int(rng.integers(0, 6))]
+    return "\n".join(lines).encode("latin-1")

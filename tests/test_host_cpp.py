@@ -182,14 +182,16 @@ def _cif_text(z, name, entry_id="1ABC"):
     from foldcomp_amd._aa_tables import ATOM_NAMES, RES3
     b = golden_batch(z, name)
     res_of_atom = np.repeat(np.arange(b.n_residues), np.diff(b.atom_off.astype(np.int64)))
-    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_comp_id", "auth_asym_id", "auth_seq_id",
+    # (the columns gemmi's reader requires: id, type_symbol, label_alt_id, label_asym_id, Cartn_*, occupancy, B_iso_or_equiv,
+    # auth_seq_id, and a comp_id / atom_id of either kind -- lib/gemmi/mmcif.hpp:565-598; without one of them there are no atoms)
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "auth_asym_id", "auth_seq_id",
             "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv"]
     out = ["data_" + entry_id, "_entry.id " + entry_id, "#", "loop_"] + ["_atom_site." + c for c in cols]
     for i in range(b.n_atoms):
         an = ATOM_NAMES[b.atom_code[i]]
         r = int(res_of_atom[i])
-        out.append("ATOM %d %s %s %s %s %d %.3f %.3f %.3f 1.00 %.2f" % (
-            int(b.first_atom_index[0]) + i, an[0], ('"%s"' % an) if "'" in an else an, RES3[b.res_code[r]], chr(b.chain_id[0]),
+        out.append("ATOM %d %s %s . %s %s %s %d %.3f %.3f %.3f 1.00 %.2f" % (
+            int(b.first_atom_index[0]) + i, an[0], ('"%s"' % an) if "'" in an else an, RES3[b.res_code[r]], chr(b.chain_id[0]), chr(b.chain_id[0]),
             int(b.first_res_index[0]) + r, b.x[i], b.y[i], b.z[i], b.bfac_ca[r]))
     out.append("#")
     return "\n".join(out) + "\n"

@@ -268,6 +268,90 @@ def test_oracle_compress_equals_live_reference_on_mutated_files(ing):
     assert same > 300 and crashed < 60, (same, refused, ref_failed, crashed)
 
 
+def _short_cif(ing, rows=260):
+    import gzip
+    lines = gzip.decompress(ing["file:test.cif.gz"].tobytes()).decode("latin-1").split("\n")
+    at = [i for i, l in enumerate(lines) if l.startswith("ATOM")]
+    return "\n".join(lines[:at[rows]] + lines[at[-1] + 1:])
+
+
+def test_python_cif_reader_equals_live_reference_on_mutated_files(ing):
+    """the mmCIF reader of the command line (foldcomp_amd.structure.parse_cif_gemmi: gemmi's CIF grammar, table look-ups and
+    make_structure restated; parse_structure_gemmi: the format read off the content as StructureReader::loadFromBuffer does) against
+    the LIVE reference on 900 seeded mutations of the reference's own mmCIF test file (_cases.mutated_cif): same verdict on the files
+    the reader fails; same atoms in the same order (residues regrouped, models, chains of any name), numbers (uncertainties in
+    brackets, nulls, defaults), title. Where the reference does not survive its own exception there is no answer to compare"""
+    if not H.have_ref():
+        pytest.skip("oracle/_ref is not built (it only exists where /root/reference does)")
+    from _cases import mutated_cif
+    from foldcomp_amd.structure import StructureError, parse_structure_gemmi
+    text = _short_cif(ing)
+    rng = np.random.default_rng(20260927)
+    ref = H.RefWorker(timeout=5)
+    same = failed = crashed = 0
+    for i in range(900):
+        data = mutated_cif(text, rng)
+        try:
+            t, title = parse_structure_gemmi(data)
+            t = remove_alternative_position(t)
+        except StructureError:
+            t = None
+        r = ref.load(data, "x.cif")
+        if r[0] == "crash":
+            crashed += 1; continue
+        assert (t is None) == (r[0] != "ok"), (i, "only one of the two readers fails the file")
+        if t is None:
+            failed += 1; continue
+        rt, rtitle = r[1], r[2]
+        assert len(t) == len(rt), i
+        # (the shim hands names on as 4 / 3 characters and the chain as one)
+        assert [a[:4] for a in t.atom] == rt.atom and [x[:3] for x in t.residue] == rt.residue and [c[:1] or " " for c in t.chain] == rt.chain, i
+        assert np.array_equal(t.atom_index, rt.atom_index) and np.array_equal(t.res_index, rt.res_index), i
+        assert np.all((t.xyz.view(np.uint32) == rt.xyz.view(np.uint32)) | (np.isnan(t.xyz) & np.isnan(rt.xyz))), i
+        assert np.array_equal(t.bfac.view(np.uint32), rt.bfac.view(np.uint32)) and (title if title else "x.cif") == rtitle, i
+        same += 1
+    ref.close()
+    assert same > 350 and failed > 250 and crashed < 60, (same, failed, crashed)
+
+
+def test_cpp_cif_reader_equals_python_reader_on_mutated_files(ing, tmp_path):
+    """the C++ host's mmCIF reader (parse_cif_gemmi / parse_structure_gemmi in host/foldcomp_hip.cpp, through dump-batch on a
+    directory) == the Python one on 300 mutated files -- named .cif and .pdb alike: the content decides"""
+    from _cases import mutated_cif
+    from foldcomp_amd.structure import StructureError, parse_structure_gemmi
+    text = _short_cif(ing, rows=120)
+    rng = np.random.default_rng(11)
+    d = tmp_path / "fz"
+    d.mkdir()
+    names, chains = [], []
+    for i in range(300):
+        data = mutated_cif(text, rng)
+        stem = f"f{i:03d}"
+        ext = ".cif" if i % 3 else ".pdb"
+        (d / (stem + ext)).write_bytes(data)
+        try:
+            t, title = parse_structure_gemmi(data)
+        except StructureError:
+            continue
+        if len(t) == 0:
+            continue
+        title = stem if (not title or title == stem + ext) else title
+        t = remove_alternative_position(t)
+        cs_all = identify_chains(t)
+        for cs in cs_all:
+            frags = identify_discontinuous(t, cs)
+            for j, sl in enumerate(frags):
+                ch = Chain(title, t.take(sl))
+                try:
+                    build_batch([ch], 25)
+                except Exception:
+                    continue
+                names.append(stem + (t.chain[cs.start] if len(cs_all) > 1 else "") + (f"_{j}" if len(frags) > 1 else "") + ".fcz")
+                chains.append(ch)
+    assert len(chains) > 100
+    _same(_dump(d), names, build_batch(chains, 25))
+
+
 def test_cpp_pdb_reader_equals_python_reader_on_mutated_files(ing, tmp_path):
     """the C++ host's reader (parse_pdb_gemmi in host/foldcomp_hip.cpp, through dump-batch on a directory) == the Python one on
     300 mutated files: fragments, names, every array of the batch; files the reader fails and fragments the codec refuses drop out

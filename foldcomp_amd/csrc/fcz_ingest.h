@@ -270,6 +270,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo, bool has_nl) {
         if (ended) return;
         const bool seen_endm_before = seen_endm;
+        bool cryst_bad = false;
         const uint32_t raw = on ? (uint32_t)(le - ls) : 0u;
         const uint32_t glen = raw + (has_nl ? 1u : 0u) < 120u ? raw + (has_nl ? 1u : 0u) : 120u;       // gemmi's len
         const uint8_t* p = base + ls;
@@ -300,10 +301,25 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         // predicted structure is) change nothing; atoms after an ENDMDL or a second MODEL start new models, with rules of their own
         const bool is_model = on && !rec && up4 == (0x45444f4du & ~0x20202020u);
         const bool is_endm = on && !rec && up4 == (0x4d444e45u & ~0x20202020u);
+        // CRYST1: the reader fails a file whose cell has a gamma and an alpha or beta of exactly zero (UnitCell::set). Decided here
+        // only for fields that start (after blanks) with a digit 1-9 -- certainly not zero; anything else goes to the host
+        if (on && !rec && up4 == (0x53595243u & ~0x20202020u) && glen > 54u) {
+            bool sure = staged;
+            if (staged) {
+#pragma unroll
+                for (int f0 = 33; f0 <= 40; f0 += 7) {
+                    uint32_t first = ' ';
+#pragma unroll
+                    for (int q = 6; q >= 0; q--) { const uint32_t c = (uint32_t)S.buf[lo + f0 + q]; if (c != ' ') first = c; }
+                    if (!(first - '1' < 9u)) sure = false;
+                }
+            }
+            if (!sure) cryst_bad = true;
+        }
         const unsigned long long m_end = __ballot(is_end);
         const int end_lane = m_end ? __builtin_ctzll(m_end) : 64;
         const bool live = on && lane < end_lane;                 // what follows an END record is not read
-        if (__any(live && foreign)) status = FCZ_INGEST_HOST_FIELD;
+        if (__any(live && (foreign || cryst_bad))) status = FCZ_INGEST_HOST_FIELD;
         const unsigned long long m_model = __ballot(live && is_model), m_endm = __ballot(live && is_endm);
         // ---- title: the last HEADER record's id code (columns 63-66, right-trimmed), else the TITLE records' text concatenated ----
         {

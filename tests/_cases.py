@@ -48,7 +48,9 @@ _FOREIGN = ["ANISOU    2  CA  MET A   1     2406   1892   1614    198    519   -
             "ANISOU    3  C   MET A   1        0   1892   1614    198    519   -328       C  ", "MODEL        1", "MODEL        2", "ENDMDL", "data_x",
             "REMARK 465 junk", "HETATM 9001  O   HOH A 900      11.000  12.000  13.000  1.00 30.00           O  ", "TITLE     SOMETHING", "TITLE    2 MORE OF IT  ",
             "HEADER    HYDROLASE                               01-JAN-00   1ABC              ", "junk", "", "END", "TER",
-            "atom      1  N   MET A   1      27.340  24.430   2.614  1.00  9.67           N"]
+            "atom      1  N   MET A   1      27.340  24.430   2.614  1.00  9.67           N",
+            "CRYST1   52.000   58.600   61.900  90.00   0.00  90.00 P 21 21 21    8", "CRYST1   52.000   58.600   61.900  90.00  90.00   0.00 P 1",
+            "CRYST1    1.000    1.000    1.000   0.50  90.00  90.00 P 1", "CRYST1    1.000    1.000    1.000  90.00 120.00  90.00 P 1", '{"data_x": 1}']
 
 
 def mutated_pdb(base_lines, rng, max_edits=5):

@@ -50,7 +50,15 @@ _FOREIGN = ["ANISOU    2  CA  MET A   1     2406   1892   1614    198    519   -
             "HEADER    HYDROLASE                               01-JAN-00   1ABC              ", "junk", "", "END", "TER",
             "atom      1  N   MET A   1      27.340  24.430   2.614  1.00  9.67           N",
             "CRYST1   52.000   58.600   61.900  90.00   0.00  90.00 P 21 21 21    8", "CRYST1   52.000   58.600   61.900  90.00  90.00   0.00 P 1",
-            "CRYST1    1.000    1.000    1.000   0.50  90.00  90.00 P 1", "CRYST1    1.000    1.000    1.000  90.00 120.00  90.00 P 1", '{"data_x": 1}']
+            "CRYST1    1.000    1.000    1.000   0.50  90.00  90.00 P 1", "CRYST1    1.000    1.000    1.000  90.00 120.00  90.00 P 1", '{"data_x": 1}',
+            "SSBOND   1 CYS A    6    CYS A  127                          1555   1555  2.03", "SSBOND   x CYS Z  999    CYS", "LINK         O   GLY A  49                CA    CA A 501     1555   1555  2.65",
+            "LINK  junk", "CISPEP   1 SER A   58    PRO A   59          0         0.30", "CISPEP junk junk", "HELIX    1   1 ALA A    2  GLY A   10  1                                   9",
+            "HELIX  x", "SHEET    1   A 2 THR A   4  VAL A   8  0", "SHEET zz", "SEQRES   1 A   26  MET ALA GLY", "SEQRES junk", "DBREF  1ABC A    1    26  UNP    P12345   X_HUMAN          1     26",
+            "MTRIX1   1  1.000000  0.000000  0.000000        0.00000    1", "MTRIX2   1  x", "SCALE1      0.019231  0.000000  0.000000        0.00000", "SCALE2 junk",
+            "ORIGX1      1.000000  0.000000  0.000000        0.00000", "REMARK 350   BIOMT1   1  1.000000  0.000000  0.000000        0.00000", "REMARK 350 APPLY THE FOLLOWING TO CHAINS: A, B",
+            "REMARK   2 RESOLUTION.    1.74 ANGSTROMS.", "REMARK   3   R VALUE            (WORKING SET) : 0.18", "CONECT  413  412  414", "COMPND    MOL_ID: 1;", "EXPDTA    X-RAY DIFFRACTION",
+            "NUMMDL    2", "MASTER      351    0    0    4    8    0    0    6 1215    1    0   11", "HETNAM     HOH WATER", "MODRES 1ABC MSE A    1  MET  SELENOMETHIONINE", "TER     216      PRO A  26",
+            "SIGATM    1  N   MET A   1       0.010   0.010   0.010  0.00  0.00           N", "JRNL        AUTH   A.B.C", "KEYWDS    X"]
 
 
 def mutated_pdb(base_lines, rng, max_edits=5):

@@ -11,6 +11,18 @@ from typing import List, Optional
 import numpy as np
 
 
+def _strtoul(w: bytes) -> int:
+    """strtoul / strtoull(word, NULL, 10): optional sign, then the digits the word starts with (0 when there are none)"""
+    i, neg = 0, False
+    if w[:1] in (b"+", b"-"):
+        neg = w[:1] == b"-"; i = 1
+    j = i
+    while j < len(w) and 0x30 <= w[j] <= 0x39:
+        j += 1
+    v = int(w[i:j]) if j > i else 0
+    return (-v) & 0xffffffffffffffff if neg else v
+
+
 class DatabaseReader:
     def __init__(self, path: str, use_lookup: bool = True):
         self.path = path
@@ -18,12 +30,18 @@ class DatabaseReader:
         size = os.path.getsize(path)
         self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ) if size else b""
         keys, offs, lens = [], [], []
-        with open(path + ".index") as fh:
-            for line in fh:
-                p = line.split()
-                if len(p) < 3:
-                    continue
-                keys.append(int(p[0])); offs.append(int(p[1])); lens.append(int(p[2]))
+        # read_index (src/database_reader.cpp:283-311): an entry per '\n' of the file (count_lines: a last line without one is not
+        # an entry), words separated by blanks and tabs (getWordsOfLine), numbers by strtoul / strtoull (the digits a word starts
+        # with); a line of more than three words fails the read. A line of fewer than three is undefined there: refused here
+        with open(path + ".index", "rb") as fh:
+            raw = fh.read()
+        for line in raw.split(b"\n")[:-1]:
+            p = [w for w in line.replace(b"\t", b" ").split(b" ") if w]
+            if len(p) > 3:
+                raise ValueError(f"{path}.index: a line of more than three columns")
+            if len(p) < 3:
+                raise ValueError(f"{path}.index: a line of fewer than three columns")
+            keys.append(_strtoul(p[0]) & 0xffffffff); offs.append(_strtoul(p[1])); lens.append(_strtoul(p[2]))
         order = np.argsort(np.asarray(keys, np.int64), kind="stable")     # the reader re-sorts by key
         self.keys = np.asarray(keys, np.int64)[order]
         self.offsets = np.asarray(offs, np.int64)[order]
@@ -31,12 +49,16 @@ class DatabaseReader:
         self.name_to_key = {}
         self.key_to_name = {}
         if use_lookup and os.path.exists(path + ".lookup"):
-            with open(path + ".lookup") as fh:
-                for line in fh:
-                    p = line.rstrip("\n").split("\t")
+            # read_lookup (:345-361): key = the first word, name = the second (words end at a blank or a tab)
+            with open(path + ".lookup", "rb") as fh:
+                for line in fh.read().split(b"\n"):
+                    p = [w for w in line.replace(b"\t", b" ").split(b" ") if w]
                     if len(p) >= 2:
-                        self.name_to_key.setdefault(p[1], int(p[0]))
-                        self.key_to_name[int(p[0])] = p[1]
+                        nm = p[1].decode("latin-1"); k = _strtoul(p[0]) & 0xffffffff
+                        # (a key or a name that comes twice: the later line wins -- the reference's stable_sort with its "<="
+                        # comparators, :313-321, leaves equal elements in reverse order, and its look-ups take the first)
+                        self.name_to_key[nm] = k
+                        self.key_to_name[k] = nm
 
     def __len__(self):
         return len(self.keys)

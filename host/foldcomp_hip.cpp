@@ -1130,21 +1130,45 @@ struct DbReader {
     struct Row { long long key, off, len; };
     std::vector<Row> rows;                 // sorted by key (stable), as the reference reader does
     std::vector<std::pair<long long, std::string>> lookup;   // sorted by key
+    std::vector<std::pair<long long, std::string>> lookup_file;   // in file order
     const char* data = nullptr; size_t size = 0; int fd = -1;
     explicit DbReader(const std::string& path) {
-        std::ifstream fi(path + ".index");
-        if (!fi) throw std::runtime_error("cannot open " + path + ".index");
-        Row r;
-        while (fi >> r.key >> r.off >> r.len) rows.push_back(r);
+        // read_index (src/database_reader.cpp:283-311): an entry per '\n' of the file (a last line without one is not an entry),
+        // words separated by blanks and tabs, numbers by strtoul / strtoull; a line of more than three words fails the read (one of
+        // fewer than three is undefined there: refused here)
+        std::string raw;
+        try { raw = read_file(path + ".index"); } catch (const std::exception&) { throw std::runtime_error("cannot open " + path + ".index"); }
+        auto words_of = [](const char* a, const char* b, std::vector<std::string>& w) {
+            w.clear();
+            while (a < b) {
+                while (a < b && (*a == ' ' || *a == '\t')) a++;
+                const char* s0 = a;
+                while (a < b && *a != ' ' && *a != '\t') a++;
+                if (a > s0) w.emplace_back(s0, (size_t)(a - s0));
+            }
+        };
+        std::vector<std::string> w;
+        for (size_t p0 = 0;;) {
+            const size_t nl = raw.find('\n', p0);
+            if (nl == std::string::npos) break;
+            words_of(raw.data() + p0, raw.data() + nl, w);
+            if (w.size() != 3) throw std::runtime_error(path + ".index: a line of " + std::to_string(w.size()) + " columns");
+            Row r; r.key = (long long)(uint32_t)strtoul(w[0].c_str(), nullptr, 10); r.off = (long long)strtoull(w[1].c_str(), nullptr, 10); r.len = (long long)strtoull(w[2].c_str(), nullptr, 10);
+            rows.push_back(r);
+            p0 = nl + 1;
+        }
         std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.key < b.key; });
         std::ifstream fl(path + ".lookup");
         std::string line;
-        while (fl && std::getline(fl, line)) {
-            const size_t t1 = line.find('\t');
-            if (t1 == std::string::npos) continue;
-            const size_t t2 = line.find('\t', t1 + 1);
-            lookup.push_back({atoll(line.substr(0, t1).c_str()), line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1)});
+        while (fl && std::getline(fl, line)) {            // read_lookup (:345-361): key = the first word, name = the second
+            words_of(line.data(), line.data() + line.size(), w);
+            if (w.size() < 2) continue;
+            lookup.push_back({(long long)(uint32_t)strtoul(w[0].c_str(), nullptr, 10), w[1]});
         }
+        // a key or a name that comes twice: the later line wins (the reference's stable_sort with "<=" comparators, :313-321, leaves
+        // equal elements in reverse order and its look-ups take the first): reversed here before the stable sort by key
+        lookup_file = lookup;
+        std::reverse(lookup.begin(), lookup.end());
         std::stable_sort(lookup.begin(), lookup.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         fd = open(path.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("cannot open " + path);
@@ -1159,7 +1183,7 @@ struct DbReader {
         return (it != rows.end() && it->key == key) ? (long long)(it - rows.begin()) : -1;
     }
     long long id_of_name(const std::string& nm) const {
-        for (const auto& kv : lookup) if (kv.second == nm) return id_of_key(kv.first);
+        for (size_t i = lookup_file.size(); i-- > 0;) if (lookup_file[i].second == nm) return id_of_key(lookup_file[i].first);
         return -1;
     }
     std::string name(size_t i) const {

@@ -176,6 +176,57 @@ def _mutation_bases(ing):
 _RefWorker = H.RefWorker
 
 
+def test_database_text_files_are_read_as_the_reference_reads_them(tmp_path):
+    """.index / .lookup files a person has touched: no line end after the last line (the reference counts entries by line ends: the
+    last one is not an entry), blanks for tabs, CR LF, a '+' before a key, a name with a blank in it (the name ends there), keys twice,
+    out of order. The Python reader == the live reference's reader (the C++ reader holds the same rules; its databases are compared
+    with the Python host's in test_host_cpp.py). Lines the reference reads undefined memory for (blank, fewer than three columns) are
+    refused by both hosts, not compared"""
+    if not H.have_ref():
+        pytest.skip("oracle/_ref is not built (it only exists where /root/reference does)")
+    rng = np.random.default_rng(3)
+    ref = H.RefWorker(timeout=5)
+    same = crashed = 0
+    for it in range(120):
+        n = int(rng.integers(1, 8))
+        datas = [bytes(rng.integers(65, 91, int(rng.integers(1, 30)), dtype=np.uint8)) + b"\0" for _ in range(n)]
+        offs = np.concatenate([[0], np.cumsum([len(d) for d in datas])])
+        keys = [int(k) for k in rng.permutation(n * 2)[:n]]
+        idx = [f"{keys[i]}\t{offs[i]}\t{len(datas[i])}" for i in range(n)]
+        lk = [f"{keys[i]}\tname{keys[i]}\t0" for i in range(n)]
+        for _ in range(int(rng.integers(0, 3))):
+            kind = int(rng.integers(0, 7)); j = int(rng.integers(0, n))
+            if kind == 0:
+                idx[j] = idx[j].replace("\t", "  ")
+            elif kind == 1:
+                idx[j] = idx[j] + "\r"
+            elif kind == 2:
+                idx[j] = " " + idx[j]
+            elif kind == 3:
+                lk.insert(j, lk[j].replace("name", "other"))
+            elif kind == 4:
+                idx.insert(j, idx[j])
+            elif kind == 5:
+                lk[j] = lk[j].replace("name", "na me")
+            else:
+                idx[j] = "+" + idx[j]
+        p = str(tmp_path / f"db{it}")
+        open(p, "wb").write(b"".join(datas))
+        open(p + ".index", "w").write("\n".join(idx) + ("\n" if rng.random() < 0.7 else ""))
+        open(p + ".lookup", "w").write("\n".join(lk) + "\n")
+        open(p + ".dbtype", "wb").write((12).to_bytes(4, "little"))
+        r = ref.call("ref_db_read", p)
+        if r[0] != "ok":
+            crashed += 1; continue
+        rd = DatabaseReader(p)
+        mine = [(int(rd.keys[i]), int(rd.offsets[i]), int(rd.lengths[i]), rd.name(i), rd.data(i)) for i in range(len(rd))]
+        rd.close()
+        assert mine == [tuple(e) for e in r[1]], (it, idx, lk)
+        same += 1
+    ref.close()
+    assert same > 80, (same, crashed)
+
+
 def test_python_pdb_reader_equals_live_reference_on_mutated_files(ing):
     """the command line's PDB reader (foldcomp_amd.structure.parse_pdb_gemmi = gemmi's read_pdb + StructureReader::updateStructure
     restated) against the LIVE reference (oracle/_ref: gemmi 0.5.1 itself) on 1 500 seeded mutations of two files: same atoms in

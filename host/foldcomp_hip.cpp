@@ -653,6 +653,11 @@ sv cif_string(sv v) {                                  // cif::as_string
 }
 double cif_number(sv v, double dflt) {                 // cif::as_number: the whole value is a number (+ an uncertainty in brackets)
     if (!v.empty() && v[0] == '+') v.remove_prefix(1);
+    // the usual value, "-12.345": digits and a point, read exactly (fast_decimal = strtod's result for up to 15 digits)
+    if (!v.empty() && v[0] != '+' && v.back() != ' ' && v.back() != '\t' && v.back() != '\r' && v[0] != ' ' && v[0] != '\t') {
+        double d;
+        if (fast_decimal(v.data(), v.data() + v.size(), d)) return d;
+    }
     size_t i = 0; const size_t n = v.size();
     if (i < n && v[i] == '-') i++;
     size_t d0 = i; while (i < n && isdigit((unsigned char)v[i])) i++;

@@ -65,13 +65,15 @@ __device__ __forceinline__ uint32_t ig_prev_lane(unsigned long long mask, int la
 
 // a stripped field of up to four characters as a packed name (host: field_pack)
 __device__ __forceinline__ uint32_t ig_pack4(uint32_t w, int n) {   // w = the n (<= 4) field bytes, little endian
-    uint32_t c[4] = {w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, (w >> 24) & 0xffu};
-    int a = 0, e = n;
-    while (a < e && ig_is_space(c[a])) a++;
-    while (e > a && ig_is_space(c[e - 1])) e--;
-    uint32_t v = 0;
-    for (int i = a; i < e; i++) v |= c[i] << (8 * (i - a));
-    return v;
+    // branch-free: blanks counted from both ends by selects, the rest shifted down and masked
+    const uint32_t c0 = w & 0xffu, c1 = (w >> 8) & 0xffu, c2 = (w >> 16) & 0xffu, c3 = (w >> 24) & 0xffu;
+    const bool s0 = ig_is_space(c0) | (n < 1), s1 = ig_is_space(c1) | (n < 2), s2 = ig_is_space(c2) | (n < 3), s3 = ig_is_space(c3) | (n < 4);
+    const uint32_t a = !s0 ? 0u : !s1 ? 1u : !s2 ? 2u : !s3 ? 3u : 4u;          // first character that is not a blank
+    const uint32_t e = !s3 ? 4u : !s2 ? 3u : !s1 ? 2u : !s0 ? 1u : 0u;          // one past the last
+    const uint32_t k = e > a ? e - a : 0u;                                       // characters kept (0 .. 4)
+    const uint32_t sh = (a & 3u) * 8u;
+    const uint32_t m = k >= 4u ? 0xffffffffu : ((1u << (8u * k)) - 1u);
+    return k ? ((w >> sh) & m) : 0u;
 }
 // fixed_field<W, F> of the host parser on W bytes: right-aligned, F decimals, digits / leading spaces / one '-'
 template <int W, int F>
@@ -117,21 +119,25 @@ template <int I> __device__ __forceinline__ uint32_t ig_b(const ig_line& L) { re
 // right-aligned integer part of a fixed field, characters [A, A + N): spaces, one optional '-', at least one digit
 template <int A, int N>
 __device__ __forceinline__ bool ig_intpart(const ig_line& L, uint32_t* val, bool* neg) {
-    uint32_t v = 0, mult = 1; bool ok = true, ng = false; int state = 0;   // 0: digits, 1: only spaces may follow (to the left)
-    auto step = [&](uint32_t c, bool rightmost) {
-        const uint32_t d = c - '0';
-        if (state == 0) {
-            if (d <= 9u) { v += d * mult; mult *= 10u; }
-            else if (rightmost) ok = false;                      // no digit before the point
-            else if (c == '-') { ng = true; state = 1; }
-            else if (c == ' ') state = 1;
-            else ok = false;
-        } else if (c != ' ') ok = false;
+    // right to left: digits (at least one), then at most one '-', then blanks. Plain boolean arithmetic: a wavefront's lanes
+    // hold lines of every shape, and every `if` here was a branch with its exec-mask bookkeeping
+    const uint32_t c0 = ig_b<A + N - 1>(L), c1 = ig_b<A + (N >= 2 ? N - 2 : 0)>(L), c2 = ig_b<A + (N >= 3 ? N - 3 : 0)>(L), c3 = ig_b<A + (N >= 4 ? N - 4 : 0)>(L);
+    const uint32_t d0 = c0 - '0', d1 = c1 - '0', d2 = c2 - '0', d3 = c3 - '0';
+    const bool g0 = d0 <= 9u, g1 = d1 <= 9u, g2 = d2 <= 9u, g3 = d3 <= 9u;
+    const bool r1 = g0, r2 = r1 & g1, r3 = r2 & g2, r4 = r3 & g3;                 // the run of digits reaches 1, 2, 3, 4 characters
+    uint32_t v = d0;
+    if (N >= 2) v += r2 ? d1 * 10u : 0u;
+    if (N >= 3) v += r3 ? d2 * 100u : 0u;
+    if (N >= 4) v += r4 ? d3 * 1000u : 0u;
+    bool ok = g0, ng = false;
+    auto left = [&](bool in_run, bool first, uint32_t c) {          // character left of the rightmost one
+        const bool is_neg = c == '-', is_sp = c == ' ';
+        ok = ok & (in_run | (first ? (is_neg | is_sp) : is_sp));
+        ng = ng | (first & is_neg);
     };
-    if (N >= 1) step(ig_b<A + N - 1>(L), true);
-    if (N >= 2) step(ig_b<A + (N >= 2 ? N - 2 : 0)>(L), false);
-    if (N >= 3) step(ig_b<A + (N >= 3 ? N - 3 : 0)>(L), false);
-    if (N >= 4) step(ig_b<A + (N >= 4 ? N - 4 : 0)>(L), false);
+    if (N >= 2) left(r2, r1 & !g1, c1);
+    if (N >= 3) left(r3, r2 & !g2, c2);
+    if (N >= 4) left(r4, r3 & !g3, c3);
     *val = v; *neg = ng;
     return ok;
 }
@@ -140,7 +146,7 @@ template <int A>
 __device__ __forceinline__ bool ig_fixed83(const ig_line& L, float* out) {
     const uint32_t d0 = ig_b<A + 5>(L) - '0', d1 = ig_b<A + 6>(L) - '0', d2 = ig_b<A + 7>(L) - '0';
     uint32_t ip; bool neg;
-    const bool ok = ig_intpart<A, 4>(L, &ip, &neg) && ig_b<A + 4>(L) == '.' && d0 <= 9u && d1 <= 9u && d2 <= 9u;
+    const bool ok = ig_intpart<A, 4>(L, &ip, &neg) & (ig_b<A + 4>(L) == '.') & (d0 <= 9u) & (d1 <= 9u) & (d2 <= 9u);
     const float v = (float)((double)(ip * 1000u + d0 * 100u + d1 * 10u + d2) * 0.001);
     *out = neg ? -v : v;
     return ok;
@@ -149,7 +155,7 @@ template <int A>
 __device__ __forceinline__ bool ig_fixed62(const ig_line& L, float* out) {
     const uint32_t d0 = ig_b<A + 4>(L) - '0', d1 = ig_b<A + 5>(L) - '0';
     uint32_t ip; bool neg;
-    const bool ok = ig_intpart<A, 3>(L, &ip, &neg) && ig_b<A + 3>(L) == '.' && d0 <= 9u && d1 <= 9u;
+    const bool ok = ig_intpart<A, 3>(L, &ip, &neg) & (ig_b<A + 3>(L) == '.') & (d0 <= 9u) & (d1 <= 9u);
     const float v = (float)((double)(ip * 100u + d0 * 10u + d1) * 0.01);
     *out = neg ? -v : v;
     return ok;
@@ -179,16 +185,8 @@ __device__ __forceinline__ bool ig_int_reg(const ig_line& L, int32_t* out) {
 }
 template <int A, int N>
 __device__ __forceinline__ uint32_t ig_pack_reg(const ig_line& L) {      // field_pack of N <= 4 characters at column A
-    const uint32_t c[4] = {ig_b<A>(L), ig_b<A + (N > 1 ? 1 : 0)>(L), ig_b<A + (N > 2 ? 2 : 0)>(L), ig_b<A + (N > 3 ? 3 : 0)>(L)};
-    int a = 0, e = N;
-#pragma unroll
-    for (int i = 0; i < N; i++) if (a == i && ig_is_space(c[i])) a = i + 1;
-#pragma unroll
-    for (int i = N - 1; i >= 0; i--) if (e == i + 1 && e > a && ig_is_space(c[i])) e = i;
-    uint32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) if (i >= a && i < e) v |= c[i] << (8 * (i - a));     // (i - a): a is a run-time shift of 0, 8, 16 or 24
-    return v;
+    const uint32_t w = ig_b<A>(L) | (ig_b<A + (N > 1 ? 1 : 0)>(L) << 8) | (ig_b<A + (N > 2 ? 2 : 0)>(L) << 16) | (ig_b<A + (N > 3 ? 3 : 0)>(L) << 24);
+    return ig_pack4(w, N);
 }
 
 constexpr int IG_BACK = 256;                      // bytes of the previous chunk kept in front of the staged one (a line that ends in a
@@ -361,36 +359,37 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
                 an = ig_pack_reg<12, 4>(L);
                 rn = ig_pack_reg<17, 3>(L);
                 ch = ig_b<21>(L);
-                if (ig_b<20>(L) != ' ' || (ch != ' ' && ig_is_space(ch))) bad = true;        // a two-character chain name
+                bad = bad | (ig_b<20>(L) != ' ') | ((ch != ' ') & ig_is_space(ch));          // a two-character chain name
                 icode = ig_b<26>(L);
-                if (!ig_int_reg<6, 5>(L, &serial) || !ig_int_reg<22, 4>(L, &resseq)) bad = true;
-                if (!ig_fixed83<30>(L, &x) || !ig_fixed83<38>(L, &y) || !ig_fixed83<46>(L, &z)) bad = true;
+                const bool i1 = ig_int_reg<6, 5>(L, &serial), i2 = ig_int_reg<22, 4>(L, &resseq);
+                const bool f1 = ig_fixed83<30>(L, &x), f2 = ig_fixed83<38>(L, &y), f3 = ig_fixed83<46>(L, &z);
+                bad = bad | !(i1 & i2 & f1 & f2 & f3);
                 // B-factor: 20 when the line ends before column 65 (the reader's default); the fixed layout; six blanks = 0
-                if (glen <= 64) bf = 20.0f;
-                else if (len >= 66 && ig_fixed62<60>(L, &bf)) {}
-                else {
-                    bool blank = len >= 66;
-#pragma unroll
-                    for (int i = 0; i < 6; i++) if (!ig_is_space(i == 0 ? ig_b<60>(L) : i == 1 ? ig_b<61>(L) : i == 2 ? ig_b<62>(L) : i == 3 ? ig_b<63>(L) : i == 4 ? ig_b<64>(L) : ig_b<65>(L))) blank = false;
-                    if (blank) bf = 0.f; else bad = true;
+                {
+                    float bfx;
+                    const bool fb = ig_fixed62<60>(L, &bfx) & (len >= 66);
+                    const bool blank = (len >= 66) & ig_is_space(ig_b<60>(L)) & ig_is_space(ig_b<61>(L)) & ig_is_space(ig_b<62>(L)) & ig_is_space(ig_b<63>(L)) &
+                                       ig_is_space(ig_b<64>(L)) & ig_is_space(ig_b<65>(L));
+                    bf = glen <= 64 ? 20.0f : (fb ? bfx : 0.f);
+                    bad = bad | ((glen > 64) & !fb & !blank);
                 }
                 // charge (columns 79-80, read_charge lib/gemmi/pdb.hpp:85-98): a digit there needs a sign (or nothing) beside it,
                 // the reader fails the file otherwise
-                if (glen > 78) {
-                    uint32_t dg = raw > 78u ? ig_b<78>(L) : (uint32_t)'\n', sg = raw > 79u ? ig_b<79>(L) : (raw == 79u && has_nl ? (uint32_t)'\n' : 0u);
-                    if (!(dg == ' ' && sg == ' ')) {
-                        if (sg - '0' < 10u) { const uint32_t t_ = dg; dg = sg; sg = t_; }
-                        if (dg - '0' < 10u && !(sg == '+' || sg == '-' || sg == 0u || ig_is_space(sg))) bad = true;
-                    }
+                {
+                    uint32_t dg = raw > 78u ? ig_b<78>(L) : (uint32_t)'\n', sg = raw > 79u ? ig_b<79>(L) : (((raw == 79u) & has_nl) ? (uint32_t)'\n' : 0u);
+                    const bool swap = sg - '0' < 10u;
+                    const uint32_t dg2 = swap ? sg : dg, sg2 = swap ? dg : sg;
+                    const bool sign_ok = (sg2 == '+') | (sg2 == '-') | (sg2 == 0u) | ig_is_space(sg2);
+                    bad = bad | ((glen > 78) & !((dg == ' ') & (sg == ' ')) & (dg2 - '0' < 10u) & !sign_ok);
                 }
-                // segment id (columns 73-76) is part of the residue's identity when the line reaches it
-                if (glen > 72) {
-                    const uint32_t c[4] = {ig_b<72>(L), ig_b<73>(L), ig_b<74>(L), ig_b<75>(L)};
-                    uint32_t nv = raw > 72u ? (raw - 72u < 4u ? raw - 72u : 4u) : 0u;       // characters of the field inside the line
-                    for (uint32_t i = 0; i < nv; i++) if (c[i] == '\r' || c[i] == '\0') { nv = i; break; }
-                    uint32_t a_ = 0; while (a_ < nv && ig_is_space(c[a_])) a_++;
-                    while (nv > a_ && ig_is_space(c[nv - 1])) nv--;
-                    for (uint32_t i = a_; i < nv; i++) seg |= c[i] << (8 * (i - a_));
+                // segment id (columns 73-76) is part of the residue's identity when the line reaches it: its characters up to the
+                // line end (or a CR / NUL), stripped
+                {
+                    const uint32_t c0 = ig_b<72>(L), c1 = ig_b<73>(L), c2 = ig_b<74>(L), c3 = ig_b<75>(L);
+                    auto term = [](uint32_t c) { return (c == '\r') | (c == 0u); };
+                    const bool v0 = (glen > 72) & (raw > 72u) & !term(c0), v1 = v0 & (raw > 73u) & !term(c1), v2 = v1 & (raw > 74u) & !term(c2), v3 = v2 & (raw > 75u) & !term(c3);
+                    const uint32_t e0 = v0 ? c0 : ' ', e1 = v1 ? c1 : ' ', e2 = v2 ? c2 : ' ', e3 = v3 ? c3 : ' ';
+                    seg = ig_pack4(e0 | (e1 << 8) | (e2 << 16) | (e3 << 24), 4);
                 }
             }
         }
@@ -480,8 +479,9 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         IG_STAMP(1)
         // ---- line ends of the chunk: every lane looks at its 64 staged bytes ----
         const uint64_t my = c0 + 64ull * (uint64_t)lane;     // file-relative start of this lane's 64 bytes
-        uint32_t t[16];
-        uint32_t cnt = 0, nul = 0;
+        // one bit per byte: the 0x80 flags of a dword's four bytes are gathered into a nibble by one multiplication
+        // ((m >> 7) has bits 0, 8, 16, 24; times 2^28 + 2^21 + 2^14 + 2^7 they land on bits 28..31 without a carry)
+        uint32_t nl_lo = 0, nl_hi = 0, z_lo = 0, z_hi = 0;
         {
             const uint4* src = reinterpret_cast<const uint4*>(&S.buf[IG_BACK + 64 * lane]);
 #pragma unroll
@@ -492,17 +492,20 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
                 for (int k = 0; k < 4; k++) {
                     const int d = 4 * q4 + k;
                     const uint32_t xz = vv[k] ^ 0x0a0a0a0au;
-                    uint32_t m = ~(((xz & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xz | 0x7f7f7f7fu);     // 0x80 in every byte that is '\n'
-                    // bytes past the end of the file were staged as zero: never a line end
-                    t[d] = (my + 4 * d < flen) ? m : 0u;
-                    cnt += (uint32_t)__builtin_popcount(t[d]);
+                    const uint32_t m = ~(((xz & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xz | 0x7f7f7f7fu);     // 0x80 in every byte that is '\n'
                     // a NUL inside the file ends the reader's line there (C strings): not this path's business
                     const uint32_t zz = ~(((vv[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | vv[k] | 0x7f7f7f7fu);
-                    const uint64_t w_at = my + 4 * d;
-                    nul |= w_at + 4 <= flen ? zz : (w_at < flen ? zz & ((1u << (8 * (uint32_t)(flen - w_at))) - 1u) : 0u);
+                    const uint32_t nn = ((m >> 7) * 0x10204080u) >> 28, nz = ((zz >> 7) * 0x10204080u) >> 28;
+                    if (d < 8) { nl_lo |= nn << (4 * d); z_lo |= nz << (4 * d); } else { nl_hi |= nn << (4 * (d - 8)); z_hi |= nz << (4 * (d - 8)); }
                 }
             }
         }
+        // bytes past the end of the file were staged as zero: neither line ends nor NULs of the file
+        const uint32_t vb = my >= flen ? 0u : (flen - my >= 64u ? 64u : (uint32_t)(flen - my));
+        const unsigned long long vmask = vb >= 64u ? ~0ull : ((1ull << vb) - 1ull);
+        const unsigned long long nlm = (((unsigned long long)nl_hi << 32) | nl_lo) & vmask;
+        const uint32_t nul = ((((unsigned long long)z_hi << 32) | z_lo) & vmask) != 0ull ? 1u : 0u;
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(nlm);
         if (__any(nul != 0u)) status = FCZ_INGEST_HOST_FIELD;
         uint32_t total;
         uint32_t ord = wave_excl_scan_dpp(cnt, &total);
@@ -510,14 +513,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         // chunks with more line ends than the table holds (blank-line runs) go through it in rounds
         for (uint32_t r0 = 0; r0 < total || r0 == 0; r0 += IG_LINES) {
             uint32_t o = ord;
-#pragma unroll
-            for (int d = 0; d < 16; d++) {
-                uint32_t m = t[d];
-                while (m) {
-                    const int bit = __builtin_ctz(m); m &= m - 1;
-                    if (o >= r0 && o < r0 + (uint32_t)IG_LINES) S.line_end[o - r0] = 64u * (uint32_t)lane + 4u * (uint32_t)d + (uint32_t)(bit >> 3);
-                    o++;
-                }
+            for (unsigned long long m = nlm; m; m &= m - 1) {        // a lane's 64 bytes hold one line end or two (81-byte records), rarely more
+                const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                if (o >= r0 && o < r0 + (uint32_t)IG_LINES) S.line_end[o - r0] = 64u * (uint32_t)lane + bit;
+                o++;
             }
             __builtin_amdgcn_wave_barrier();
             IG_STAMP(3)

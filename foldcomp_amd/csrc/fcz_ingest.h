@@ -163,25 +163,32 @@ __device__ __forceinline__ bool ig_fixed62(const ig_line& L, float* out) {
 // field_int on characters [A, A + N), N <= 5: spaces on both sides, optional sign, digits
 template <int A, int N>
 __device__ __forceinline__ bool ig_int_reg(const ig_line& L, int32_t* out) {
-    uint32_t c[5] = {ig_b<A>(L), ig_b<A + (N > 1 ? 1 : 0)>(L), ig_b<A + (N > 2 ? 2 : 0)>(L), ig_b<A + (N > 3 ? 3 : 0)>(L), ig_b<A + (N > 4 ? 4 : 0)>(L)};
-    int a = 0, e = N;
+    // blanks, then the number -- an optional sign and digits, at least one --, then blanks or CRs. Boolean arithmetic over the
+    // N <= 5 characters (a wavefront's lanes hold fields of every shape): lead[i] = everything up to i is a blank, tail[i] =
+    // everything from i on is a blank or a CR, the number is what lies between
+    const uint32_t c[5] = {ig_b<A>(L), ig_b<A + (N > 1 ? 1 : 0)>(L), ig_b<A + (N > 2 ? 2 : 0)>(L), ig_b<A + (N > 3 ? 3 : 0)>(L), ig_b<A + (N > 4 ? 4 : 0)>(L)};
+    bool lead[5], tail[5];
+    bool run = true;
 #pragma unroll
-    for (int i = 0; i < N; i++) if (a == i && c[i] == ' ') a = i + 1;
+    for (int i = 0; i < N; i++) { run = run & (c[i] == ' '); lead[i] = run; }
+    run = true;
 #pragma unroll
-    for (int i = N - 1; i >= 0; i--) if (e == i + 1 && e > a && (c[i] == ' ' || c[i] == '\r')) e = i;
-    bool neg = false, ok = true;
-    int32_t v = 0; int nd = 0; bool sign_seen = false;
+    for (int i = N - 1; i >= 0; i--) { run = run & ((c[i] == ' ') | (c[i] == '\r')); tail[i] = run; }
+    bool ok = true, neg = false;
+    int32_t v = 0; uint32_t nd = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        if (i < a || i >= e) continue;
         const uint32_t d = c[i] - '0';
-        if (i == a && (c[i] == '-' || c[i] == '+')) { neg = c[i] == '-'; sign_seen = true; }
-        else if (d <= 9u) { v = v * 10 + (int32_t)d; nd++; }
-        else ok = false;
+        const bool dig = d <= 9u, core = !lead[i] & !tail[i], first = core & (i == 0 ? true : lead[i > 0 ? i - 1 : 0]);
+        const bool sign = first & ((c[i] == '-') | (c[i] == '+'));
+        ok = ok & (!core | sign | dig);
+        neg = neg | (sign & (c[i] == '-'));
+        const bool take = core & dig;
+        v = take ? v * 10 + (int32_t)d : v;
+        nd += take ? 1u : 0u;
     }
-    (void)sign_seen;
     *out = neg ? -v : v;
-    return ok && nd > 0;
+    return ok & (nd > 0u);
 }
 template <int A, int N>
 __device__ __forceinline__ uint32_t ig_pack_reg(const ig_line& L) {      // field_pack of N <= 4 characters at column A
@@ -291,28 +298,33 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         const uint32_t w0 = on ? (nvis >= 4 ? L.w[0] : (L.w[0] & ((1u << (8 * nvis)) - 1u))) : 0u;
         const uint32_t up4 = w0 & ~0x20202020u;
         const bool rec = on && (up4 == (0x4d4f5441u & ~0x20202020u) || up4 == (0x41544548u & ~0x20202020u));     // ATOM, HETA(TM)
-        const bool is_end = on && !rec && (up4 & 0x00ffffffu) == 0x00444e45u && ((up4 >> 24) & 0xf0u) == 0u;          // END, not ENDMDL
-        // records this path does not model: ANISOU (attached to atoms, can fail the file), data_
-        const bool foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_') ||
-                                            (up4 == (0x6164227bu & ~0x20202020u) && ((L.w[1] & 0x00ffffffu) & ~0x00202020u) == (0x005f6174u & ~0x00202020u)));   // ANISOU, data_, {"data_
-        // MODEL / ENDMDL: one MODEL record before the first atom and ENDMDL records after the last one (the single-model file every
-        // predicted structure is) change nothing; atoms after an ENDMDL or a second MODEL start new models, with rules of their own
-        const bool is_model = on && !rec && up4 == (0x45444f4du & ~0x20202020u);
-        const bool is_endm = on && !rec && up4 == (0x4d444e45u & ~0x20202020u);
-        // CRYST1: the reader fails a file whose cell has a gamma and an alpha or beta of exactly zero (UnitCell::set). Decided here
-        // only for fields that start (after blanks) with a digit 1-9 -- certainly not zero; anything else goes to the host
-        if (on && !rec && up4 == (0x53595243u & ~0x20202020u) && glen > 54u) {
-            bool sure = staged;
-            if (staged) {
+        // a step of nothing but ATOM / HETATM lines (all but two or three steps of a file) skips what the other records need
+        const bool any_other = __any(on && !rec);
+        bool is_end = false, foreign = false, is_model = false, is_endm = false;
+        if (any_other) {
+            is_end = on && !rec && (up4 & 0x00ffffffu) == 0x00444e45u && ((up4 >> 24) & 0xf0u) == 0u;          // END, not ENDMDL
+            // records this path does not model: ANISOU (attached to atoms, can fail the file), data_
+            foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_') ||
+                                                (up4 == (0x6164227bu & ~0x20202020u) && ((L.w[1] & 0x00ffffffu) & ~0x00202020u) == (0x005f6174u & ~0x00202020u)));   // ANISOU, data_, {"data_
+            // MODEL / ENDMDL: one MODEL record before the first atom and ENDMDL records after the last one (the single-model file every
+            // predicted structure is) change nothing; atoms after an ENDMDL or a second MODEL start new models, with rules of their own
+            is_model = on && !rec && up4 == (0x45444f4du & ~0x20202020u);
+            is_endm = on && !rec && up4 == (0x4d444e45u & ~0x20202020u);
+            // CRYST1: the reader fails a file whose cell has a gamma and an alpha or beta of exactly zero (UnitCell::set). Decided here
+            // only for fields that start (after blanks) with a digit 1-9 -- certainly not zero; anything else goes to the host
+            if (on && !rec && up4 == (0x53595243u & ~0x20202020u) && glen > 54u) {
+                bool sure = staged;
+                if (staged) {
 #pragma unroll
-                for (int f0 = 33; f0 <= 40; f0 += 7) {
-                    uint32_t first = ' ';
+                    for (int f0 = 33; f0 <= 40; f0 += 7) {
+                        uint32_t first = ' ';
 #pragma unroll
-                    for (int q = 6; q >= 0; q--) { const uint32_t c = (uint32_t)S.buf[lo + f0 + q]; if (c != ' ') first = c; }
-                    if (!(first - '1' < 9u)) sure = false;
+                        for (int q = 6; q >= 0; q--) { const uint32_t c = (uint32_t)S.buf[lo + f0 + q]; if (c != ' ') first = c; }
+                        if (!(first - '1' < 9u)) sure = false;
+                    }
                 }
+                if (!sure) cryst_bad = true;
             }
-            if (!sure) cryst_bad = true;
         }
         const unsigned long long m_end = __ballot(is_end);
         const int end_lane = m_end ? __builtin_ctzll(m_end) : 64;
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         if (__any(live && (foreign || cryst_bad))) status = FCZ_INGEST_HOST_FIELD;
         const unsigned long long m_model = __ballot(live && is_model), m_endm = __ballot(live && is_endm);
         // ---- title: the last HEADER record's id code (columns 63-66, right-trimmed), else the TITLE records' text concatenated ----
-        {
+        if (any_other) {
             const bool is_title = live && !rec && up4 == (0x4c544954u & ~0x20202020u) && glen > 10;
             bool is_hdr = false; uint32_t hid = 0, hn = 0;
             if (live && !rec && up4 == (0x44414548u & ~0x20202020u) && glen > 66) {

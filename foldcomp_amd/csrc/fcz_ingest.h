@@ -597,16 +597,27 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
     }
     const size_t A0 = (size_t)abase[f];
     const uint32_t PKN = 'N';
+    constexpr int FR_U = 4;                               // steps of 64 atoms whose loads are in flight together
     // ---- chain ranges ----
     uint32_t n_ch = 0; bool overflow = false;
     {
         uint32_t start = 0, resume = 1; bool stopped = false;
         auto push = [&](uint32_t a, uint32_t b) { if (n_ch < (uint32_t)IG_MAX_FRAGS) { if (lane == 0) { s_cut[2 * n_ch] = a; s_cut[2 * n_ch + 1] = b; } n_ch++; } else overflow = true; };
-        for (uint32_t i0 = 0; i0 < n && !stopped; i0 += WAVE) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            const bool in = i < n && i >= 1;
-            const bool chg = in && T.chain[A0 + i] != T.chain[A0 + i - 1];
-            unsigned long long m = __ballot(chg);
+        // (this kernel walks a file's atoms three times in steps of 64 and every step waits for its loads: four steps' loads are
+        // issued together)
+        for (uint32_t ib = 0; ib < n && !stopped; ib += FR_U * WAVE) {
+          uint32_t cc[FR_U], cp[FR_U];
+#pragma unroll
+          for (int u = 0; u < FR_U; u++) {
+              const uint32_t i = ib + (uint32_t)(u * WAVE + lane);
+              const bool in = i < n && i >= 1;
+              cc[u] = in ? (uint32_t)T.chain[A0 + i] : 0u; cp[u] = in ? (uint32_t)T.chain[A0 + i - 1] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < FR_U; u++) {
+            const uint32_t i0 = ib + (uint32_t)(u * WAVE);
+            if (i0 >= n || stopped) break;
+            unsigned long long m = __ballot(cc[u] != cp[u]);
             while (m && !stopped) {
                 const int l = __builtin_ctzll(m); m &= m - 1;
                 const uint32_t ci = i0 + (uint32_t)l;
@@ -622,6 +633,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
                 if (j == n) { stopped = true; break; }
                 push(start, ci); start = j; resume = j + 1;
             }
+          }
         }
         push(start, n);
     }
@@ -637,10 +649,20 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
         uint32_t fstart[IG_MAX_FRAGS + 1]; uint32_t nfr = 0;    // uniform values, small
         {
             bool have_n = false; int32_t prev_seq = 0; uint32_t cur = 0;
-            for (uint32_t i0 = ca; i0 < cb; i0 += WAVE) {
+            for (uint32_t ib = ca; ib < cb; ib += FR_U * WAVE) {
+              uint32_t nm[FR_U]; int32_t sq[FR_U];
+#pragma unroll
+              for (int u = 0; u < FR_U; u++) {
+                  const uint32_t i = ib + (uint32_t)(u * WAVE + lane);
+                  nm[u] = i < cb ? T.name[A0 + i] : 0u; sq[u] = i < cb ? T.resseq[A0 + i] : 0;
+              }
+#pragma unroll
+              for (int u = 0; u < FR_U; u++) {
+                const uint32_t i0 = ib + (uint32_t)(u * WAVE);
+                if (i0 >= cb) break;
                 const uint32_t i = i0 + (uint32_t)lane;
-                const bool isn = i < cb && T.name[A0 + i] == PKN;
-                const int32_t seq = isn ? T.resseq[A0 + i] : 0;
+                const bool isn = i < cb && nm[u] == PKN;
+                const int32_t seq = isn ? sq[u] : 0;
                 const unsigned long long mn = __ballot(isn);
                 if (!mn) continue;
                 const uint32_t pl = ig_prev_lane(mn, lane);
@@ -659,6 +681,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
                 (void)cur;
                 const int hl = 63 - __builtin_clzll(mn);
                 prev_seq = __shfl(seq, hl, WAVE); have_n = true;
+              }
             }
         }
         if (nfr == 0 || overflow) continue;                // a chain without an N atom has no fragment
@@ -669,12 +692,22 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
             uint32_t reason = (skip_discontinuous && multi_frag) ? IG_REF_SKIP_DISC : IG_REF_NONE;
             // residue starts: atom a, and every atom in (a, b - 1) whose residue number differs from its predecessor's
             uint32_t nres = 0;
-            for (uint32_t i0 = a; i0 < b; i0 += WAVE) {
-                const uint32_t i = i0 + (uint32_t)lane;
-                const bool st = i < b && (i == a || (i != b - 1 && T.resseq[A0 + i] != T.resseq[A0 + i - 1]));
-                const unsigned long long ms = __ballot(st);
-                if (st) T.r_first[A0 + r_next + nres + (uint32_t)__builtin_popcountll(ms & ((1ull << lane) - 1ull))] = i;
-                nres += (uint32_t)__builtin_popcountll(ms);
+            for (uint32_t ib = a; ib < b; ib += FR_U * WAVE) {
+                int32_t rq[FR_U], rp[FR_U];
+#pragma unroll
+                for (int u = 0; u < FR_U; u++) {
+                    const uint32_t i = ib + (uint32_t)(u * WAVE + lane);
+                    const bool in = i < b && i > a;
+                    rq[u] = in ? T.resseq[A0 + i] : 0; rp[u] = in ? T.resseq[A0 + i - 1] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < FR_U; u++) {
+                    const uint32_t i = ib + (uint32_t)(u * WAVE + lane);
+                    const bool st = i < b && (i == a || (i != b - 1 && rq[u] != rp[u]));
+                    const unsigned long long ms = __ballot(st);
+                    if (st) T.r_first[A0 + r_next + nres + (uint32_t)__builtin_popcountll(ms & ((1ull << lane) - 1ull))] = i;
+                    nres += (uint32_t)__builtin_popcountll(ms);
+                }
             }
             __threadfence();                                 // the residue starts are read back by other lanes below
             // the FCZ header holds nResidue in 16 bits and nAnchor in 8 (src/foldcomp.h:120-125): refused, not wrapped

@@ -39,9 +39,13 @@ def load_structure(name: str, data: bytes) -> Tuple[AtomTable, str]:
     the NAME only says whether the bytes are gzipped; whether they are PDB or mmCIF text is read off the content
     (gemmi::coor_format_from_content), and either is read by gemmi's rules (structure.parse_pdb_gemmi / parse_cif_gemmi)"""
     base = os.path.basename(name)
-    if base.endswith(".gz"):
-        data = gzip.decompress(data)
-    t, title = parse_structure_gemmi(data)
+    from . import _hostlib
+    if _hostlib.load() is not None:                      # the C++ host's readers (the same rules, held equal by the tests)
+        t, title = _hostlib.read_structure(data, gz=base.endswith(".gz"))
+    else:
+        if base.endswith(".gz"):
+            data = gzip.decompress(data)
+        t, title = parse_structure_gemmi(data)
     return t, (title if title else base)
 
 

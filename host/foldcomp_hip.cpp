@@ -2299,3 +2299,49 @@ int main(int argc, char** argv) {
     usage();
     return 1;
 }
+
+// ---- the readers as a library (host/libfcz_host.so): what the Python command line calls instead of its own restatement of the
+//      same rules (foldcomp_amd/structure.py; the two are held equal on mutated files in tests/test_ingest_vs_reference.py) ----
+extern "C" {
+struct fcz_host_atoms {
+    uint64_t n;                                  // atoms, in the order StructureReader hands them on (before removeAlternativePosition)
+    char *atom, *residue, *chain;                // n names each, NUL-separated
+    uint64_t atom_bytes, residue_bytes, chain_bytes;
+    int32_t *atom_index, *res_index;
+    float *x, *y, *z, *bfac;
+    char* title; uint64_t title_len;             // "" when the file has none
+    char error[256];                             // why the reader fails the file (return value 1)
+};
+// data: the bytes of a structure file; gz != 0: a gzip stream to inflate first. PDB or mmCIF by content (loadFromBuffer).
+int fcz_host_read_structure(const uint8_t* data, uint64_t len, int gz, fcz_host_atoms* out) {
+    memset(out, 0, sizeof *out);
+    try {
+        std::string unz;
+        const char* d = (const char*)data; size_t n = (size_t)len;
+        if (gz) { unz = gunzip(std::string(d, n)); d = unz.data(); n = unz.size(); }
+        std::string title;
+        AtomTable t = parse_structure_gemmi(d, n, title);
+        const size_t na = t.size();
+        std::string a, r, c;
+        for (size_t i = 0; i < na; i++) { a += t.name(t.atom[i]); a.push_back('\0'); r += t.name(t.residue[i]); r.push_back('\0'); c += t.chain_name(i); c.push_back('\0'); }
+        auto dup = [](const void* p, size_t bytes) { void* q = malloc(bytes ? bytes : 1); if (bytes) memcpy(q, p, bytes); return q; };
+        out->n = na;
+        out->atom = (char*)dup(a.data(), a.size()); out->atom_bytes = a.size();
+        out->residue = (char*)dup(r.data(), r.size()); out->residue_bytes = r.size();
+        out->chain = (char*)dup(c.data(), c.size()); out->chain_bytes = c.size();
+        out->atom_index = (int32_t*)dup(t.atom_index.data(), 4 * na); out->res_index = (int32_t*)dup(t.res_index.data(), 4 * na);
+        out->x = (float*)dup(t.x.data(), 4 * na); out->y = (float*)dup(t.y.data(), 4 * na); out->z = (float*)dup(t.z.data(), 4 * na);
+        out->bfac = (float*)dup(t.bfac.data(), 4 * na);
+        out->title = (char*)dup(title.data(), title.size()); out->title_len = title.size();
+        table_pool().put(std::move(t));
+        return 0;
+    } catch (const std::exception& e) {
+        snprintf(out->error, sizeof out->error, "%s", e.what());
+        return 1;
+    }
+}
+void fcz_host_free(fcz_host_atoms* o) {
+    free(o->atom); free(o->residue); free(o->chain); free(o->atom_index); free(o->res_index); free(o->x); free(o->y); free(o->z); free(o->bfac); free(o->title);
+    memset(o, 0, sizeof *o);
+}
+}

@@ -403,6 +403,41 @@ def test_cpp_cif_reader_equals_python_reader_on_mutated_files(ing, tmp_path):
     _same(_dump(d), names, build_batch(chains, 25))
 
 
+def test_host_library_readers_equal_python_readers_on_mutated_files(ing):
+    """host/libfcz_host.so (fcz_host_read_structure: what `python -m foldcomp_amd` reads files with) == the Python restatement
+    (structure.parse_structure_gemmi) on 600 mutated PDB files and 600 mutated mmCIF files, plain and gzipped: the same atoms, names
+    of any length, chain names, numbers bit for bit, title -- or both fail the file"""
+    import gzip
+    from _cases import mutated_cif, mutated_pdb
+    from foldcomp_amd import _hostlib
+    from foldcomp_amd.structure import StructureError, parse_structure_gemmi
+    assert _hostlib.load() is not None, "host/libfcz_host.so is not built (make -C host)"
+    bases = _mutation_bases(ing)
+    cif = _short_cif(ing, rows=150)
+    rng = np.random.default_rng(5)
+    same = failed = 0
+    for i in range(1200):
+        data = mutated_pdb(bases[i % 2], rng) if i % 2 == 0 else mutated_cif(cif, rng)
+        gz = i % 5 == 0
+        try:
+            p, ptitle = parse_structure_gemmi(data)
+        except StructureError:
+            p = None
+        try:
+            t, title = _hostlib.read_structure(gzip.compress(data, 1) if gz else data, gz=gz)
+        except StructureError:
+            t = None
+        assert (p is None) == (t is None), (i, "only one of the two fails the file")
+        if p is None:
+            failed += 1; continue
+        assert t.atom == p.atom and t.residue == p.residue and t.chain == p.chain, i
+        assert np.array_equal(t.atom_index, p.atom_index) and np.array_equal(t.res_index, p.res_index), i
+        assert np.all((t.xyz.view(np.uint32) == p.xyz.view(np.uint32)) | (np.isnan(t.xyz) & np.isnan(p.xyz))), i
+        assert np.array_equal(t.bfac.view(np.uint32), p.bfac.view(np.uint32)) and title == ptitle, i
+        same += 1
+    assert same > 500 and failed > 200, (same, failed)
+
+
 def test_cpp_pdb_reader_equals_python_reader_on_mutated_files(ing, tmp_path):
     """the C++ host's reader (parse_pdb_gemmi in host/foldcomp_hip.cpp, through dump-batch on a directory) == the Python one on
     300 mutated files: fragments, names, every array of the batch; files the reader fails and fragments the codec refuses drop out

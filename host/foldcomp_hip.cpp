@@ -57,6 +57,7 @@
 
 extern "C" {
 #include "../include/fcz_hip.h"
+#include "../include/fcz_host.h"
 }
 
 namespace {
@@ -2303,15 +2304,6 @@ int main(int argc, char** argv) {
 // ---- the readers as a library (host/libfcz_host.so): what the Python command line calls instead of its own restatement of the
 //      same rules (foldcomp_amd/structure.py; the two are held equal on mutated files in tests/test_ingest_vs_reference.py) ----
 extern "C" {
-struct fcz_host_atoms {
-    uint64_t n;                                  // atoms, in the order StructureReader hands them on (before removeAlternativePosition)
-    char *atom, *residue, *chain;                // n names each, NUL-separated
-    uint64_t atom_bytes, residue_bytes, chain_bytes;
-    int32_t *atom_index, *res_index;
-    float *x, *y, *z, *bfac;
-    char* title; uint64_t title_len;             // "" when the file has none
-    char error[256];                             // why the reader fails the file (return value 1)
-};
 // data: the bytes of a structure file; gz != 0: a gzip stream to inflate first. PDB or mmCIF by content (loadFromBuffer).
 int fcz_host_read_structure(const uint8_t* data, uint64_t len, int gz, fcz_host_atoms* out) {
     memset(out, 0, sizeof *out);

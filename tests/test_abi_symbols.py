@@ -32,6 +32,18 @@ def test_library_built_and_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= set(names)
 
 
+def test_host_library_exports_what_its_header_declares():
+    """include/fcz_host.h (the C++ host's structure readers as a library) against host/libfcz_host.so"""
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fcz_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(fcz_host_[a-z0-9_]+)\s*\(", txt)))
+    assert names == ["fcz_host_free", "fcz_host_read_structure"]
+    path = os.path.join(ROOT, "host", "libfcz_host.so")
+    assert os.path.exists(path), "host/libfcz_host.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(path)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
 def test_code_tables():
     lib = _lib.load()
     assert lib.fcz_atom_code_name(0) == b"N" and lib.fcz_atom_code_name(36) == b"OXT"

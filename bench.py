@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-chains", type=int, default=4096,
                     help="chains of the GPU result compared with the oracle bit for bit after the timed region (FCZ bytes and coordinates)")
+    ap.add_argument("--seed-base", type=int, default=0,
+                    help="first chain id of rank 0's batch (chain c of rank r is seeded with seed-base + r x chains + c): another value = another batch")
+    ap.add_argument("--parity-chunk", type=int, default=65536, help="chains per oracle call of the parity check (bounds its host memory)")
     ap.add_argument("--pdb-sample", type=int, default=65536,
                     help="chains rendered to PDB text on the device after the timed region (SURVEY §8 f2 leg; 0 = skip)")
     ap.add_argument("--mixed-chains", type=int, default=542_000,
@@ -133,17 +136,31 @@ def c_batch(d) -> CChainBatch:
     return s
 
 
-def host_sample(d, n_sample):
-    """first n_sample chains of the device batch as a host ChainBatch"""
-    n_sample = min(n_sample, d["res_off"].numel() - 1)
-    r1 = int(d["res_off"][n_sample]); a1 = int(d["atom_off"][r1]) & 0xFFFFFFFF; t1 = int(d["title_off"][n_sample])
-    sub = {k: d[k][:a1] for k in ("x", "y", "z", "atom_code")}
-    sub.update({k: d[k][:r1] for k in ("res_code", "bfac_ca")})
-    sub.update({k: d[k][:n_sample] for k in ("first_res_index", "first_atom_index", "chain_id")})
-    sub["res_off"] = d["res_off"][:n_sample + 1]; sub["atom_off"] = d["atom_off"][:r1 + 1]
-    sub["titles"] = d["titles"][:t1]; sub["title_off"] = d["title_off"][:n_sample + 1]
+def _u32(t):
+    return int(t) & 0xFFFFFFFF            # the ABI's uint32 counts are carried in torch int32
+
+
+def host_slice(d, c0, c1):
+    """chains [c0, c1) of the device batch as a host ChainBatch (offsets rebased to the slice)"""
+    C = d["res_off"].numel() - 1
+    c0 = max(0, min(c0, C)); c1 = max(c0, min(c1, C))
+    r0, r1 = _u32(d["res_off"][c0]), _u32(d["res_off"][c1])
+    a0, a1 = _u32(d["atom_off"][r0]), _u32(d["atom_off"][r1])
+    t0, t1 = _u32(d["title_off"][c0]), _u32(d["title_off"][c1])
+    sub = {k: d[k][a0:a1] for k in ("x", "y", "z", "atom_code")}
+    sub.update({k: d[k][r0:r1] for k in ("res_code", "bfac_ca")})
+    sub.update({k: d[k][c0:c1] for k in ("first_res_index", "first_atom_index", "chain_id")})
+    sub["res_off"] = (d["res_off"][c0:c1 + 1].to(torch.int64) & 0xFFFFFFFF) - r0
+    sub["atom_off"] = (d["atom_off"][r0:r1 + 1].to(torch.int64) & 0xFFFFFFFF) - a0
+    sub["titles"] = d["titles"][t0:t1]
+    sub["title_off"] = (d["title_off"][c0:c1 + 1].to(torch.int64) & 0xFFFFFFFF) - t0
     sub["anchor_threshold"] = d["anchor_threshold"]
     return synthetic.to_chain_batch(sub)
+
+
+def host_sample(d, n_sample):
+    """first n_sample chains of the device batch as a host ChainBatch"""
+    return host_slice(d, 0, n_sample)
 
 
 def effective_cores():
@@ -229,19 +246,54 @@ def copy_ceiling(dev, nbytes=1 << 30, reps=5):
     return 2 * nbytes / (ms * 1e-3) / 1e9
 
 
-def parity_sample(hb, blob_dev, off_dev, out_t, atom_off_host, n):
-    """GPU results of the first n chains against the oracle (checker only, outside the timed region)"""
+def parity_check(d, w, n, chunk=65536, threads=None):
+    """GPU results of the rank's first n chains against the oracle, bit for bit (checker only, outside the timed region):
+    FCZ offsets and bytes of `w.blob_dev`, then x / y / z / per-residue B-factors of `w.out_t` (the default atom order) against the
+    oracle's decode of ITS OWN records. In chunks of `chunk` chains, so that the host never holds more than one chunk of atoms
+    (the full 1 M-chain batch is 38 GB in, 36 GB out). -> dict with the two flags and the first differing chain of each."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _harness as H
-    oblob, ooff, ost = H.oracle_compress(hb, n_threads=effective_cores())
-    nb = int(ooff[-1])
-    got = blob_dev[:nb].cpu().numpy()
-    goff = off_dev[:n + 1].cpu().numpy().astype(np.uint64)
-    ok_c = bool(np.array_equal(goff, ooff) and got.tobytes() == oblob.tobytes())
-    o = H.oracle_decompress(oblob, ooff, n_threads=effective_cores())
-    na = int(o["atom_off"][-1])
-    ok_d = all(np.array_equal(out_t[k][:na].cpu().numpy().view(np.uint32), o[k].view(np.uint32)) for k in ("x", "y", "z"))
-    return ok_c, bool(ok_d)
+    threads = threads or effective_cores()
+    n = min(n, w.C)
+    ok_c = ok_d = True
+    first_c = first_d = None
+    for c0 in range(0, n, max(1, chunk)):
+        c1 = min(n, c0 + max(1, chunk))
+        hb = host_slice(d, c0, c1)
+        oblob, ooff, ost = H.oracle_compress(hb, n_threads=threads)
+        goff = w.off_dev[c0:c1 + 1].cpu().numpy().astype(np.int64)
+        b0, b1 = int(goff[0]), int(goff[-1])
+        got = w.blob_dev[b0:b1].cpu().numpy()
+        same = np.array_equal(goff - b0, ooff.astype(np.int64)) and got.tobytes() == oblob.tobytes()
+        if not same and first_c is None:
+            k = 0
+            if np.array_equal(goff - b0, ooff.astype(np.int64)):
+                diff = np.nonzero(got != np.asarray(oblob))[0]
+                k = int(np.searchsorted(ooff, diff[0], side="right") - 1) if len(diff) else 0
+            else:
+                k = int(np.nonzero((goff - b0) != ooff.astype(np.int64))[0][0]) - 1
+            first_c = c0 + max(k, 0)
+        ok_c = ok_c and bool(same)
+        o = H.oracle_decompress(oblob, ooff, n_threads=threads)
+        a0, a1 = _u32(w.atom_off_dev[c0]), _u32(w.atom_off_dev[c1])
+        r0, r1 = _u32(w.res_off_dev[c0]), _u32(w.res_off_dev[c1])
+        good = (a1 - a0) == int(o["atom_off"][-1]) and (r1 - r0) == int(o["res_off"][-1])
+        bad_atom = None
+        if good:
+            for k_ in ("x", "y", "z"):
+                g = w.out_t[k_][a0:a1].cpu().numpy().view(np.uint32)
+                ne = np.nonzero(g != o[k_].view(np.uint32))[0]
+                if len(ne):
+                    good = False; bad_atom = int(ne[0]) if bad_atom is None else min(bad_atom, int(ne[0]))
+            g = w.out_t["bfac_res"][r0:r1].cpu().numpy().view(np.uint32)
+            if not np.array_equal(g, o["bfac_res"].view(np.uint32)):
+                good = False
+        if not good and first_d is None:
+            first_d = c0 + (int(np.searchsorted(o["atom_off"], bad_atom, side="right") - 1) if bad_atom is not None else 0)
+        ok_d = ok_d and bool(good)
+        del hb, oblob, o, got
+    return {"chains_checked": n, "fcz_bit_exact": bool(ok_c), "coords_bit_exact": bool(ok_d),
+            "first_fcz_mismatch_chain": first_c, "first_coords_mismatch_chain": first_d}
 
 
 class Workload:
@@ -327,24 +379,62 @@ def span_ms(codec):
     return out
 
 
-def timed(fn, steps, world, dist, dev):
+class Comm:
+    """what the ranks exchange outside the data path: reductions of clocks and check flags, the barrier, and a wait that does not
+    spin (the store). `dist` None = no group (a single process). Backend "nccl" = RCCL with device tensors; "gloo" (test mode:
+    FCZ_BENCH_BACKEND=gloo, several ranks sharing one GPU, or the CPU dry run) goes through host tensors."""
+
+    def __init__(self, dist, dev, backend, rank, world):
+        self.dist, self.dev, self.backend, self.rank, self.world = dist, dev, backend, rank, world
+        self.tdev = dev if backend == "nccl" else "cpu"
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce(self, values, op):
+        """element-wise max / min of a list of floats over the ranks"""
+        if self.dist is None or not len(values):
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.MIN)
+        return [float(v) for v in t.cpu()]
+
+    def all_true(self, flags):
+        """{name: bool} -> {name: bool}: true where every rank says true (all_reduce MIN of 0 / 1); None stays None"""
+        keys = [k for k, v in flags.items() if v is not None]
+        red = self.reduce([1.0 if flags[k] else 0.0 for k in keys], "min")
+        out = dict(flags)
+        out.update({k: bool(v >= 0.5) for k, v in zip(keys, red)})
+        return out
+
+    def wait_for_rank0(self, key, work=None):
+        """rank 0 runs `work` while the other ranks SLEEP on the rendezvous store (a barrier on the GPU would spin their host
+        threads on the cores the work is being timed on); -> work's result on rank 0, None elsewhere"""
+        if self.dist is None or self.world == 1:
+            return work() if work else None
+        store = self.dist.distributed_c10d._get_default_store()
+        if self.rank == 0:
+            try:
+                return work() if work else None
+            finally:
+                store.set(key, "1")
+        store.wait([key])
+        return None
+
+
+def timed(fn, steps, comm):
     """`steps` calls of fn bracketed by barrier + synchronize on both sides; seconds, max over ranks"""
-    if world > 1:
-        dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    return comm.reduce([dt], "max")[0]
 
 
 def end_to_end_leg(args, codec, w, dev):
@@ -640,7 +730,7 @@ def host_boundary_leg(args, codec, hb):
             lib.fcz_pinned_free(p)
 
 
-def alt_numerics_leg(args, codec, w, dev, rank, world, dist, timed_mode, compress_ms):
+def alt_numerics_leg(args, codec, w, dev, comm, timed_mode, compress_ms):
     """the decompress side once more in the OTHER numerics mode (see --numerics): time, per-kernel times, roofline fraction of
     its longest kernel, and the deviation of its coordinates from the timed mode's on the first 65 536 chains. Leaves the
     outputs and the ctx in the timed mode."""
@@ -652,7 +742,8 @@ def alt_numerics_leg(args, codec, w, dev, rank, world, dist, timed_mode, compres
     w.decompress(); codec.synchronize()
     codec.reset_timing()
     steps = max(1, min(args.steps, 5))
-    dt = timed(lambda: (w.decompress(), codec.synchronize()), steps, world, dist, dev)
+    world = comm.world
+    dt = timed(lambda: (w.decompress(), codec.synchronize()), steps, comm)
     km = span_ms(codec)
     devv = torch.stack([(w.out_t[k][:na] - ref[k]).abs() for k in ("x", "y", "z")]).max(0).values
     stats = {"sample_chains": ns, "sample_atoms": na, "median_A": float(devv[::5].median()),
@@ -682,7 +773,7 @@ def alt_numerics_leg(args, codec, w, dev, rank, world, dist, timed_mode, compres
     return out
 
 
-def secondary_legs(args, codec, dev, rank, world, dist):
+def secondary_legs(args, codec, dev, comm):
     """BASELINE configs[2] and configs[4] at their shape (the datasets themselves cannot be fetched): `--mixed-chains` chains
     per GPU with log-normal lengths (AFDB Swiss-Prot has 542 k structures), anchor -b 25.
       decompress_only  device-resident FCZ records -> SoA atoms (sizes pass + batch), the configs[2] operation
@@ -690,7 +781,8 @@ def secondary_legs(args, codec, dev, rank, world, dist):
     Each with its own time, residues/s (all ranks), per-kernel times, roofline fraction of its longest kernel, a 256-chain
     oracle sample (bit-exact bar) and the full-batch round-trip deviation. Outside the headline `value`."""
     Cm = args.mixed_chains
-    d = generate_resident(Cm, 0, args.anchor, args.gen_chunk, dev, seed_base=(1 << 30) + rank * Cm, mixed=True)
+    rank, world = comm.rank, comm.world
+    d = generate_resident(Cm, 0, args.anchor, args.gen_chunk, dev, seed_base=(1 << 30) + args.seed_base + rank * Cm, mixed=True)
     note(f"secondary legs: generated {Cm} mixed-length chains")
     w = Workload(codec, d, dev)
     w.compress(); w.decompress(); codec.synchronize()            # warm-up; leaves the FCZ records resident
@@ -699,7 +791,7 @@ def secondary_legs(args, codec, dev, rank, world, dist):
 
     def leg(fn, names, nbytes):
         codec.reset_timing()
-        dt = timed(lambda: (fn(), codec.synchronize()), steps, world, dist, dev)
+        dt = timed(lambda: (fn(), codec.synchronize()), steps, comm)
         km = span_ms(codec)
         dom = max(names, key=lambda k: km[KERNEL_SPANS[k]])
         ms = km[KERNEL_SPANS[dom]]
@@ -714,14 +806,17 @@ def secondary_legs(args, codec, dev, rank, world, dist):
     A = w.M / w.R; f = w.fcz_bytes / w.R
     dec = leg(w.decompress, ("k_backbone", "k_res_index", "k_sidechain"), (f + 12 * A + 4) * w.R)
     mix = leg(lambda: (w.compress(), w.decompress()), tuple(KERNEL_SPANS), (13 * A + 9 + f + f + 12 * A + 4) * w.R)
-    if rank == 0 and not args.no_parity:
+    if not args.no_parity:
+        # every rank checks its own batch; the flags are AND-ed over the ranks, the deviations are the worst of any rank
         n = min(256, Cm)
-        hb = host_sample(d, n)
-        ok_c, ok_d = parity_sample(hb, w.blob_dev, w.off_dev, w.out_t, None, n)
+        pc = parity_check(d, w, n, chunk=args.parity_chunk)
         rmsd, mx = w.round_trip_deviation()
-        par = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": int((w.status_dev != 0).sum()),
-               "all_atom_rmsd_A": round(rmsd, 4), "max_atom_deviation_A": round(mx, 3),
-               "residue_counts_round_trip": bool(torch.equal(w.res_off_dev, d["res_off"].to(torch.int32)))}
+        flags = comm.all_true({"fcz_bit_exact": pc["fcz_bit_exact"], "coords_bit_exact": pc["coords_bit_exact"],
+                               "all_status_ok": int((w.status_dev != 0).sum()) == 0,
+                               "residue_counts_round_trip": bool(torch.equal(w.res_off_dev, d["res_off"].to(torch.int32)))})
+        rmsd, mx = comm.reduce([rmsd, mx], "max")
+        par = {"chains_checked": n * world, "ranks_checked": world, **flags,
+               "all_atom_rmsd_A": round(rmsd, 4), "max_atom_deviation_A": round(mx, 3)}
         dec["parity"] = par; mix["parity"] = par
     del w, d
     torch.cuda.empty_cache()
@@ -746,22 +841,42 @@ def self_launch_command(args_gpus, argv, env):
 
 
 def dry_run(args, world, rank):
-    """rendezvous only (see --dry-run): proves that N ranks were started and see each other"""
+    """rendezvous + the post-clock plumbing of an N-rank line (see --dry-run), without a codec call: the ranks meet in a process
+    group, every rank runs its own check and the flags are AND-ed exactly as the real run does it (Comm.all_true), rank 0 times the
+    CPU baseline while the others sleep on the store (Comm.wait_for_rank0). With no GPU result to compare, a rank's check is the
+    oracle against itself on 64 small chains of ITS OWN seed range (records decode, and re-encode to the same bytes)."""
     import torch.distributed as dist
     have_gpu = torch.cuda.is_available()
+    backend = os.environ.get("FCZ_BENCH_BACKEND") or ("nccl" if have_gpu else "gloo")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = f"cuda:{local}" if (have_gpu and backend == "nccl") else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if have_gpu else "gloo")
-        t = torch.ones(1, device=f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}" if have_gpu else "cpu")
-        dist.all_reduce(t)
-        seen = int(t.item())
+        dist.init_process_group(backend)
+        comm = Comm(dist, dev, backend, rank, world)
+        seen = int(comm.reduce([1.0], "max")[0] * dist.get_world_size())
         dist.barrier()
     else:
+        comm = Comm(None, dev, backend, 0, 1)
         seen = 1
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _harness as H
+    n = 64
+    d = synthetic.generate(n, 120, seed=0xF01DC0DE, device="cpu", anchor_threshold=args.anchor, first_chain_id=args.seed_base + rank * n)
+    hb = synthetic.to_chain_batch(d)
+    blob, off, st = H.oracle_compress(hb, n_threads=1)
+    o = H.oracle_decompress(blob, off, n_threads=1)
+    blob2, off2, _ = H.oracle_compress(hb, n_threads=2)
+    flags = comm.all_true({"fcz_bit_exact": bool((st == 0).all()) and blob.tobytes() == blob2.tobytes() and np.array_equal(off, off2),
+                           "coords_bit_exact": int(o["res_off"][-1]) == hb.n_residues and bool(np.isfinite(o["x"]).all())})
+    cpu = comm.wait_for_rank0("cpu_baseline_done", (lambda: cpu_baseline(hb, args.anchor)) if args.cpu_sample else None)
     if rank == 0:
         emit_line({"metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs", "value": None,
-                   "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "dry_run": True})
+                   "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "cpu_baseline": cpu,
+                   "parity": {"chains_checked": n * world, "ranks_checked": world, **flags,
+                              "kind": "dry run: no GPU result exists; every rank checked the oracle against itself on its own seed range"}})
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -789,7 +904,7 @@ def main():
     cmd = self_launch_command(args.gpus, sys.argv[1:], os.environ)
     if cmd is not None:
         import subprocess
-        if not args.dry_run and torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+        if not args.dry_run and torch.cuda.is_available() and torch.cuda.device_count() < args.gpus and os.environ.get("FCZ_BENCH_BACKEND") != "gloo":
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
         raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -805,6 +920,11 @@ def main():
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the FCZ hot path has no CPU fallback")
+    # FCZ_BENCH_BACKEND=gloo is the TEST mode of the N > 1 code path on a box with fewer GPUs than ranks: the ranks share devices
+    # (RCCL refuses two ranks on one GPU) and the index exchange goes through host tensors; the line says so and is not a scaling point.
+    backend = os.environ.get("FCZ_BENCH_BACKEND") or "nccl"
+    if backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     # One code path for every N: also a single GPU runs in a (1-rank) RCCL process group, so that the step timed at N = 1 --
@@ -817,16 +937,21 @@ def main():
             s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
     group_note = None
     try:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            group_note = f"TEST MODE: {world} ranks over {backend} sharing {torch.cuda.device_count()} GPU(s); record lengths gathered through host tensors"
         world = dist.get_world_size()   # what RCCL actually formed; n_gpus below reports this, not the flag
         assert world == args.gpus, (world, args.gpus)
     except Exception as e:   # noqa: BLE001
         if world > 1:
             raise
         dist = None; group_note = f"no 1-rank RCCL group ({type(e).__name__}): the index exchange of the step is skipped at N = 1"
+    comm = Comm(dist, dev, backend, rank, world)
 
     C, n_res = args.chains, args.residues
-    d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=rank * C, mixed=args.mixed)
+    d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=args.seed_base + rank * C, mixed=args.mixed)
     note(f"generated {C} chains")
     codec = Codec(local)
     codec.set_numerics(args.numerics == "fast")
@@ -836,7 +961,8 @@ def main():
     off_dev, blob_dev, status_dev, res_off_dev, atom_off_dev, out_t, cout = (w.off_dev, w.blob_dev, w.status_dev, w.res_off_dev,
                                                                              w.atom_off_dev, w.out_t, w.cout)
     lengths_dev = torch.zeros(C, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(world)] if (dist is not None and rank == 0) else None
+    gdev = comm.tdev
+    gathered = [torch.zeros(C, dtype=torch.int64, device=gdev) for _ in range(world)] if (dist is not None and rank == 0) else None
     torch.cuda.synchronize()
 
     def step():
@@ -845,53 +971,50 @@ def main():
             # the only exchange of the sharded job: per-record lengths -> rank 0 builds the global index
             codec.synchronize()
             torch.sub(off_dev[1:], off_dev[:-1], out=lengths_dev)
-            dist.gather(lengths_dev, gathered, dst=0)
+            dist.gather(lengths_dev if backend == "nccl" else lengths_dev.cpu(), gathered, dst=0)
         w.decompress()
 
     for _ in range(args.warmup):
         step()
     codec.synchronize(); torch.cuda.synchronize()
-    warm_csum = w.checksum() if (rank == 0 and args.warmup and not args.no_parity) else None
+    warm_csum = w.checksum() if (args.warmup and not args.no_parity) else None
     codec.enable_timing(True); codec.reset_timing()
     # the timed region: exactly --steps steps between barrier + synchronize pairs, max over ranks
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     codec.synchronize(); torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = comm.reduce([dt], "max")[0]
 
     # per-kernel device time (HIP events on the codec's own stream)
     ktime = span_ms(codec)
     note(f"headline timed: {dt / args.steps * 1e3:.2f} ms/step")
-    alt = alt_numerics_leg(args, codec, w, dev, rank, world, dist, args.numerics,
+    alt = alt_numerics_leg(args, codec, w, dev, comm, args.numerics,
                            ktime["compress_sizes"] + ktime["compress_index"] + ktime["compress_angles"] + ktime["compress_pack"])
     note(f"alt numerics ({alt['mode']}) done: decompress {alt['decompress_ms']} ms")
     # ---- BASELINE configs[2] / configs[4] at their shape: every rank runs them (their clocks are max-over-ranks too) ----
-    legs = secondary_legs(args, codec, dev, rank, world, dist) if (args.mixed_chains and not args.mixed) else None
+    legs = secondary_legs(args, codec, dev, comm) if (args.mixed_chains and not args.mixed) else None
     note("secondary legs done")
     # ---- size-independent properties of the FULL batch (outside the timed region) ----
     props = None
-    if rank == 0 and not args.no_parity:
+    if not args.no_parity:
+        # every rank checks its own batch; flags AND-ed over the ranks, deviations = the worst of any rank
         # (1) determinism: the blob after the timed steps has the checksum it had after the warm-up steps
         csum = w.checksum()
         # (2) decode(encode(x)) ~ x: decompress once more in the input's atom order (`-a`) and compare every atom
         rmsd, mxdev = w.round_trip_deviation()
         # (3) sizes: decompress counts == input counts, every chain compressed with status OK
-        same_counts = bool(torch.equal(res_off_dev, d["res_off"].to(torch.int32)))
-        props = {"all_atom_rmsd_A": round(rmsd, 4), "max_atom_deviation_A": round(mxdev, 3),
-                 "residue_counts_round_trip": same_counts, "blob_checksum": csum,
-                 "deterministic": csum == warm_csum if warm_csum is not None else None}
-        # restore the default-order outputs the PDB leg below formats
+        pf = comm.all_true({"residue_counts_round_trip": bool(torch.equal(res_off_dev, d["res_off"].to(torch.int32))),
+                            "deterministic": (csum == warm_csum) if warm_csum is not None else None})
+        rmsd, mxdev = comm.reduce([rmsd, mxdev], "max")
+        props = {"all_atom_rmsd_A": round(rmsd, 4), "max_atom_deviation_A": round(mxdev, 3), **pf,
+                 "blob_checksum_rank0": csum, "ranks_checked": world}
+        # restore the default-order outputs the parity check and the PDB leg below read
         w.decompress()
         codec.synchronize()
 
@@ -967,7 +1090,7 @@ def main():
         del text_dev
     # ---- §8 f4 leg: `extract --plddt -p 2` of every record straight from the FCZ bytes ----
     ext = None
-    if rank == 0 and not args.no_parity:
+    if not args.no_parity:
         data_off = torch.zeros(C + 1, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         _lib.check(lib.fcz_extract_sizes_dev(codec.ctx, blob_dev.data_ptr(), off_dev.data_ptr(), C, 0, 2, data_off.data_ptr()), "extract sizes")
@@ -989,7 +1112,7 @@ def main():
                "residues_per_s": round(R / (ms_e * 1e-3)) if ms_e else None,
                # algorithmic bytes: header (84 B) + one B-factor byte per residue in, the characters out
                "algorithmic_GBs": round((84 * C + R + dbytes) / (ms_e * 1e-3) / 1e9, 1) if ms_e else None,
-               "first_record_equals_host": bool(ok_e)}
+               **comm.all_true({"first_record_equals_host": bool(ok_e)}), "ranks_checked": world}
         del data_dev
     e2e = None
     if rank == 0 and world == 1 and args.e2e_files and not args.mixed:
@@ -1002,6 +1125,26 @@ def main():
     codec.enable_timing(False)
     note("pdb / extract legs done")
     bad_status = int((status_dev != 0).sum())
+    # ---- parity: EVERY rank compares the first --parity-chains chains of its own batch with the oracle (FCZ bytes and
+    #      coordinates, bit for bit); the flags are AND-ed over the ranks ----
+    parity = None
+    if not args.no_parity:
+        pc = parity_check(d, w, args.parity_chains, chunk=args.parity_chunk)
+        flags = comm.all_true({"fcz_bit_exact": pc["fcz_bit_exact"], "coords_bit_exact": pc["coords_bit_exact"]})
+        none = float(1 << 62)
+        gid = lambda c: none if c is None else float(args.seed_base + rank * C + c)   # noqa: E731 - the chain's generator seed offset
+        firsts = comm.reduce([gid(pc["first_fcz_mismatch_chain"]), gid(pc["first_coords_mismatch_chain"])], "min")
+        parity = {"chains_checked": pc["chains_checked"] * world, "chains_checked_per_rank": pc["chains_checked"], "ranks_checked": world, **flags,
+                  "bad_status": int(comm.reduce([bad_status], "max")[0]), "seed_base": args.seed_base,
+                  "first_fcz_mismatch_chain_id": None if firsts[0] >= none else int(firsts[0]),
+                  "first_coords_mismatch_chain_id": None if firsts[1] >= none else int(firsts[1])}
+        if args.numerics == "fast":
+            parity["coords_bit_exact_note"] = "timed in FCZ_NUMERICS_FAST: coordinates are not expected to be bit-identical; see alt_numerics.deviation_from_timed_mode"
+        note(f"parity check done: {parity['chains_checked']} chains, fcz {parity['fcz_bit_exact']}, coords {parity['coords_bit_exact']}")
+    # ---- CPU baseline: rank 0, at any world size, with an explicit thread count (a launcher exports OMP_NUM_THREADS=1; the
+    #      reference loop takes num_threads(cores) itself); the other ranks sleep on the store meanwhile, off the host cores ----
+    cpu = comm.wait_for_rank0("cpu_baseline_done", (lambda: cpu_baseline(host_sample(d, args.cpu_sample), args.anchor)) if args.cpu_sample else None)
+    note("cpu baseline done")
 
     if rank == 0:
         A = M / R                                   # atoms per residue
@@ -1056,21 +1199,6 @@ def main():
                     "per_kernel_GBs": {k: round(b / (t * 1e-3) / 1e9, 1) if t else None for k, (b, t) in kern.items()},
                     "decompress_pair_GBs": round(bytes_decompress / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
                     "hbm_copy_measured_GBs": round(copy_ceiling(dev), 1)}
-        parity = None
-        hb = None
-        if not args.no_parity or args.cpu_sample:
-            hb = host_sample(d, max(args.parity_chains, args.cpu_sample))
-        if not args.no_parity:
-            n = min(args.parity_chains, hb.n_chains)
-            hb256 = host_sample(d, n)
-            ok_c, ok_d = parity_sample(hb256, blob_dev, off_dev, out_t, None, n)
-            parity = {"chains_checked": n, "fcz_bit_exact": ok_c, "coords_bit_exact": ok_d, "bad_status": bad_status}
-            if args.numerics == "fast":
-                parity["coords_bit_exact_note"] = "timed in FCZ_NUMERICS_FAST: coordinates are not expected to be bit-identical; see alt_numerics.deviation_from_timed_mode"
-        # the CPU baseline is timed at N=1 only (a launcher pins every rank to one OpenMP thread, and the host cores would be
-        # shared with the other ranks' launch threads)
-        cpu = cpu_baseline(host_sample(d, args.cpu_sample), args.anchor) if (args.cpu_sample and world == 1) else None
-        note("parity sample + cpu baseline done")
         hostb = None
         if args.host_chains and world == 1 and not args.mixed:
             try:
@@ -1094,7 +1222,8 @@ def main():
                                    + f"compress+decompress, anchor -b {args.anchor}",
                        "chains_per_gpu": C, "residues_per_chain": round(R / C, 1) if args.mixed else n_res, "atoms_per_residue": round(A, 3),
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective",
-                       "index_exchange": group_note or f"record lengths gathered on rank 0 over RCCL inside every step ({world}-rank group)"},
+                       "index_exchange": group_note or f"record lengths gathered on rank 0 over RCCL inside every step ({world}-rank group)",
+                       "seed_base": args.seed_base, "backend": backend},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,

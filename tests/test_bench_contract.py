@@ -59,8 +59,13 @@ def test_plain_python_gpus_2_starts_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    assert json.loads(line)["n_gpus"] == 2
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    # an N > 1 line must be creditable: the CPU baseline is timed on rank 0 at any world size (with more than the one OpenMP
+    # thread a launcher exports) and EVERY rank's check enters the parity flags
+    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] in ("reference", "port")
+    assert line["parity"]["ranks_checked"] == 2 and line["parity"]["chains_checked"] == 2 * 64
+    assert line["parity"]["fcz_bit_exact"] is True and line["parity"]["coords_bit_exact"] is True
     # and a real (non-dry) run on a box without GPUs fails loudly instead of printing a number
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     import torch

@@ -82,3 +82,28 @@ def test_end_to_end_both_directions(line):
 def test_resident_ingest_leg(line):
     i = line["pdb_text"]["ingest_of_the_same_text"]
     assert i["files"] == 1024 and i["counts_equal_decoded"] and i["refused"] == 0 and i["text_GBs"] > 0
+
+
+def test_two_rank_line_is_creditable():
+    """The N > 1 code path with two REAL ranks (gloo test mode: both on the box's one GPU, RCCL refuses that): the line carries a
+    CPU baseline timed on rank 0, both ranks' parity checks enter the flags, their batches differ (seed ranges), the value counts
+    both ranks' residues"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["FCZ_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "8192", "--steps", "2", "--warmup", "1",
+           "--cpu-sample", "512", "--parity-chains", "700", "--parity-chunk", "256", "--pdb-sample", "0", "--mixed-chains", "3000",
+           "--mixed-steps", "1", "--e2e-files", "0", "--host-chains", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1, r.stdout[-2000:]
+    ln = json.loads(out[0])
+    assert ln["n_gpus"] == 2 and ln["config"]["backend"] == "gloo"
+    assert ln["cpu_baseline"] is not None and ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["cores"] >= 1
+    p = ln["parity"]
+    assert p["ranks_checked"] == 2 and p["chains_checked"] == 1400 and p["fcz_bit_exact"] and p["coords_bit_exact"] and p["bad_status"] == 0
+    assert ln["properties"]["ranks_checked"] == 2 and ln["properties"]["deterministic"] and ln["properties"]["residue_counts_round_trip"]
+    assert ln["mixed"]["parity"]["ranks_checked"] == 2 and ln["mixed"]["parity"]["fcz_bit_exact"] and ln["mixed"]["parity"]["coords_bit_exact"]
+    assert abs(ln["value"] - 2 * 8192 * 350 / (ln["ms_per_step"] * 1e-3)) / ln["value"] < 1e-6

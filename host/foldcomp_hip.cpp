@@ -1244,6 +1244,263 @@ struct Options {
     int workers_per_gpu = 2;    // host threads (each with its own ctx and stream) per device
     int write_threads = 8;      // threads a decompress worker writes its job's text with (set from -t: threads / workers)
     bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
+    int shard_rank = 0, shard_world = 1;   // --shard R/N: this process is rank R of N of a sharded database run (see InputPlan)
+    int device = 0;             // --device D: first HIP device of this process (a rank of a sharded run drives device LOCAL_RANK)
+};
+
+// ---- the inputs of a run, as a stream ------------------------------------------------------------------------------------------
+// The reference's driver walks a directory or a database entry by entry (src/input_processor.h:85-101, :237-257). Here a run's
+// inputs -- files of directories, entries of databases, in the order they are listed -- form ONE sequence of items, and a process
+// takes a contiguous range of it: everything (one process), or, as rank R of N (--shard R/N), the range whose cumulative input
+// bytes lie between R/N and (R+1)/N of the total (contiguous ranges balanced by bytes ~ residues). Every rank
+// computes the same cuts from the same listing; no rank ever holds another rank's entries.
+//
+// Databases are streamed. free_writer (src/database_writer.cpp:59-73) writes .index and .lookup sorted by key, one line per entry:
+// entry i of the reader (rows sorted by key, src/database_reader.cpp:109) IS line i of both files, so a rank needs only its own
+// stretch of lines. One pass over both files (DbScan) checks exactly that -- keys strictly increasing, the same key on line i of
+// both, three / at least two clean words per line -- and keeps the file positions and the cumulative entry bytes of every 4 096th
+// line (214 M entries: 52 k marks). A database that is not of that shape (hand-edited, doubled keys, no lookup, --id-list) is read
+// through DbReader instead: correct, but with every row and name in memory.
+struct LineFile {                              // forward reader of a text file, line by line, with the file position of each line
+    int fd = -1; std::vector<char> buf; size_t a = 0, b = 0; uint64_t pos = 0; bool eof = false;   // pos: file position of buf[a]
+    ~LineFile() { if (fd >= 0) close(fd); }
+    bool open_at(const std::string& path, uint64_t at = 0) {
+        if (fd >= 0) close(fd);
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        if (buf.empty()) buf.resize(1 << 20);
+        a = b = 0; pos = at; eof = false;
+        return lseek(fd, (off_t)at, SEEK_SET) == (off_t)at;
+    }
+    // the next line without its line end; false at the end of the file (read_index counts line ENDS: a last line without one is
+    // not an entry, src/database_reader.cpp:283-311)
+    bool next(const char*& s, size_t& n) {
+        for (;;) {
+            if (const void* e = a < b ? memchr(buf.data() + a, '\n', b - a) : nullptr) {
+                s = buf.data() + a; n = (size_t)((const char*)e - s);
+                pos += n + 1; a += n + 1;
+                return true;
+            }
+            if (eof) return false;
+            if (a > 0) { memmove(buf.data(), buf.data() + a, b - a); b -= a; a = 0; }
+            if (b == buf.size()) buf.resize(buf.size() * 2);
+            const ssize_t k = read(fd, buf.data() + b, buf.size() - b);
+            if (k < 0) throw std::runtime_error("read failed");
+            if (k == 0) eof = true; else b += (size_t)k;
+        }
+    }
+};
+
+// the words of an index / lookup line: separated by blanks and tabs (src/database_reader.cpp:283-361)
+inline int line_words(const char* s, size_t n, const char* w[4], size_t wl[4]) {
+    int k = 0; size_t i = 0;
+    while (i < n) {
+        while (i < n && (s[i] == ' ' || s[i] == '\t')) i++;
+        const size_t st = i;
+        while (i < n && s[i] != ' ' && s[i] != '\t') i++;
+        if (i > st) { if (k < 4) { w[k] = s + st; wl[k] = i - st; } k++; }
+    }
+    return k;
+}
+inline bool all_digits_u64(const char* s, size_t n, uint64_t& v) {   // a plain decimal number (what strtoull reads the same way)
+    if (n == 0 || n > 19) return false;
+    v = 0;
+    for (size_t i = 0; i < n; i++) { if (s[i] < '0' || s[i] > '9') return false; v = v * 10 + (uint64_t)(s[i] - '0'); }
+    return true;
+}
+
+struct DbScan {
+    static constexpr uint64_t STRIDE = 4096;
+    struct Mark { uint64_t ipos, lpos, cum; };   // positions of line k x STRIDE in .index / .lookup, entry bytes before it
+    std::vector<Mark> marks; uint64_t n = 0, bytes = 0; std::string path, why;
+    // true: the database can be streamed (see above); false: `why` says what stands in the way
+    bool scan(const std::string& db) {
+        path = db; marks.clear(); n = bytes = 0;
+        LineFile fi, fl;
+        if (!fi.open_at(db + ".index")) throw std::runtime_error("cannot open " + db + ".index");
+        if (!fl.open_at(db + ".lookup")) { why = "no .lookup file"; return false; }
+        const char *s, *t; size_t sn, tn; const char* w[4]; size_t wl[4];
+        uint64_t prev = 0;
+        for (;;) {
+            const uint64_t ipos = fi.pos, lpos = fl.pos;
+            const bool hi_ = fi.next(s, sn), hl = fl.next(t, tn);
+            if (!hi_ || !hl) {
+                // (a lookup may end without a line end: std::getline still reads that line -- not streamable, rare)
+                if (hi_ != hl || fi.a < fi.b || fl.a < fl.b) { why = "index and lookup differ in their number of lines"; return false; }
+                break;
+            }
+            uint64_t key, off, len, lkey;
+            if (line_words(s, sn, w, wl) != 3 || !all_digits_u64(w[0], wl[0], key) || !all_digits_u64(w[1], wl[1], off) || !all_digits_u64(w[2], wl[2], len) || key > UINT32_MAX) {
+                why = "an index line that is not three plain numbers"; return false; }
+            if (line_words(t, tn, w, wl) < 2 || !all_digits_u64(w[0], wl[0], lkey)) { why = "a lookup line without a key and a name"; return false; }
+            if (lkey != key) { why = "line " + std::to_string(n) + " of index and lookup carry different keys"; return false; }
+            if (n > 0 && key <= prev) { why = "keys are not strictly increasing"; return false; }
+            prev = key;
+            if (n % STRIDE == 0) marks.push_back({ipos, lpos, bytes});
+            n++; bytes += len;
+        }
+        return true;
+    }
+};
+
+struct InputItem { int kind = 0; std::string name; uint64_t off = 0, len = 0; int src = 0; };   // kind 0: a file (name = path, len = its size or UINT64_MAX: not asked yet); 1: a database entry (name = lookup name)
+
+struct InputPlan {
+    struct Src {
+        int kind = 0;                          // 0 files, 1 database streamed, 2 database through DbReader
+        std::string path;
+        std::vector<std::string> files; std::vector<uint64_t> fsize;
+        DbScan scan;
+        std::unique_ptr<DbReader> db; std::vector<size_t> ids;
+        int dfd = -1; uint64_t dsize = 0;
+        uint64_t n = 0, bytes = 0, lo = 0, hi = 0;   // items, their bytes, this process's items [lo, hi)
+        ~Src() { if (dfd >= 0) close(dfd); }
+        uint64_t weight(uint64_t i) const { return kind == 0 ? fsize[i] : (uint64_t)db->rows[ids[i]].len; }   // kinds 0 and 2
+    };
+    std::vector<std::unique_ptr<Src>> srcs;
+    uint64_t n_items = 0, n_mine = 0, bytes_total = 0;
+    bool streamed_all = true;
+
+    // first item e of a source with (bytes of the items before it) >= t; n when there is none
+    static uint64_t first_at_least(Src& s, uint64_t t) {
+        if (t == 0) return 0;
+        if (t > s.bytes) return s.n;
+        if (s.kind != 1) {
+            uint64_t c = 0;
+            for (uint64_t i = 0; i < s.n; i++) { if (c >= t) return i; c += s.weight(i); }
+            return s.n;
+        }
+        const auto& mk = s.scan.marks;
+        size_t m = (size_t)(std::lower_bound(mk.begin(), mk.end(), t, [](const DbScan::Mark& a, uint64_t v) { return a.cum < v; }) - mk.begin());
+        if (m < mk.size() && mk[m].cum >= t && (m == 0 || mk[m - 1].cum >= t)) return (uint64_t)m * DbScan::STRIDE;   // (m == 0 only: t == 0 handled above)
+        const size_t from = m == 0 ? 0 : m - 1;                       // the cut lies after mark `from`
+        LineFile fi;
+        if (!fi.open_at(s.path + ".index", mk[from].ipos)) throw std::runtime_error("cannot open " + s.path + ".index");
+        uint64_t c = mk[from].cum, e = (uint64_t)from * DbScan::STRIDE;
+        const char* q; size_t qn; const char* w[4]; size_t wl[4];
+        while (e < s.n) {
+            if (c >= t) return e;
+            uint64_t len = 0;
+            if (!fi.next(q, qn) || line_words(q, qn, w, wl) != 3 || !all_digits_u64(w[2], wl[2], len)) throw std::runtime_error(s.path + ".index changed during the run");
+            c += len; e++;
+        }
+        return s.n;
+    }
+
+    // list the inputs; cut this process's range. `quiet`: messages about ids that are not found come from rank 0 only
+    void build(const Options& o) {
+        const bool quiet = o.shard_rank != 0;
+        for (const std::string& input : o.inputs) {
+            std::unique_ptr<Src> sp(new Src()); Src& s = *sp;
+            s.path = input;
+            if (is_db(input)) {
+                if (o.id_list.empty() && s.scan.scan(input)) { s.kind = 1; s.n = s.scan.n; s.bytes = s.scan.bytes; }
+                else {
+                    if (o.id_list.empty() && !quiet) fprintf(stderr, "[Info] %s is read into memory (%s)\n", input.c_str(), s.scan.why.c_str());
+                    s.kind = 2; streamed_all = false;
+                    s.db.reset(new DbReader(input));
+                    if (!o.id_list.empty()) {
+                        std::ifstream f(o.id_list);
+                        if (!f && !quiet) fprintf(stderr, "[Error] user id '%s' does not exist.\n", o.id_list.c_str());
+                        std::string line;
+                        while (f && std::getline(f, line)) {
+                            line = strip(line);
+                            if (line.empty()) continue;
+                            const long long id = o.id_mode == 0 ? s.db->id_of_key(atoll(line.c_str())) : s.db->id_of_name(line);
+                            if (id < 0) { if (!quiet) fprintf(stderr, "[Warning] %s not found in database.\n", line.c_str()); continue; }
+                            s.ids.push_back((size_t)id);
+                        }
+                    } else { s.ids.resize(s.db->n()); for (size_t i = 0; i < s.db->n(); i++) s.ids[i] = i; }
+                    s.n = s.ids.size();
+                    for (size_t i : s.ids) s.bytes += (uint64_t)std::max<long long>(0, s.db->rows[i].len);
+                }
+                if (s.kind == 1) {
+                    s.dfd = open(input.c_str(), O_RDONLY);
+                    if (s.dfd < 0) throw std::runtime_error("cannot open " + input);
+                    struct stat st; fstat(s.dfd, &st); s.dsize = (uint64_t)st.st_size;
+                }
+            } else {
+                if (is_dir(input)) list_files(input, o.recursive, s.files); else s.files.push_back(input);
+                s.n = s.files.size();
+                if (o.shard_world > 1) {                                // sizes only where a cut needs them
+                    s.fsize.assign(s.n, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+                    for (long long i = 0; i < (long long)s.n; i++) { struct stat st; if (stat(s.files[(size_t)i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) s.fsize[(size_t)i] = (uint64_t)st.st_size; }
+                    for (uint64_t v : s.fsize) s.bytes += v;
+                }
+            }
+            n_items += s.n; bytes_total += s.bytes;
+            srcs.push_back(std::move(sp));
+        }
+        // cuts: item g belongs to rank r iff cut_r <= g < cut_(r+1), cut_r = the first item with ceil(total x r / world) bytes before it
+        // (cut_0 = 0, cut_world = every item); integer arithmetic, so every rank and every implementation agrees
+        const int R = o.shard_rank, W = std::max(1, o.shard_world);
+        auto target = [&](int r) { return (uint64_t)(((unsigned __int128)bytes_total * (unsigned)r + (unsigned)(W - 1)) / (unsigned)W); };
+        auto cut = [&](int r, std::vector<uint64_t>& at) {              // -> per source, the first item at or after the cut
+            at.assign(srcs.size(), 0);
+            if (r >= W) { for (size_t k = 0; k < srcs.size(); k++) at[k] = srcs[k]->n; return; }
+            if (r <= 0) return;
+            const uint64_t t = target(r);
+            uint64_t before = 0; bool found = false;
+            for (size_t k = 0; k < srcs.size(); k++) {
+                Src& s = *srcs[k];
+                if (found) { at[k] = 0; continue; }
+                // the cut falls into this source when some item of it has >= t bytes before it (t - before <= s.bytes counts the
+                // position after the last item too: that one belongs to the next source's first item)
+                const uint64_t e = t <= before ? 0 : first_at_least(s, t - before);
+                if (e < s.n) { at[k] = e; found = true; } else { at[k] = s.n; before += s.bytes; }
+            }
+        };
+        std::vector<uint64_t> a, b;
+        cut(R, a); cut(R + 1, b);
+        for (size_t k = 0; k < srcs.size(); k++) { srcs[k]->lo = a[k]; srcs[k]->hi = std::max(a[k], b[k]); n_mine += srcs[k]->hi - srcs[k]->lo; }
+    }
+
+    // this process's items in order: f(const InputItem&)
+    template <class F> void for_each(F&& f) {
+        for (size_t k = 0; k < srcs.size(); k++) {
+            Src& s = *srcs[k];
+            if (s.lo >= s.hi) continue;
+            InputItem it; it.src = (int)k;
+            if (s.kind == 0) {
+                it.kind = 0;
+                for (uint64_t i = s.lo; i < s.hi; i++) { it.name = s.files[i]; it.len = s.fsize.empty() ? UINT64_MAX : s.fsize[i]; f(it); }
+            } else if (s.kind == 2) {
+                it.kind = 1;
+                for (uint64_t i = s.lo; i < s.hi; i++) {
+                    const auto& r = s.db->rows[s.ids[i]];
+                    it.name = s.db->name(s.ids[i]); it.off = (uint64_t)r.off; it.len = (uint64_t)r.len; f(it);
+                }
+            } else {
+                it.kind = 1;
+                const size_t m = (size_t)(s.lo / DbScan::STRIDE);
+                LineFile fi, fl;
+                if (!fi.open_at(s.path + ".index", s.scan.marks[m].ipos) || !fl.open_at(s.path + ".lookup", s.scan.marks[m].lpos)) throw std::runtime_error("cannot open the index of " + s.path);
+                const char *q, *t; size_t qn, tn; const char* w[4]; size_t wl[4];
+                for (uint64_t i = (uint64_t)m * DbScan::STRIDE; i < s.hi; i++) {
+                    if (!fi.next(q, qn) || !fl.next(t, tn)) throw std::runtime_error(s.path + ".index changed during the run");
+                    if (i < s.lo) continue;
+                    uint64_t off = 0, len = 0;
+                    if (line_words(q, qn, w, wl) != 3 || !all_digits_u64(w[1], wl[1], off) || !all_digits_u64(w[2], wl[2], len)) throw std::runtime_error(s.path + ".index changed during the run");
+                    if (line_words(t, tn, w, wl) < 2) throw std::runtime_error(s.path + ".lookup changed during the run");
+                    it.name.assign(w[1], wl[1]); it.off = off; it.len = len; f(it);
+                }
+            }
+        }
+    }
+
+    // the bytes of a database entry into dst (exactly it.len); false: the entry lies outside the data file
+    bool read_entry(const InputItem& it, uint8_t* dst) const {
+        const Src& s = *srcs[(size_t)it.src];
+        if (s.kind == 2) {
+            if (it.off + it.len > s.db->size) return false;
+            memcpy(dst, s.db->data + it.off, it.len); return true;
+        }
+        if (it.off + it.len > s.dsize) return false;
+        uint64_t got = 0;
+        while (got < it.len) { const ssize_t k = pread(s.dfd, dst + got, it.len - got, (off_t)(it.off + got)); if (k <= 0) return false; got += (uint64_t)k; }
+        return true;
+    }
 };
 
 struct Fragment {

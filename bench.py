@@ -545,6 +545,41 @@ def end_to_end_leg(args, codec, w, dev):
         dec["gpu_host"]["link_GB_per_s"] = dec["gpu_host"]["steady_text_GB_per_s"]
         out["decompress"] = dec
 
+        # ---- the sharded driver at N = 1 (what `--gpus 8` runs per rank): `python -m foldcomp_amd <mode> -d --gpus 1`
+        #      = a 1-rank RCCL group around the same engine (`foldcomp-hip --shard 0/1`) + the count exchange + the splice, on the
+        #      same inputs as gpu_host above: what the process group, the second process and the exchange cost beside the bare engine
+        def run_sharded(mode, inp_list, out_db):
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
+            env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, "-m", "foldcomp_amd", mode, "-d", "-y", "--gpus", "1", "-t", str(eff), "--json-stats", "-f", inp_list, out_db],
+                               capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+            wall = time.perf_counter() - t0
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError((r.stderr or r.stdout)[-400:])
+            st = json.loads(line[-1]); st["process_wall_s"] = round(wall, 4)
+            return st
+        try:
+            sh = {}
+            for mode, lst_, ref_db, ref_leg in (("compress", lst, os.path.join(tmp, f"db{tcounts[0]}"), comp["gpu_host"]), ("decompress", dlist, os.path.join(tmp, "pdbdb"), dec["gpu_host"])):
+                st = run_sharded(mode, lst_, os.path.join(tmp, f"sharded_{mode}"))
+                same = all(open(os.path.join(tmp, f"sharded_{mode}") + ext, "rb").read() == open(ref_db + ext, "rb").read() for ext in (".index", ".lookup", ".dbtype"))
+                same = same and os.path.getsize(os.path.join(tmp, f"sharded_{mode}")) == os.path.getsize(ref_db)
+                with open(os.path.join(tmp, f"sharded_{mode}"), "rb") as fa, open(ref_db, "rb") as fb:
+                    same = same and fa.read(1 << 24) == fb.read(1 << 24)
+                sh[mode] = {"command": f"python -m foldcomp_amd {mode} -d --gpus 1 -f <list> <db>   (1-rank {st['backend']} group; engine = host/foldcomp-hip --shard 0/1)",
+                            "world": st["world"], "records": st["records"], "wall_s": st["wall_s"], "process_wall_s": st["process_wall_s"],
+                            "group_init_s": st["group_init_s"], "engine_s": st["engine_s"], "engine_steady_s": st["engine_steady_s_max"],
+                            "exchange_and_splice_s": st["exchange_and_splice_s"], "residues_per_s": st["residues_per_s"],
+                            "steady_residues_per_s": st["steady_residues_per_s"], "engine_max_rss_kb": st["engine_max_rss_kb_per_rank"],
+                            "steady_over_gpu_host": round(st["steady_residues_per_s"] / max(ref_leg["steady_residues_per_s"], 1), 3),
+                            "database_equals_gpu_host": bool(same)}
+                os.remove(os.path.join(tmp, f"sharded_{mode}"))
+            out["sharded"] = sh
+        except (RuntimeError, subprocess.TimeoutExpired, OSError, KeyError) as e:
+            out["sharded"] = {"failed": str(e)[-400:]}
+
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _harness as H
         if H.have_ref():

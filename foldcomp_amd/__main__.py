@@ -389,5 +389,14 @@ def main(argv=None):
     return 0
 
 
+def _main_guarded(argv=None):
+    """main() with the database reader's refusals (a malformed .index line, database.py) printed like every other input error"""
+    try:
+        return main(argv)
+    except ValueError as e:
+        print(f"[Error] {e}", file=sys.stderr)
+        return 1
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(_main_guarded())

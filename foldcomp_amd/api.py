@@ -152,7 +152,10 @@ class FoldcompDatabase:
     """Sequence over a Foldcomp database (foldcomp.cxx:44-185): len(), db[i], iteration, context manager."""
 
     def __init__(self, path, ids=None, decompress=True, err_on_missing=False):
-        self._reader = DatabaseReader(os.fspath(path), use_lookup=bool(ids))
+        try:
+            self._reader = DatabaseReader(os.fspath(path), use_lookup=bool(ids))
+        except ValueError as e:                  # an index line the reader cannot take (database.py): the module's own error, not a stray ValueError
+            raise error(str(e)) from None
         self._decompress = decompress
         self._ids = None
         if ids:

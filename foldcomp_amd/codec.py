@@ -148,7 +148,8 @@ class Codec:
         name_off = np.zeros(len(nb) + 1, np.uint32)
         name_off[1:] = np.cumsum([len(n) for n in nb])
         name_blob = np.frombuffer(b"".join(nb) or b"\0", np.uint8)
-        stem_len = np.asarray([n.rfind(".") if "." in n else len(n.encode()) for n in names], np.uint32)
+        # byte counts of the ENCODED names (name_blob is UTF-8: a character index would cut a non-ASCII stem short)
+        stem_len = np.asarray([n.rfind(b".") if b"." in n else len(n) for n in nb], np.uint32)
         return text, file_off, name_blob, name_off, stem_len
 
     def ingest_pdb(self, texts, names, anchor_threshold: int = 25, skip_discontinuous: bool = False):

@@ -2,30 +2,31 @@
 (reference driver loop src/input_processor.h:200-300, writer src/database_writer.cpp:59-73).
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" when several ranks have to share a device
-or FCZ_SHARD_BACKEND=gloo says so). Structures are independent: the inputs -- the files of the input directories, or the
-entries of the input databases in key order -- are listed identically on every rank, cut into `world` contiguous ranges
-balanced by bytes (shard.shard_range), and every rank runs the codec on its own range:
+or FCZ_SHARD_BACKEND=gloo says so). A rank is two things:
 
-    compress    plain PDB files through the structure ingest on the device (Codec.compress_pdb: text -> FCZ in HBM), what the
-                device does not read or hands back (mmCIF, gzip, fields outside the fixed-column layout) through the host parser;
-    decompress  FCZ entries -> PDB text with decode and formatting on the device (Codec.decompress_pdb).
+    engine    `host/foldcomp-hip <mode> -d --shard R/N --device D ...`: the pipelined C++ host (read threads -> page-locked
+              buffers -> structure ingest + codec on the device -> sequenced writes) on the rank's byte-balanced contiguous range
+              of the inputs -- files of the input directories, or entries of the input databases streamed from their index --
+              writing a complete partial database with keys and offsets from 0, its index appended job by job;
+    exchange  this process: ONE all_gather of {records, bytes} (shard.exchange_counts), then the partial databases are spliced
+              into one (shard.splice: in-kernel data copy at the prefix offset, index lines rebased, rank 0 appends them).
 
-The only exchange is the index: record counts (keys are numbered in input order over the records that made it), then
-shard.write_sharded_db -- byte totals -> every rank pwrites its slice of the data file at its prefix offset, packed index rows
-gathered on rank 0, which writes .index / .lookup / .dbtype as free_writer does. N = 1 runs the very same code in a 1-rank
-group. Without a launcher in the environment the command starts its own N ranks (torch.distributed.run on 127.0.0.1).
+Memory of a rank does not grow with its shard: nothing per record is held by the engine (jobs stream through) or by this
+process (two integers per rank cross the group). configs[3] (214 M records over 8 GPUs) is 27 M records and ~160 GB of FCZ per
+rank: the engine's job buffers stay at a few hundred MB. N = 1 runs the very same code in a 1-rank group. Without a launcher
+in the environment the command starts its own N ranks (torch.distributed.run on 127.0.0.1).
 """
 from __future__ import annotations
 
+import json
 import os
 import socket
 import subprocess
 import sys
-from typing import List, Optional, Tuple
+import time
+from typing import List
 
-import numpy as np
-
-PDB_EXT = (".pdb", ".ent")
+from . import shard
 
 
 def _free_port() -> int:
@@ -43,160 +44,105 @@ def launch(argv: List[str], gpus: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-# ---- the inputs, listed the same way on every rank -----------------------------------------------------------------------
-class Item:
-    __slots__ = ("name", "size", "src", "idx")
-
-    def __init__(self, name, size, src, idx):
-        self.name, self.size, self.src, self.idx = name, int(size), src, idx   # src: a path, or a DatabaseReader with entry idx
-
-
-def list_items(inputs: List[str], recursive: bool, id_list: Optional[str], id_mode: int) -> List[Item]:
-    from .database import DatabaseReader
-    items: List[Item] = []
-    for inp in inputs:
-        if os.path.exists(inp + ".dbtype"):
-            r = DatabaseReader(inp)
-            ids = range(len(r))
-            if id_list:
-                want = [l.strip() for l in open(id_list) if l.strip()]
-                ids = [r.id_of_key(int(w)) if id_mode == 0 else r.id_of_name(w) for w in want]
-                ids = [i for i in ids if i >= 0]
-            for i in ids:
-                items.append(Item(r.name(i), r.lengths[i], r, i))
-        elif os.path.isdir(inp):
-            for root, dirs, files in os.walk(inp):
-                dirs.sort()
-                for f in sorted(files):
-                    p = os.path.join(root, f)
-                    items.append(Item(p, os.path.getsize(p), p, -1))
-                if not recursive:
-                    break
-        else:
-            items.append(Item(inp, os.path.getsize(inp), inp, -1))
-    return items
+def host_threads(world: int) -> int:
+    """read / parse threads of one rank's engine: this process's CPUs (affinity, cut by a cgroup quota) shared by the ranks"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n // max(1, world))
 
 
-def read_item(it: Item) -> bytes:
-    if it.idx >= 0:
-        return it.src.data(it.idx)
-    with open(it.src, "rb") as f:
-        return f.read()
-
-
-# ---- one rank's share ------------------------------------------------------------------------------------------------------
-def compress_items(items: List[Item], a, codec) -> List[Tuple[str, bytes]]:
-    """-> [(database name, FCZ record)] of the items, in item order then fragment order"""
-    from .__main__ import host_fragments
-    from .structure import StructureError, build_batch
-    per_file: List[List[Tuple[str, bytes]]] = [[] for _ in items]
-    step = 2048
-    for s0 in range(0, len(items), step):
-        chunk = list(range(s0, min(len(items), s0 + step)))
-        datas = {i: read_item(items[i]) for i in chunk}
-        dev = [i for i in chunk if items[i].name.endswith(PDB_EXT)]
-        host = [i for i in chunk if i not in set(dev)]
-        if dev:
-            names = [os.path.basename(items[i].name) for i in dev]
-            r = codec.compress_pdb([datas[i] for i in dev], names, a.brk, a.skip_discontinuous)
-            for c in range(len(r["status"])):
-                i = dev[int(r["chain_file"][c])]
-                if r["status"][c] != 0:
-                    print(f"[Error] compressing {os.path.basename(items[i].name)}", file=sys.stderr); continue
-                per_file[i].append((os.path.basename(items[i].name).rsplit(".", 1)[0], r["blob"][int(r["off"][c]):int(r["off"][c + 1])].tobytes()))
-            for f, meta in r["refused"]:
-                print(f"[Error] compressing {names[int(f)]}: fragment refused (reason {int(meta) >> 24})", file=sys.stderr)
-            for k, st in enumerate(r["file_status"]):
-                if st == 4:
-                    print(f"[Error] No atoms found in the input file: {names[k]}", file=sys.stderr)
-                elif st != 0:
-                    host.append(dev[k])                    # handed back: the host parser takes the file
-        pend = []                                           # (item, db name, chain)
-        for i in sorted(host):
-            try:
-                for fname, dbname, ch in host_fragments(items[i].name, datas[i], a, "db", False, None):
-                    pend.append((i, dbname, ch))
-            except Exception as e:  # noqa: BLE001 - parse errors are reported and skipped like the reference
-                print(f"[Error] {os.path.basename(items[i].name)}: {e}", file=sys.stderr)
-        good = []
-        for p in pend:
-            try:
-                build_batch([p[2]], a.brk); good.append(p)
-            except StructureError as e:
-                print(f"[Error] compressing {p[1]}: {e}", file=sys.stderr)
-        if good:
-            blob, off, st = codec.compress_batch(build_batch([p[2] for p in good], a.brk), strict=False)
-            for q, (i, dbname, _) in enumerate(good):
-                if st[q] != 0:
-                    print(f"[Error] compressing {dbname}", file=sys.stderr); continue
-                per_file[i].append((dbname, blob[int(off[q]):int(off[q + 1])].tobytes()))
-    return [rec for recs in per_file for rec in recs]
-
-
-def decompress_items(items: List[Item], a, codec) -> List[Tuple[str, bytes]]:
-    """-> [(database name, PDB text + NUL)] of the items (src/main.cpp:656-664)"""
-    from . import _lib
-    out: List[Tuple[str, bytes]] = []
-    step = 4096
-    for s0 in range(0, len(items), step):
-        chunk = items[s0:s0 + step]
-        ents = [read_item(it) for it in chunk]
+def engine_command(a, rank: int, world: int, device_index: int, out_path: str, host: str = shard.HOST) -> List[str]:
+    """the rank's engine: the C++ host on its range of the inputs (same option letters as the reference's command line)"""
+    cmd = [host, a.mode, "-d", "-y", "--gpus", "1", "--device", str(device_index), "--shard", f"{rank}/{world}", "--json-stats",
+           "-t", str(a.threads if a.threads and a.threads > 1 else host_threads(world)), "-b", str(a.brk)]
+    if a.recursive:
+        cmd.append("-r")
+    if a.mode == "compress" and a.skip_discontinuous:
+        cmd.append("--skip-discontinuous")
+    if a.mode == "decompress":
+        if a.alt:
+            cmd.append("-a")
         if a.check:
-            keep = []
-            for it, e in zip(chunk, ents):
-                arr = np.frombuffer(e, np.uint8)
-                if len(arr) == 0 or _lib.load().fcz_check(arr.ctypes.data, len(arr)) != 0:
-                    print(f"[Error] invalid FCZ entry skipped: {it.name}", file=sys.stderr); continue
-                keep.append((it, e))
-            chunk, ents = [k[0] for k in keep], [k[1] for k in keep]
-        if not ents:
-            continue
-        off = np.zeros(len(ents) + 1, np.uint64)
-        off[1:] = np.cumsum([len(e) for e in ents])
-        texts, status = codec.decompress_pdb(np.frombuffer(b"".join(ents), np.uint8), off, alt_order=a.alt)
-        for it, t, st in zip(chunk, texts, status):
-            if st != 0:
-                print(f"[Error] decompressing {it.name}", file=sys.stderr); continue
-            out.append((os.path.basename(it.name).rsplit(".", 1)[0] if "." in os.path.basename(it.name) else os.path.basename(it.name), t + b"\0"))
-    return out
+            cmd.append("--check")
+        if a.id_list:
+            cmd += ["-l", a.id_list, "-m", str(a.id_mode)]
+    if a.file_input:
+        cmd.append("-f")
+    return cmd + [a.input.rstrip("/") if len(a.input) > 1 else a.input, out_path]
 
 
 def run(a, inputs: List[str], output: str) -> int:
     """this process's rank of the sharded run (a 1-rank group when no launcher set the environment)"""
     import torch
     import torch.distributed as dist
-    from . import shard
-    from .codec import Codec
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", str(rank)))
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if n_dev <= 0:
         print("[Error] no HIP device (the codec has no CPU fallback)", file=sys.stderr); return 1
+    if not os.path.exists(shard.HOST):
+        print(f"[Error] the engine {shard.HOST} is not built (make -C host)", file=sys.stderr); return 1
+    for inp in inputs:
+        if inp.endswith((".tar", ".tar.gz", ".tgz")):
+            print("[Error] --gpus shards directories and databases; unpack tar inputs first", file=sys.stderr); return 1
     backend = os.environ.get("FCZ_SHARD_BACKEND") or ("nccl" if world <= n_dev else "gloo")
     device_index = local % n_dev
     if backend == "nccl":
         torch.cuda.set_device(device_index)
     if "MASTER_ADDR" not in os.environ:
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_free_port())
+    t_start = time.perf_counter()
     dist.init_process_group(backend, rank=rank, world_size=world)
     tdev = torch.device("cuda", device_index) if backend == "nccl" else None
+    rc = 0
     try:
-        items = list_items(inputs, a.recursive, a.id_list if a.mode != "compress" else None, a.id_mode)
-        lo, hi = shard.shard_range(len(items), [it.size for it in items], rank, world)
-        with Codec(device_index) as codec:
-            recs = (compress_items if a.mode == "compress" else decompress_items)(items[lo:hi], a, codec)
-        # keys: input order over the records that made it -> this rank's first key = the counts of the ranks before it
-        n = torch.tensor([len(recs)], dtype=torch.int64, device=tdev)
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n)
-        key0 = sum(int(c.item()) for c in counts[:rank])
-        blob = b"".join(r[1] for r in recs)
-        lengths = np.asarray([len(r[1]) for r in recs], np.int64)
-        keys = np.arange(key0, key0 + len(recs), dtype=np.int64)
-        shard.write_sharded_db(output, blob, lengths, keys, [r[0] for r in recs], tdev)
+        t_group = time.perf_counter()
+        part = output if rank == 0 else f"{output}.part{rank}"
+        env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}     # (a launcher exports OMP_NUM_THREADS=1: the engine gets -t)
+        r = subprocess.run(engine_command(a, rank, world, device_index, part), env=env, stdout=subprocess.PIPE, text=True)
+        st = {}
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                st = json.loads(line)
+        failed = r.returncode != 0 or not st
+        t_engine = time.perf_counter()
+        extra = [st.get("residues", 0), int(st.get("wall_s", 0.0) * 1e6), int(st.get("ctx_ready_s", 0.0) * 1e6), st.get("max_rss_kb", 0),
+                 st.get("items", st.get("files", 0)), st.get("input_bytes", st.get("fcz_bytes", 0))]
+        key0, off0, any_failed, rows = shard.exchange_counts(st.get("records", 0), st.get("data_bytes", 0), failed, tdev, extra)
+        if any_failed:
+            # a database without one rank's records looks complete: nothing is left behind
+            shard.remove_db(part)
+            if rank == 0:
+                print(f"[Error] the run failed: {output} was not written", file=sys.stderr)
+            rc = 1
+        else:
+            if not shard.splice(output, part, key0, off0, tdev):
+                if rank == 0:
+                    print(f"[Error] splicing the ranks' databases failed: {output} is incomplete", file=sys.stderr)
+                rc = 1
+        t_done = time.perf_counter()
         if rank == 0 and getattr(a, "json_stats", False):
-            import json
-            print(json.dumps({"mode": a.mode, "world": world, "backend": backend, "items": len(items),
-                              "records": int(sum(int(c.item()) for c in counts))}))
+            res = sum(r_[3] for r_ in rows)
+            eng_wall = max(r_[4] for r_ in rows) / 1e6
+            steady = max((r_[4] - r_[5]) for r_ in rows) / 1e6
+            print(json.dumps({"mode": a.mode, "world": world, "backend": backend, "engine": "host/foldcomp-hip --shard R/N",
+                              "items": sum(r_[7] for r_ in rows), "records": sum(r_[0] for r_ in rows), "data_bytes": sum(r_[1] for r_ in rows),
+                              "residues": res, "input_bytes": sum(r_[8] for r_ in rows),
+                              "records_per_rank": [r_[0] for r_ in rows], "bytes_per_rank": [r_[1] for r_ in rows],
+                              "engine_max_rss_kb_per_rank": [r_[6] for r_ in rows],
+                              "wall_s": round(t_done - t_start, 4), "group_init_s": round(t_group - t_start, 4),
+                              "engine_s": round(t_engine - t_group, 4), "engine_wall_s_max": round(eng_wall, 4),
+                              "engine_steady_s_max": round(steady, 4), "exchange_and_splice_s": round(t_done - t_engine, 4),
+                              "residues_per_s": round(res / (t_done - t_start), 1) if t_done > t_start else None,
+                              # the steady rate: without the group's and the engines' start-up (HIP context), WITH the exchange
+                              "steady_residues_per_s": round(res / (steady + (t_done - t_engine)), 1) if steady + (t_done - t_engine) > 0 else None}))
     finally:
         dist.destroy_process_group()
-    return 0
+    return rc

@@ -8,6 +8,8 @@
 //   no GPU needed (used by the tests):
 //   foldcomp-hip dump-batch [-b N] <pdb file>          the host-side batch of a file as text
 //   foldcomp-hip db-pack <dir> <db> / db-unpack <db> <dir>   files <-> database container
+//   foldcomp-hip db-splice --shard R/N [--key0 K --off0 B] <part db> <final db>   exchange step of a sharded run (see run_db_splice)
+//   sharded runs:  compress|decompress -d --shard R/N --device D ...   rank R of N takes its byte-balanced range of the inputs
 //
 // It mirrors the reference's own driver (src/main.cpp:438-536 compress, :612-689 decompress, :780-795 extract, :912-926
 // check) for PDB text files and directories: structures are parsed on the host threads, fragments (one chain without gaps
@@ -26,6 +28,7 @@
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
@@ -881,6 +884,20 @@ int coor_format_from_content(const char* d, size_t size) {
     }
     return 0;
 }
+// the same decision from the first `have` bytes of a text of `full` bytes; -1: the prefix does not reach the deciding characters
+int coor_format_from_prefix(const char* d, size_t have, size_t full) {
+    size_t i = 0; const long end = (long)full - 8;
+    while ((long)i < end) {
+        if (i + 5 > have) return have >= full ? 0 : -1;
+        const unsigned char c = (unsigned char)d[i];
+        if (c == ' ' || (c >= 9 && c <= 13)) i++;
+        else if (c == '#') { while ((long)i < end && i < have && d[i] != '\n') i++; if (i >= have && have < full) return -1; }
+        else if (c == '{') return 3;
+        else if ((d[i] & ~0x20) == 'D' && (d[i + 1] & ~0x20) == 'A' && (d[i + 2] & ~0x20) == 'T' && (d[i + 3] & ~0x20) == 'A' && d[i + 4] == '_') return 2;
+        else return 1;
+    }
+    return 0;
+}
 AtomTable parse_pdb_gemmi(const char* data, size_t size, std::string& title);
 AtomTable parse_structure_gemmi(const char* data, size_t size, std::string& title) {
     const int fmt = coor_format_from_content(data, size);
@@ -1580,6 +1597,18 @@ void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t 
 
 }
 
+// peak resident set of this process: VmHWM (ru_maxrss starts from the PARENT's peak after fork + exec, so a small child of a large
+// parent would report the parent)
+long max_rss_kb() {
+    if (FILE* f = fopen("/proc/self/status", "r")) {
+        char line[256]; long kb = -1;
+        while (fgets(line, sizeof line, f)) if (sscanf(line, "VmHWM: %ld", &kb) == 1) break;
+        fclose(f);
+        if (kb >= 0) return kb;
+    }
+    struct rusage u; return getrusage(RUSAGE_SELF, &u) == 0 ? u.ru_maxrss : -1;
+}
+
 int need_ctx(fcz_ctx** ctx) {
     const int rc = fcz_ctx_create(0, ctx);
     if (rc != FCZ_OK) fprintf(stderr, "[Error] %s\n", fcz_status_string(rc));
@@ -1660,20 +1689,28 @@ void pwrite_all(int fd, const uint8_t* p, uint64_t n, uint64_t off) {
     }
 }
 
-int run_compress_device(const Options& o, const std::vector<std::string>& files, const std::string& output);
+int run_compress_device(const Options& o, InputPlan& plan, const std::string& output);
 int run_compress(const Options& o) {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
     const bool single = o.single;
     const std::string output = o.output;             // main() resolved the reference's defaults (src/main.cpp:356-369)
-    std::vector<std::string> files;
-    for (const std::string& in : o.inputs) { if (is_dir(in)) list_files(in, o.recursive, files); else files.push_back(in); }
     const int n_dev = fcz_device_count();
     if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
-    const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
-    if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
-    // directories and databases of files: the structure ingest runs on the device (the host threads only read)
-    if (!single && !o.host_parse) return run_compress_device(o, files, output);
+    const int gpus = o.gpus <= 0 ? n_dev - o.device : o.gpus;
+    if (gpus < 1 || o.device + gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d from device %d but only %d device(s) are visible\n", gpus, o.device, n_dev); return 1; }
+    std::vector<std::string> files;
+    if (single) files.push_back(o.inputs[0]);
+    else {
+        // directories of files and databases of file images: this process's range of the listing (all of it unless --shard)
+        InputPlan plan;
+        try { plan.build(o); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); return 1; }
+        // the structure ingest runs on the device (the host threads only read)
+        if (!o.host_parse) return run_compress_device(o, plan, output);
+        bool db_items = false;
+        plan.for_each([&](const InputItem& it) { if (it.kind == 0) files.push_back(it.name); else db_items = true; });
+        if (db_items) { fprintf(stderr, "[Error] --host-parse reads structure files, not database entries\n"); return 1; }
+    }
     const int n_workers = gpus * std::max(1, o.workers_per_gpu);
     pinned_enabled() = true;
     int db_fd = -1;
@@ -1691,7 +1728,7 @@ int run_compress(const Options& o) {
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
         fcz_ctx* ctx = nullptr;
-        if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        if (fcz_ctx_create(o.device + w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", o.device + w % gpus); }
         ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
         Batch b;                         // reused: its page-locked buffers grow to the largest job and stay
         pvec<uint8_t> blob;
@@ -1847,13 +1884,13 @@ bool is_plain_pdb(const std::string& path) { return ends_with(path, ".pdb") || e
 bool is_gz_pdb(const std::string& path) { return ends_with(path, ".pdb.gz") || ends_with(path, ".ent.gz"); }
 // PDB text the device ingest takes: plain files are read straight into the page-locked buffer, gzipped ones are inflated by
 // the reader threads first (their parse still happens on the device)
-bool is_device_text(const std::string& path) { return is_plain_pdb(path) || is_gz_pdb(path); }
+[[maybe_unused]] bool is_device_text(const std::string& path) { return is_plain_pdb(path) || is_gz_pdb(path); }
 
-int run_compress_device(const Options& o, const std::vector<std::string>& files, const std::string& output) {
+int run_compress_device(const Options& o, InputPlan& plan, const std::string& output) {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
     const int n_dev = fcz_device_count();
-    const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
+    const int gpus = o.gpus <= 0 ? n_dev - o.device : o.gpus;
     const int n_workers = gpus * std::max(1, o.workers_per_gpu);
     pinned_enabled() = true;
     int db_fd = -1;
@@ -1875,7 +1912,7 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
         fcz_ctx* ctx = nullptr;
-        if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        if (fcz_ctx_create(o.device + w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", o.device + w % gpus); }
         ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
         pvec<uint8_t> blob, blob_host, packed;
         Batch hb;
@@ -1909,7 +1946,8 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
             if (!failed && n_text) {
                 auto frag_name = [&](size_t file, uint32_t meta) {
                     std::string nm = stem_of(file);
-                    if (meta & FCZ_INGEST_MULTI_CHAIN) nm.push_back((char)(meta & 0xffu));
+                    // (a blank chain id names nothing: gemmi's read_string trims it to "", AtomTable::chain_name likewise)
+                    if ((meta & FCZ_INGEST_MULTI_CHAIN) && (char)(meta & 0xffu) != ' ') nm.push_back((char)(meta & 0xffu));
                     if (meta & FCZ_INGEST_MULTI_FRAG) nm += "_" + std::to_string((meta >> 8) & 0xffu);
                     return nm;
                 };
@@ -1995,35 +2033,77 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
         if (ctx) fcz_ctx_destroy(ctx);
     });
 
-    // ---- producer: size, then read, the files of a job side by side on the host threads ----
+    // ---- producer: size, then read, the inputs of a job side by side on the host threads. Inputs are files or database entries
+    //      (InputPlan: this process's range of the listing); a database entry is a file image under its lookup name
+    //      (src/input_processor.h:237-257 hands `name, data, length` to the same lambda as a directory's files) ----
     double t_read = 0.0; uint64_t in_bytes = 0;
-    {
-        const size_t JOB = std::max<size_t>(64, std::min<size_t>(2048, files.size() / (4 * (size_t)n_workers) + 1));
+    try {
+        const size_t JOB = std::max<size_t>(64, std::min<size_t>(2048, (size_t)plan.n_mine / (4 * (size_t)n_workers) + 1));
         size_t job_index = 0;
-        for (size_t f0 = 0; f0 < files.size(); f0 += JOB) {
+        std::vector<InputItem> cur;
+        auto make_job = [&]() {
+            if (cur.empty()) return;
             const auto t0 = clk::now();
-            const size_t f1 = std::min(files.size(), f0 + JOB), nf = f1 - f0;
+            const size_t nf = cur.size();
             TextJob j; j.index = job_index++;
-            j.paths.assign(files.begin() + f0, files.begin() + f1);
+            j.paths.resize(nf);
+            for (size_t i = 0; i < nf; i++) j.paths[i] = cur[i].name;
             j.slot.assign(nf, -1); j.host_frags.resize(nf);
             std::vector<uint64_t> size(nf, 0);
-            std::vector<std::string> unz(nf);                         // the inflated text of the gzipped PDB files
+            std::vector<int> cls(nf, 0);                              // 0: the host reader takes it, 1: text read straight into the job's buffer, 2: text that waits in unz[]
+            std::vector<std::string> unz(nf);                         // inflated text of gzipped inputs; entries the host reader takes
             std::vector<std::string> err(nf);
 #pragma omp parallel for schedule(dynamic, 16)
             for (long long i = 0; i < (long long)nf; i++) {
-                if (is_gz_pdb(j.paths[i])) {
-                    try { const std::string z = read_file(j.paths[i]); g_bytes_read += z.size(); unz[i] = gunzip(z); size[i] = unz[i].size(); }
-                    catch (const std::exception& e) { err[i] = "[Error] " + base_name(j.paths[i]) + ": " + e.what() + "\n"; size[i] = UINT64_MAX - 1; }
+                const InputItem& it = cur[(size_t)i];
+                const std::string& nm = j.paths[(size_t)i];
+                if (it.kind == 1) {
+                    // a database entry: gzipped by its NAME, PDB or mmCIF by its CONTENT (StructureReader::loadFromBuffer)
+                    try {
+                        if (ends_with(nm, ".gz")) {
+                            std::string z(it.len, '\0');
+                            if (!plan.read_entry(it, (uint8_t*)&z[0])) throw std::runtime_error("database entry out of range");
+                            g_bytes_read += z.size();
+                            unz[i] = gunzip(z);
+                            if (coor_format_from_content(unz[i].data(), unz[i].size()) == 1) { cls[i] = 2; size[i] = unz[i].size(); }
+                            continue;
+                        }
+                        char head[4096];
+                        InputItem pre = it; pre.len = std::min<uint64_t>(it.len, sizeof head);
+                        if (!plan.read_entry(pre, (uint8_t*)head)) throw std::runtime_error("database entry out of range");
+                        int fmt = coor_format_from_prefix(head, (size_t)pre.len, (size_t)it.len);
+                        if (fmt == 1) {
+                            // MMseqs-made databases end an entry with a NUL after the text's last line end: not part of the text
+                            // (the reader ignores a line of one NUL; the device parser would hand the file back for it)
+                            size[i] = it.len; cls[i] = 1;
+                            if (it.len >= 2) {
+                                InputItem tail = it; tail.off = it.off + it.len - 2; tail.len = 2; char t2[2];
+                                if (plan.read_entry(tail, (uint8_t*)t2) && t2[1] == '\0' && t2[0] == '\n') size[i] = it.len - 1;
+                            }
+                            continue;
+                        }
+                        unz[i].resize(it.len);
+                        if (it.len && !plan.read_entry(it, (uint8_t*)&unz[i][0])) throw std::runtime_error("database entry out of range");
+                        g_bytes_read += it.len;
+                        if (fmt < 0 && coor_format_from_content(unz[i].data(), unz[i].size()) == 1) { cls[i] = 2; size[i] = unz[i].size(); }
+                    } catch (const std::exception& e) { err[i] = "[Error] " + base_name(nm) + ": " + e.what() + "\n"; size[i] = UINT64_MAX - 1; cls[i] = 2; }
                     continue;
                 }
-                if (!is_plain_pdb(j.paths[i])) continue;
+                if (is_gz_pdb(nm)) {
+                    cls[i] = 2;
+                    try { const std::string z = read_file(nm); g_bytes_read += z.size(); unz[i] = gunzip(z); size[i] = unz[i].size(); }
+                    catch (const std::exception& e) { err[i] = "[Error] " + base_name(nm) + ": " + e.what() + "\n"; size[i] = UINT64_MAX - 1; }
+                    continue;
+                }
+                if (!is_plain_pdb(nm)) continue;
+                cls[i] = 1;
                 struct stat st;
-                if (stat(j.paths[i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) size[i] = (uint64_t)st.st_size; else size[i] = UINT64_MAX;
+                if (stat(nm.c_str(), &st) == 0 && S_ISREG(st.st_mode)) size[i] = (uint64_t)st.st_size; else size[i] = UINT64_MAX;
             }
             uint32_t n_text = 0;
             for (size_t i = 0; i < nf; i++) {
-                if (!is_device_text(j.paths[i])) continue;
-                if (size[i] == UINT64_MAX - 1) continue;               // a gzip stream that does not inflate (reported below)
+                if (cls[i] == 0) continue;
+                if (size[i] == UINT64_MAX - 1) continue;               // a gzip stream that does not inflate, an entry outside its file (reported below)
                 if (size[i] == UINT64_MAX) { fprintf(stderr, "[Error] cannot open %s\n", j.paths[i].c_str()); continue; }
                 j.slot[i] = (int)n_text++;
                 j.file_off.push_back(j.file_off.back() + size[i]);
@@ -2035,9 +2115,14 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
             if (j.text->size() < j.file_off.back() + 64) j.text->resize(j.file_off.back() + j.file_off.back() / 8 + 64);   // grows, never shrinks: a resize touches (zero-fills) what it adds
 #pragma omp parallel for schedule(dynamic, 8)
             for (long long i = 0; i < (long long)nf; i++) {
-                if (j.slot[i] >= 0 && is_gz_pdb(j.paths[i])) {
+                const InputItem& it = cur[(size_t)i];
+                if (j.slot[i] >= 0 && cls[i] == 2) {
                     memcpy(j.text->data() + j.file_off[(size_t)j.slot[i]], unz[i].data(), unz[i].size());
                     std::string().swap(unz[i]);
+                } else if (j.slot[i] >= 0 && it.kind == 1) {
+                    InputItem body = it; body.len = size[i];
+                    if (!plan.read_entry(body, j.text->data() + j.file_off[(size_t)j.slot[i]])) memset(j.text->data() + j.file_off[(size_t)j.slot[i]], ' ', size[i]);
+                    g_bytes_read += size[i];
                 } else if (j.slot[i] >= 0) {
                     // straight into the page-locked buffer; a file that shrank since stat() leaves spaces (an empty line), one that
                     // grew is cut at its stat size
@@ -2050,19 +2135,26 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
                     }
                     if (got < want) memset(j.text->data() + at + got, ' ', want - got);
                     g_bytes_read += got;
-                } else if (!is_device_text(j.paths[i])) {
+                } else if (cls[i] == 0) {
                     std::string stem, ext; file_parts(base_name(j.paths[i]), stem, ext);
-                    try { fragments_of(j.paths[i], stem, ext, !o.db, o, j.host_frags[i]); }
+                    try {
+                        if (it.kind == 1) fragments_from_memory(unz[i].data(), unz[i].size(), base_name(j.paths[i]), stem, ext, !o.db, o, j.host_frags[i], /*inflated=*/ends_with(j.paths[i], ".gz"));
+                        else fragments_of(j.paths[i], stem, ext, !o.db, o, j.host_frags[i]);
+                    }
                     catch (const std::exception& e) { err[i] = "[Error] " + base_name(j.paths[i]) + ": " + e.what() + "\n"; }
+                    std::string().swap(unz[i]);
                 }
             }
             for (const std::string& e : err) if (!e.empty()) fputs(e.c_str(), stderr);
             t_read += std::chrono::duration<double>(clk::now() - t0).count();
             in_bytes = g_bytes_read.load();
             queue.put(std::move(j));
-        }
-        queue.close();
-    }
+            cur.clear();
+        };
+        plan.for_each([&](const InputItem& it) { cur.push_back(it); if (cur.size() >= JOB) make_job(); });
+        make_job();
+    } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
+    queue.close();
     const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
     for (std::thread& t : workers) t.join();
     const double t_joined = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -2078,10 +2170,11 @@ int run_compress_device(const Options& o, const std::vector<std::string>& files,
         printf("{\"mode\": \"compress\", \"ingest\": \"device\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
                "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"host_parsed_files\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
                "\"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_parsed_s\": %.4f, \"workers_done_s\": %.4f, \"residues_per_s\": %.1f, "
-               "\"input_MB_per_s\": %.1f, \"pinned_blocks\": %llu}\n",
-               gpus, n_workers, omp_get_max_threads(), files.size(), (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
+               "\"input_MB_per_s\": %.1f, \"pinned_blocks\": %llu, \"shard\": \"%d/%d\", \"items_total\": %llu, \"data_bytes\": %llu, \"streamed_inputs\": %s, \"max_rss_kb\": %ld}\n",
+               gpus, n_workers, omp_get_max_threads(), (size_t)plan.n_mine, (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
                (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), (unsigned long long)n_host_files.load(), wall, t_read, busy,
-               ready, t_queued, t_joined, wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load());
+               ready, t_queued, t_joined, wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load(),
+               o.shard_rank, o.shard_world, (unsigned long long)plan.n_items, (unsigned long long)seq.pos, plan.streamed_all ? "true" : "false", max_rss_kb());
     }
     return hard_fail ? 1 : 0;
 }
@@ -2145,8 +2238,8 @@ int run_decompress(const Options& o) {
     const std::string output = o.output;
     const int n_dev = fcz_device_count();
     if (n_dev <= 0) { fprintf(stderr, "[Error] %s\n", fcz_status_string(FCZ_E_NO_DEVICE)); return 1; }
-    const int gpus = o.gpus <= 0 ? n_dev : o.gpus;
-    if (gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d but only %d device(s) are visible\n", gpus, n_dev); return 1; }
+    const int gpus = o.gpus <= 0 ? n_dev - o.device : o.gpus;
+    if (gpus < 1 || o.device + gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d from device %d but only %d device(s) are visible\n", gpus, o.device, n_dev); return 1; }
     const int n_workers = single ? 1 : gpus * std::max(1, o.workers_per_gpu);
     pinned_enabled() = true;
     int db_fd = -1;
@@ -2156,6 +2249,7 @@ int run_decompress(const Options& o) {
     } else if (!single) make_dir(output);
 
     JobQueue<DecompressJob> queue((size_t)n_workers + 2);
+    InputPlan plan;
     Sequencer seq;
     if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
@@ -2164,7 +2258,7 @@ int run_decompress(const Options& o) {
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
         fcz_ctx* ctx = nullptr;
-        if (fcz_ctx_create(w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", w % gpus); }
+        if (fcz_ctx_create(o.device + w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", o.device + w % gpus); }
         ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
         pvec<uint8_t> text, packed;
         DecompressJob job;
@@ -2254,7 +2348,22 @@ int run_decompress(const Options& o) {
             ents = Entries();
             queue.put(std::move(j));
         };
-        for_each_entry(o, ents, flush, JOB);
+        if (single) for_each_entry(o, ents, flush, JOB);
+        else try {
+            // this process's range of the listing (all of it unless --shard), database entries streamed from their files
+            plan.build(o);
+            plan.for_each([&](const InputItem& it) {
+                if (it.kind == 0) { try { ents.add(it.name, read_file(it.name)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); } }
+                else {
+                    const size_t at = ents.blob.size();
+                    ents.blob.resize(at + it.len);
+                    if (!plan.read_entry(it, ents.blob.data() + at)) { ents.blob.resize(at); fprintf(stderr, "[Error] database entry out of range\n"); }
+                    else { ents.names.push_back(it.name); ents.off.push_back(ents.blob.size()); }
+                }
+                if (ents.n() >= JOB) flush();
+            });
+            flush();
+        } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
         queue.close();
     }
     const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -2273,9 +2382,11 @@ int run_decompress(const Options& o) {
         for (double g : write_s) wrote += g;
         printf("{\"mode\": \"decompress\", \"gpus\": %d, \"workers\": %d, \"records\": %llu, \"residues\": %llu, \"fcz_bytes\": %llu, \"text_bytes\": %llu, "
                "\"wall_s\": %.4f, \"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_queued_s\": %.4f, \"residues_per_s\": %.1f, \"text_MB_per_s\": %.1f, "
-               "\"pinned_blocks\": %llu, \"queue_wait_s_sum\": %.4f, \"write_s_sum\": %.4f, \"buffer_alloc_s_sum\": %.4f, \"host_threads\": %d}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
+               "\"pinned_blocks\": %llu, \"queue_wait_s_sum\": %.4f, \"write_s_sum\": %.4f, \"buffer_alloc_s_sum\": %.4f, \"host_threads\": %d, "
+               "\"shard\": \"%d/%d\", \"items\": %llu, \"items_total\": %llu, \"data_bytes\": %llu, \"streamed_inputs\": %s, \"max_rss_kb\": %ld}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
                (unsigned long long)n_text.load(), wall, busy, *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_queued,
-               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? n_text.load() / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load(), waited, wrote, alloc, o.write_threads * n_workers);
+               wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? n_text.load() / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load(), waited, wrote, alloc, o.write_threads * n_workers,
+               o.shard_rank, o.shard_world, (unsigned long long)plan.n_mine, (unsigned long long)plan.n_items, (unsigned long long)seq.pos, plan.streamed_all ? "true" : "false", max_rss_kb());
     }
     return hard_fail ? 1 : 0;
 }
@@ -2378,6 +2489,89 @@ int run_db_unpack(const Options& o) {
         // names come from the (untrusted) .lookup file: only their last path component is used
         write_out(o.output + "/" + base_name(r.name(i)), d.data(), d.size(), true);
     }
+    return 0;
+}
+
+// ---- db-splice: the exchange step of a sharded database run, file side (free_writer's layout,
+//      src/database_writer.cpp:59-73). Every rank's engine has written a complete partial database with keys and offsets counted
+//      from 0: rank 0 straight into <final>, rank r > 0 into its own <part>. After the ranks have exchanged {records, bytes} (the
+//      only collective of the run) rank r knows key0 = records of the ranks before it, off0 = their bytes, and runs
+//          db-splice --shard r/N --key0 K --off0 B <part> <final>      r > 0: the data of <part> goes to <final> at byte B (in-kernel
+//                       copy, no user-space buffer beyond 8 MB), its index / lookup lines are rewritten with K and B added into
+//                       <final>.index.r / <final>.lookup.r, <part>* are removed;
+//          db-splice --shard 0/N <final> <final>                        rank 0, after the others: appends <final>.index.1 .. N-1 and
+//                       <final>.lookup.1 .. N-1 to its own index and lookup (already in key order: ranks own contiguous key ranges)
+//                       and removes them.
+//      Nothing per record stays in memory on any rank.
+long long g_key0 = 0; unsigned long long g_off0 = 0;
+static void copy_range(int in, int out, uint64_t n, uint64_t off_out) {
+    off_t oi = 0, oo = (off_t)off_out;
+    bool kernel_copy = true;
+    std::vector<char> buf;
+    while (n) {
+        if (kernel_copy) {
+            const ssize_t k = copy_file_range(in, &oi, out, &oo, (size_t)std::min<uint64_t>(n, 1u << 30), 0);
+            if (k > 0) { n -= (uint64_t)k; continue; }
+            if (k == 0) throw std::runtime_error("partial database is shorter than its index says");
+            kernel_copy = false;                                      // EXDEV / ENOSYS / EINVAL: plain reads and writes
+        }
+        if (buf.empty()) buf.resize(8u << 20);
+        const ssize_t r = pread(in, buf.data(), (size_t)std::min<uint64_t>(n, buf.size()), oi);
+        if (r <= 0) throw std::runtime_error("cannot read the partial database");
+        pwrite_all(out, (const uint8_t*)buf.data(), (uint64_t)r, (uint64_t)oo);
+        oi += r; oo += r; n -= (uint64_t)r;
+    }
+}
+static void append_file(const std::string& from, FILE* to) {
+    const int fd = open(from.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + from);
+    std::vector<char> buf(8u << 20);
+    for (;;) { const ssize_t k = read(fd, buf.data(), buf.size()); if (k < 0) { close(fd); throw std::runtime_error("cannot read " + from); } if (k == 0) break; if (fwrite(buf.data(), 1, (size_t)k, to) != (size_t)k) { close(fd); throw std::runtime_error("cannot write the index"); } }
+    close(fd);
+}
+int run_db_splice(const Options& o) {
+    const std::string part = o.input, fin = o.output;
+    try {
+        if (o.shard_rank == 0) {
+            FILE* fi = fopen((fin + ".index").c_str(), "a"); FILE* fl = fopen((fin + ".lookup").c_str(), "a");
+            if (!fi || !fl) throw std::runtime_error("cannot append to " + fin + ".index");
+            for (int r = 1; r < o.shard_world; r++) {
+                append_file(fin + ".index." + std::to_string(r), fi); append_file(fin + ".lookup." + std::to_string(r), fl);
+            }
+            if (fclose(fi) != 0 || fclose(fl) != 0) throw std::runtime_error("cannot write " + fin + ".index");
+            for (int r = 1; r < o.shard_world; r++) { unlink((fin + ".index." + std::to_string(r)).c_str()); unlink((fin + ".lookup." + std::to_string(r)).c_str()); }
+            return 0;
+        }
+        const int in = open(part.c_str(), O_RDONLY);
+        if (in < 0) throw std::runtime_error("cannot open " + part);
+        struct stat st; fstat(in, &st);
+        const int out = open(fin.c_str(), O_WRONLY | O_CREAT, 0666);
+        if (out < 0) { close(in); throw std::runtime_error("cannot write " + fin); }
+        copy_range(in, out, (uint64_t)st.st_size, g_off0);
+        close(in);
+        if (close(out) != 0) throw std::runtime_error("cannot write " + fin);
+        const std::string tag = "." + std::to_string(o.shard_rank);
+        LineFile li, ll;
+        if (!li.open_at(part + ".index") || !ll.open_at(part + ".lookup")) throw std::runtime_error("cannot open " + part + ".index");
+        FILE* fi = fopen((fin + ".index" + tag).c_str(), "w"); FILE* fl = fopen((fin + ".lookup" + tag).c_str(), "w");
+        if (!fi || !fl) throw std::runtime_error("cannot write " + fin + ".index" + tag);
+        std::vector<char> b1(4u << 20), b2(4u << 20);
+        setvbuf(fi, b1.data(), _IOFBF, b1.size()); setvbuf(fl, b2.data(), _IOFBF, b2.size());
+        const char* q; size_t qn; const char* w[4]; size_t wl[4];
+        while (li.next(q, qn)) {
+            uint64_t k, off, len;
+            if (line_words(q, qn, w, wl) != 3 || !all_digits_u64(w[0], wl[0], k) || !all_digits_u64(w[1], wl[1], off) || !all_digits_u64(w[2], wl[2], len)) throw std::runtime_error("unexpected line in " + part + ".index");
+            fprintf(fi, "%llu\t%llu\t%llu\n", (unsigned long long)k + (unsigned long long)g_key0, (unsigned long long)off + g_off0, (unsigned long long)len);
+        }
+        while (ll.next(q, qn)) {
+            uint64_t k;
+            if (line_words(q, qn, w, wl) < 2 || !all_digits_u64(w[0], wl[0], k)) throw std::runtime_error("unexpected line in " + part + ".lookup");
+            fprintf(fl, "%llu\t", (unsigned long long)k + (unsigned long long)g_key0);
+            fwrite(w[1], 1, (size_t)(q + qn - w[1]), fl); fputc('\n', fl);     // the name and what follows it, as written
+        }
+        if (fclose(fi) != 0 || fclose(fl) != 0) throw std::runtime_error("cannot write " + fin + ".index" + tag);
+        for (const char* ext : {"", ".index", ".lookup", ".dbtype"}) unlink((part + ext).c_str());
+    } catch (const std::exception& e) { fprintf(stderr, "[Error] db-splice: %s\n", e.what()); return 1; }
     return 0;
 }
 
@@ -2493,6 +2687,13 @@ int main(int argc, char** argv) {
         else if (a == "--gpus") next_int(o.gpus);
         else if (a == "--workers-per-gpu") next_int(o.workers_per_gpu);
         else if (a == "--json-stats") o.json_stats = true;
+        else if (a == "--device") next_int(o.device);
+        else if (a == "--key0") { if (i + 1 < argc) g_key0 = atoll(argv[++i]); }
+        else if (a == "--off0") { if (i + 1 < argc) g_off0 = strtoull(argv[++i], nullptr, 10); }
+        else if (a == "--shard") {   // R/N: rank R of N of a sharded run
+            if (i + 1 >= argc || sscanf(argv[++i], "%d/%d", &o.shard_rank, &o.shard_world) != 2 || o.shard_world < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_world) {
+                fprintf(stderr, "[Error] --shard takes R/N with 0 <= R < N\n"); return 1; }
+        }
         else if (a == "--plddt") o.ext_mode = 0;
         else if (a == "--fasta" || a == "--amino-acid") o.ext_mode = 1;
         else if (a == "--use-title") o.use_title = true;
@@ -2552,6 +2753,20 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (o.mode == "rmsd") return run_rmsd(o);
+    if (o.mode == "plan-dump") {   // no GPU: this process's range of the inputs (--shard R/N), one line per item, then a summary line
+        try {
+            InputPlan plan; plan.build(o);
+            uint64_t bytes = 0;
+            plan.for_each([&](const InputItem& it) {
+                if (!o.json_stats) printf("%d\t%s\t%llu\t%llu\n", it.kind, it.name.c_str(), (unsigned long long)it.off, (unsigned long long)(it.len == UINT64_MAX ? 0 : it.len));
+                bytes += it.len == UINT64_MAX ? 0 : it.len;
+            });
+            printf("{\"shard\": \"%d/%d\", \"items\": %llu, \"items_total\": %llu, \"bytes\": %llu, \"bytes_total\": %llu, \"streamed_inputs\": %s, \"max_rss_kb\": %ld}\n", o.shard_rank, o.shard_world,
+                   (unsigned long long)plan.n_mine, (unsigned long long)plan.n_items, (unsigned long long)bytes, (unsigned long long)plan.bytes_total, plan.streamed_all ? "true" : "false", max_rss_kb());
+        } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); return 1; }
+        return 0;
+    }
+    if (o.mode == "db-splice") return run_db_splice(o);
     if (o.mode == "db-pack") return run_db_pack(o);
     if (o.mode == "db-unpack") return run_db_unpack(o);
     usage();

@@ -79,6 +79,15 @@ def test_end_to_end_both_directions(line):
         assert d["first_text_equals_reference"] and d["text_bytes_equal_reference_total"] and d["cpu_reference"]["failed_entries"] == 0
 
 
+def test_sharded_driver_leg(line):
+    """the sharded driver at N = 1 (1-rank group + engine + exchange) writes the database the bare engine writes, both directions"""
+    sh = line["end_to_end"]["sharded"]
+    assert "failed" not in sh, sh
+    for mode in ("compress", "decompress"):
+        assert sh[mode]["world"] == 1 and sh[mode]["database_equals_gpu_host"] and sh[mode]["steady_residues_per_s"] > 0
+    assert sh["compress"]["records"] == 384 * 8
+
+
 def test_resident_ingest_leg(line):
     i = line["pdb_text"]["ingest_of_the_same_text"]
     assert i["files"] == 1024 and i["counts_equal_decoded"] and i["refused"] == 0 and i["text_GBs"] > 0

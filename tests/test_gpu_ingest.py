@@ -210,6 +210,20 @@ def test_text_to_fcz_in_one_call(codec, golden):
         assert no_title(rec) == no_title(z[f"{n}/fcz"].tobytes()), n
 
 
+def test_non_ascii_file_name_keeps_its_whole_stem(codec, golden):
+    """a title that falls back to the file's stem: the stem is cut at the last dot of the ENCODED name (the name blob is UTF-8;
+    a character index would drop one byte per two-byte character before it)"""
+    z, _ = golden
+    text = "".join(l + "\n" for l in _pdb_text(z, "syn:len26").splitlines() if not l.startswith(("TITLE", "HEADER"))).encode()
+    names = ["prot\u00e9ine.v2.pdb", "\u86cb\u767d\u8d28.pdb", "plain.v3.pdb"]
+    r = codec.compress_pdb([text] * 3, names)
+    assert (r["status"] == 0).all() and (r["file_status"] == 0).all()
+    for i, nm in enumerate(names):
+        rec = r["blob"][int(r["off"][i]):int(r["off"][i + 1])].tobytes()
+        na, tl = rec[12], int.from_bytes(rec[24:28], "little")
+        assert rec[76 + 4 * na:76 + 4 * na + tl] == nm.rsplit(".", 1)[0].encode(), nm
+
+
 def test_device_ingest_fuzz_never_parses_differently(codec, golden):
     """seeded mutations of PDB files (characters replaced anywhere, lines cut, moved, duplicated, swapped, CR, tabs and lower case,
     HETATM / ANISOU / MODEL / END / junk lines spliced in; _cases.mutated_pdb, the mutations test_ingest_vs_reference.py puts to

@@ -1,7 +1,10 @@
 """`python -m foldcomp_amd compress|decompress -d --gpus N` (foldcomp_amd/sharded_cli.py): the product driver of the sharded
 database. Two REAL ranks (gloo: they share GPU 0 of the test box; on a node with a GPU per rank the
-backend is nccl = RCCL) run the real codec on their byte-balanced ranges and write one database with shard.write_sharded_db;
-data, .index, .lookup and .dbtype equal the single-process output byte for byte. N = 1 runs the same code in a 1-rank group."""
+backend is nccl = RCCL) each run the pipelined C++ engine (`host/foldcomp-hip --shard R/N`) on their byte-balanced range, exchange
+{records, bytes} in one all_gather and splice their partial databases into one (foldcomp_amd/shard.py); data, .index, .lookup and
+.dbtype equal the single-process output byte for byte. N = 1 runs the same code in a 1-rank group. The engine's memory does not
+grow with the shard (10x the database: the same peak resident set)."""
+import json
 import gzip
 import os
 import subprocess
@@ -74,3 +77,64 @@ def test_two_ranks_compress_and_decompress_equal_the_single_process(tmp_path, go
     # --gpus without -d is refused
     r = _cli("compress", "-y", "--gpus", "2", str(d), str(tmp_path / "dir"))
     assert r.returncode != 0 and "add -d" in r.stderr
+
+
+def _stats(r):
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_shard_memory_is_independent_of_the_shard_size_and_databases_round_trip(tmp_path, golden):
+    """configs[3] / [4] in the small: database in, database out, both directions, two ranks. A database 10x the size leaves the
+    engines' peak resident set where it was (nothing per record is held: jobs stream through, the index is read line by line and
+    written job by job); the PDB-text database goes back through `compress -d --gpus 2` (entries = file images under their lookup
+    names, MMseqs NUL stripped, structure ingest on the device) and equals the single process's and the C++ host's database."""
+    from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+    z, _ = golden
+    recs = [z[f"{n}/fcz"].tobytes() for n in ("syn:len26", "syn:len64", "syn:len129")]
+    host = os.path.join(ROOT, "host", "foldcomp-hip")
+
+    def make(path, n):
+        w = DatabaseWriter(str(path))
+        for k in range(n):
+            w.append(recs[k % 3], k, f"e{k:06d}")
+        w.close()
+    n_small = 12_288                                  # >= 2 workers x 2 full jobs of 2 048 entries per rank: the job buffers reach their size
+    make(tmp_path / "small", n_small); make(tmp_path / "big", 10 * n_small)
+    rss = {}
+    for name in ("small", "big"):
+        r = _cli("decompress", "-d", "-y", "--gpus", "2", "--json-stats", str(tmp_path / name), str(tmp_path / f"{name}_pdb"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        st = _stats(r)
+        assert st["world"] == 2 and st["records"] == (n_small if name == "small" else 10 * n_small) and len(st["records_per_rank"]) == 2
+        assert abs(st["records_per_rank"][0] - st["records"] / 2) <= 2
+        rss[name] = max(st["engine_max_rss_kb_per_rank"])
+    assert rss["big"] < 1.15 * rss["small"] + 32_768, rss
+    # the sharded output == the C++ host's single process, every entry the reference text + NUL
+    r = subprocess.run([host, "decompress", "-d", "-y", str(tmp_path / "small"), str(tmp_path / "small_one")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    _same_db(tmp_path / "small_pdb", tmp_path / "small_one")
+    rd = DatabaseReader(str(tmp_path / "small_pdb"))
+    assert len(rd) == n_small and rd.name(4) == "e000004" and rd.data(4) == z["syn:len64/pdb0"].tobytes() + b"\0"
+    rd.close()
+    # ... and back: PDB-text database -> FCZ database, 2 ranks == 1 rank == the C++ host == the unsharded Python driver
+    r = _cli("compress", "-d", "-y", "--gpus", "2", "--json-stats", str(tmp_path / "small_pdb"), str(tmp_path / "back2"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = _stats(r)
+    assert st["records"] == n_small and st["world"] == 2
+    r = _cli("compress", "-d", "-y", "--gpus", "1", str(tmp_path / "small_pdb"), str(tmp_path / "back1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([host, "compress", "-d", "-y", "--json-stats", str(tmp_path / "small_pdb"), str(tmp_path / "backh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.splitlines()[-1])["host_parsed_files"] == 0     # every entry went through the device ingest
+    _same_db(tmp_path / "back2", tmp_path / "back1")
+    _same_db(tmp_path / "back2", tmp_path / "backh")
+    small = tmp_path / "tiny"
+    w = DatabaseWriter(str(small)); src = DatabaseReader(str(tmp_path / "small_pdb"))
+    for k in range(300):
+        w.append(src.data(k), k, src.name(k))
+    w.close(); src.close()
+    r = _cli("compress", "-d", "-y", str(small), str(tmp_path / "tiny_py"))
+    assert r.returncode == 0, r.stderr
+    r = _cli("compress", "-d", "-y", "--gpus", "2", str(small), str(tmp_path / "tiny_2"))
+    assert r.returncode == 0, r.stderr
+    _same_db(tmp_path / "tiny_py", tmp_path / "tiny_2")

@@ -476,6 +476,9 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
     (d / "f0331.ent.gz").write_bytes(gzip.compress(texts["syn:len129"].encode()))
     (d / "f0337_sci.pdb.gz").write_bytes(gzip.compress(("\n".join(lines[:k] + [lines[k][:30] + " 1.0e+01" + lines[k][38:]] + lines[k + 1:]) + "\n").encode()))
     (d / "f0341_bad.pdb.gz").write_bytes(b"not a gzip stream")
+    # two chains, the first with a BLANK chain id: a blank names nothing ("f0043_blank.fcz", not "f0043_blank .fcz")
+    blank = "".join((l[:21] + " " + l[22:] if l.startswith(("ATOM", "TER")) and len(l) > 22 else l) + "\n" for l in texts["pdb:multichainA"].splitlines() if not l.startswith("END"))
+    (d / "f0043_blank.pdb").write_text(blank + _pdb_text(z, "pdb:multichainB_0"))
     outs = {}
     for tag, extra in (("dev", []), ("host", ["--host-parse"])):
         r = _run("compress", "-d", "-y", "-t", "8", "--gpus", "1", "--json-stats", *extra, str(d), str(tmp_path / f"db_{tag}"))
@@ -483,7 +486,7 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
         st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         outs[tag] = (st, r.stderr)
     assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 2      # the scientific-notation files
-    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1 + 2
+    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1 + 2 + 2
     assert all("f0341_bad" in outs[tag][1] for tag in ("dev", "host"))
     for ext in ("", ".index", ".lookup", ".dbtype"):
         assert (tmp_path / f"db_dev{ext}").read_bytes() == (tmp_path / f"db_host{ext}").read_bytes(), ext
@@ -498,6 +501,6 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
         r = _run("compress", "-y", "-t", "8", *extra, str(d), str(tmp_path / f"dir_{tag}"))
         assert r.returncode == 0, r.stderr
     a, b = sorted(os.listdir(tmp_path / "dir_dev")), sorted(os.listdir(tmp_path / "dir_host"))
-    assert a == b and "f0017_multiB_1.fcz" in a
+    assert a == b and "f0017_multiB_1.fcz" in a and "f0043_blank.fcz" in a and "f0043_blankB.fcz" in a
     for f in a:
         assert (tmp_path / "dir_dev" / f).read_bytes() == (tmp_path / "dir_host" / f).read_bytes(), f

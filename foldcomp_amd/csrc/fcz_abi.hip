@@ -77,6 +77,7 @@ struct fcz_ctx {
     dev_buf ang;        // compress: 6 x R floats
     dev_buf sizes;      // compress: C x u64
     dev_buf scan_tmp;   // block partials of the device scans
+    dev_buf codes;      // decompress: residue codes, one byte per residue at (record offset >> 3) + k (k_entry_sizes -> k_res_index)
     dev_buf res_sc_addr; // compress: residue -> output byte offset of its side-chain torsion bytes
     dev_buf tile_work;   // compress: per 256-residue tile flag + list + count of the tiles left to the block-tile kernel
     // decompress: the totals and the length order computed by fcz_decompress_sizes_dev are reused by the
@@ -225,7 +226,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
+    c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->codes.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
     for (auto& b : c->stage) b.release();
     for (auto& b : c->ig) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -439,7 +440,7 @@ int fcz_compress_sizes_dev(fcz_ctx* ctx, const fcz_chain_batch* in, uint64_t* ou
     int rc = ctx->sizes.ensure(sizeof(uint64_t) * (size_t)in->n_chains);
     if (rc) return rc;
     span_guard g(ctx, "compress_sizes");
-    hipLaunchKernelGGL(k_compress_sizes, dim3(grid_for(in->n_chains, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in, ctx->sizes.as<uint64_t>());
+    hipLaunchKernelGGL(k_compress_sizes, dim3(grid_for(in->n_chains, GROUPS_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in, ctx->sizes.as<uint64_t>());
     rc = device_scan<uint64_t>(ctx, ctx->sizes.as<uint64_t>(), out_off_dev, in->n_chains);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -838,48 +839,47 @@ int fcz_check(const uint8_t* e, uint64_t len) {
     return 0;
 }
 
-// entries ordered by residue count for k_backbone (counting sort: histogram, scan, scatter); cnt_res = per-entry counts
-static int build_len_perm(fcz_ctx* ctx, const uint32_t* cnt_res, uint32_t n) {
-    int rc = ctx->len_perm.ensure(sizeof(uint32_t) * ((size_t)n + 2 * LEN_BUCKETS + 2)); if (rc) return rc;
-    if (!n) return FCZ_OK;
-    uint32_t* perm = ctx->len_perm.as<uint32_t>(); uint32_t* hist = perm + n; uint32_t* cursor = hist + LEN_BUCKETS;
-    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(uint32_t) * LEN_BUCKETS, ctx->stream));
-    hipLaunchKernelGGL(k_len_sort, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, cnt_res, n, hist, perm, 0);
-    if ((rc = device_scan<uint32_t>(ctx, hist, cursor, LEN_BUCKETS))) return rc;
-    hipLaunchKernelGGL(k_len_sort, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, cnt_res, n, cursor, perm, 1);
-    return FCZ_OK;
-}
-
-// The sizes pass of the decompress path: per-entry validation and counts (k_entry_sizes), their exclusive prefixes, the
-// longest anchor segment of the batch (sizes the ring of k_backbone) and the length order of the entries. The totals come
-// back through pinned host words after one stream synchronisation. atom_off_dev may be null (prefix not needed).
+// The sizes pass of the decompress path: per-entry validation and counts (k_entry_sizes), then -- in three launches -- their
+// exclusive prefixes, the longest anchor segment of the batch (sizes the ring of k_backbone), the totals, and the entries ordered by
+// residue count for k_backbone (counting sort, longest first): k_sizes_reduce / _mid / _apply (fcz_kernels.h). The totals come
+// back as ONE 32-byte copy into pinned host words after one stream synchronisation. atom_off_dev may be null (prefix not needed).
 static int run_entry_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n, uint32_t* res_off_dev,
                            uint32_t* atom_off_dev) {
-    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)std::max<uint32_t>(n, 1)); if (rc) return rc;
+    for (int k = 0; k < 8; k++) ctx->pinned[k] = 0;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(res_off_dev, 0, 4, ctx->stream));
+        if (atom_off_dev) HIP_TRY(hipMemsetAsync(atom_off_dev, 0, 4, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return FCZ_OK;
+    }
+    int rc = ctx->cnt.ensure(sizeof(uint32_t) * 4 * (size_t)n); if (rc) return rc;
     uint32_t* cr = ctx->cnt.as<uint32_t>(); uint32_t* ca = cr + n; int32_t* st = (int32_t*)(ca + n); uint32_t* seg = (uint32_t*)(st + n);
-    if ((rc = ctx->maxseg.ensure(16))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->maxseg.p, 0, 16, ctx->stream));   // [0] longest segment, [1] most segments, [2] offset overflow
-    if (n) {
-        hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, st, seg);
-        hipLaunchKernelGGL(k_seg_max, dim3(std::min<uint32_t>(grid_for(n, 1024), 256)), dim3(1024), 0, ctx->stream, seg, n, ctx->maxseg.as<uint32_t>());
+    // len_perm: [perm n][hist LEN_BUCKETS][cursor LEN_BUCKETS + 1][pad][maxseg 2][pad 2][totals 8]
+    if ((rc = ctx->len_perm.ensure(sizeof(uint32_t) * ((size_t)n + 2 * LEN_BUCKETS + 16)))) return rc;
+    uint32_t* perm = ctx->len_perm.as<uint32_t>(); uint32_t* hist = perm + n; uint32_t* cursor = hist + LEN_BUCKETS;
+    uint32_t* maxseg = cursor + LEN_BUCKETS + 4; sizes_totals* totals = (sizes_totals*)(maxseg + 4);
+    const unsigned nb = grid_for(n, SZ_CHUNK);
+    if ((rc = ctx->scan_tmp.ensure(sizeof(unsigned long long) * 2 * ((size_t)nb + 1)))) return rc;
+    unsigned long long* part_r = ctx->scan_tmp.as<unsigned long long>(); unsigned long long* part_a = part_r + nb + 1;
+    // The residue-code array (k_entry_sizes -> k_res_index) has one slot per 8 bytes of the records; their total size is only known
+    // on the device, so the array grows when a pass reports that it needed more -- that pass runs again (the first call, or a larger
+    // batch than any before), every later one runs once with no host round trip before the launches.
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIP_TRY(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (2 * LEN_BUCKETS + 16), ctx->stream));
+        hipLaunchKernelGGL(k_entry_sizes, dim3(grid_for(n, GROUPS_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n, cr, ca, st, seg,
+                           ctx->codes.as<uint8_t>(), (uint64_t)ctx->codes.cap);
+        hipLaunchKernelGGL(k_sizes_reduce, dim3(nb), dim3(1024), 0, ctx->stream, cr, ca, seg, n, part_r, part_a, hist, maxseg);
+        hipLaunchKernelGGL(k_sizes_mid, dim3(1), dim3(1024), 0, ctx->stream, nb, part_r, part_a, hist, cursor, maxseg, totals, off_dev + n);
+        hipLaunchKernelGGL(k_sizes_apply, dim3(nb), dim3(1024), 0, ctx->stream, cr, ca, n, part_r, part_a, res_off_dev, atom_off_dev, cursor, perm);
+        HIP_TRY(hipGetLastError());
+        // pinned: [0] residues [1] atoms [3] longest segment [4] most segments [5] long chains [6] offset overflow; [2], [7] code slots
+        HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], totals, sizeof(sizes_totals), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const uint64_t need = (uint64_t)ctx->pinned[2] | ((uint64_t)ctx->pinned[7] << 32);
+        if (need <= ctx->codes.cap) break;
+        if (attempt == 1) return FCZ_E_HIP;
+        if ((rc = ctx->codes.ensure((size_t)(need + need / 8)))) return rc;
     }
-    // offsets are 32-bit: a batch whose residues or atoms reach 2^32 is refused, not wrapped (the scans add in 64 bits)
-    uint32_t* ovf = ctx->maxseg.as<uint32_t>() + 2;
-    if ((rc = device_scan<uint32_t>(ctx, cr, res_off_dev, n, ovf))) return rc;
-    if (atom_off_dev && (rc = device_scan<uint32_t>(ctx, ca, atom_off_dev, n, ovf))) return rc;
-    if ((rc = build_len_perm(ctx, cr, n))) return rc;
-    HIP_TRY(hipGetLastError());
-    ctx->pinned[1] = 0;
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[0], res_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (atom_off_dev) HIP_TRY(hipMemcpyAsync(&ctx->pinned[1], atom_off_dev + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[3], ctx->maxseg.p, 8, hipMemcpyDeviceToHost, ctx->stream));   // [3] longest segment, [4] most segments
-    HIP_TRY(hipMemcpyAsync(&ctx->pinned[6], ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->pinned[5] = 0;
-    if (n) {   // chains of FCZ_LONG_CHAIN residues or more lead the length order: the end of their last bucket is their count
-        const uint32_t* cursor = ctx->len_perm.as<uint32_t>() + n + LEN_BUCKETS;
-        HIP_TRY(hipMemcpyAsync(&ctx->pinned[5], cursor + len_bucket(FCZ_LONG_CHAIN), 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->pinned[6]) return FCZ_E_INVALID_ARG;   // 2^32 residues or atoms in one batch: split it
     return FCZ_OK;
 }
@@ -994,7 +994,7 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
         span_guard g(ctx, "decompress_index");
         hipLaunchKernelGGL(k_res_index, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
                            res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
-                           ctx->res_sc.as<uint32_t>(), *out_dev);
+                           ctx->res_sc.as<uint32_t>(), *out_dev, ctx->codes.as<uint8_t>());
     }
     {
         span_guard g(ctx, "decompress_sidechain");

@@ -118,22 +118,38 @@ __host__ __device__ __forceinline__ rec_layout make_layout(uint32_t n_res, uint3
 // compress
 // ==================================================================================================
 
-// FCZ size of every chain (Foldcomp::getSize). One wavefront per chain (coalesced residue-code reads).
+// ---- sub-wavefront groups: GROUP lanes (one DPP row) per chain / entry. The per-chain bookkeeping kernels are chains of
+// dependent loads (offset -> header -> arrays) over a few hundred bytes: with one wavefront per chain a SIMD has 8 chains in
+// flight and waits; with a row per chain it has 32, and a row's load of 16 consecutive words is still one whole cache line.
+constexpr int GROUP = 16;
+constexpr int GROUPS_PER_BLOCK = BLOCK / GROUP;
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+    for (int d = GROUP / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, GROUP);
+    return v;
+}
+__device__ __forceinline__ uint32_t group_max(uint32_t v) {
+#pragma unroll
+    for (int d = GROUP / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(v, d, GROUP); v = o > v ? o : v; }
+    return v;
+}
+
+// FCZ size of every chain (Foldcomp::getSize). One 16-lane group per chain (coalesced residue-code reads).
 __global__ __launch_bounds__(BLOCK) void k_compress_sizes(fcz_chain_batch in, uint64_t* __restrict__ sizes) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (c >= in.n_chains) return;
-    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
+    const int sub = threadIdx.x & (GROUP - 1);
+    const uint32_t c = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
+    const bool live = c < in.n_chains;
+    const uint32_t r0 = live ? in.res_off[c] : 0u, n = live ? in.res_off[c + 1] - r0 : 0u;
     uint32_t nsc = 0;
-    for (uint32_t k0 = 0; k0 < n; k0 += 8 * WAVE) {   // eight independent loads in flight per memory round trip
+    for (uint32_t k0 = 0; k0 < n; k0 += 8 * GROUP) {   // eight independent loads in flight per memory round trip
         uint32_t rcs[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * WAVE + lane; rcs[u] = in.res_code[r0 + (k < n ? k : n - 1)]; }
+        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * GROUP + sub; rcs[u] = in.res_code[r0 + (k < n ? k : n - 1)]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (k0 + u * WAVE + lane < n) nsc += fcz_res_natoms[rcs[u] < 24 ? rcs[u] : 23] - 3;
+        for (int u = 0; u < 8; u++) if (k0 + u * GROUP + sub < n) nsc += fcz_res_natoms[rcs[u] < 24 ? rcs[u] : 23] - 3;
     }
-    nsc = wave_sum(nsc);
-    if (lane == 0) {
+    nsc = group_sum(nsc);
+    if (live && sub == 0) {
         const uint32_t n_anchor = n / (uint32_t)in.anchor_threshold + 2;
         sizes[c] = make_layout(n, n_anchor, in.title_off[c + 1] - in.title_off[c], nsc).size;
     }
@@ -222,21 +238,26 @@ __device__ __forceinline__ int res_code_from_letter(uint8_t ch) {
     return 23;
 }
 
-// One wavefront per entry: validate + count (residues, output atoms, status); seg_info[i] = longest anchor segment << 16 |
-// number of segments (0 for a skipped entry)
+// One 16-lane group per entry: validate + count (residues, output atoms, status); seg_info[i] = longest anchor segment << 16 |
+// number of segments (0 for a skipped entry); codes[(record offset >> 3) + k] = residue code of residue k (see below)
 __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                        uint32_t n_entries, uint32_t* __restrict__ cnt_res,
                                                        uint32_t* __restrict__ cnt_atoms, int32_t* __restrict__ status,
-                                                       uint32_t* __restrict__ seg_info) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (i >= n_entries) return;
+                                                       uint32_t* __restrict__ seg_info, uint8_t* __restrict__ codes, uint64_t codes_cap) {
+    const int sub = threadIdx.x & (GROUP - 1);
+    const uint32_t i = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
+    const bool live = i < n_entries;
     uint32_t seg_max = 0;
-    const uint8_t* e = blob + off[i];
-    const uint64_t len = off[i + 1] - off[i];
+    const uint64_t o0 = live ? off[i] : 0ull;
+    const uint8_t* e = blob + o0;
+    const uint64_t len = live ? off[i + 1] - o0 : 0ull;
     int st = FCZ_OK;
     uint32_t n = 0, na_total = 0, n_seg = 0;
-    if (len < 76) st = FCZ_E_TRUNCATED;
+    // every branch below is decided by the entry, i.e. uniform inside a group: the group reductions run with all its lanes
+    uint32_t na = 0, nsc = 0, bad = 0, n_sc_hdr = 0, has_oxt = 0;
+    bool counted = false;
+    if (!live) st = FCZ_E_TRUNCATED;
+    else if (len < 76) st = FCZ_E_TRUNCATED;
     else if (!(e[0] == 'F' && e[1] == 'C' && e[2] == 'M' && e[3] == 'P')) st = FCZ_E_BAD_MAGIC;
     else {
         entry_view v = view_entry(e);
@@ -244,68 +265,53 @@ __global__ __launch_bounds__(BLOCK) void k_entry_sizes(const uint8_t* __restrict
         if ((uint64_t)v.L.size > len || v.title_len > len || v.n_sc > len) st = FCZ_E_TRUNCATED;
         else if (n < 2 || v.n_anchor < 2) st = FCZ_E_TOO_SHORT;
         else {
-            uint32_t na = 0, nsc = 0; int bad = 0;
+            counted = true; n_sc_hdr = v.n_sc; n_seg = v.n_anchor - 1;
             const uint32_t rc_first = (uint32_t)res_code_from_letter(e[20]);  // header.firstResidue, src/foldcomp.cpp:863
-            for (uint32_t k0 = 0; k0 < n; k0 += 8 * WAVE) {   // eight independent loads in flight per memory round trip
+            has_oxt = e[v.L.o_oxt] ? 1u : 0u;
+            for (uint32_t k0 = 0; k0 < n; k0 += 8 * GROUP) {   // eight independent loads in flight per memory round trip
                 uint32_t wb[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * WAVE + lane; wb[u] = e[v.L.o_words + 8 * (size_t)(k < n ? k : n - 1)]; }
+                for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * GROUP + sub; wb[u] = e[v.L.o_words + 8 * (size_t)(k < n ? k : n - 1)]; }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const uint32_t k = k0 + u * WAVE + lane;
+                    const uint32_t k = k0 + u * GROUP + sub;
                     if (k >= n) continue;
                     uint32_t rc = k == 0 ? rc_first : (wb[u] >> 3);
                     if (rc >= 24) rc = 23;
-                    if (!res_code_ok(rc)) bad = 1;
+                    if (!res_code_ok(rc)) bad |= 1u;
                     na += fcz_res_natoms[rc]; nsc += fcz_res_natoms[rc] - 3;
+                    // the residue codes, one byte each, where k_res_index finds them without walking the 8-byte words again: a record
+                    // holds at least 8 bytes per residue, so slot (record offset / 8) + k is this residue's alone
+                    const uint64_t ci = (o0 >> 3) + k;
+                    if (ci < codes_cap) codes[ci] = (uint8_t)rc;
                 }
             }
             // anchor indices must be usable as segment bounds
-            for (uint32_t s = lane; s + 1 < v.n_anchor; s += WAVE) {
+            for (uint32_t s = sub; s + 1 < v.n_anchor; s += GROUP) {
                 int a = (int)ld_u32(e + v.L.o_aidx + 4 * s), b = (int)ld_u32(e + v.L.o_aidx + 4 * (s + 1));
-                if (a < 0 || b < a || b > (int)n - 1) bad = 2;
-                if (s == 0 && a != 0) bad = 2;
-                if (s + 2 == v.n_anchor && b != (int)n - 1) bad = 2;
+                if (a < 0 || b < a || b > (int)n - 1) bad |= 2u;
+                if (s == 0 && a != 0) bad |= 2u;
+                if (s + 2 == v.n_anchor && b != (int)n - 1) bad |= 2u;
                 if (b >= a && (uint32_t)(b - a + 1) > seg_max) seg_max = (uint32_t)(b - a + 1);
             }
-            na = wave_sum(na); nsc = wave_sum(nsc);
-            if (__any(bad == 1)) st = FCZ_E_RESIDUE;
-            else if (__any(bad == 2) || nsc != v.n_sc) st = FCZ_E_TRUNCATED;
-            else { na_total = na + (e[v.L.o_oxt] ? 1 : 0); n_seg = v.n_anchor - 1; }
         }
     }
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(seg_max, d, WAVE); seg_max = o > seg_max ? o : seg_max; }
-    if (lane == 0) {
+    // (whole wavefront here: groups that skipped the counting carry zeros)
+    na = group_sum(na); nsc = group_sum(nsc);
+    const uint32_t bad1 = group_max(bad & 1u), bad2 = group_max(bad & 2u);
+    seg_max = group_max(seg_max);
+    if (counted) {
+        if (bad1) st = FCZ_E_RESIDUE;
+        else if (bad2 || nsc != n_sc_hdr) st = FCZ_E_TRUNCATED;
+        else na_total = na + has_oxt;
+    }
+    if (live && sub == 0) {
         const bool ok = st == FCZ_OK;
         cnt_res[i] = ok ? n : 0; cnt_atoms[i] = ok ? na_total : 0;
         status[i] = st;
-        // one contended atomic per entry would serialise (~88 atomics/us on one address): only the rare raisers go through
-        // longest segment and segment count of the entry; k_seg_max reduces them over the batch (a global atomic per entry
+        // longest segment and segment count of the entry; k_sizes_reduce reduces them over the batch (a global atomic per entry
         // serialises on its address: 2.2 ms per 100 000 entries of mixed length)
         seg_info[i] = ok ? ((seg_max < 0xffffu ? seg_max : 0xffffu) << 16) | (n_seg < 0xffffu ? n_seg : 0xffffu) : 0u;
-    }
-}
-
-// out[0] = longest anchor segment of the batch, out[1] = most segments of a chain (out zeroed by the caller): block-level
-// reduction, then one atomic per block
-__global__ __launch_bounds__(1024) void k_seg_max(const uint32_t* __restrict__ seg_info, uint32_t n, uint32_t* __restrict__ out) {
-    __shared__ uint32_t s_a[16], s_b[16];
-    uint32_t a = 0, b = 0;
-    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
-        const uint32_t v = seg_info[i];
-        a = (v >> 16) > a ? (v >> 16) : a; b = (v & 0xffffu) > b ? (v & 0xffffu) : b;
-    }
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) {
-        const uint32_t oa = __shfl_xor(a, d, WAVE), ob = __shfl_xor(b, d, WAVE);
-        a = oa > a ? oa : a; b = ob > b ? ob : b;
-    }
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++) { a = s_a[w] > a ? s_a[w] : a; b = s_b[w] > b ? s_b[w] : b; }
-        atomicMax(out, a); atomicMax(out + 1, b);
     }
 }
 
@@ -372,32 +378,155 @@ __host__ __device__ __forceinline__ uint32_t len_bucket(uint32_t n_res) {
     const uint32_t b = n_res >> 4;
     return (uint32_t)LEN_BUCKETS - 1u - (b < (uint32_t)LEN_BUCKETS ? b : (uint32_t)LEN_BUCKETS - 1u);
 }
-// mode 0: hist[bucket] += 1 per chain; mode 1: perm[cursor[bucket]++] = chain
-__global__ __launch_bounds__(BLOCK) void k_len_sort(const uint32_t* __restrict__ cnt_res, uint32_t n, uint32_t* __restrict__ counter,
-                                                    uint32_t* __restrict__ perm, int mode) {
-    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool act = c < n;
-    const uint32_t b = act ? len_bucket(cnt_res[c]) : 0xffffffffu;
-    unsigned long long todo = __ballot(act);
-    // a few aggregated rounds take care of buckets shared by many lanes (a uniform batch: one atomic per wavefront); lanes
-    // whose bucket is rare in the wavefront then go one by one -- their addresses hardly collide
-    for (int round = 0; round < 4 && todo; round++) {
-        const int leader = __builtin_ctzll(todo);
-        const uint32_t b0 = __shfl(b, leader, WAVE);
-        const unsigned long long same = __ballot(act && b == b0) & todo;
-        if (act && b == b0 && ((todo >> lane) & 1ull)) {
-            const uint32_t rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&counter[b0], (uint32_t)__builtin_popcountll(same));
-            base = __shfl(base, leader, WAVE);
-            if (mode) perm[base + rank] = c;
-        }
-        todo &= ~same;
+// ---- after k_entry_sizes: offsets, totals and the length order in three launches -----------------------------------------------
+// (round 3 ran 13: two three-launch scans, a segment-maximum reduction, and a two-pass counting sort whose wavefront-aggregated
+// atomics still serialised -- a uniform batch puts one atomic per wavefront on ONE address, 15 625 of them at ~88 per
+// microsecond = the 0.18 ms each pass took.) Chunks of 4 096 entries per block:
+//   k_sizes_reduce  chunk sums of residue and atom counts (scan partials), batch maxima of segment length / count, and the
+//                   chunk's length histogram built in LDS -- one global atomic per bucket the chunk actually holds;
+//   k_sizes_mid     one block: exclusive scans of the chunk sums and of the histogram (bucket cursors), the totals word
+//                   {residues, atoms, -, longest segment, most segments, long chains, overflow};
+//   k_sizes_apply   per chunk: the offsets (block scan + chunk carry) and the scatter of the length order -- LDS histogram again,
+//                   one global atomic per held bucket hands the chunk its run of the bucket, ranks inside the run from LDS.
+constexpr int SZ_CHUNK = 4096;
+struct sizes_totals { uint32_t residues, atoms, codes_lo, max_seg, max_nseg, n_long, overflow, codes_hi; };
+
+__global__ __launch_bounds__(1024) void k_sizes_reduce(const uint32_t* __restrict__ cnt_res, const uint32_t* __restrict__ cnt_atoms,
+                                                       const uint32_t* __restrict__ seg_info, uint32_t n,
+                                                       unsigned long long* __restrict__ part_res, unsigned long long* __restrict__ part_atoms,
+                                                       uint32_t* __restrict__ hist, uint32_t* __restrict__ maxseg) {
+    __shared__ uint32_t s_h[LEN_BUCKETS];
+    __shared__ unsigned long long s_r[16], s_a[16];
+    __shared__ uint32_t s_ms[16], s_mn[16];
+    for (int k = threadIdx.x; k < LEN_BUCKETS; k += 1024) s_h[k] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SZ_CHUNK;
+    unsigned long long sr = 0, sa = 0; uint32_t ms = 0, mn = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t i = base + u * 1024 + threadIdx.x;
+        const bool act = i < n;
+        const uint32_t r = act ? cnt_res[i] : 0u, a = act ? cnt_atoms[i] : 0u, sg = act ? seg_info[i] : 0u;
+        sr += r; sa += a;
+        ms = (sg >> 16) > ms ? (sg >> 16) : ms; mn = (sg & 0xffffu) > mn ? (sg & 0xffffu) : mn;
+        const uint32_t b = len_bucket(r);
+        // (every lane of the wavefront takes part in the ballots)
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        const unsigned long long all = __ballot(act), same = __ballot(act && b == b0);
+        if (all != 0ull && same == all && act) { if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(all)) atomicAdd(&s_h[b], (uint32_t)__builtin_popcountll(all)); }
+        else if (act) atomicAdd(&s_h[b], 1u);
     }
-    if ((todo >> lane) & 1ull) {
-        const uint32_t base = atomicAdd(&counter[b], 1u);
-        if (mode) perm[base] = c;
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        sr += __shfl_xor(sr, d, WAVE); sa += __shfl_xor(sa, d, WAVE);
+        const uint32_t o1 = __shfl_xor(ms, d, WAVE), o2 = __shfl_xor(mn, d, WAVE);
+        ms = o1 > ms ? o1 : ms; mn = o2 > mn ? o2 : mn;
+    }
+    if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6] = sr; s_a[threadIdx.x >> 6] = sa; s_ms[threadIdx.x >> 6] = ms; s_mn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) { sr += s_r[w]; sa += s_a[w]; ms = s_ms[w] > ms ? s_ms[w] : ms; mn = s_mn[w] > mn ? s_mn[w] : mn; }
+        part_res[blockIdx.x] = sr; part_atoms[blockIdx.x] = sa;
+        if (ms) atomicMax(maxseg, ms);
+        if (mn) atomicMax(maxseg + 1, mn);
+    }
+    for (int k = threadIdx.x; k < LEN_BUCKETS; k += 1024) { const uint32_t v = s_h[k]; if (v) atomicAdd(&hist[k], v); }
+}
+
+// block-wide exclusive scan of one value per thread (1 024 threads); *total = the sum. Two barriers.
+__device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long* s_w, unsigned long long* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const unsigned long long t = __shfl_up(inc, d, WAVE); if (lane >= d) inc += t; }
+    __syncthreads();                         // (s_w may still be read from the previous call)
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+    for (int w = 0; w < 16; w++) { const unsigned long long x = s_w[w]; if (w < wave) pre += x; tot += x; }
+    *total = tot;
+    return pre + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void k_sizes_mid(uint32_t nb, unsigned long long* __restrict__ part_res, unsigned long long* __restrict__ part_atoms,
+                                                    const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+                                                    const uint32_t* __restrict__ maxseg, sizes_totals* __restrict__ totals,
+                                                    const uint64_t* __restrict__ off_end) {
+    __shared__ unsigned long long s_w[16];
+    unsigned long long carry_r = 0, carry_a = 0, tot;
+    for (uint32_t base = 0; base < nb; base += 1024) {            // the chunk sums, in place: sum -> sum of the chunks before
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long vr = i < nb ? part_res[i] : 0ull, va = i < nb ? part_atoms[i] : 0ull;
+        const unsigned long long er = block_excl_scan_1024(vr, s_w, &tot); if (i < nb) part_res[i] = carry_r + er; carry_r += tot;
+        const unsigned long long ea = block_excl_scan_1024(va, s_w, &tot); if (i < nb) part_atoms[i] = carry_a + ea; carry_a += tot;
+    }
+    // bucket cursors: four consecutive buckets per thread
+    uint32_t h[4]; unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { h[k] = hist[4 * threadIdx.x + k]; mine += h[k]; }
+    unsigned long long ex = block_excl_scan_1024(mine, s_w, &tot);
+    const uint32_t long_b = len_bucket(FCZ_LONG_CHAIN);            // chains of FCZ_LONG_CHAIN residues or more lead the order: buckets 0 .. long_b
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        cursor[4 * threadIdx.x + k] = (uint32_t)ex; ex += h[k];
+        if (4 * threadIdx.x + k == long_b) totals->n_long = (uint32_t)ex;
+    }
+    if (threadIdx.x == 0) {
+        cursor[LEN_BUCKETS] = (uint32_t)tot;
+        totals->residues = (uint32_t)carry_r; totals->atoms = (uint32_t)carry_a;
+        const uint64_t need = (*off_end >> 3) + 1;                  // slots of the residue-code array (k_entry_sizes)
+        totals->codes_lo = (uint32_t)need; totals->codes_hi = (uint32_t)(need >> 32);
+        totals->max_seg = maxseg[0]; totals->max_nseg = maxseg[1];
+        // offsets are 32-bit: a batch whose residues or atoms reach 2^32 is refused, not wrapped (the sums are 64-bit)
+        totals->overflow = ((carry_r >> 32) || (carry_a >> 32)) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sizes_apply(const uint32_t* __restrict__ cnt_res, const uint32_t* __restrict__ cnt_atoms, uint32_t n,
+                                                      const unsigned long long* __restrict__ part_res, const unsigned long long* __restrict__ part_atoms,
+                                                      uint32_t* __restrict__ res_off, uint32_t* __restrict__ atom_off,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t s_h[LEN_BUCKETS];      // the chunk's entries per bucket, then the next free slot of the chunk's run
+    __shared__ unsigned long long s_w[16];
+    for (int k = threadIdx.x; k < LEN_BUCKETS; k += 1024) s_h[k] = 0;
+    const uint32_t base = blockIdx.x * SZ_CHUNK;
+    unsigned long long carry_r = part_res[blockIdx.x], carry_a = part_atoms[blockIdx.x], tot;
+    uint32_t r[4];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t i = base + u * 1024 + threadIdx.x;
+        const bool act = i < n;
+        r[u] = act ? cnt_res[i] : 0u;
+        const uint32_t a = act ? cnt_atoms[i] : 0u;
+        const unsigned long long er = block_excl_scan_1024(r[u], s_w, &tot); if (act) res_off[i] = (uint32_t)(carry_r + er); carry_r += tot;
+        if (atom_off) { const unsigned long long ea = block_excl_scan_1024(a, s_w, &tot); if (act) atom_off[i] = (uint32_t)(carry_a + ea); carry_a += tot; }
+        const uint32_t b = len_bucket(r[u]);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        const unsigned long long all = __ballot(act), same = __ballot(act && b == b0);
+        if (all != 0ull && same == all && act) { if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(all)) atomicAdd(&s_h[b], (uint32_t)__builtin_popcountll(all)); }
+        else if (act) atomicAdd(&s_h[b], 1u);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { res_off[n] = (uint32_t)carry_r; if (atom_off) atom_off[n] = (uint32_t)carry_a; }
+    __syncthreads();
+    // the chunk's run of every bucket it holds: count -> first slot
+    for (int k = threadIdx.x; k < LEN_BUCKETS; k += 1024) { const uint32_t v = s_h[k]; if (v) s_h[k] = atomicAdd(&cursor[k], v); }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t i = base + u * 1024 + threadIdx.x;
+        const bool act = i < n;
+        const uint32_t b = len_bucket(r[u]);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        const unsigned long long all = __ballot(act), same = __ballot(act && b == b0);
+        if (all != 0ull && same == all && act) {
+            // the whole wavefront in one bucket: one LDS atomic, ranks by lane order
+            const int leader = __builtin_ctzll(all);
+            uint32_t slot = 0;
+            if ((int)(threadIdx.x & 63) == leader) slot = atomicAdd(&s_h[b], (uint32_t)__builtin_popcountll(all));
+            slot = __shfl(slot, leader, WAVE);
+            perm[slot + (uint32_t)__builtin_popcountll(all & ((1ull << (threadIdx.x & 63)) - 1ull))] = i;
+        } else if (act) perm[atomicAdd(&s_h[b], 1u)] = i;
     }
 }
 

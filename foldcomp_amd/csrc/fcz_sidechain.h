@@ -37,7 +37,7 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
                                                      uint32_t n_entries, const uint32_t* __restrict__ res_off,
                                                      const uint32_t* __restrict__ atom_off, uint32_t n_res,
                                                      uint32_t* __restrict__ res_aoff, uint8_t* __restrict__ res_rc,
-                                                     uint32_t* __restrict__ res_sc, fcz_atoms_out out) {
+                                                     uint32_t* __restrict__ res_sc, fcz_atoms_out out, const uint8_t* __restrict__ codes) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= n_entries) return;
@@ -46,9 +46,10 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
     const uint8_t* e = blob + off[c];
     const entry_view v = view_entry(e);
     const uint32_t abase = atom_off[c];
-    const uint32_t first_rc = (uint32_t)res_code_from_letter(e[20]);
     const float tmin = ld_f32(e + v.L.o_tmp), tcf = ld_f32(e + v.L.o_tmp + 4);
-    const uint8_t* words = e + v.L.o_words;
+    // residue codes: the byte array the sizes pass left (k_entry_sizes: first residue already from the header, codes clamped) --
+    // consecutive bytes instead of one byte out of every 8-byte word (a whole extra pass over the words array)
+    const uint8_t* rcs = codes + (off[c] >> 3);
     const uint8_t* scb = e + v.L.o_sc;
     uint32_t run = 0;
     auto emit = [&](uint32_t k, uint32_t rc, uint32_t tq, uint32_t ex, uint32_t q0, uint32_t q1, uint32_t q2) {
@@ -69,13 +70,13 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t k = u * WAVE + lane, kc = k < n ? k : n - 1;
-            wb[u] = words[8 * (size_t)kc];
+            wb[u] = rcs[kc];
             tq[u] = e[v.L.o_tbytes + kc];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t k = u * WAVE + lane;
-            uint32_t r = (k == 0) ? first_rc : (wb[u] >> 3);
+            uint32_t r = wb[u];
             if (r >= 24) r = 23;
             rc[u] = r;
             na[u] = k < n ? (uint32_t)fcz_res_natoms[r] : 0u;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
             const bool act = k < n;
             uint32_t na = 0, rc = 23, tq = 0;
             if (act) {
-                rc = (k == 0) ? first_rc : (uint32_t)(words[8 * (size_t)k] >> 3);
+                rc = rcs[k];
                 tq = e[v.L.o_tbytes + k];
                 if (rc >= 24) rc = 23;
                 na = fcz_res_natoms[rc];

@@ -34,10 +34,10 @@ def test_mixed_100k_oracle_sample_bit_exact(mixed_workload):
     lens = (d["res_off"][1:] - d["res_off"][:-1]).cpu().numpy()
     assert len(lens) == 100_000 and lens.min() >= 16 and lens.max() > 1024     # the split long-chain path is exercised
     n = 4096                       # 1.2 M residues, 6.6 M side-chain torsion bytes: rare mis-rounded values would show
-    hb = bench.host_sample(d, n)
-    ok_c, ok_d = bench.parity_sample(hb, w.blob_dev, w.off_dev, w.out_t, None, n)
-    assert ok_c, "FCZ bytes of the first 4096 chains differ from the oracle"
-    assert ok_d, "coordinates of the first 4096 chains differ from the oracle"
+    pc = bench.parity_check(d, w, n, chunk=1024)
+    assert pc["chains_checked"] == n
+    assert pc["fcz_bit_exact"], f"FCZ bytes of the first 4096 chains differ from the oracle (first: chain {pc['first_fcz_mismatch_chain']})"
+    assert pc["coords_bit_exact"], f"coordinates of the first 4096 chains differ from the oracle (first: chain {pc['first_coords_mismatch_chain']})"
     # the longest chains sit anywhere in the batch: check the 8 longest against the oracle too
     big = np.argsort(lens)[-8:]
     off = w.off_dev.cpu().numpy().astype(np.int64)
@@ -113,9 +113,8 @@ def test_configs2_full_size_decompress_only(codec):
     assert w.R > 150_000_000 and torch.equal(w.res_off_dev, d["res_off"].to(torch.int32))
     x0 = w.out_t["x"].clone()
     n = 4096
-    hb = bench.host_sample(d, n)
-    ok_c, ok_d = bench.parity_sample(hb, w.blob_dev, w.off_dev, w.out_t, None, n)
-    assert ok_c and ok_d, "the 4 096-chain sample differs from the oracle"
+    pc = bench.parity_check(d, w, n)
+    assert pc["fcz_bit_exact"] and pc["coords_bit_exact"], f"the 4 096-chain sample differs from the oracle: {pc}"
     w.decompress(); codec.synchronize()
     assert torch.equal(w.out_t["x"].view(torch.int32), x0.view(torch.int32)), "decompress-only is not repeatable"
     rmsd, mx = w.round_trip_deviation()

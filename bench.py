@@ -232,6 +232,21 @@ def measured_traffic(kernel, n_residues, n_res_per_chain):
         return None, None
 
 
+def controller_side_traffic(kernel, n_residues, n_res_per_chain):
+    """the same kernel's bytes per launch as the MEMORY CONTROLLERS saw them (profiles/traffic.json `controller_side`, from
+    tools/hbm_busy_probe.py: the driver's mem_busy_percent during a seconds-long loop of that one kernel, calibrated on device
+    copies); (bytes, fabric-side bytes of the same scope, source) or (None, None, None)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        if int(t["residues_per_chain"]) != int(n_res_per_chain):
+            return None, None, None
+        c = t["controller_side"]
+        return c["bytes_per_residue"][kernel] * n_residues, c["fabric_side_counters_same_scope"][kernel] * n_residues, c["source"]
+    except (OSError, KeyError, ValueError):
+        return None, None, None
+
+
 def copy_ceiling(dev, nbytes=1 << 30, reps=5):
     """measured device-to-device copy rate (read + write bytes) -- the practical HBM ceiling next to the 8 TB/s peak"""
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
@@ -1220,14 +1235,19 @@ def main():
                     "simd_cycles_per_valu_wave_inst": round(ms * 1e-3 * 2.4e9 * n_simd / (tk["valu_wave_insts_per_residue"] * R), 2) if ms else None,
                     "issue_cost_of_the_mix_cycles": "2.9 (f32 add/mul/fma) ... 4.6 (f64, compares, 3-operand integer) ... 16 (f64 rsq): profiles/r3_valu_rates.txt",
                     "valu_active_share_of_simd_cycles": round(tk["valu_active_share_of_wave_cycles"] * occ, 3) if occ else None,
-                    "resident_wavefronts_per_simd": occ, "source": "profiles/traffic.json (r3_v1 PMC passes) + this run's HIP-event time; 2.4 GHz"}
+                    "resident_wavefronts_per_simd": occ, "source": "profiles/traffic.json (PMC passes) + this run's HIP-event time; 2.4 GHz"}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
+        ctl, ctl_fabric, ctl_src = controller_side_traffic(dom, R, -1 if args.mixed else n_res)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "traffic_note": "FETCH_SIZE / WRITE_SIZE count requests that leave the L2 towards the fabric, hits in the 256 MB Infinity Cache "
-                                    "included (MI355X_MICROARCH.md); k_backbone's per-group ring (~190 MB live) fits that cache, so for it this is an "
-                                    "upper bound on HBM bytes, not a measurement of them",
+                    "traffic_controller_side": ctl, "traffic_controller_side_source": ctl_src,
+                    "traffic_note": "`traffic` = FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes (requests leaving the L2 towards the fabric; the exact-unit "
+                                    "TCC_EA0_*_DRAM_32B counters of the same passes give the same bytes). `traffic_controller_side` = what the memory controllers "
+                                    "saw of the same launch (mem_busy_percent during a loop of this one kernel, calibrated on copies): for k_res_index, k_sidechain "
+                                    "and the compress kernels the two agree within 1 %; for k_backbone the controllers see 165 of the 198 B/residue -- the Infinity "
+                                    "Cache absorbs a sixth of its ring traffic, the rest is real HBM traffic (forward atoms and torsion trig of a segment, written "
+                                    "once and read back once by the reverse pass: 120 B/residue by construction of the two-sweep algorithm, 17x the algorithmic bytes)",
                     "secondary_bound": valu,
                     "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
                     "kernel_ms": {k: round(v, 4) for k, v in ktime.items()},

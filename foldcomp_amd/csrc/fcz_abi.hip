@@ -105,6 +105,10 @@ struct fcz_ctx {
     bool timing = false;
     bool keep_first_angle = false;
     int numerics = FCZ_NUMERICS_EXACT;
+    // profiling aid (tools/hbm_busy_probe.py): FCZ_PROFILE_STAGES=<mask> in the environment (read at every decompress batch call)
+    // leaves out stages of the call so that ONE kernel fills the device for seconds (1 backbone, 2 residue index, 4 side chains;
+    // unset = all). The outputs are then stale by construction: never set outside a profiling run.
+    unsigned profile_stages = 7u;
     dev_buf fast_scratch;   // decompress, FCZ_NUMERICS_FAST: forward atoms of segments longer than one chunk
     // structure ingest: scratch atom table, per-file lists, the resident batch of the last ingest call
     dev_buf ig[40];
@@ -930,7 +934,9 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     const uint32_t* perm = ctx->len_perm.as<uint32_t>();
     const bool fast_bb = ctx->numerics == FCZ_NUMERICS_FAST, fast_sc = fast_bb;
-    if (fast_bb) {
+    { const char* ps = getenv("FCZ_PROFILE_STAGES"); ctx->profile_stages = ps ? ((unsigned)strtoul(ps, nullptr, 0) & 7u) : 7u; }
+    if (!(ctx->profile_stages & 1u)) { /* profiling aid: no backbone launch */ }
+    else if (fast_bb) {
         // plain-float backbone: 8 chains per wavefront, the forward atoms of a segment stay in LDS; only segments longer than
         // one chunk (FB_K residue steps) park them in a scratch column, and then the launch is cut so that the columns of the
         // wavefronts in flight fit 4 GB
@@ -990,13 +996,13 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     rc = ctx->res_aoff.ensure(sizeof(uint32_t) * ((size_t)R + 1)); if (rc) return rc;
     rc = ctx->res_rc.ensure((size_t)R); if (rc) return rc;
     rc = ctx->res_sc.ensure(sizeof(uint32_t) * 3 * (size_t)R); if (rc) return rc;
-    {
+    if (ctx->profile_stages & 2u) {
         span_guard g(ctx, "decompress_index");
         hipLaunchKernelGGL(k_res_index, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
                            res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
                            ctx->res_sc.as<uint32_t>(), *out_dev, ctx->codes.as<uint8_t>());
     }
-    {
+    if (ctx->profile_stages & 4u) {
         span_guard g(ctx, "decompress_sidechain");
         const uint32_t n_tiles = grid_for(R, SC_TILE);
         const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_SIDECHAIN_MIN_BLOCKS * FCZ_SC_GRID_FACTOR);

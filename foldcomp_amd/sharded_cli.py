@@ -106,12 +106,20 @@ def run(a, inputs: List[str], output: str) -> int:
         t_group = time.perf_counter()
         part = output if rank == 0 else f"{output}.part{rank}"
         env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}     # (a launcher exports OMP_NUM_THREADS=1: the engine gets -t)
-        r = subprocess.run(engine_command(a, rank, world, device_index, part), env=env, stdout=subprocess.PIPE, text=True)
+        proc = subprocess.Popen(engine_command(a, rank, world, device_index, part), env=env, stdout=subprocess.PIPE, text=True)
+        # while the engine works: the communicator. RCCL builds its rings on the first collective (~1 s); doing that here keeps it
+        # off the path between the engines' end and the exchange
+        warm = torch.zeros(1, dtype=torch.int64, device=tdev)
+        dist.all_reduce(warm)
+        if tdev is not None:
+            torch.cuda.synchronize(tdev)
+        t_comm = time.perf_counter()
+        stdout, _ = proc.communicate()
         st = {}
-        for line in r.stdout.splitlines():
+        for line in stdout.splitlines():
             if line.startswith("{"):
                 st = json.loads(line)
-        failed = r.returncode != 0 or not st
+        failed = proc.returncode != 0 or not st
         t_engine = time.perf_counter()
         extra = [st.get("residues", 0), int(st.get("wall_s", 0.0) * 1e6), int(st.get("ctx_ready_s", 0.0) * 1e6), st.get("max_rss_kb", 0),
                  st.get("items", st.get("files", 0)), st.get("input_bytes", st.get("fcz_bytes", 0))]
@@ -137,7 +145,7 @@ def run(a, inputs: List[str], output: str) -> int:
                               "residues": res, "input_bytes": sum(r_[8] for r_ in rows),
                               "records_per_rank": [r_[0] for r_ in rows], "bytes_per_rank": [r_[1] for r_ in rows],
                               "engine_max_rss_kb_per_rank": [r_[6] for r_ in rows],
-                              "wall_s": round(t_done - t_start, 4), "group_init_s": round(t_group - t_start, 4),
+                              "wall_s": round(t_done - t_start, 4), "group_init_s": round(t_group - t_start, 4), "communicator_s_beside_engine": round(t_comm - t_group, 4),
                               "engine_s": round(t_engine - t_group, 4), "engine_wall_s_max": round(eng_wall, 4),
                               "engine_steady_s_max": round(steady, 4), "exchange_and_splice_s": round(t_done - t_engine, 4),
                               "residues_per_s": round(res / (t_done - t_start), 1) if t_done > t_start else None,

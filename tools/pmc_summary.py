@@ -17,6 +17,8 @@ for k, v in sorted(d.items()):
     print("  per residue: valu wave-insts %.2f (thread util %.0f%%) vmem_rd %.3f vmem_wr %.3f lds %.3f salu %.2f | fetch %.1f B (x2 corrected) write %.1f B" % (
         g("SQ_INSTS_VALU") / R, 100 * g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_ACTIVE_INST_VALU") * 64, 1), g("SQ_INSTS_VMEM_RD") / R, g("SQ_INSTS_VMEM_WR") / R,
         g("SQ_INSTS_LDS") / R, g("SQ_INSTS_SALU") / R, 2 * g("FETCH_SIZE") * 1024 / R, g("WRITE_SIZE") * 1024 / R))
+    if "TCC_EA0_RDREQ_DRAM_32B_sum" in v:
+        print("  per residue, 32-byte request pieces towards DRAM: read %.1f B write %.1f B" % (32.0 * g("TCC_EA0_RDREQ_DRAM_32B_sum") / R, 32.0 * g("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum") / R))
 
 # calibration (tools/pmc_calibrate.hip: every kernel reads 2^30 and writes 2^30 bytes, last two slightly less)
 cal = {}
@@ -48,6 +50,10 @@ for k, v in d.items():
     if "fcz::k_" not in k or "FETCH_SIZE" not in v: continue
     out["kernels"][short(k)] = {"fetch_bytes_per_residue": round(2 * v["FETCH_SIZE"] * 1024 / R, 2),
                                         "write_bytes_per_residue": round(v.get("WRITE_SIZE", 0.0) * 1024 / R, 2)}
+    if "TCC_EA0_RDREQ_DRAM_32B_sum" in v and "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum" in v:
+        # exact units (32-byte pieces of the L2's requests towards the memory controllers): preferred by bench.py when present
+        out["kernels"][short(k)]["dram_read_bytes_per_residue"] = round(32.0 * v["TCC_EA0_RDREQ_DRAM_32B_sum"] / R, 2)
+        out["kernels"][short(k)]["dram_write_bytes_per_residue"] = round(32.0 * v["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] / R, 2)
     if "SQ_WAVE_CYCLES" in v:
         # the other bound: VALU issue. Share of its lifetime a wavefront spends issuing VALU instructions, and the
         # VALU wave-instructions per residue (x resident wavefronts per SIMD = share of the SIMD's cycles that issue VALU work)

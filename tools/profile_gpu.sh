@@ -56,7 +56,12 @@ fi
 run pmc_sq1 --kernel-include-regex "fcz" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --kernel-include-regex "fcz" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
 if [ -z "${NO_MEM:-}" ]; then run pmc_fetch --kernel-include-regex "fcz" --pmc FETCH_SIZE
-run pmc_write --kernel-include-regex "fcz" --pmc WRITE_SIZE; fi
+run pmc_write --kernel-include-regex "fcz" --pmc WRITE_SIZE
+# the same traffic in exact units: the L2's requests towards the memory controllers counted in 32-byte pieces (a 64-byte request
+# counts 2, a 128-byte one 4), reads and writes in separate passes. Like FETCH_SIZE / WRITE_SIZE they sit on the L2's fabric side;
+# tools/hbm_busy_probe.py holds them against the memory controllers' own activity level.
+run pmc_dram_rd --kernel-include-regex "fcz" --pmc TCC_EA0_RDREQ_DRAM_32B_sum
+run pmc_dram_wr --kernel-include-regex "fcz" --pmc TCC_EA0_WRREQ_WRITE_DRAM_32B_sum; fi
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts in the kernels' own access patterns
 if [ -z "${NO_MEM:-}" ]; then
   hipcc --offload-arch=gfx950 -O3 -w -o /tmp/pmc_calibrate $REPO/tools/pmc_calibrate.hip

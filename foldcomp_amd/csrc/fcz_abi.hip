@@ -27,6 +27,7 @@
 #include "fcz_pdb.h"
 #include "fcz_extract.h"
 #include "fcz_ingest.h"
+#include "fcz_ingest_cif.h"
 
 // second, host-side instance of the generated tables (integer metadata for sizes/validation)
 namespace host_tab {
@@ -598,6 +599,13 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
     {
         span_guard g(ctx, "ingest_parse");
         hipLaunchKernelGGL(k_ingest_parse, dim3(n_files), dim3(WAVE), 0, ctx->stream, text_dev, file_off_dev, n_files, text_bytes,
+                           (const uint64_t*)P(B_ABASE), T, (uint8_t*)P(B_TITLES), (uint32_t*)P(B_TLEN), (uint32_t*)P(B_NKEPT), (int32_t*)P(B_STATUS));
+    }
+    {
+        // mmCIF text: the files the PDB kernel left to the host because they open with `data_` (a wavefront of any other file returns
+        // at once); what this kernel cannot promise to read as the reference's reader would stays handed back
+        span_guard g(ctx, "ingest_parse_cif");
+        hipLaunchKernelGGL(k_ingest_parse_cif, dim3(n_files), dim3(WAVE), 0, ctx->stream, text_dev, file_off_dev, n_files,
                            (const uint64_t*)P(B_ABASE), T, (uint8_t*)P(B_TITLES), (uint32_t*)P(B_TLEN), (uint32_t*)P(B_NKEPT), (int32_t*)P(B_STATUS));
     }
     ingest_counts tot{(uint32_t*)P(B_TOTC), (uint32_t*)P(B_TOTR), (uint32_t*)P(B_TOTA), (uint32_t*)P(B_TOTT)};

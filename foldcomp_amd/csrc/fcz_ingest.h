@@ -474,7 +474,8 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     };
     load_chunk(0);
     IG_STAMP(0)
-    for (uint64_t c0 = 0; c0 < flen && !ended; c0 += IG_CHUNK) {
+    // (a file that is marked for the host is not read any further: nothing of it is used)
+    for (uint64_t c0 = 0; c0 < flen && !ended && status == FCZ_OK; c0 += IG_CHUNK) {
         // ---- stage the chunk: the tail of the previous window moves to the front, then the chunk's 16 coalesced dwords per lane,
         //      which were requested while the previous chunk was being parsed ----
         {

@@ -27,14 +27,24 @@ def ing():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
 
 
-def _host_expect(texts, names, brk=25, skip_disc=False):
+def _read_any(text):
+    """the host reader as the drivers call it: PDB or mmCIF by content (StructureReader::loadFromBuffer). The C++ readers when
+    built (forty times the speed; held equal to the Python restatement and to the live reference in test_ingest_vs_reference.py)"""
+    from foldcomp_amd import _hostlib
+    from foldcomp_amd.structure import parse_structure_gemmi
+    if _hostlib.load() is not None:
+        return _hostlib.read_structure(bytes(text), gz=False)
+    return parse_structure_gemmi(bytes(text))
+
+
+def _host_expect(texts, names, brk=25, skip_disc=False, reader=None):
     """what the host reader (gemmi's rules, checked against the live reference in test_ingest_vs_reference.py) makes of the files:
     (batch, fragment names, chain_file, refused [(file, name)], files the reader fails)"""
     chains, out_names, cfile, refused, failed = [], [], [], [], set()
     for fi, (text, base) in enumerate(zip(texts, names)):
         stem = base.rsplit(".", 1)[0] if "." in base else base
         try:
-            t, title = parse_pdb_gemmi(text)
+            t, title = (reader or parse_pdb_gemmi)(text)
         except StructureError:
             failed.add(fi); continue
         t = remove_alternative_position(t)
@@ -77,8 +87,8 @@ def _same_batch(got, exp):
     assert bytes(got.titles) == bytes(exp.titles)
 
 
-def _check(codec, texts, names, brk=25, skip_disc=False):
-    exp, exp_names, exp_file, exp_ref, failed = _host_expect(texts, names, brk, skip_disc)
+def _check(codec, texts, names, brk=25, skip_disc=False, reader=None):
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect(texts, names, brk, skip_disc, reader)
     assert not failed
     b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names, brk, skip_disc)
     assert set(int(v) for v in fstat) <= {0, 4}, fstat        # nothing here needs the host parser (4 = a file without atoms)
@@ -92,7 +102,7 @@ def _check(codec, texts, names, brk=25, skip_disc=False):
     return b, cfile, cmeta, fstat, refused
 
 
-@pytest.mark.parametrize("fn", ["test.pdb", "test_af.pdb", "multichain.pdb"])
+@pytest.mark.parametrize("fn", ["test.pdb", "test_af.pdb", "multichain.pdb", "test.cif.gz"])
 def test_device_ingest_equals_reference_reader(codec, ing, fn):
     """the device's batch == the batch built from the REFERENCE reader's atom table and fragments (reference-minted goldens)"""
     strs = lambda a: [bytes(r).rstrip(b"\0").decode() for r in a]
@@ -110,7 +120,11 @@ def test_device_ingest_equals_reference_reader(codec, ing, fn):
         names.append(stem + (t.chain[a] if n_chains > 1 else "") + (f"_{fj}" if n_in > 1 else ""))
         chains.append(Chain(title, t.take(slice(a, b))))
     exp = build_batch(chains, 25)
-    got, cfile, cmeta, fstat, refused = codec.ingest_pdb([ing[f"file:{fn}"].tobytes()], [fn])
+    data = ing[f"file:{fn}"].tobytes()
+    if fn.endswith(".gz"):                       # (the hosts' read threads inflate; the text is parsed on the device: mmCIF here)
+        import gzip
+        data = gzip.decompress(data)
+    got, cfile, cmeta, fstat, refused = codec.ingest_pdb([data], [fn])
     assert fstat[0] == 0 and len(refused) == 0
     _same_batch(got, exp)
     assert [_name_of(fn, int(m)) for m in cmeta] == names
@@ -239,7 +253,7 @@ def test_device_ingest_fuzz_never_parses_differently(codec, golden):
     ok = [i for i in range(len(texts)) if fstat[i] == 0]
     assert len(ok) > 300, "the fuzz should leave many files in the fixed layout"
     remap = {f: k for k, f in enumerate(ok)}
-    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok])
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok], reader=_read_any if names[0].endswith(".cif") else None)
     assert not failed, [names[ok[k]] for k in failed]
     got_names = [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)]
     assert got_names == exp_names
@@ -250,3 +264,63 @@ def test_device_ingest_fuzz_never_parses_differently(codec, golden):
     for i in range(len(texts)):
         if fstat[i] == 4:
             assert len(parse_pdb_gemmi(texts[i])[0]) == 0, names[i]
+
+
+def test_device_mmcif_equals_host_reader_on_plain_files(codec, golden, ing):
+    """mmCIF text on the device (k_ingest_parse_cif): AFDB's own file, synthetic files with the columns in another order, CR LF
+    line ends, a file without a last line end, comments and blank lines between the rows -- the batch of the host reader; text ->
+    FCZ in one call equals the golden record of the reference's test.cif.gz"""
+    import gzip
+    from test_host_cpp import _cif_text
+    z, _ = golden
+    af = gzip.decompress(ing["file:test.cif.gz"].tobytes())
+    syn = _cif_text(z, "pdb:test_af").encode()
+    lines = syn.decode().split("\n")
+    k0 = next(i for i, l in enumerate(lines) if l.startswith("ATOM"))
+    texts = [af, syn, syn.replace(b"\n", b"\r\n"), syn.rstrip(b"\n"),
+             "\n".join(lines[:k0 + 5] + ["# a comment between the rows", "", "   "] + lines[k0 + 5:]).encode(),
+             "\n".join(["# leading comment", ""] + lines).encode(),
+             _cif_text(z, "pdb:multichainA", entry_id="MULT").encode()]
+    names = [f"c{i}.cif" for i in range(len(texts))]
+    b, cfile, cmeta, fstat, refused = _check(codec, texts, names, reader=_read_any)
+    assert list(fstat) == [0] * len(texts)
+    r = codec.compress_pdb([af], ["test.cif"])
+    assert (r["status"] == 0).all() and (r["file_status"] == 0).all()
+    rec = r["blob"][int(r["off"][0]):int(r["off"][1])].tobytes()
+    ref = ing["cif:test/fcz"].tobytes()
+    assert rec == ref[:len(rec)] or _same_but_title(rec, ref)
+
+
+def _same_but_title(a, b):
+    def no_title(f):
+        na, tl = f[12], int.from_bytes(f[24:28], "little")
+        return f[:24] + f[28:76 + 4 * na] + f[76 + 4 * na + tl:]
+    return no_title(a) == no_title(b[:len(b)])
+
+
+def test_device_mmcif_fuzz_never_parses_differently(codec, golden, ing):
+    """seeded mutations of mmCIF files (_cases.mutated_cif: values nulled / quoted / glued, rows moved, model / chain / alt /
+    insertion columns, tags removed / doubled / re-cased, blocks, comments, text fields, reserved words, cuts, random bytes -- the
+    mutations test_ingest_vs_reference.py puts to the live reference): whenever the device takes a file its batch, names and
+    refusals equal the host reader's; everything else it hands back -- it never takes a file the reader fails"""
+    import gzip
+    from _cases import mutated_cif
+    from test_host_cpp import _cif_text
+    z, _ = golden
+    bases = [gzip.decompress(ing["file:test.cif.gz"].tobytes()).decode("latin-1"), _cif_text(z, "syn:len26"),
+             _cif_text(z, "pdb:multichainA", entry_id="M1")]
+    rng = np.random.default_rng(20260928)
+    texts, names = [], []
+    for i in range(900):
+        texts.append(mutated_cif(bases[i % 3], rng)); names.append(f"cz{i:04d}.cif")
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    ok = [i for i in range(len(texts)) if fstat[i] == 0]
+    assert len(ok) > 120, f"the fuzz should leave many files in the plain shape ({len(ok)})"
+    remap = {f: k for k, f in enumerate(ok)}
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok], reader=_read_any if names[0].endswith(".cif") else None)
+    assert not failed, [names[ok[k]] for k in failed]
+    got_names = [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)]
+    assert got_names == exp_names
+    assert [remap[int(f)] for f in cfile] == exp_file
+    _same_batch(b, exp)
+    assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)

@@ -394,6 +394,22 @@ def span_ms(codec):
     return out
 
 
+def cif_from_pdb_text(pdb: bytes, entry_id: str) -> bytes:
+    """the ATOM records of a PDB text as an mmCIF file of the shape AFDB ships (one data_ block, _entry.id, an _atom_site loop of
+    21 columns, one row per line): input of the end_to_end mmCIF leg"""
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_entity_id", "label_seq_id",
+            "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "pdbx_formal_charge", "auth_seq_id", "auth_comp_id",
+            "auth_asym_id", "auth_atom_id", "pdbx_PDB_model_num"]
+    out = ["data_" + entry_id, "#", "_entry.id " + entry_id, "#", "loop_"] + ["_atom_site." + c for c in cols]
+    for l in pdb.decode("latin-1").split("\n"):
+        if l.startswith("ATOM"):
+            name, res, ch, seq = l[12:16].strip(), l[17:20].strip(), l[21], l[22:26].strip()
+            out.append(f"ATOM {l[6:11].strip()} {(l[76:78].strip() or name[:1])} {name} . {res} {ch} 1 {seq} ? {l[30:38].strip()} {l[38:46].strip()} "
+                       f"{l[46:54].strip()} 1.0 {l[60:66].strip()} ? {seq} {res} {ch} {name} 1")
+    out.append("#")
+    return ("\n".join(out) + "\n").encode("latin-1")
+
+
 class Comm:
     """what the ranks exchange outside the data path: reductions of clocks and check flags, the barrier, and a wait that does not
     spin (the store). `dist` None = no group (a single process). Backend "nccl" = RCCL with device tensors; "gloo" (test mode:
@@ -542,6 +558,31 @@ def end_to_end_leg(args, codec, w, dev):
             same = same and open(os.path.join(tmp, f"db{tcounts[0]}") + ext, "rb").read() == open(os.path.join(tmp, "dbh") + ext, "rb").read()
         comp["databases_identical"] = same
         out["compress"] = comp
+        # ---- the same chains as mmCIF text (the format AFDB ships): structure ingest of mmCIF on the device (k_ingest_parse_cif) beside
+        #      the host reader on the same files ----
+        try:
+            n_cif = min(n, max(64, args.e2e_files // 8))
+            cdir = os.path.join(tmp, "cif"); os.mkdir(cdir)
+            cif_bytes = 0
+            for i in range(n_cif):
+                cb = cif_from_pdb_text(text[toff[i]:toff[i + 1]].tobytes(), f"S{i:07d}")
+                cif_bytes += len(cb)
+                with open(os.path.join(cdir, f"s{i:07d}.cif"), "wb") as fh:
+                    fh.write(cb)
+            clst = os.path.join(tmp, "cifs.txt")
+            with open(clst, "w") as fh:
+                fh.write((cdir + "\n") * passes)
+            runs_c = [run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", *wpg, "--json-stats", "-f", clst, os.path.join(tmp, "dbc")])]
+            runs_ch = [run_host(["compress", "-d", "-y", "-t", str(eff), "--host-parse", "--gpus", "1", "--json-stats", "-f", clst, os.path.join(tmp, "dbch")])]
+            cc = {"files": n_cif, "passes": passes, "text_bytes_per_pass": cif_bytes,
+                  "gpu_host": summarise(runs_c, "input_bytes", "host/foldcomp-hip compress -d -f <list of .cif> <db>   (mmCIF parsed on the device)"),
+                  "gpu_host_parse": summarise(runs_ch, "input_bytes", "... --host-parse   (the host's mmCIF reader)")}
+            cc["device_ingest_over_host_parse"] = round(cc["gpu_host"]["steady_residues_per_s"] / max(cc["gpu_host_parse"]["steady_residues_per_s"], 1), 2)
+            cc["databases_identical"] = all(open(os.path.join(tmp, "dbc") + ext, "rb").read() == open(os.path.join(tmp, "dbch") + ext, "rb").read() for ext in ("", ".index", ".lookup"))
+            comp["mmcif"] = cc
+            shutil.rmtree(cdir, ignore_errors=True)
+        except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
+            comp["mmcif"] = {"failed": str(e)[-300:]}
         # one pass as the decompress leg's input
         db1 = os.path.join(tmp, "db_one")
         run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", "--json-stats", src, db1])

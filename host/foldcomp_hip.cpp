@@ -1880,8 +1880,10 @@ struct TextPool {                              // the page-locked text buffers g
     void put(pvec<uint8_t>* b) { { std::lock_guard<std::mutex> l(m); free_.push_back(b); } cv.notify_one(); }
 };
 
-bool is_plain_pdb(const std::string& path) { return ends_with(path, ".pdb") || ends_with(path, ".ent"); }
-bool is_gz_pdb(const std::string& path) { return ends_with(path, ".pdb.gz") || ends_with(path, ".ent.gz"); }
+// structure text the device ingest reads: PDB records (k_ingest_parse) and mmCIF (k_ingest_parse_cif: the files k_ingest_parse leaves
+// because they open with data_); what either kernel cannot promise to read as the reference's reader would comes back for the host reader
+bool is_plain_pdb(const std::string& path) { return ends_with(path, ".pdb") || ends_with(path, ".ent") || ends_with(path, ".cif"); }
+bool is_gz_pdb(const std::string& path) { return ends_with(path, ".pdb.gz") || ends_with(path, ".ent.gz") || ends_with(path, ".cif.gz"); }
 // PDB text the device ingest takes: plain files are read straight into the page-locked buffer, gzipped ones are inflated by
 // the reader threads first (their parse still happens on the device)
 [[maybe_unused]] bool is_device_text(const std::string& path) { return is_plain_pdb(path) || is_gz_pdb(path); }
@@ -2065,14 +2067,14 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                             if (!plan.read_entry(it, (uint8_t*)&z[0])) throw std::runtime_error("database entry out of range");
                             g_bytes_read += z.size();
                             unz[i] = gunzip(z);
-                            if (coor_format_from_content(unz[i].data(), unz[i].size()) == 1) { cls[i] = 2; size[i] = unz[i].size(); }
+                            { const int fz = coor_format_from_content(unz[i].data(), unz[i].size()); if (fz == 1 || fz == 2) { cls[i] = 2; size[i] = unz[i].size(); } }
                             continue;
                         }
                         char head[4096];
                         InputItem pre = it; pre.len = std::min<uint64_t>(it.len, sizeof head);
                         if (!plan.read_entry(pre, (uint8_t*)head)) throw std::runtime_error("database entry out of range");
                         int fmt = coor_format_from_prefix(head, (size_t)pre.len, (size_t)it.len);
-                        if (fmt == 1) {
+                        if (fmt == 1 || fmt == 2) {
                             // MMseqs-made databases end an entry with a NUL after the text's last line end: not part of the text
                             // (the reader ignores a line of one NUL; the device parser would hand the file back for it)
                             size[i] = it.len; cls[i] = 1;
@@ -2085,7 +2087,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                         unz[i].resize(it.len);
                         if (it.len && !plan.read_entry(it, (uint8_t*)&unz[i][0])) throw std::runtime_error("database entry out of range");
                         g_bytes_read += it.len;
-                        if (fmt < 0 && coor_format_from_content(unz[i].data(), unz[i].size()) == 1) { cls[i] = 2; size[i] = unz[i].size(); }
+                        if (fmt < 0) { const int fz = coor_format_from_content(unz[i].data(), unz[i].size()); if (fz == 1 || fz == 2) { cls[i] = 2; size[i] = unz[i].size(); } }
                     } catch (const std::exception& e) { err[i] = "[Error] " + base_name(nm) + ": " + e.what() + "\n"; size[i] = UINT64_MAX - 1; cls[i] = 2; }
                     continue;
                 }

@@ -79,6 +79,13 @@ def test_end_to_end_both_directions(line):
         assert d["first_text_equals_reference"] and d["text_bytes_equal_reference_total"] and d["cpu_reference"]["failed_entries"] == 0
 
 
+def test_mmcif_leg(line):
+    """the same chains as mmCIF files: parsed on the device, the database the host reader's pipeline writes"""
+    c = line["end_to_end"]["compress"]["mmcif"]
+    assert "failed" not in c, c
+    assert c["databases_identical"] and c["gpu_host"]["host_parsed_files"] == 0 and c["gpu_host"]["records"] == c["files"] * c["passes"]
+
+
 def test_sharded_driver_leg(line):
     """the sharded driver at N = 1 (1-rank group + engine + exchange) writes the database the bare engine writes, both directions"""
     sh = line["end_to_end"]["sharded"]

@@ -479,14 +479,19 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
     # two chains, the first with a BLANK chain id: a blank names nothing ("f0043_blank.fcz", not "f0043_blank .fcz")
     blank = "".join((l[:21] + " " + l[22:] if l.startswith(("ATOM", "TER")) and len(l) > 22 else l) + "\n" for l in texts["pdb:multichainA"].splitlines() if not l.startswith("END"))
     (d / "f0043_blank.pdb").write_text(blank + _pdb_text(z, "pdb:multichainB_0"))
+    # mmCIF goes through the device too (k_ingest_parse_cif): the reference's own AFDB file, gzipped as it ships; a synthetic one is
+    # f0011.cif above. A file with a quoted atom name is handed back to the host reader
+    ing = np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
+    (d / "f0047_af.cif.gz").write_bytes(ing["file:test.cif.gz"].tobytes())
+    (d / "f0051_quoted.cif").write_text(_cif_text(z, "syn:len26").replace(" CA ", ' "CA" ', 1))
     outs = {}
     for tag, extra in (("dev", []), ("host", ["--host-parse"])):
         r = _run("compress", "-d", "-y", "-t", "8", "--gpus", "1", "--json-stats", *extra, str(d), str(tmp_path / f"db_{tag}"))
         assert r.returncode == 0, r.stderr
         st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         outs[tag] = (st, r.stderr)
-    assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 2      # the scientific-notation files
-    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1 + 2 + 2
+    assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 3      # the scientific-notation files, the quoted atom name
+    assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1 + 2 + 2 + 2
     assert all("f0341_bad" in outs[tag][1] for tag in ("dev", "host"))
     for ext in ("", ".index", ".lookup", ".dbtype"):
         assert (tmp_path / f"db_dev{ext}").read_bytes() == (tmp_path / f"db_host{ext}").read_bytes(), ext

@@ -1176,8 +1176,43 @@ def main():
                       "counts_equal_decoded": bool(res.batch.n_chains == npdb and res.batch.n_residues == n_r and res.batch.n_atoms == n_at),
                       "refused": int(res.n_refused)}
             pdb["ingest_of_the_same_text"] = ingest
+            # ---- ... and as mmCIF text (k_ingest_parse_cif): the first chains rendered as AFDB-shaped mmCIF on the host, tiled to the
+            #      same number of files on the device ----
+            n_src = min(npdb, 1024)
+            th = text_dev[:int(text_off[n_src])].cpu().numpy(); to = text_off[:n_src + 1].cpu().numpy()
+            cifs = [cif_from_pdb_text(th[to[i]:to[i + 1]].tobytes(), f"S{i:07d}") for i in range(n_src)]
+            reps_t = max(1, npdb // n_src)
+            one = np.frombuffer(b"".join(cifs), np.uint8)
+            lens = np.asarray([len(c) for c in cifs] * reps_t, np.int64)
+            coff = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)])).to(dev)
+            ctext = torch.from_numpy(one.copy()).to(dev).repeat(reps_t)
+            nf = n_src * reps_t
+            nmc = [f"s{i:07d}.cif".encode() for i in range(nf)]
+            cname_off = torch.from_numpy(np.arange(nf + 1, dtype=np.int64) * len(nmc[0])).to(torch.int32).to(dev)
+            cnames = torch.from_numpy(np.frombuffer(b"".join(nmc), np.uint8).copy()).to(dev)
+            cstem = torch.full((nf,), len(nmc[0]) - 4, dtype=torch.int32, device=dev)
+            resc = CIngestResult()
+            torch.cuda.synchronize()
+            _lib.check(lib.fcz_ingest_pdb_dev(codec.ctx, ctext.data_ptr(), coff.data_ptr(), nf, int(ctext.numel()), cnames.data_ptr(), cname_off.data_ptr(),
+                                              cstem.data_ptr(), args.anchor, 0, ctypes.byref(resc)), "fcz_ingest_pdb_dev (mmCIF)")
+            codec.synchronize(); codec.reset_timing()
+            for _ in range(reps_i):
+                _lib.check(lib.fcz_ingest_pdb_dev(codec.ctx, ctext.data_ptr(), coff.data_ptr(), nf, int(ctext.numel()), cnames.data_ptr(), cname_off.data_ptr(),
+                                                  cstem.data_ptr(), args.anchor, 0, ctypes.byref(resc)), "fcz_ingest_pdb_dev (mmCIF)")
+            codec.synchronize()
+            cms = {k: codec.kernel_time(k)[0] / reps_i for k in ("ingest_parse", "ingest_parse_cif", "ingest_frags", "ingest_fill")}
+            ctot = sum(cms.values())
+            n_rc = int(res_off_dev[n_src]) * reps_t
+            pdb["ingest_of_the_same_chains_as_mmcif"] = {
+                "files": nf, "distinct_files": n_src, "text_bytes": int(ctext.numel()), "ms": {k: round(v, 4) for k, v in cms.items()},
+                "text_GBs": round(int(ctext.numel()) / (ctot * 1e-3) / 1e9, 1) if ctot else None,
+                "frac_of_hbm_peak": round(int(ctext.numel()) / (ctot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ctot else None,
+                "residues_per_s": round(n_rc / (ctot * 1e-3)) if ctot else None,
+                "counts_equal_decoded": bool(resc.batch.n_chains == nf and resc.batch.n_residues == n_rc), "refused": int(resc.n_refused)}
+            del ctext
         except Exception as e:   # noqa: BLE001
-            pdb["ingest_of_the_same_text"] = {"failed": repr(e)[:300]}
+            pdb.setdefault("ingest_of_the_same_text", {"failed": repr(e)[:300]})
+            pdb["ingest_of_the_same_chains_as_mmcif"] = pdb.get("ingest_of_the_same_chains_as_mmcif") or {"failed": repr(e)[:300]}
         del text_dev
     # ---- §8 f4 leg: `extract --plddt -p 2` of every record straight from the FCZ bytes ----
     ext = None

@@ -31,7 +31,8 @@ namespace fcz {
 constexpr int CIF_MAXTOK = 32;                    // columns of an _atom_site row this path takes (AFDB: 25, PDB archive: 21-26)
 constexpr int CIF_MAXLINE = 255;                  // characters of a lexed line
 constexpr int CIF_NCOL = 23;
-constexpr int CIF_TAGSET = 2048;                  // slots of the duplicate-tag table (a block has a few hundred tags)
+constexpr int CIF_TAGSET = 1024;                  // slots of the duplicate-tag table (a block has a few hundred tags)
+constexpr int CIF_LINES = 512;                    // line ends of a chunk held at a time (the rest in further rounds)
 
 __device__ const char cif_col_names[CIF_NCOL][20] = {
     "id", "group_pdb", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_entity_id", "label_seq_id",
@@ -46,11 +47,11 @@ enum { CL_BLANK = 0, CL_DATA, CL_LOOP, CL_TAG, CL_PAIR, CL_VALUES, CL_TEXT_OPEN,
 
 struct cif_lds {
     alignas(16) uint8_t buf[IG_BACK + IG_CHUNK + 80];
-    uint32_t line_end[IG_LINES];
+    uint32_t line_end[CIF_LINES];
     uint32_t akey[64], rkey[32];
     uint8_t aval[64], rval[32];
     uint32_t tagset[CIF_TAGSET];
-    uint8_t tok_s[WAVE][CIF_MAXTOK], tok_e[WAVE][CIF_MAXTOK];
+    uint8_t tok_s[CIF_MAXTOK][WAVE], tok_e[CIF_MAXTOK][WAVE];   // [token][lane]: a wavefront's accesses to one token ordinal touch 16 banks once
     int8_t pos[CIF_NCOL + 1];
 };
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
     // no tag twice in a block, any case (cif_document: "duplicate tag"): 32-bit hashes, a collision only costs a hand-back
     auto tag_seen = [&](uint32_t h) -> bool {
         h |= 1u;
-        for (uint32_t s = (h * 0x9E3779B1u) >> 21, n = 0; n < (uint32_t)CIF_TAGSET; s = (s + 1) & (CIF_TAGSET - 1), n++) {
+        for (uint32_t s = (h * 0x9E3779B1u) >> 22, n = 0; n < (uint32_t)CIF_TAGSET; s = (s + 1) & (CIF_TAGSET - 1), n++) {
             const uint32_t v = S.tagset[s];
             if (v == h) return true;
             if (v == 0) { if (lane == 0) S.tagset[s] = h; __builtin_amdgcn_wave_barrier(); return false; }
@@ -149,72 +150,151 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         return true;                                    // table full: to the host
     };
 
+    // unaligned dword of the staged text (the line starts anywhere)
+    auto ldw = [&](int at) -> uint32_t { uint32_t v; __builtin_memcpy(&v, &S.buf[at], 4); return v; };
+    // 0x80 in every byte of v that is zero; the four flags of a dword as a nibble
+    auto zf = [](uint32_t v) -> uint32_t { return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu); };
+    auto nib = [](uint32_t fl) -> uint32_t { return ((fl >> 7) * 0x10204080u) >> 28; };
+
     // ---- one step: up to 64 lines, lane = line. ls / le file-relative, lo = offset of the line's first byte in S.buf or -1 ----
     auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo) {
         if (dead) return;
-        uint32_t len = on ? (uint32_t)(le - ls) : 0u;
+        const uint32_t len = on ? (uint32_t)(le - ls) : 0u;
         // ---- 1. lexing, every lane its own line ----
         const uint32_t c_first = !on || len == 0 ? (uint32_t)'\n' : (lo >= 0 ? (uint32_t)S.buf[lo] : (uint32_t)base[ls]);
         const bool semi = on && c_first == ';';
         const unsigned long long m_semi = __ballot(semi);
         const bool text_before = in_text ^ ((__builtin_popcountll(m_semi & ((1ull << lane) - 1ull)) & 1) != 0);   // inside a text field when this line starts
-        int cls = CL_BLANK; uint32_t ntok = 0, tag_hash = 0, kw_first = 0; bool bad = false;
-        if (on && text_before) {
-            if (semi) {                                                    // the closing line: nothing but blanks may follow the ';'
-                if (lo < 0 || len > (uint32_t)CIF_MAXLINE) bad = true;
-                else for (uint32_t i = 1; i < len; i++) if (!cif_is_ws(S.buf[lo + i])) bad = true;
+        int cls = CL_BLANK; uint32_t ntok = 0; bool bad = false;
+        // lines that are lexed: outside text fields, not a text field's first line, not empty. A line that is not staged or too long
+        // may only be a comment
+        bool lex = on && !text_before && !semi && len != 0;
+        if (on && text_before && semi) {                                   // a text field's last line: nothing but blanks may follow the ';'
+            if (lo < 0 || len > (uint32_t)CIF_MAXLINE) bad = true;
+            else for (uint32_t i = 1; i < len; i++) if (!cif_is_ws(S.buf[lo + i])) bad = true;
+        } else if (on && !text_before && semi) cls = CL_TEXT_OPEN;
+        if (lex && (lo < 0 || len > (uint32_t)CIF_MAXLINE)) {
+            bool comment = false;
+            for (uint32_t i = 0; i < len; i++) { const uint32_t c = lo >= 0 ? (uint32_t)S.buf[lo + i] : (uint32_t)base[ls + i]; if (cif_is_ws(c)) continue; comment = c == '#'; break; }
+            bad = bad || !comment; lex = false;
+        }
+        // (a) blanks by dword: one bit per character, set where a blank (or a control character: those fail the line below) stands;
+        //     characters past the line count as blanks
+        unsigned long long W0 = ~0ull, W1 = ~0ull, W2 = ~0ull, W3 = ~0ull;
+        {
+            const uint32_t nd = lex ? (len + 3u) >> 2 : 0u;
+            uint32_t maxd = nd;
+#pragma unroll
+            for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxd, d, WAVE); maxd = o > maxd ? o : maxd; }
+            for (uint32_t d = 0; d < maxd; d++) {
+                uint32_t x = 0x20202020u;
+                if (d < nd) {
+                    x = ldw(lo + 4 * (int)d);
+                    const uint32_t rest = len - 4u * d;
+                    if (rest < 4u) { const uint32_t keep = (1u << (8u * rest)) - 1u; x = (x & keep) | (0x20202020u & ~keep); }
+                }
+                const uint32_t lt20 = zf(x & 0x60606060u);                                  // characters below 0x20 (of 7-bit characters)
+                const uint32_t wsf = zf(x ^ 0x20202020u) | lt20;
+                bool b2 = (x & 0x80808080u) != 0u || zf(x ^ 0x7f7f7f7fu) != 0u;              // outside printable ASCII
+                if (lt20) b2 = b2 || (lt20 & ~(zf(x ^ 0x09090909u) | zf(x ^ 0x0d0d0d0du))) != 0u;      // a control character that is no tab / CR
+                bad = bad || (d < nd && b2);
+                const unsigned long long n4 = (unsigned long long)nib(wsf) << (4u * (d & 15u));
+                const unsigned long long clr = ~(0xfull << (4u * (d & 15u)));
+                if ((d >> 4) == 0u) W0 = (W0 & clr) | n4; else if ((d >> 4) == 1u) W1 = (W1 & clr) | n4; else if ((d >> 4) == 2u) W2 = (W2 & clr) | n4; else W3 = (W3 & clr) | n4;
             }
-        } else if (on && semi) cls = CL_TEXT_OPEN;
-        else if (on && len) {
-            if (lo < 0 || len > (uint32_t)CIF_MAXLINE) {
-                // only a comment line may be that long here
-                bool comment = false;
-                for (uint32_t i = 0; i < len; i++) { const uint32_t c = lo >= 0 ? (uint32_t)S.buf[lo + i] : (uint32_t)base[ls + i]; if (cif_is_ws(c)) continue; comment = c == '#'; break; }
-                bad = !comment;
-            } else {
-                bool in_tok = false, quoted = false, is_tag = false; uint32_t quote = 0, ts = 0, tl = 0; unsigned long long acc = 0; uint32_t h = 2166136261u;
-                auto close = [&](uint32_t end) {
-                    if (ntok < (uint32_t)CIF_MAXTOK) { S.tok_s[lane][ntok] = (uint8_t)ts; S.tok_e[lane][ntok] = (uint8_t)end; }
-                    ntok++; in_tok = false; quote = 0;
-                };
+        }
+        // (b) token bounds: a token starts where a character follows a blank (or the line's start), ends at the next blank
+        bool slow = false; uint32_t tag_like = 0;
+        if (lex && !bad) {
+            const unsigned long long p1 = W0 >> 63, p2 = W1 >> 63, p3 = W2 >> 63;
+            const unsigned long long S0 = ~W0 & ((W0 << 1) | 1ull), S1 = ~W1 & ((W1 << 1) | p1), S2 = ~W2 & ((W2 << 1) | p2), S3 = ~W3 & ((W3 << 1) | p3);
+            const unsigned long long E0 = W0 & ~((W0 << 1) | 1ull), E1 = W1 & ~((W1 << 1) | p1), E2 = W2 & ~((W2 << 1) | p2), E3 = W3 & ~((W3 << 1) | p3);
+            ntok = (uint32_t)(__builtin_popcountll(S0) + __builtin_popcountll(S1) + __builtin_popcountll(S2) + __builtin_popcountll(S3));
+            uint32_t t = 0, u = 0;
+            auto put = [&](unsigned long long ms, unsigned long long me, uint32_t off) {
+                for (; ms; ms &= ms - 1) { if (t < (uint32_t)CIF_MAXTOK) S.tok_s[t][lane] = (uint8_t)(off + (uint32_t)__builtin_ctzll(ms)); t++; }
+                for (; me; me &= me - 1) { if (u < (uint32_t)CIF_MAXTOK) S.tok_e[u][lane] = (uint8_t)(off + (uint32_t)__builtin_ctzll(me)); u++; }
+            };
+            put(S0, E0, 0u); put(S1, E1, 64u); put(S2, E2, 128u); put(S3, E3, 192u);
+            if (ntok > (uint32_t)CIF_MAXTOK) slow = true;              // (the character-by-character lexer counts any number of tokens)
+        }
+        // (c) what a token starts with: a quote opens a string (that lexer), '#' a comment, '$' a frame reference, '_' a tag;
+        //     reserved words open no value (CifScanner::value): data_ loop_ stop_ save_ global_, any case
+        uint32_t kw_first = 0;
+        {
+            uint32_t nchk = (lex && !bad && !slow) ? ntok : 0u, maxt = nchk;
+#pragma unroll
+            for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxt, d, WAVE); maxt = o > maxt ? o : maxt; }
+            bool comment = false;
+            for (uint32_t t = 0; t < maxt; t++) {
+                const bool in = t < nchk && !comment;
+                const int at = in ? lo + (int)S.tok_s[t][lane] : 0;
+                const uint32_t w0 = in ? ldw(at) : 0x30303030u;
+                const uint32_t c0 = w0 & 0xffu;
+                const uint32_t n = in ? (uint32_t)S.tok_e[t][lane] - (uint32_t)S.tok_s[t][lane] : 0u;
+                if (in && c0 == '#') { if (t == 0) { comment = true; ntok = 0; } else bad = true; }
+                const bool live = in && !comment;
+                if (live && (c0 == '\'' || c0 == '"')) slow = true;
+                if (live && (c0 == '$' || (c0 == '_' && t != 0))) bad = true;
+                if (live && c0 == '_' && t == 0) tag_like = 1;
+                const uint32_t l4 = w0 | 0x20202020u;                                    // (letters folded; '_' is not among the four)
+                const bool cand = live && n >= 5u && (l4 == 0x61746164u || l4 == 0x706f6f6cu || l4 == 0x706f7473u || l4 == 0x65766173u || l4 == 0x626f6c67u);   // data loop stop save glob
+                if (__any(cand)) {
+                    const uint32_t w1 = cand ? ldw(at + 4) : 0u;
+                    uint32_t kw = 0;
+                    if (cand && (w1 & 0xffu) == '_') kw = l4 == 0x61746164u ? 1u : l4 == 0x706f6f6cu ? 2u : l4 == 0x706f7473u ? 5u : l4 == 0x65766173u ? 4u : 0u;
+                    if (cand && l4 == 0x626f6c67u && n >= 7u && ((w1 | 0x00002020u) & 0x00ffffffu) == 0x005f6c61u) kw = 3u;                      // "al_"
+                    if (kw) { if (t == 0) kw_first = kw; else bad = true; }
+                }
+            }
+        }
+        // (d) the character-by-character lexer for the lines that hold a quoted string (or more tokens than the table)
+        if (__any(slow && !bad)) {
+            if (slow && !bad) {
+                ntok = 0; kw_first = 0; tag_like = 0;
+                bool in_tok = false, quoted = false; uint32_t quote = 0, ts = 0, tl = 0; unsigned long long acc = 0;
                 for (uint32_t i = 0; i < len; i++) {
                     const uint32_t c = S.buf[lo + i];
-                    if ((c < 0x20u && c != '\t' && c != '\r') || c > 0x7eu) { bad = true; break; }
+                    bool ends = false; uint32_t end_at = i;
                     if (!in_tok) {
                         if (cif_is_ws(c)) continue;
-                        if (c == '#') { if (ntok != 0) bad = true; break; }          // a comment line; a comment after tokens goes to the host
+                        if (c == '#') { if (ntok != 0) bad = true; break; }
                         in_tok = true; ts = i; tl = 0; acc = 0; quoted = c == '\'' || c == '"'; quote = quoted ? c : 0u;
-                        is_tag = c == '_';
-                        if (c == '$' || (is_tag && ntok != 0)) bad = true;            // a frame reference; a tag after something else on its line
-                        if (is_tag) h = 2166136261u;
+                        if (c == '$' || (c == '_' && ntok != 0)) bad = true;
+                        if (c == '_' && ntok == 0) tag_like = 1;
                     } else if (quote) {
-                        if (c == quote) { const uint32_t nx = i + 1 < len ? (uint32_t)S.buf[lo + i + 1] : (uint32_t)' '; if (cif_is_ws(nx) || nx == '#') { close(i + 1); continue; } }
-                    } else if (cif_is_ws(c)) { close(i); continue; }
-                    if (in_tok && !quoted) {
-                        // reserved words open no value (CifScanner::value): data_ loop_ stop_ save_ global_, any case
+                        if (c == quote) { const uint32_t nx = i + 1 < len ? (uint32_t)S.buf[lo + i + 1] : (uint32_t)' '; if (cif_is_ws(nx) || nx == '#') { ends = true; end_at = i + 1; } }
+                    } else if (cif_is_ws(c)) { ends = true; end_at = i; }
+                    if (ends) {
+                        if (ntok < (uint32_t)CIF_MAXTOK) { S.tok_s[ntok][lane] = (uint8_t)ts; S.tok_e[ntok][lane] = (uint8_t)end_at; }
+                        ntok++; in_tok = false; quote = 0;
+                        continue;
+                    }
+                    if (!quoted) {
                         if (tl < 7u) acc |= (unsigned long long)cif_lower(c) << (8 * tl);
                         tl++;
                         if (tl == 5u) {
                             const unsigned long long a5 = acc & 0xffffffffffull;
-                            const uint32_t kw = a5 == 0x5f61746164ull ? 1u : a5 == 0x5f706f6f6cull ? 2u : a5 == 0x5f706f7473ull ? 5u : a5 == 0x5f65766173ull ? 4u : 0u;   // "data_" "loop_" "stop_" "save_"
+                            const uint32_t kw = a5 == 0x5f61746164ull ? 1u : a5 == 0x5f706f6f6cull ? 2u : a5 == 0x5f706f7473ull ? 5u : a5 == 0x5f65766173ull ? 4u : 0u;
                             if (kw) { if (ntok == 0) kw_first = kw; else bad = true; }
                         }
-                        if (tl == 7u && (acc & 0xffffffffffffffull) == 0x5f6c61626f6c67ull) bad = true;                                                                  // "global_"
-                        if (is_tag && ntok == 0) h = (h ^ cif_lower(c)) * 16777619u;
+                        if (tl == 7u && (acc & 0xffffffffffffffull) == 0x5f6c61626f6c67ull) { if (ntok == 0) kw_first = 3u; else bad = true; }
                     }
                 }
-                if (in_tok) { if (quote) bad = true; else close(len); }
-                if (!bad) {
-                    const uint32_t l0 = ntok ? (uint32_t)S.tok_e[lane][0] - (uint32_t)S.tok_s[lane][0] : 0u;
-                    const bool tag0 = ntok && S.buf[lo + S.tok_s[lane][0]] == '_';
-                    if (ntok == 0) cls = CL_BLANK;
-                    else if (kw_first == 2u) { cls = CL_LOOP; if (ntok != 1 || l0 != 5u) bad = true; }
-                    else if (kw_first == 1u) { cls = CL_DATA; if (ntok != 1 || l0 <= 5u) bad = true; }
-                    else if (kw_first) bad = true;                                  // save_, stop_ as the first token
-                    else if (tag0) { cls = ntok == 1 ? CL_TAG : CL_PAIR; if (ntok > 2 || l0 < 2u) bad = true; tag_hash = h; }
-                    else cls = CL_VALUES;
+                if (in_tok) {
+                    if (quote) bad = true;
+                    else { if (ntok < (uint32_t)CIF_MAXTOK) { S.tok_s[ntok][lane] = (uint8_t)ts; S.tok_e[ntok][lane] = (uint8_t)len; } ntok++; }
                 }
             }
+        }
+        if (lex && !bad) {
+            const uint32_t l0 = ntok ? (uint32_t)S.tok_e[0][lane] - (uint32_t)S.tok_s[0][lane] : 0u;
+            if (ntok == 0) cls = CL_BLANK;
+            else if (kw_first == 2u) { cls = CL_LOOP; if (ntok != 1 || l0 != 5u) bad = true; }
+            else if (kw_first == 1u) { cls = CL_DATA; if (ntok != 1 || l0 <= 5u) bad = true; }
+            else if (kw_first) bad = true;                                  // save_, stop_, global_ as the first token
+            else if (tag_like) { cls = ntok == 1 ? CL_TAG : CL_PAIR; if (ntok > 2 || l0 < 2u) bad = true; }
+            else cls = CL_VALUES;
         }
         if (bad) cls = CL_BAD;
         if (__any(cls == CL_BAD)) { dead = true; return; }
@@ -239,8 +319,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 if (ctx == CX_START) { dead = true; break; }
                 if (c == CL_LOOP) { end_item(); ctx = CX_LOOP_HDR; ntags = 0; nvals = 0; in_as = false; other_cat = false; continue; }
                 if (c == CL_TAG || c == CL_PAIR) {
-                    const uint32_t t0 = S.tok_s[l][0], tn = (uint32_t)S.tok_e[l][0] - t0;
-                    if (tag_seen((uint32_t)__shfl((int)tag_hash, l, WAVE))) { dead = true; break; }
+                    const uint32_t t0 = S.tok_s[0][l], tn = (uint32_t)S.tok_e[0][l] - t0;
+                    uint32_t h = 2166136261u;
+                    for (uint32_t i = 0; i < tn; i++) h = (h ^ cif_lower(S.buf[llo + t0 + i])) * 16777619u;
+                    if (tag_seen(h)) { dead = true; break; }
                     const bool cat_as = tn > 11u && eq_lower(llo, t0, "_atom_site.", 11);
                     const bool cat_cell = tn > 6u && eq_lower(llo, t0, "_cell.", 6);
                     const bool is_entry = tn == 9u && eq_lower(llo, t0, "_entry.id", 9);
@@ -264,15 +346,14 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                     if (dead) break;
                     if (cat_as) { dead = true; break; }                              // _atom_site items as pairs (a one-atom file): to the host
                     // values this path must see: the title, the angles of the zero-angle rule
-                    const bool ang = cat_cell && (tn == 17u && eq_lower(llo, t0, "_cell.angle_alpha", 17)) | (tn == 16u && eq_lower(llo, t0, "_cell.angle_beta", 16));
+                    const bool ang = cat_cell && ((tn == 17u && eq_lower(llo, t0, "_cell.angle_alpha", 17)) || (tn == 16u && eq_lower(llo, t0, "_cell.angle_beta", 16)));
                     if (is_entry && !eq_exact(llo, t0, "_entry.id", 9)) { dead = true; break; }   // (a pair is looked up by its exact spelling)
                     if (c == CL_TAG) { pending_special = is_entry || ang; ctx = CX_AFTER_TAG; continue; }
-                    const uint32_t v0 = S.tok_s[l][1], vn = (uint32_t)S.tok_e[l][1] - v0;
+                    const uint32_t v0 = S.tok_s[1][l], vn = (uint32_t)S.tok_e[1][l] - v0;
                     const uint32_t vc = S.buf[llo + v0];
                     if (is_entry) {
                         if (vc == '\'' || vc == '"' || (vn == 1u && (vc == '?' || vc == '.')) || vn > (uint32_t)IG_TITLE_CAP) { dead = true; break; }
-                        if (lane < (int)vn) tbuf[lane] = S.buf[llo + v0 + lane];
-                        for (uint32_t i = WAVE + lane; i < vn; i += WAVE) tbuf[i] = S.buf[llo + v0 + i];
+                        for (uint32_t i = (uint32_t)lane; i < vn; i += WAVE) tbuf[i] = S.buf[llo + v0 + i];
                         tlen = vn; have_title = true;
                     }
                     if (ang && !(vc - '1' < 9u)) { dead = true; break; }              // certainly not zero only when it starts with 1-9
@@ -301,61 +382,78 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             }
         }
         if (dead) return;
-        // ---- 3. the _atom_site rows of the step, every lane its own ----
+        // ---- 3. the _atom_site rows of the step, every lane its own: a field's characters come into registers as four dwords, the
+        //         readers are boolean arithmetic over their (at most sixteen) characters ----
         if (rowmask == 0ull) return;
         const bool row = ((rowmask >> lane) & 1ull) != 0;
         bool rbad = false;
         uint32_t an = 0, rn = 0, ch = ' '; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
-        if (row) {
-            auto tb = [&](int col, uint32_t i) -> uint32_t { return S.buf[lo + S.tok_s[lane][col] + i]; };
-            auto tl = [&](int col) -> uint32_t { return (uint32_t)S.tok_e[lane][col] - (uint32_t)S.tok_s[lane][col]; };
-            auto is_null = [&](int col) -> bool { return tl(col) == 1u && (tb(col, 0) == '?' || tb(col, 0) == '.'); };
-            auto integer = [&](int col, int32_t* out) -> bool {                      // [+-]digits, at most nine of them
-                const uint32_t n = tl(col); uint32_t i = 0; bool neg = false;
-                if (n && (tb(col, 0) == '-' || tb(col, 0) == '+')) { neg = tb(col, 0) == '-'; i = 1; }
-                if (i >= n || n - i > 9u) return false;
-                uint32_t v = 0;
-                for (; i < n; i++) { const uint32_t d = tb(col, i) - '0'; if (d > 9u) return false; v = v * 10u + d; }
-                *out = neg ? -(int32_t)v : (int32_t)v;
-                return true;
+        {
+            struct fld { uint32_t w[4]; uint32_t n; };
+            auto get = [&](int col) -> fld {                                         // col >= 0 (uniform); lanes that hold no row read their own line start
+                fld f; const uint32_t s0 = row ? (uint32_t)S.tok_s[col][lane] : 0u, e0 = row ? (uint32_t)S.tok_e[col][lane] : 0u;
+                f.n = e0 - s0;
+                const int at = row ? lo + (int)s0 : 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) f.w[q] = ldw(at + 4 * q);
+                return f;
             };
-            auto decimal = [&](int col, float* out) -> bool {                        // -digits.digits, at most 15 digits: cif::as_number's fast path
-                const uint32_t n = tl(col); uint32_t i = 0; bool neg = false;
-                if (n && tb(col, 0) == '-') { neg = true; i = 1; }
-                unsigned long long m = 0; uint32_t nd = 0, nf = 0; bool point = false;
-                for (; i < n; i++) {
-                    const uint32_t c = tb(col, i);
-                    if (c == '.') { if (point) return false; point = true; continue; }
-                    const uint32_t d = c - '0';
-                    if (d > 9u) return false;
-                    m = m * 10ull + d; nd++; if (point) nf++;
+            auto ch_at = [](const fld& f, int i) -> uint32_t { return (f.w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+            auto is_null = [&](const fld& f) -> bool { return f.n == 1u && ((f.w[0] & 0xffu) == '?' || (f.w[0] & 0xffu) == '.'); };
+            auto integer = [&](const fld& f, int32_t* out) -> bool {                  // [+-]digits, at most nine of them
+                const uint32_t c0 = f.w[0] & 0xffu;
+                const bool sg = (c0 == '-') | (c0 == '+');
+                uint32_t v = 0, nd = 0; bool ok = f.n <= 10u;
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    const uint32_t d = ch_at(f, i) - '0';
+                    const bool in = (uint32_t)i < f.n && !(i == 0 && sg);
+                    ok = ok & (!in | (d <= 9u));
+                    v = in ? v * 10u + d : v; nd += in ? 1u : 0u;
                 }
-                if (nd == 0u || nd > 15u) return false;
-                const double v = (double)m / cif_pow10[nf];
+                *out = c0 == '-' ? -(int32_t)v : (int32_t)v;
+                return ok & (nd >= 1u) & (nd <= 9u);
+            };
+            auto decimal = [&](const fld& f, float* out) -> bool {                   // -digits.digits, at most 15 digits in 16 characters: cif::as_number's fast path
+                const bool neg = (f.w[0] & 0xffu) == '-';
+                unsigned long long m = 0; uint32_t nd = 0, nf = 0; bool point = false, ok = f.n <= 16u;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t c = ch_at(f, i), d = c - '0';
+                    const bool in = (uint32_t)i < f.n && !(i == 0 && neg);
+                    const bool dig = d <= 9u, pt = c == '.';
+                    ok = ok & (!in | dig | (pt & !point));
+                    const bool take = in & dig;
+                    m = take ? m * 10ull + d : m; nd += take ? 1u : 0u; nf += (take & point) ? 1u : 0u;
+                    point = point | (in & pt);
+                }
+                const double v = (double)m / cif_pow10[nf & 15u];
                 *out = (float)(neg ? -v : v);
-                return true;
+                return ok & (nd >= 1u) & (nd <= 15u);
             };
-            auto pack = [&](int col, uint32_t* out) -> bool {                        // a name of one to four characters
-                const uint32_t n = tl(col);
-                if (n == 0u || n > 4u || is_null(col)) return false;
-                uint32_t w = 0;
-                for (uint32_t i = 0; i < n; i++) w |= tb(col, i) << (8 * i);
-                *out = w;
-                return true;
+            auto pack = [&](const fld& f, uint32_t* out) -> bool {                   // a name of one to four characters
+                *out = f.n >= 4u ? f.w[0] : (f.w[0] & ((1u << (8u * f.n)) - 1u));
+                return (f.n >= 1u) & (f.n <= 4u) & !is_null(f);
             };
-            // no quotes anywhere in the row (a quoted value's content is what the reader takes: the host strips them)
-            for (uint32_t t = 0; t < ntags; t++) { const uint32_t c = tb((int)t, 0); if (c == '\'' || c == '"') rbad = true; }
-            const int pId = S.pos[CK_ID], pAlt = S.pos[CK_ALT], pIns = S.pos[CK_INS], pLs = S.pos[CK_LSEQ], pCh = S.pos[CK_CHARGE], pMo = S.pos[CK_MODEL];
-            rbad = rbad | !integer(pId, &serial) | !integer(S.pos[CK_ASEQ], &num);
-            rbad = rbad | !decimal(S.pos[CK_X], &x) | !decimal(S.pos[CK_Y], &y) | !decimal(S.pos[CK_Z], &z) | !decimal(S.pos[CK_B], &bf);
-            rbad = rbad | !pack(S.pos[kAtom], &an) | !pack(S.pos[kComp], &rn);
-            if (tl(S.pos[kAsym]) != 1u || is_null(S.pos[kAsym])) rbad = true; else ch = tb(S.pos[kAsym], 0);
-            if (!is_null(pAlt) && tl(pAlt) != 1u) rbad = true;
-            if (pIns >= 0 && !is_null(pIns)) rbad = true;
+            const int pAlt = S.pos[CK_ALT], pIns = S.pos[CK_INS], pLs = S.pos[CK_LSEQ], pCh = S.pos[CK_CHARGE], pMo = S.pos[CK_MODEL];
+            // no quoted value anywhere in the row (the host strips the quotes): such a line went through the character lexer
+            if (row && slow) rbad = true;
+            { const fld f = get(S.pos[CK_ID]); rbad = rbad | !integer(f, &serial); }
+            { const fld f = get(S.pos[CK_ASEQ]); rbad = rbad | !integer(f, &num); }
+            { const fld f = get(S.pos[CK_X]); rbad = rbad | !decimal(f, &x); }
+            { const fld f = get(S.pos[CK_Y]); rbad = rbad | !decimal(f, &y); }
+            { const fld f = get(S.pos[CK_Z]); rbad = rbad | !decimal(f, &z); }
+            { const fld f = get(S.pos[CK_B]); rbad = rbad | !decimal(f, &bf); }
+            { const fld f = get(S.pos[kAtom]); rbad = rbad | !pack(f, &an); }
+            { const fld f = get(S.pos[kComp]); rbad = rbad | !pack(f, &rn); }
+            { const fld f = get(S.pos[kAsym]); rbad = rbad | (f.n != 1u) | is_null(f); ch = f.w[0] & 0xffu; }
+            { const fld f = get(pAlt); rbad = rbad | (!is_null(f) & (f.n != 1u)); }
             int32_t dummy;
-            if (pLs >= 0 && !is_null(pLs) && !integer(pLs, &dummy)) rbad = true;
-            if (pCh >= 0 && !is_null(pCh) && !integer(pCh, &dummy)) rbad = true;
-            if (pMo >= 0) { const uint32_t n = tl(pMo); if (n > 8u) rbad = true; else for (uint32_t i = 0; i < n; i++) mdl |= (unsigned long long)tb(pMo, i) << (8 * i); }
+            if (pIns >= 0) { const fld f = get(pIns); rbad = rbad | !is_null(f); }
+            if (pLs >= 0) { const fld f = get(pLs); rbad = rbad | (!is_null(f) & !integer(f, &dummy)); }
+            if (pCh >= 0) { const fld f = get(pCh); rbad = rbad | (!is_null(f) & !integer(f, &dummy)); }
+            if (pMo >= 0) { const fld f = get(pMo); rbad = rbad | (f.n > 8u); const unsigned long long v8 = (unsigned long long)f.w[0] | ((unsigned long long)f.w[1] << 32); mdl = f.n >= 8u ? v8 : (v8 & ((1ull << (8u * f.n)) - 1ull)); }
+            rbad = rbad & row;
         }
         // one model; residues of a chain run in rising order (the reader regroups anything else); keep rule of removeAlternativePosition
         const uint32_t pl = ig_prev_lane(rowmask, lane);
@@ -366,7 +464,9 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             const bool has_p = pl < 64u ? true : have_last;
             const int32_t p_num = pl < 64u ? s_num : last_num;
             const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name;
-            const unsigned long long m0 = have_model ? model0 : (unsigned long long)__shfl((long long)mdl, __builtin_ctzll(rowmask), WAVE);
+            const int fl = __builtin_ctzll(rowmask);
+            const unsigned long long m_first = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(mdl >> 32), fl, WAVE) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)mdl, fl, WAVE);
+            const unsigned long long m0 = have_model ? model0 : m_first;
             if (row && mdl != m0) rbad = true;
             if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_rn == rn) && !(num > p_num)) rbad = true;
             if (__any(row && rbad)) { dead = true; return; }
@@ -443,15 +543,15 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         const uint32_t cnt = (uint32_t)__builtin_popcountll(nlm);
         uint32_t total;
         uint32_t ord = wave_excl_scan_dpp(cnt, &total);
-        for (uint32_t r0 = 0; (r0 < total || r0 == 0) && !dead; r0 += IG_LINES) {
+        for (uint32_t r0 = 0; (r0 < total || r0 == 0) && !dead; r0 += CIF_LINES) {
             uint32_t o = ord;
             for (unsigned long long m = nlm; m; m &= m - 1) {
                 const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-                if (o >= r0 && o < r0 + (uint32_t)IG_LINES) S.line_end[o - r0] = 64u * (uint32_t)lane + bit;
+                if (o >= r0 && o < r0 + (uint32_t)CIF_LINES) S.line_end[o - r0] = 64u * (uint32_t)lane + bit;
                 o++;
             }
             __builtin_amdgcn_wave_barrier();
-            const uint32_t n_here = total - r0 < (uint32_t)IG_LINES ? total - r0 : (uint32_t)IG_LINES;
+            const uint32_t n_here = total - r0 < (uint32_t)CIF_LINES ? total - r0 : (uint32_t)CIF_LINES;
             for (uint32_t k0 = 0; k0 < n_here && !dead; k0 += WAVE) {
                 const uint32_t k = k0 + (uint32_t)lane;
                 const bool on = k < n_here;

@@ -216,7 +216,7 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
                              uint64_t* text_off, int32_t* status);
 int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
 
-/* ---- structure ingest: PDB text -> fcz_chain_batch on the device ------------------------------------ */
+/* ---- structure ingest: PDB / mmCIF text -> fcz_chain_batch on the device ----------------------------- */
 /* What the reference's driver does to every input file before Foldcomp::compress (src/main.cpp:455-508): StructureReader
  * (src/structure_reader.cpp:31-61; the fixed-column ATOM / HETATM record as foldcomp/foldcomp.cxx:259-278 reads it),
  * removeAlternativePosition (src/atom_coordinate.cpp:362-370), identifyChains (:469-497), identifyDiscontinousResInd (:506-530),
@@ -239,7 +239,16 @@ int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
  * repository restate every rule: foldcomp_amd/structure.py parse_pdb_gemmi, host/foldcomp_hip.cpp parse_pdb_gemmi). refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the
  * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order or with a second one
  * of them, a last atom that carries another residue name than its residue, chain beyond the header's counts,
- * --skip-discontinuous). mmCIF and gzip stay on the host. */
+ * --skip-discontinuous). Gzip stays on the host (its read threads inflate; the inflated text is parsed here).
+ * mmCIF text (round 4, k_ingest_parse_cif): a file that opens with data_ (gemmi::coor_format_from_content, lib/gemmi/mmread.hpp:31-47)
+ * is read by gemmi's mmCIF rules (cif.hpp:37-148 grammar, mmcif.hpp:560-680 make_structure: the _atom_site loop's 23 columns by any
+ * case, chain = auth_asym_id else label_asym_id, residue = auth_seq_id + comp id, atom name = auth_atom_id else label_atom_id,
+ * title = _entry.id) when it has the shape every predicted-structure file has: one block, one item per line (or a tag line and its
+ * value / text field on the following lines), loops of whole-line rows, _atom_site rows of one line each without quoted values,
+ * one-character chain names, integer residue numbers without insertion codes, one model, residues rising inside a chain run,
+ * coordinates as plain decimals of at most 15 digits. Every other mmCIF file comes back as FCZ_INGEST_HOST_FIELD exactly as a PDB
+ * file outside the fixed layout does (save_ frames, several blocks, comments after values, quoted atom names, multi-letter chains,
+ * several models, '?' coordinates, duplicate tags, a _cell angle that is not plainly non-zero, lines beyond 255 characters ...). */
 enum fcz_ingest_status { FCZ_INGEST_HOST_FIELD = 1, FCZ_INGEST_HOST_TITLE = 2, FCZ_INGEST_HOST_FRAGS = 3, FCZ_INGEST_NO_ATOMS = 4 };
 enum fcz_ingest_reason { FCZ_INGEST_REF_RESNAME = 1, FCZ_INGEST_REF_BACKBONE = 2, FCZ_INGEST_REF_TOO_LONG = 3, FCZ_INGEST_REF_SKIP_DISC = 4,
                          FCZ_INGEST_REF_BACKBONE_TWICE = 5, FCZ_INGEST_REF_LAST_NAME = 6 };
@@ -299,7 +308,7 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
  * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
  * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format", "extract_sizes", "extract",
- * "ingest_parse", "ingest_frags", "ingest_fill". */
+ * "ingest_parse", "ingest_parse_cif", "ingest_frags", "ingest_fill". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

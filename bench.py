@@ -665,6 +665,8 @@ def end_to_end_leg(args, codec, w, dev):
             comp["fcz_bytes_equal_reference_total"] = runs[0]["fcz_bytes"] * rpasses == int(rbytes.value) * passes
             comp["speedup_vs_cpu_reference"] = round(comp["gpu_host"]["residues_per_s"] / comp["cpu_reference"]["residues_per_s"], 2)
             comp["steady_speedup_vs_cpu_reference"] = round(comp["gpu_host"]["steady_residues_per_s"] / comp["cpu_reference"]["residues_per_s"], 2)
+            comp["speedup_note"] = (f"per-residue rates: the GPU host walks the files {passes} times, the reference's loop {rpasses} times (it has no start-up to amortise); "
+                                    "speedup_vs_cpu_reference compares full walls (HIP start-up inside), the steady ratio leaves the GPU host's start-up (ctx_ready_s) out")
             # decompress: the reference's loop over the same database
             rl.ref_decompress_db.restype = ctypes.c_int
             rl.ref_decompress_db.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,

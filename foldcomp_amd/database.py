@@ -49,7 +49,11 @@ class DatabaseReader:
         self.name_to_key = {}
         self.key_to_name = {}
         if use_lookup and os.path.exists(path + ".lookup"):
-            # read_lookup (:345-361): key = the first word, name = the second (words end at a blank or a tab)
+            # read_lookup (:345-361): key = the first word, name = the second (words end at a blank or a tab). Deviations, on purpose:
+            # the reference fails the WHOLE lookup on a line of fewer than three words and takes the name as the bytes up to the third
+            # word minus one (so a name followed by several blanks keeps all but the last); here a two-word line is accepted and the
+            # name ends at its first blank -- equal on every file free_writer writes ("%d\t%s\t0\n") and on the mutated ones
+            # tests/test_ingest_vs_reference.py puts to the live reference
             with open(path + ".lookup", "rb") as fh:
                 for line in fh.read().split(b"\n"):
                     p = [w for w in line.replace(b"\t", b" ").split(b" ") if w]

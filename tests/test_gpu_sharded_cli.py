@@ -138,3 +138,43 @@ def test_shard_memory_is_independent_of_the_shard_size_and_databases_round_trip(
     r = _cli("compress", "-d", "-y", "--gpus", "2", str(small), str(tmp_path / "tiny_2"))
     assert r.returncode == 0, r.stderr
     _same_db(tmp_path / "tiny_py", tmp_path / "tiny_2")
+
+
+def test_more_ranks_than_work_and_mixed_input_lists(tmp_path, golden):
+    """edge shapes of the range cut: three ranks over two files (one rank's engine finds an empty range and writes an empty partial
+    database), and a `-f` list that names a database and a directory (the cut crosses the boundary between the two sources)"""
+    from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+    z, _ = golden
+    d = tmp_path / "two"
+    d.mkdir()
+    (d / "a.pdb").write_text(_pdb_text(z, "syn:len129"))
+    (d / "b.pdb").write_text(_pdb_text(z, "pdb:test_af"))
+    r = _cli("compress", "-d", "-y", "--gpus", "1", str(d), str(tmp_path / "t1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _cli("compress", "-d", "-y", "--gpus", "3", "--json-stats", str(d), str(tmp_path / "t3"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = _stats(r)
+    assert st["world"] == 3 and st["records"] == 2 and sorted(st["records_per_rank"]) in ([0, 0, 2], [0, 1, 1])
+    _same_db(tmp_path / "t1", tmp_path / "t3")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f or ".index." in f or ".lookup." in f]
+    # a database of PDB texts + a directory of files, listed in one -f file
+    w = DatabaseWriter(str(tmp_path / "texts"))
+    for k, n in enumerate(["syn:len26", "syn:len64", "pdb:test", "syn:len350", "syn:len129"] * 8):
+        w.append(_pdb_text(z, n).encode() + b"\0", k, f"entry{k:03d}")
+    w.close()
+    d2 = tmp_path / "more"
+    d2.mkdir()
+    for i in range(23):
+        (d2 / f"m{i:02d}.pdb").write_text(_pdb_text(z, ["syn:len26", "pdb:test_af", "syn:len350"][i % 3]))
+    (d2 / "m99.cif").write_text(_cif_text(z, "syn:len64"))
+    lst = tmp_path / "inputs.txt"
+    lst.write_text(f"{tmp_path / 'texts'}\n{d2}\n")
+    for g in (1, 2, 3):
+        r = _cli("compress", "-d", "-y", "-f", "--gpus", str(g), "--json-stats", str(lst), str(tmp_path / f"mix{g}"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert _stats(r)["records"] == 40 + 24
+    _same_db(tmp_path / "mix1", tmp_path / "mix2")
+    _same_db(tmp_path / "mix1", tmp_path / "mix3")
+    rd = DatabaseReader(str(tmp_path / "mix1"))
+    assert rd.name(0) == "entry000" and rd.name(40) == "m00" and rd.name(63) == "m99"
+    rd.close()

@@ -561,7 +561,7 @@ def end_to_end_leg(args, codec, w, dev):
         # ---- the same chains as mmCIF text (the format AFDB ships): structure ingest of mmCIF on the device (k_ingest_parse_cif) beside
         #      the host reader on the same files ----
         try:
-            n_cif = min(n, max(64, args.e2e_files // 8))
+            n_cif = min(n, max(64, args.e2e_files // 4))
             cdir = os.path.join(tmp, "cif"); os.mkdir(cdir)
             cif_bytes = 0
             for i in range(n_cif):

@@ -400,13 +400,30 @@ def cif_from_pdb_text(pdb: bytes, entry_id: str) -> bytes:
     cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_entity_id", "label_seq_id",
             "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "pdbx_formal_charge", "auth_seq_id", "auth_comp_id",
             "auth_asym_id", "auth_atom_id", "pdbx_PDB_model_num"]
-    out = ["data_" + entry_id, "#", "_entry.id " + entry_id, "#", "loop_"] + ["_atom_site." + c for c in cols]
+    rows, seqres = [], []
     for l in pdb.decode("latin-1").split("\n"):
         if l.startswith("ATOM"):
             name, res, ch, seq = l[12:16].strip(), l[17:20].strip(), l[21], l[22:26].strip()
-            out.append(f"ATOM {l[6:11].strip()} {(l[76:78].strip() or name[:1])} {name} . {res} {ch} 1 {seq} ? {l[30:38].strip()} {l[38:46].strip()} "
-                       f"{l[46:54].strip()} 1.0 {l[60:66].strip()} ? {seq} {res} {ch} {name} 1")
-    out.append("#")
+            rows.append(f"ATOM {l[6:11].strip()} {(l[76:78].strip() or name[:1])} {name} . {res} {ch} 1 {seq} ? {l[30:38].strip()} {l[38:46].strip()} "
+                        f"{l[46:54].strip()} 1.0 {l[60:66].strip()} ? {seq} {res} {ch} {name} 1")
+            if name == "CA":
+                seqres.append((seq, res, l[60:66].strip()))
+    # what stands before the atoms in an AFDB file: items, a loop with quoted strings, text fields, and three per-residue tables
+    # (about as many lines again as the chain has residues x 3)
+    one3 = dict(zip("ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL".split(), "ARNDCQEGHILKMFPSTWYV"))
+    one = "".join(one3.get(r, "X") for _, r, _ in seqres)
+    out = ["data_" + entry_id, "#", "_entry.id " + entry_id, "#", "loop_", "_audit_author.name", "_audit_author.pdbx_ordinal",
+           '"Jumper, John" 1', '"Evans, Richard" 2', "'Hassabis, Demis' 3", "#",
+           "_entity_poly.entity_id 1", "_entity_poly.type polypeptide(L)", "_entity_poly.pdbx_seq_one_letter_code"] + \
+          [(";" if k == 0 else "") + one[k:k + 80] for k in range(0, max(len(one), 1), 80)] + [";", "#", "loop_", "_entity_poly_seq.entity_id",
+           "_entity_poly_seq.hetero", "_entity_poly_seq.mon_id", "_entity_poly_seq.num"] + [f"1 n {r} {q}" for q, r, _ in seqres] + \
+          ["#", "loop_", "_ma_qa_metric_local.label_asym_id", "_ma_qa_metric_local.label_comp_id", "_ma_qa_metric_local.label_seq_id",
+           "_ma_qa_metric_local.metric_id", "_ma_qa_metric_local.metric_value", "_ma_qa_metric_local.model_id", "_ma_qa_metric_local.ordinal_id"] + \
+          [f"A {r} {q} 2 {b} 1 {q}" for q, r, b in seqres] + \
+          ["#", "loop_", "_pdbx_poly_seq_scheme.asym_id", "_pdbx_poly_seq_scheme.auth_seq_num", "_pdbx_poly_seq_scheme.entity_id", "_pdbx_poly_seq_scheme.hetero",
+           "_pdbx_poly_seq_scheme.mon_id", "_pdbx_poly_seq_scheme.pdb_ins_code", "_pdbx_poly_seq_scheme.pdb_mon_id", "_pdbx_poly_seq_scheme.pdb_seq_num",
+           "_pdbx_poly_seq_scheme.pdb_strand_id", "_pdbx_poly_seq_scheme.seq_id"] + [f"A {q} 1 n {r} . {r} {q} A {q}" for q, r, _ in seqres] + \
+          ["#", "loop_"] + ["_atom_site." + c for c in cols] + rows + ["#"]
     return ("\n".join(out) + "\n").encode("latin-1")
 
 

@@ -303,8 +303,16 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         unsigned long long rowmask = 0;
         const unsigned long long m_on = __ballot(on);
         const unsigned long long m_rowlike = __ballot(on && cls == CL_VALUES && ntok == ntags);
+        const unsigned long long m_values = __ballot(on && cls == CL_VALUES), m_quiet = __ballot(on && (cls == CL_VALUES || cls == CL_BLANK));
         if (ctx == CX_LOOP_BODY && in_as && as_ready && m_on && m_rowlike == m_on) {
             rowmask = m_on; nvals += (unsigned long long)ntags * (unsigned)__builtin_popcountll(m_on);      // a step of nothing but rows
+        } else if (ctx == CX_LOOP_BODY && !in_as && m_on && m_quiet == m_on) {
+            // a step of nothing but values (and blank lines) of another category's loop (the per-residue tables of a predicted-structure
+            // file): they only count
+            uint32_t kv = ((m_values >> lane) & 1ull) ? ntok : 0u;
+#pragma unroll
+            for (int d = WAVE / 2; d > 0; d >>= 1) kv += (uint32_t)__shfl_xor((int)kv, d, WAVE);
+            nvals += kv;
         } else {
             auto end_item = [&]() {                                                   // what stands before a new tag / loop_ must be complete
                 if (ctx == CX_LOOP_BODY) { if (ntags == 0 || nvals % ntags != 0) dead = true; if (in_as) as_done = true; ctx = CX_NONE; }

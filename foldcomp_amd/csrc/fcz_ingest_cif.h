@@ -55,6 +55,12 @@ struct cif_lds {
     int8_t pos[CIF_NCOL + 1];
 };
 
+#ifdef FCZ_CIF_TIMING
+// measurement aid (not built into the product): wavefront-cycles in the parts of k_ingest_parse_cif, in g_ig_timing (FCZ_IG_TIMING)
+#define CIF_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define CIF_STAMP(i)
+#endif
 __device__ __forceinline__ bool cif_is_ws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r'; }
 __device__ __forceinline__ uint32_t cif_lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32u : c; }
 
@@ -109,6 +115,9 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         return -1;
     };
 
+#ifdef FCZ_CIF_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     const uint64_t A0 = abase[f];
     const uint32_t cap = (uint32_t)(abase[f + 1] - A0);
     uint8_t* tbuf = titles + (size_t)f * IG_TITLE_CAP;
@@ -186,68 +195,73 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             uint32_t maxd = nd;
 #pragma unroll
             for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxd, d, WAVE); maxd = o > maxd ? o : maxd; }
-            for (uint32_t d = 0; d < maxd; d++) {
-                uint32_t x = 0x20202020u;
-                if (d < nd) {
-                    x = ldw(lo + 4 * (int)d);
-                    const uint32_t rest = len - 4u * d;
-                    if (rest < 4u) { const uint32_t keep = (1u << (8u * rest)) - 1u; x = (x & keep) | (0x20202020u & ~keep); }
+            for (uint32_t d0 = 0; d0 < maxd; d0 += 4) {               // four dwords in flight per round trip to the LDS
+                uint32_t xs[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) xs[u] = (d0 + (uint32_t)u < nd) ? ldw(lo + 4 * (int)(d0 + (uint32_t)u)) : 0x20202020u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t d = d0 + (uint32_t)u;
+                    uint32_t x = xs[u];
+                    if (d < nd) { const uint32_t rest = len - 4u * d; if (rest < 4u) { const uint32_t keep = (1u << (8u * rest)) - 1u; x = (x & keep) | (0x20202020u & ~keep); } }
+                    const uint32_t lt20 = zf(x & 0x60606060u);                                  // characters below 0x20 (of 7-bit characters)
+                    const uint32_t wsf = zf(x ^ 0x20202020u) | lt20;
+                    bool b2 = (x & 0x80808080u) != 0u || zf(x ^ 0x7f7f7f7fu) != 0u;              // outside printable ASCII
+                    b2 = b2 || (lt20 & ~(zf(x ^ 0x09090909u) | zf(x ^ 0x0d0d0d0du))) != 0u;      // a control character that is no tab / CR
+                    bad = bad || (d < nd && b2);
+                    const unsigned long long n4 = (unsigned long long)nib(wsf) << (4u * (d & 15u));
+                    const unsigned long long clr = ~(0xfull << (4u * (d & 15u)));
+                    if ((d >> 4) == 0u) W0 = (W0 & clr) | n4; else if ((d >> 4) == 1u) W1 = (W1 & clr) | n4; else if ((d >> 4) == 2u) W2 = (W2 & clr) | n4; else W3 = (W3 & clr) | n4;
                 }
-                const uint32_t lt20 = zf(x & 0x60606060u);                                  // characters below 0x20 (of 7-bit characters)
-                const uint32_t wsf = zf(x ^ 0x20202020u) | lt20;
-                bool b2 = (x & 0x80808080u) != 0u || zf(x ^ 0x7f7f7f7fu) != 0u;              // outside printable ASCII
-                if (lt20) b2 = b2 || (lt20 & ~(zf(x ^ 0x09090909u) | zf(x ^ 0x0d0d0d0du))) != 0u;      // a control character that is no tab / CR
-                bad = bad || (d < nd && b2);
-                const unsigned long long n4 = (unsigned long long)nib(wsf) << (4u * (d & 15u));
-                const unsigned long long clr = ~(0xfull << (4u * (d & 15u)));
-                if ((d >> 4) == 0u) W0 = (W0 & clr) | n4; else if ((d >> 4) == 1u) W1 = (W1 & clr) | n4; else if ((d >> 4) == 2u) W2 = (W2 & clr) | n4; else W3 = (W3 & clr) | n4;
             }
         }
-        // (b) token bounds: a token starts where a character follows a blank (or the line's start), ends at the next blank
-        bool slow = false; uint32_t tag_like = 0;
+        CIF_STAMP(3)
+        // (b) token bounds: a token starts where a character follows a blank (or the line's start), ends at the next blank. With a
+        //     token's start in a register its first characters are fetched at once (two tokens per round trip) and looked at:
+        //     a quote opens a string (the character-by-character lexer takes the line), '#' a comment, '$' a frame reference, '_' a
+        //     tag; reserved words open no value (CifScanner::value): data_ loop_ stop_ save_ global_, any case
+        bool slow = false; uint32_t tag_like = 0, kw_first = 0;
         if (lex && !bad) {
             const unsigned long long p1 = W0 >> 63, p2 = W1 >> 63, p3 = W2 >> 63;
             const unsigned long long S0 = ~W0 & ((W0 << 1) | 1ull), S1 = ~W1 & ((W1 << 1) | p1), S2 = ~W2 & ((W2 << 1) | p2), S3 = ~W3 & ((W3 << 1) | p3);
             const unsigned long long E0 = W0 & ~((W0 << 1) | 1ull), E1 = W1 & ~((W1 << 1) | p1), E2 = W2 & ~((W2 << 1) | p2), E3 = W3 & ~((W3 << 1) | p3);
             ntok = (uint32_t)(__builtin_popcountll(S0) + __builtin_popcountll(S1) + __builtin_popcountll(S2) + __builtin_popcountll(S3));
-            uint32_t t = 0, u = 0;
+            uint32_t t = 0, u = 0; bool comment = false;
+            auto look = [&](uint32_t ti, int at, uint32_t w0) {
+                const uint32_t c0 = w0 & 0xffu;
+                if (c0 == '#') { if (ti == 0) comment = true; else if (!comment) bad = true; }
+                if (comment) return;
+                if (c0 == '\'' || c0 == '"') slow = true;
+                if (c0 == '$' || (c0 == '_' && ti != 0)) bad = true;
+                if (c0 == '_' && ti == 0) tag_like = 1;
+                const uint32_t l4 = w0 | 0x20202020u;                                    // (letters folded; a blank or '_' among the four matches nothing)
+                if (l4 == 0x61746164u || l4 == 0x706f6f6cu || l4 == 0x706f7473u || l4 == 0x65766173u || l4 == 0x626f6c67u) {   // data loop stop save glob
+                    const uint32_t w1 = ldw(at + 4);
+                    uint32_t kw = 0;
+                    if ((w1 & 0xffu) == '_') kw = l4 == 0x61746164u ? 1u : l4 == 0x706f6f6cu ? 2u : l4 == 0x706f7473u ? 5u : l4 == 0x65766173u ? 4u : 0u;
+                    if (l4 == 0x626f6c67u && ((w1 | 0x00002020u) & 0x00ffffffu) == 0x005f6c61u) kw = 3u;                                    // "al_"
+                    if (kw) { if (ti == 0) kw_first = kw; else bad = true; }
+                }
+            };
             auto put = [&](unsigned long long ms, unsigned long long me, uint32_t off) {
-                for (; ms; ms &= ms - 1) { if (t < (uint32_t)CIF_MAXTOK) S.tok_s[t][lane] = (uint8_t)(off + (uint32_t)__builtin_ctzll(ms)); t++; }
+                while (ms) {
+                    const uint32_t q0 = off + (uint32_t)__builtin_ctzll(ms); ms &= ms - 1;
+                    const bool two = ms != 0ull;
+                    const uint32_t q1 = two ? off + (uint32_t)__builtin_ctzll(ms) : q0; ms &= ms - 1;
+                    const uint32_t w0 = ldw(lo + (int)q0), w1 = ldw(lo + (int)q1);
+                    if (t < (uint32_t)CIF_MAXTOK) S.tok_s[t][lane] = (uint8_t)q0;
+                    if (two && t + 1 < (uint32_t)CIF_MAXTOK) S.tok_s[t + 1][lane] = (uint8_t)q1;
+                    look(t, lo + (int)q0, w0);
+                    if (two) look(t + 1, lo + (int)q1, w1);
+                    t += two ? 2u : 1u;
+                }
                 for (; me; me &= me - 1) { if (u < (uint32_t)CIF_MAXTOK) S.tok_e[u][lane] = (uint8_t)(off + (uint32_t)__builtin_ctzll(me)); u++; }
             };
             put(S0, E0, 0u); put(S1, E1, 64u); put(S2, E2, 128u); put(S3, E3, 192u);
-            if (ntok > (uint32_t)CIF_MAXTOK) slow = true;              // (the character-by-character lexer counts any number of tokens)
+            if (comment) { ntok = 0; slow = false; bad = false; tag_like = 0; kw_first = 0; }   // (what a comment holds is nobody's business)
+            else if (ntok > (uint32_t)CIF_MAXTOK) slow = true;              // (the character-by-character lexer counts any number of tokens)
         }
-        // (c) what a token starts with: a quote opens a string (that lexer), '#' a comment, '$' a frame reference, '_' a tag;
-        //     reserved words open no value (CifScanner::value): data_ loop_ stop_ save_ global_, any case
-        uint32_t kw_first = 0;
-        {
-            uint32_t nchk = (lex && !bad && !slow) ? ntok : 0u, maxt = nchk;
-#pragma unroll
-            for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxt, d, WAVE); maxt = o > maxt ? o : maxt; }
-            bool comment = false;
-            for (uint32_t t = 0; t < maxt; t++) {
-                const bool in = t < nchk && !comment;
-                const int at = in ? lo + (int)S.tok_s[t][lane] : 0;
-                const uint32_t w0 = in ? ldw(at) : 0x30303030u;
-                const uint32_t c0 = w0 & 0xffu;
-                const uint32_t n = in ? (uint32_t)S.tok_e[t][lane] - (uint32_t)S.tok_s[t][lane] : 0u;
-                if (in && c0 == '#') { if (t == 0) { comment = true; ntok = 0; } else bad = true; }
-                const bool live = in && !comment;
-                if (live && (c0 == '\'' || c0 == '"')) slow = true;
-                if (live && (c0 == '$' || (c0 == '_' && t != 0))) bad = true;
-                if (live && c0 == '_' && t == 0) tag_like = 1;
-                const uint32_t l4 = w0 | 0x20202020u;                                    // (letters folded; '_' is not among the four)
-                const bool cand = live && n >= 5u && (l4 == 0x61746164u || l4 == 0x706f6f6cu || l4 == 0x706f7473u || l4 == 0x65766173u || l4 == 0x626f6c67u);   // data loop stop save glob
-                if (__any(cand)) {
-                    const uint32_t w1 = cand ? ldw(at + 4) : 0u;
-                    uint32_t kw = 0;
-                    if (cand && (w1 & 0xffu) == '_') kw = l4 == 0x61746164u ? 1u : l4 == 0x706f6f6cu ? 2u : l4 == 0x706f7473u ? 5u : l4 == 0x65766173u ? 4u : 0u;
-                    if (cand && l4 == 0x626f6c67u && n >= 7u && ((w1 | 0x00002020u) & 0x00ffffffu) == 0x005f6c61u) kw = 3u;                      // "al_"
-                    if (kw) { if (t == 0) kw_first = kw; else bad = true; }
-                }
-            }
-        }
+        CIF_STAMP(4)
         // (d) the character-by-character lexer for the lines that hold a quoted string (or more tokens than the table)
         if (__any(slow && !bad)) {
             if (slow && !bad) {
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         if (bad) cls = CL_BAD;
         if (__any(cls == CL_BAD)) { dead = true; return; }
         in_text = in_text ^ ((__builtin_popcountll(m_semi) & 1) != 0);
+        CIF_STAMP(5)
         // ---- 2. the grammar over the step's lines, in order (uniform) ----
         unsigned long long rowmask = 0;
         const unsigned long long m_on = __ballot(on);
@@ -320,9 +335,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             };
             for (unsigned long long m = m_on & __ballot(cls != CL_BLANK); m && !dead; m &= m - 1) {
                 const int l = __builtin_ctzll(m);
-                const int c = __shfl(cls, l, WAVE);
-                const uint32_t k = (uint32_t)__shfl((int)ntok, l, WAVE);
-                const int llo = __shfl(lo, l, WAVE);
+                // (l is uniform: v_readlane, not the LDS crossbar of a shuffle)
+                const int c = __builtin_amdgcn_readlane(cls, l);
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)ntok, l);
+                const int llo = __builtin_amdgcn_readlane(lo, l);
                 if (c == CL_DATA) { if (ctx != CX_START) dead = true; ctx = CX_NONE; continue; }      // a second block: to the host
                 if (ctx == CX_START) { dead = true; break; }
                 if (c == CL_LOOP) { end_item(); ctx = CX_LOOP_HDR; ntags = 0; nvals = 0; in_as = false; other_cat = false; continue; }
@@ -389,6 +405,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 if (in_as) { if (c != CL_VALUES || k != ntags) { dead = true; break; } rowmask |= 1ull << l; }
             }
         }
+        CIF_STAMP(6)
         if (dead) return;
         // ---- 3. the _atom_site rows of the step, every lane its own: a field's characters come into registers as four dwords, the
         //         readers are boolean arithmetic over their (at most sixteen) characters ----
@@ -398,14 +415,6 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         uint32_t an = 0, rn = 0, ch = ' '; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
         {
             struct fld { uint32_t w[4]; uint32_t n; };
-            auto get = [&](int col) -> fld {                                         // col >= 0 (uniform); lanes that hold no row read their own line start
-                fld f; const uint32_t s0 = row ? (uint32_t)S.tok_s[col][lane] : 0u, e0 = row ? (uint32_t)S.tok_e[col][lane] : 0u;
-                f.n = e0 - s0;
-                const int at = row ? lo + (int)s0 : 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) f.w[q] = ldw(at + 4 * q);
-                return f;
-            };
             auto ch_at = [](const fld& f, int i) -> uint32_t { return (f.w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
             auto is_null = [&](const fld& f) -> bool { return f.n == 1u && ((f.w[0] & 0xffu) == '?' || (f.w[0] & 0xffu) == '.'); };
             auto integer = [&](const fld& f, int32_t* out) -> bool {                  // [+-]digits, at most nine of them
@@ -443,24 +452,42 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 *out = f.n >= 4u ? f.w[0] : (f.w[0] & ((1u << (8u * f.n)) - 1u));
                 return (f.n >= 1u) & (f.n <= 4u) & !is_null(f);
             };
-            const int pAlt = S.pos[CK_ALT], pIns = S.pos[CK_INS], pLs = S.pos[CK_LSEQ], pCh = S.pos[CK_CHARGE], pMo = S.pos[CK_MODEL];
             // no quoted value anywhere in the row (the host strips the quotes): such a line went through the character lexer
             if (row && slow) rbad = true;
-            { const fld f = get(S.pos[CK_ID]); rbad = rbad | !integer(f, &serial); }
-            { const fld f = get(S.pos[CK_ASEQ]); rbad = rbad | !integer(f, &num); }
-            { const fld f = get(S.pos[CK_X]); rbad = rbad | !decimal(f, &x); }
-            { const fld f = get(S.pos[CK_Y]); rbad = rbad | !decimal(f, &y); }
-            { const fld f = get(S.pos[CK_Z]); rbad = rbad | !decimal(f, &z); }
-            { const fld f = get(S.pos[CK_B]); rbad = rbad | !decimal(f, &bf); }
-            { const fld f = get(S.pos[kAtom]); rbad = rbad | !pack(f, &an); }
-            { const fld f = get(S.pos[kComp]); rbad = rbad | !pack(f, &rn); }
-            { const fld f = get(S.pos[kAsym]); rbad = rbad | (f.n != 1u) | is_null(f); ch = f.w[0] & 0xffu; }
-            { const fld f = get(pAlt); rbad = rbad | (!is_null(f) & (f.n != 1u)); }
-            int32_t dummy;
-            if (pIns >= 0) { const fld f = get(pIns); rbad = rbad | !is_null(f); }
-            if (pLs >= 0) { const fld f = get(pLs); rbad = rbad | (!is_null(f) & !integer(f, &dummy)); }
-            if (pCh >= 0) { const fld f = get(pCh); rbad = rbad | (!is_null(f) & !integer(f, &dummy)); }
-            if (pMo >= 0) { const fld f = get(pMo); rbad = rbad | (f.n > 8u); const unsigned long long v8 = (unsigned long long)f.w[0] | ((unsigned long long)f.w[1] << 32); mdl = f.n >= 8u ? v8 : (v8 & ((1ull << (8u * f.n)) - 1ull)); }
+            // the fourteen fields: first every field's bounds, then their characters, four dwords each -- the loads of a group leave
+            // together (one round trip to the LDS per group instead of two per field)
+            const int cols[14] = {S.pos[CK_ID], S.pos[CK_ASEQ], S.pos[CK_X], S.pos[CK_Y], S.pos[CK_Z], S.pos[CK_B], S.pos[kAtom], S.pos[kComp], S.pos[kAsym],
+                                  S.pos[CK_ALT], S.pos[CK_INS], S.pos[CK_LSEQ], S.pos[CK_CHARGE], S.pos[CK_MODEL]};
+            uint32_t fs[14], fe[14];
+#pragma unroll
+            for (int q = 0; q < 14; q++) {
+                const int c = cols[q] >= 0 ? cols[q] : 0;
+                fs[q] = row ? (uint32_t)S.tok_s[c][lane] : 0u; fe[q] = row ? (uint32_t)S.tok_e[c][lane] : 0u;
+            }
+            auto load = [&](int q) -> fld {
+                fld f; f.n = fe[q] - fs[q];
+                const int at = row ? lo + (int)fs[q] : 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) f.w[k] = ldw(at + 4 * k);
+                return f;
+            };
+            {
+                const fld f0 = load(0), f1 = load(1), f2 = load(2), f3 = load(3), f4 = load(4);
+                rbad = rbad | !integer(f0, &serial) | !integer(f1, &num) | !decimal(f2, &x) | !decimal(f3, &y) | !decimal(f4, &z);
+            }
+            {
+                const fld f5 = load(5), f6 = load(6), f7 = load(7), f8 = load(8), f9 = load(9);
+                rbad = rbad | !decimal(f5, &bf) | !pack(f6, &an) | !pack(f7, &rn) | (f8.n != 1u) | is_null(f8) | (!is_null(f9) & (f9.n != 1u));
+                ch = f8.w[0] & 0xffu;
+            }
+            {
+                const fld f10 = load(10), f11 = load(11), f12 = load(12), f13 = load(13);
+                int32_t dummy;
+                if (cols[10] >= 0) rbad = rbad | !is_null(f10);
+                if (cols[11] >= 0) rbad = rbad | (!is_null(f11) & !integer(f11, &dummy));
+                if (cols[12] >= 0) rbad = rbad | (!is_null(f12) & !integer(f12, &dummy));
+                if (cols[13] >= 0) { rbad = rbad | (f13.n > 8u); const unsigned long long v8 = (unsigned long long)f13.w[0] | ((unsigned long long)f13.w[1] << 32); mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull)); }
+            }
             rbad = rbad & row;
         }
         // one model; residues of a chain run in rising order (the reader regroups anything else); keep rule of removeAlternativePosition
@@ -473,7 +500,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             const int32_t p_num = pl < 64u ? s_num : last_num;
             const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name;
             const int fl = __builtin_ctzll(rowmask);
-            const unsigned long long m_first = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(mdl >> 32), fl, WAVE) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)mdl, fl, WAVE);
+            const unsigned long long m_first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mdl >> 32), fl) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mdl, fl);
             const unsigned long long m0 = have_model ? model0 : m_first;
             if (row && mdl != m0) rbad = true;
             if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_rn == rn) && !(num > p_num)) rbad = true;
@@ -492,9 +519,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             }
             kept += n_new;
             const int hl = 63 - __builtin_clzll(rowmask);
-            last_name = (uint32_t)__shfl((int)an, hl, WAVE); last_comp = (uint32_t)__shfl((int)rn, hl, WAVE); last_ch = (uint32_t)__shfl((int)ch, hl, WAVE);
-            last_num = __shfl(num, hl, WAVE); have_last = true;
+            last_name = (uint32_t)__builtin_amdgcn_readlane((int)an, hl); last_comp = (uint32_t)__builtin_amdgcn_readlane((int)rn, hl); last_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, hl);
+            last_num = __builtin_amdgcn_readlane(num, hl); have_last = true;
         }
+        CIF_STAMP(7)
     };
 
     // ---- the chunk walk of k_ingest_parse: coalesced loads a chunk ahead, staged in LDS behind the previous chunk's tail ----
@@ -511,6 +539,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         }
     };
     load_chunk(0);
+    CIF_STAMP(0)
     uint64_t c0 = 0;
     for (; c0 < flen && !dead; c0 += IG_CHUNK) {
         {
@@ -524,6 +553,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             c0_staged = c0;
             load_chunk(c0 + IG_CHUNK);
         }
+        CIF_STAMP(1)
         const uint64_t my = c0 + 64ull * (uint64_t)lane;
         uint32_t nl_lo = 0, nl_hi = 0, z_lo = 0, z_hi = 0;
         {
@@ -566,6 +596,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 const uint64_t le = on ? c0 + S.line_end[k] : 0;
                 const uint64_t ls = on ? (k == 0 ? line_start : c0 + S.line_end[k - 1] + 1) : 0;
                 const long long rel = (long long)ls - (long long)c0;
+                CIF_STAMP(2)
                 do_lines(on, ls, le, (on && rel >= -(long long)IG_BACK) ? (int)(IG_BACK + rel) : -1);
             }
             if (n_here) line_start = c0 + S.line_end[n_here - 1] + 1;
@@ -589,6 +620,9 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         n_kept[f] = kept;
         file_status[f] = FCZ_OK;
     }
+#ifdef FCZ_CIF_TIMING
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_ig_timing[i], tacc[i]);
+#endif
 }
 
 }  // namespace fcz

@@ -922,6 +922,7 @@ static int ensure_sizes(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* o
         *total_res = ctx->sized_R; *max_seg_len = ctx->sized_maxseg; *max_nseg = ctx->sized_maxnseg; *n_long = ctx->sized_nlong;
         return FCZ_OK;
     }
+    ctx->sizes_fresh = false;   // the pass below overwrites what a remembered sizes call left (length order, residue codes)
     int rc = ctx->stage[16].ensure(sizeof(uint32_t) * ((size_t)n + 1)); if (rc) return rc;
     if ((rc = run_entry_sizes(ctx, blob_dev, off_dev, n, ctx->stage[16].as<uint32_t>(), nullptr))) return rc;
     *total_res = ctx->pinned[0]; *max_seg_len = ctx->pinned[3]; *max_nseg = ctx->pinned[4]; *n_long = ctx->pinned[5];

@@ -154,3 +154,38 @@ def test_configs2_database_to_pdb_text_equals_reference(codec, tmp_path):
     rd.close()
     del w, d
     torch.cuda.empty_cache()
+
+
+def test_a_remembered_sizes_pass_is_forgotten_when_another_batch_runs_in_between():
+    """fcz_decompress_sizes_dev leaves totals, the length order and the residue-code array for the batch call that follows on the SAME
+    records; a batch call on OTHER records in between recomputes them for those -- the remembered ones must not be used afterwards"""
+    import ctypes
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from foldcomp_amd import _lib
+    from foldcomp_amd.codec import Codec
+    dev = "cuda:0"
+    codec = Codec(0)
+    ws = []
+    for seed, n_res in ((0, 120), (5000, 77)):
+        d = bench.generate_resident(700, n_res, 25, 4096, dev, seed_base=seed)
+        w = bench.Workload(codec, d, dev)
+        w.compress(); w.decompress(); codec.synchronize()
+        ws.append(w)
+    a, b = ws
+    want = {k: a.out_t[k].clone() for k in ("x", "y", "z", "bfac_res")}
+    for k in ("x", "y", "z", "bfac_res"):
+        a.out_t[k].zero_()
+    lib = codec.lib
+    tr = ctypes.c_uint32(); ta = ctypes.c_uint32()
+    _lib.check(lib.fcz_decompress_sizes_dev(codec.ctx, a.blob_dev.data_ptr(), a.off_dev.data_ptr(), a.C, a.res_off_dev.data_ptr(), a.atom_off_dev.data_ptr(),
+                                            ctypes.byref(tr), ctypes.byref(ta)), "sizes a")
+    _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, b.blob_dev.data_ptr(), b.off_dev.data_ptr(), b.C, b.res_off_dev.data_ptr(), b.atom_off_dev.data_ptr(), 0,
+                                            ctypes.byref(b.cout)), "batch b")
+    _lib.check(lib.fcz_decompress_batch_dev(codec.ctx, a.blob_dev.data_ptr(), a.off_dev.data_ptr(), a.C, a.res_off_dev.data_ptr(), a.atom_off_dev.data_ptr(), 0,
+                                            ctypes.byref(a.cout)), "batch a")
+    codec.synchronize()
+    for k in ("x", "y", "z", "bfac_res"):
+        assert torch.equal(a.out_t[k].view(torch.int32), want[k].view(torch.int32)), k
+    codec.close()

@@ -101,6 +101,19 @@ constexpr int CK_CAP = 2288;                // staged atom records per pass (a t
                                             // below the block's LDS stays under a third of the CU's 160 KB at the allocation granularity
 constexpr int CK_ZERO = CK_CAP;             // index of the all-zero record (missing atoms)
 
+// res_sc_addr in memory: five bytes per residue instead of eight (round 4: the index kernel is a write stream, 8 of its 9.4 bytes per
+// residue were this array) -- a dword plane with the address's low 32 bits, then a byte plane with bits 32..38 and the
+// last-of-chain flag in bit 7 (a blob of up to 512 GB). The kernels keep handling the 64-bit value with CK_LAST in bit 63.
+__device__ __forceinline__ void sc_addr_put(uint64_t* base, uint32_t n_res, size_t r, uint64_t addr, bool last) {
+    reinterpret_cast<uint32_t*>(base)[r] = (uint32_t)addr;
+    (reinterpret_cast<uint8_t*>(base) + 4 * (size_t)n_res)[r] = (uint8_t)(((addr >> 32) & 0x7fu) | (last ? 0x80u : 0u));
+}
+__device__ __forceinline__ unsigned long long sc_addr_get(const uint64_t* base, size_t n_res, size_t r) {
+    const uint32_t lo = reinterpret_cast<const uint32_t*>(base)[r];
+    const uint32_t hi = (reinterpret_cast<const uint8_t*>(base) + 4 * n_res)[r];
+    return (unsigned long long)lo | ((unsigned long long)(hi & 0x7fu) << 32) | ((unsigned long long)(hi >> 7) << 63);
+}
+
 // =====================================================================================================================
 // k_compress_index
 // =====================================================================================================================
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(BLOCK) void k_compress_index(fcz_chain_batch in, co
             uint32_t tot;
             const uint32_t ex = run + wave_excl_scan(c3, lane, &tot);
             run += tot;
-            if (k < n) res_sc_addr[r0 + k] = (base + ex) | (k == n - 1 ? CK_LAST : 0ull);
+            if (k < n) sc_addr_put(res_sc_addr, in.n_residues, r0 + k, base + ex, k == n - 1);
         }
     } else {
         for (uint32_t b = 0; b < n; b += WAVE) {
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void k_compress_index(fcz_chain_batch in, co
             uint32_t tot;
             const uint32_t ex = run + wave_excl_scan(cnt, lane, &tot);
             run += tot;
-            if (k < n) res_sc_addr[r0 + k] = (base + ex) | (k == n - 1 ? CK_LAST : 0ull);
+            if (k < n) sc_addr_put(res_sc_addr, in.n_residues, r0 + k, base + ex, k == n - 1);
         }
     }
 }
@@ -237,7 +250,7 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles_all, const uint32_t*
         m.ox = in.atom_off[cl(r_lo + CK_TILE + (size_t)(t & 1))];            // olo[256], olo[257]
         m.rc = in.res_code[r < Rz ? r : Rz - 1];
         m.rc_succ = in.res_code[r_lo + CK_TILE < Rz ? r_lo + CK_TILE : Rz - 1];
-        m.sa = res_sc_addr[r < Rz ? r : Rz - 1];
+        m.sa = sc_addr_get(res_sc_addr, Rz, r < Rz ? r : Rz - 1);
         const size_t r_n = (size_t)tile_next * CK_TILE;                      // this block's next tile
         m.a0_next = in.atom_off[cl(r_n)];
         m.e_next = in.atom_off[cl(r_n + CK_TILE + 1)];
@@ -624,7 +637,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
         wmeta m;
         m.olo = in.atom_off[r_ < Rz ? r_ : Rz]; m.ohi = in.atom_off[r_ + 1 < Rz ? r_ + 1 : Rz];
         m.rc = in.res_code[r_ < Rz ? r_ : Rz - 1];
-        m.sa = res_sc_addr[r_ < Rz ? r_ : Rz - 1];
+        m.sa = sc_addr_get(res_sc_addr, Rz, r_ < Rz ? r_ : Rz - 1);
         return m;
     };
     const uint32_t wt0 = blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wave;

@@ -465,7 +465,7 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
     const dim3 per_chain(grid_for(in->n_chains, WAVES_PER_BLOCK));
     {
         span_guard g(ctx, "compress_index");
-        hipLaunchKernelGGL(k_compress_index, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, ctx->res_sc_addr.as<uint64_t>());
+        hipLaunchKernelGGL(k_compress_index, dim3(grid_for(in->n_chains, GROUPS_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, ctx->res_sc_addr.as<uint64_t>());
     }
     if (in->n_residues) {
         // wavefront-private tiles first; what does not fit them (atom-rich stretches, the tail of the arrays) is listed per

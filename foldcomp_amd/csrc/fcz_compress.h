@@ -117,38 +117,36 @@ __device__ __forceinline__ unsigned long long sc_addr_get(const uint64_t* base, 
 // =====================================================================================================================
 // k_compress_index
 // =====================================================================================================================
+// One 16-lane group (a DPP row) per chain, lane = residue k0 + sub: four chains' dependent loads (offsets -> codes) in flight per
+// wavefront instead of one (round 4; the kernel is a write stream of 5 B/residue behind two round trips per chain).
 __global__ __launch_bounds__(BLOCK) void k_compress_index(fcz_chain_batch in, const uint64_t* __restrict__ out_off,
                                                           uint64_t* __restrict__ res_sc_addr) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (c >= in.n_chains) return;
-    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
-    if (n == 0) return;
+    const int sub = threadIdx.x & (GROUP - 1);
+    const uint32_t c = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
+    const bool live = c < in.n_chains;
+    const uint32_t r0 = live ? in.res_off[c] : 0u, n = live ? in.res_off[c + 1] - r0 : 0u;
     const uint32_t thr = in.anchor_threshold > 0 ? (uint32_t)in.anchor_threshold : 1u;
-    const rec_layout RL = make_layout(n, n / thr + 2, in.title_off[c + 1] - in.title_off[c], 0);   // o_sc does not depend on n_sc
-    const uint64_t base = out_off[c] + RL.o_sc;
+    const rec_layout RL = make_layout(n, n / thr + 2, live ? in.title_off[c + 1] - in.title_off[c] : 0u, 0);   // o_sc does not depend on n_sc
+    const uint64_t base = (live ? out_off[c] : 0ull) + RL.o_sc;
     uint32_t run = 0;
-    constexpr int U = 6;
-    if (n <= (uint32_t)(U * WAVE)) {   // a normal chain: one memory round trip for all residue codes
+    // exclusive prefix inside the row: Hillis-Steele on the DPP network (zeros shift in), the row's total from its last lane
+    auto row_scan = [&](uint32_t x, uint32_t* total) -> uint32_t {
+        uint32_t v = x;
+        v += dpp_u32_or0<0x111, 0xf>(v); v += dpp_u32_or0<0x112, 0xf>(v); v += dpp_u32_or0<0x114, 0xf>(v); v += dpp_u32_or0<0x118, 0xf>(v);
+        *total = (uint32_t)__shfl((int)v, GROUP - 1, GROUP);
+        return v - x;
+    };
+    constexpr int U = 8;                                   // residue codes in flight per lane and round trip (128 residues per round)
+    for (uint32_t k0 = 0; k0 < n; k0 += U * GROUP) {       // (the trip count differs between the rows of a wavefront: rows that are done idle)
         uint32_t cnt[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const uint32_t k = u * WAVE + lane; cnt[u] = in.res_code[r0 + (k < n ? k : n - 1)]; }
+        for (int u = 0; u < U; u++) { const uint32_t k = k0 + (uint32_t)(u * GROUP + sub); cnt[u] = in.res_code[r0 + (k < n ? k : n - 1)]; }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t k = u * WAVE + lane;
+            const uint32_t k = k0 + (uint32_t)(u * GROUP + sub);
             const uint32_t c3 = k < n ? (uint32_t)fcz_res_natoms[cnt[u] < 24 ? cnt[u] : 23] - 3u : 0u;
             uint32_t tot;
-            const uint32_t ex = run + wave_excl_scan(c3, lane, &tot);
-            run += tot;
-            if (k < n) sc_addr_put(res_sc_addr, in.n_residues, r0 + k, base + ex, k == n - 1);
-        }
-    } else {
-        for (uint32_t b = 0; b < n; b += WAVE) {
-            const uint32_t k = b + lane;
-            uint32_t cnt = 0;
-            if (k < n) { const uint32_t rc = in.res_code[r0 + k]; cnt = fcz_res_natoms[rc < 24 ? rc : 23] - 3; }
-            uint32_t tot;
-            const uint32_t ex = run + wave_excl_scan(cnt, lane, &tot);
+            const uint32_t ex = run + row_scan(c3, &tot);
             run += tot;
             if (k < n) sc_addr_put(res_sc_addr, in.n_residues, r0 + k, base + ex, k == n - 1);
         }

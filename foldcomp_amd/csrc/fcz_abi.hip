@@ -87,7 +87,6 @@ struct fcz_ctx {
     bool sizes_fresh = false;
     dev_buf cnt;        // decompress: 2 x n u32 counts (residues, atoms) + n i32 status + n u32 segment info
     dev_buf fwd;        // decompress: per-group ring of forward atoms (one segment deep)
-    dev_buf maxseg;     // decompress: two words: longest anchor segment of the batch, most segments of a chain
     dev_buf wring;      // decompress: per-group ring of cos/sin of the segment's torsions
     dev_buf fwd_long, wring_long;   // decompress: the same per (group, segment) for the long chains' split form
     dev_buf bb;         // decompress: blended backbone
@@ -231,7 +230,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     (void)hipSetDevice(c->device);
     drain_spans(c);
     (void)hipStreamSynchronize(c->stream);
-    c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->codes.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->maxseg.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
+    c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->codes.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
     for (auto& b : c->stage) b.release();
     for (auto& b : c->ig) b.release();
     if (c->pinned) (void)hipHostFree(c->pinned);

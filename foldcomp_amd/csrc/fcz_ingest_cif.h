@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
     enum { CX_START, CX_NONE, CX_AFTER_TAG, CX_LOOP_HDR, CX_LOOP_BODY };
     int ctx = CX_START;
     uint32_t ntags = 0; unsigned long long nvals = 0;
-    bool in_as = false, other_cat = false, as_done = false, as_ready = false;   // the open loop is the _atom_site loop / holds other tags too; the loop was read; its column map is final
+    bool in_as = false, as_done = false, as_ready = false;   // the open loop is the _atom_site loop; that loop was read; its column map is final
     bool pending_special = false;          // the tag waiting for its value on a later line is one whose value this path must see
     bool in_text = false;                  // inside a text field
     uint32_t tlen = 0; bool have_title = false;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 const int llo = __builtin_amdgcn_readlane(lo, l);
                 if (c == CL_DATA) { if (ctx != CX_START) dead = true; ctx = CX_NONE; continue; }      // a second block: to the host
                 if (ctx == CX_START) { dead = true; break; }
-                if (c == CL_LOOP) { end_item(); ctx = CX_LOOP_HDR; ntags = 0; nvals = 0; in_as = false; other_cat = false; continue; }
+                if (c == CL_LOOP) { end_item(); ctx = CX_LOOP_HDR; ntags = 0; nvals = 0; in_as = false; continue; }
                 if (c == CL_TAG || c == CL_PAIR) {
                     const uint32_t t0 = S.tok_s[0][l], tn = (uint32_t)S.tok_e[0][l] - t0;
                     uint32_t h = 2166136261u;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                                 if (tn == 11u + wl && eq_lower(llo, t0 + 11u, cif_col_names[q], wl)) { if (lane == 0) S.pos[q] = (int8_t)ntags; }
                             }
                             __builtin_amdgcn_wave_barrier();
-                        } else { if (in_as) { dead = true; break; } other_cat = true; }
+                        } else if (in_as) { dead = true; break; }                          // another category's tag inside the _atom_site loop
                         ntags++;
                         if (in_as && ntags > (uint32_t)CIF_MAXTOK) { dead = true; break; }
                         continue;

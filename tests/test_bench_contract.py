@@ -71,3 +71,23 @@ def test_plain_python_gpus_2_starts_two_ranks():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_mmcif_rendering_holds_the_same_atoms():
+    """the mmCIF files of bench.py's mmCIF legs are the chains of its PDB legs: cif_from_pdb_text of a PDB text reads back (host
+    reader, mmCIF rules) as the atoms the PDB text reads back as (host reader, PDB rules), title = the entry id"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    b = _bench()
+    from foldcomp_amd.structure import parse_pdb_gemmi, parse_structure_gemmi
+    from test_host_cpp import _pdb_text
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+    for name in ("syn:len26", "syn:len129", "pdb:test_af"):
+        pdb = _pdb_text(z, name).encode()
+        cif = b.cif_from_pdb_text(pdb, "ENTRY1")
+        tp, _ = parse_pdb_gemmi(pdb)
+        tc, title = parse_structure_gemmi(cif)
+        assert title == "ENTRY1" and len(tc) == len(tp) > 0
+        assert list(tc.atom) == list(tp.atom) and list(tc.residue) == list(tp.residue) and list(tc.chain) == list(tp.chain)
+        assert np.array_equal(np.asarray(tc.res_index), np.asarray(tp.res_index)) and np.array_equal(np.asarray(tc.atom_index), np.asarray(tp.atom_index))
+        assert np.array_equal(tc.xyz.view(np.uint32), tp.xyz.view(np.uint32)) and np.array_equal(np.asarray(tc.bfac, np.float32).view(np.uint32), np.asarray(tp.bfac, np.float32).view(np.uint32))

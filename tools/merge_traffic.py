@@ -3,19 +3,20 @@
      gpurun_out/prof_<tag>/traffic.json        tools/pmc_summary.py <tag>          the codec kernels (262 144 chains per launch)
      gpurun_out/prof_<tag>p/traffic.json       tools/pmc_summary.py <tag>p <R>     the text kernels (k_ingest_*, k_pdb_*: 65 536 chains)
      <probe.json>                               tools/hbm_busy_probe.py             memory-controller-side activity per stage
-   usage: tools/merge_traffic.py <tag> <probe.json>   -> profiles/traffic.json"""
+   usage: tools/merge_traffic.py <tag> <probe.json> [<text tag, default <tag>p>]   -> profiles/traffic.json"""
 import json, os, sys
 tag, probe_path = sys.argv[1], sys.argv[2]
+ttag = sys.argv[3] if len(sys.argv) > 3 else tag + "p"
 t = json.load(open(os.path.join("gpurun_out", "prof_" + tag, "traffic.json")))
 t["source"] = t["source"].replace("profiles/%s_pmc_per_kernel.csv" % tag, "profiles/%s_pmc_per_kernel.csv" % tag)
-pdir = os.path.join("gpurun_out", "prof_" + tag + "p", "traffic.json")
+pdir = os.path.join("gpurun_out", "prof_" + ttag, "traffic.json")
 if os.path.exists(pdir):
     tp = json.load(open(pdir))
     for k, v in tp["kernels"].items():
         if k.startswith(("k_ingest", "k_pdb")):
             v["residues_per_launch"] = 22937600
             t["kernels"][k] = v
-    t["text_kernels_source"] = "profiles/%sp_pmc_per_kernel.csv (the same passes with --pdb-sample 65536: 22 937 600 residues of PDB text per launch)" % tag
+    t["text_kernels_source"] = "profiles/%s_pmc_per_kernel.csv (the same passes with --pdb-sample 65536: 22 937 600 residues of PDB / mmCIF text per launch)" % ttag
 pr = json.load(open(probe_path))
 if "probes" in pr:
     ks = t["kernels"]

@@ -401,8 +401,24 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                     }
                 }
                 if (ctx != CX_LOOP_BODY) { dead = true; break; }
-                nvals += kv;
-                if (in_as) { if (c != CL_VALUES || k != ntags) { dead = true; break; } rowmask |= 1ull << l; }
+                if (c == CL_VALUES) {
+                    // a loop's body is a run of value lines (and blank / comment lines): the whole run from this line on is taken at
+                    // once -- a masked sum of its token counts -- instead of a turn of this loop per line
+                    const unsigned long long quiet = m_quiet >> l;                              // bit 0 = this line
+                    const int run = ~quiet ? __builtin_ctzll(~quiet) : 64;
+                    const unsigned long long in_run = (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << l;
+                    const bool mine = ((in_run & m_values) >> lane) & 1ull;
+                    uint32_t sum = mine ? ntok : 0u; uint32_t odd = (mine && ntok != ntags) ? 1u : 0u;
+#pragma unroll
+                    for (int d = WAVE / 2; d > 0; d >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, d, WAVE); odd |= (uint32_t)__shfl_xor((int)odd, d, WAVE); }
+                    nvals += sum;
+                    if (in_as) { if (odd) { dead = true; break; } rowmask |= in_run & m_values; }
+                    m &= ~in_run;                                                              // (the loop's own `m &= m - 1` then clears nothing of ours)
+                    m |= 1ull << l;
+                    continue;
+                }
+                nvals += kv;                                                                   // a text field
+                if (in_as) { dead = true; break; }
             }
         }
         CIF_STAMP(6)

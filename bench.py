@@ -855,10 +855,24 @@ def alt_numerics_leg(args, codec, w, dev, comm, timed_mode, compress_ms):
     world = comm.world
     dt = timed(lambda: (w.decompress(), codec.synchronize()), steps, comm)
     km = span_ms(codec)
-    devv = torch.stack([(w.out_t[k][:na] - ref[k]).abs() for k in ("x", "y", "z")]).max(0).values
-    stats = {"sample_chains": ns, "sample_atoms": na, "median_A": float(devv[::5].median()),
-             "p999_A": float(torch.quantile(devv[::max(1, na // 4_000_000)].float(), 0.999)), "max_A": float(devv.max()),
-             "frac_above_1e-2_A": float((devv > 1e-2).double().mean())}
+    # per-atom deviation = the largest of |dx|, |dy|, |dz|. In pieces of 2^27 atoms (one stacked tensor of 3 x 547 M floats -- 65 536
+    # chains of 1 000 residues -- made torch's own reduction kernel fault), the order statistics on a strided sample of <= 2^24 atoms
+    piece = 1 << 27; stride = max(1, na // (1 << 24))
+    mx_dev = 0.0; n_above = 0; samp = []
+    for a0 in range(0, na, piece):
+        a1 = min(na, a0 + piece)
+        dv = (w.out_t["x"][a0:a1] - ref["x"][a0:a1]).abs()
+        dv = torch.maximum(dv, (w.out_t["y"][a0:a1] - ref["y"][a0:a1]).abs())
+        dv = torch.maximum(dv, (w.out_t["z"][a0:a1] - ref["z"][a0:a1]).abs())
+        if dv.numel():
+            mx_dev = max(mx_dev, float(dv.max())); n_above += int((dv > 1e-2).sum())
+            first = (-a0) % stride
+            samp.append(dv[first::stride].clone())
+        del dv
+    devv = torch.cat(samp) if samp else torch.zeros(1, device=dev)
+    stats = {"sample_chains": ns, "sample_atoms": na, "order_statistics_on_atoms": int(devv.numel()), "median_A": float(devv.median()),
+             "p999_A": float(torch.quantile(devv[::max(1, devv.numel() // 4_000_000)].float(), 0.999)), "max_A": mx_dev,
+             "frac_above_1e-2_A": n_above / max(na, 1)}
     rmsd, mx = w.round_trip_deviation()
     kb = w.kernel_bytes()
     names = ("k_backbone", "k_res_index", "k_sidechain")
@@ -879,7 +893,7 @@ def alt_numerics_leg(args, codec, w, dev, comm, timed_mode, compress_ms):
            "deviation_from_timed_mode": stats, "all_atom_rmsd_vs_input_A": round(rmsd, 4)}
     codec.set_numerics(timed_mode == "fast")
     w.decompress(); codec.synchronize()
-    del ref, devv
+    del ref, devv, samp
     return out
 
 

@@ -245,7 +245,7 @@ def test_device_ingest_fuzz_never_parses_differently(codec, golden):
     everything else it hands back or reports as atom-free -- it never parses differently, and never takes a file the reader fails"""
     z, _ = golden
     bases = [_pdb_text(z, "syn:len26").splitlines(), _pdb_text(z, "pdb:multichainA").splitlines()[:300] + _pdb_text(z, "pdb:multichainB_0").splitlines()[:200]]
-    rng = np.random.default_rng(20260927)
+    rng = np.random.default_rng(int(os.environ.get("FCZ_FUZZ_SEED", "20260927")))     # (FCZ_FUZZ_SEED: the same test on other mutations)
     texts, names = [], []
     for i in range(1200):
         texts.append(mutated_pdb(bases[i % 2], rng)); names.append(f"fz{i:04d}.pdb")
@@ -309,7 +309,7 @@ def test_device_mmcif_fuzz_never_parses_differently(codec, golden, ing):
     z, _ = golden
     bases = [gzip.decompress(ing["file:test.cif.gz"].tobytes()).decode("latin-1"), _cif_text(z, "syn:len26"),
              _cif_text(z, "pdb:multichainA", entry_id="M1")]
-    rng = np.random.default_rng(20260928)
+    rng = np.random.default_rng(int(os.environ.get("FCZ_FUZZ_SEED", "20260927")) + 1)
     texts, names = [], []
     for i in range(900):
         texts.append(mutated_cif(bases[i % 3], rng)); names.append(f"cz{i:04d}.cif")

@@ -643,7 +643,7 @@ def end_to_end_leg(args, codec, w, dev):
                     same = same and fa.read(1 << 24) == fb.read(1 << 24)
                 sh[mode] = {"command": f"python -m foldcomp_amd {mode} -d --gpus 1 -f <list> <db>   (1-rank {st['backend']} group; engine = host/foldcomp-hip --shard 0/1)",
                             "world": st["world"], "records": st["records"], "wall_s": st["wall_s"], "process_wall_s": st["process_wall_s"],
-                            "group_init_s": st["group_init_s"], "engine_s": st["engine_s"], "engine_steady_s": st["engine_steady_s_max"],
+                            "torch_and_group_s_beside_engine": st["torch_and_group_s_beside_engine"], "engine_s": st["engine_s"], "engine_steady_s": st["engine_steady_s_max"],
                             "exchange_and_splice_s": st["exchange_and_splice_s"], "residues_per_s": st["residues_per_s"],
                             "steady_residues_per_s": st["steady_residues_per_s"], "engine_max_rss_kb": st["engine_max_rss_kb_per_rank"],
                             "steady_over_gpu_host": round(st["steady_residues_per_s"] / max(ref_leg["steady_residues_per_s"], 1), 3),

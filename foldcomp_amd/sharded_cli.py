@@ -26,7 +26,9 @@ import sys
 import time
 from typing import List
 
-from . import shard
+# (torch -- through foldcomp_amd.shard -- is imported only after the engine has been started: its import and the communicator's
+# set-up take seconds, which the engine spends working)
+ENGINE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "host", "foldcomp-hip")
 
 
 def _free_port() -> int:
@@ -59,9 +61,9 @@ def host_threads(world: int) -> int:
     return max(1, n // max(1, world))
 
 
-def engine_command(a, rank: int, world: int, device_index: int, out_path: str, host: str = shard.HOST) -> List[str]:
+def engine_command(a, rank: int, world: int, device_index: int, out_path: str, host: str = ENGINE) -> List[str]:
     """the rank's engine: the C++ host on its range of the inputs (same option letters as the reference's command line)"""
-    cmd = [host, a.mode, "-d", "-y", "--gpus", "1", "--device", str(device_index), "--shard", f"{rank}/{world}", "--json-stats",
+    cmd = [host, a.mode, "-d", "-y", "--gpus", "1", "--device", str(device_index), "--device-mod", "--shard", f"{rank}/{world}", "--json-stats",
            "-t", str(a.threads if a.threads and a.threads > 1 else host_threads(world)), "-b", str(a.brk)]
     if a.recursive:
         cmd.append("-r")
@@ -81,34 +83,43 @@ def engine_command(a, rank: int, world: int, device_index: int, out_path: str, h
 
 def run(a, inputs: List[str], output: str) -> int:
     """this process's rank of the sharded run (a 1-rank group when no launcher set the environment)"""
-    import torch
-    import torch.distributed as dist
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if n_dev <= 0:
-        print("[Error] no HIP device (the codec has no CPU fallback)", file=sys.stderr); return 1
-    if not os.path.exists(shard.HOST):
-        print(f"[Error] the engine {shard.HOST} is not built (make -C host)", file=sys.stderr); return 1
+    if not os.path.exists(ENGINE):
+        print(f"[Error] the engine {ENGINE} is not built (make -C host)", file=sys.stderr); return 1
     for inp in inputs:
         if inp.endswith((".tar", ".tar.gz", ".tgz")):
             print("[Error] --gpus shards directories and databases; unpack tar inputs first", file=sys.stderr); return 1
+    part = output if rank == 0 else f"{output}.part{rank}"
+    env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}     # (a launcher exports OMP_NUM_THREADS=1: the engine gets -t)
+    t_spawn = time.perf_counter()
+    # (the engine takes device LOCAL_RANK modulo the device count: this process must not touch HIP before torch does -- the library
+    # links the system's runtime, torch brings its own, and whichever initialises second finds no device)
+    proc = subprocess.Popen(engine_command(a, rank, world, local, part), env=env, stdout=subprocess.PIPE, text=True)
+    # ---- beside the running engine: torch, the process group, the communicator ----
+    import torch
+    import torch.distributed as dist
+    from . import shard
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev <= 0:
+        proc.kill(); proc.wait()
+        print("[Error] no HIP device (the codec has no CPU fallback)", file=sys.stderr); return 1
     backend = os.environ.get("FCZ_SHARD_BACKEND") or ("nccl" if world <= n_dev else "gloo")
     device_index = local % n_dev
     if backend == "nccl":
         torch.cuda.set_device(device_index)
     if "MASTER_ADDR" not in os.environ:
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_free_port())
-    t_start = time.perf_counter()
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    except Exception:
+        proc.kill(); proc.wait()
+        raise
     tdev = torch.device("cuda", device_index) if backend == "nccl" else None
     rc = 0
     try:
         t_group = time.perf_counter()
-        part = output if rank == 0 else f"{output}.part{rank}"
-        env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}     # (a launcher exports OMP_NUM_THREADS=1: the engine gets -t)
-        proc = subprocess.Popen(engine_command(a, rank, world, device_index, part), env=env, stdout=subprocess.PIPE, text=True)
-        # while the engine works: the communicator. RCCL builds its rings on the first collective (~1 s); doing that here keeps it
-        # off the path between the engines' end and the exchange
+        # RCCL builds its rings on the first collective (~1 s): done here it stays off the path between the engines' end and the exchange
         warm = torch.zeros(1, dtype=torch.int64, device=tdev)
         dist.all_reduce(warm)
         if tdev is not None:
@@ -145,8 +156,8 @@ def run(a, inputs: List[str], output: str) -> int:
                               "residues": res, "input_bytes": sum(r_[8] for r_ in rows),
                               "records_per_rank": [r_[0] for r_ in rows], "bytes_per_rank": [r_[1] for r_ in rows],
                               "engine_max_rss_kb_per_rank": [r_[6] for r_ in rows],
-                              "wall_s": round(t_done - t_start, 4), "group_init_s": round(t_group - t_start, 4), "communicator_s_beside_engine": round(t_comm - t_group, 4),
-                              "engine_s": round(t_engine - t_group, 4), "engine_wall_s_max": round(eng_wall, 4),
+                              "wall_s": round(t_done - t_start, 4), "torch_and_group_s_beside_engine": round(t_group - t_spawn, 4), "communicator_s_beside_engine": round(t_comm - t_group, 4),
+                              "engine_s": round(t_engine - t_spawn, 4), "engine_wall_s_max": round(eng_wall, 4),
                               "engine_steady_s_max": round(steady, 4), "exchange_and_splice_s": round(t_done - t_engine, 4),
                               "residues_per_s": round(res / (t_done - t_start), 1) if t_done > t_start else None,
                               # the steady rate: without the group's and the engines' start-up (HIP context), WITH the exchange

@@ -2676,6 +2676,7 @@ int default_threads() {
 int main(int argc, char** argv) {
     Options o;
     std::vector<std::string> pos;
+    bool device_mod = false;
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(default_threads());
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -2690,6 +2691,7 @@ int main(int argc, char** argv) {
         else if (a == "--workers-per-gpu") next_int(o.workers_per_gpu);
         else if (a == "--json-stats") o.json_stats = true;
         else if (a == "--device") next_int(o.device);
+        else if (a == "--device-mod") device_mod = true;     // the device number wraps at the device count (ranks of a test run that share GPUs)
         else if (a == "--key0") { if (i + 1 < argc) g_key0 = atoll(argv[++i]); }
         else if (a == "--off0") { if (i + 1 < argc) g_off0 = strtoull(argv[++i], nullptr, 10); }
         else if (a == "--shard") {   // R/N: rank R of N of a sharded run
@@ -2738,6 +2740,7 @@ int main(int argc, char** argv) {
         else if (o.single) { const size_t i = o.input.rfind('.'); o.output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + "." + suffix; }
         else o.output = o.input + "_" + suffix;
     }
+    if (device_mod && (o.mode == "compress" || o.mode == "decompress")) { const int nd = fcz_device_count(); if (nd > 0) o.device %= nd; }
     if (o.mode == "compress") return run_compress(o);
     o.write_threads = std::max(1, omp_get_max_threads() / std::max(1, (o.gpus <= 0 ? 1 : o.gpus) * std::max(1, o.workers_per_gpu)));
     if (o.mode == "decompress") return run_decompress(o);

@@ -1354,7 +1354,7 @@ def main():
                     "traffic_note": "`traffic` = FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes (requests leaving the L2 towards the fabric; the exact-unit "
                                     "TCC_EA0_*_DRAM_32B counters of the same passes give the same bytes). `traffic_controller_side` = what the memory controllers "
                                     "saw of the same launch (mem_busy_percent during a loop of this one kernel, calibrated on copies): for k_res_index, k_sidechain "
-                                    "and the compress kernels the two agree within 1 %; for k_backbone the controllers see 165 of the 198 B/residue -- the Infinity "
+                                    "and the compress kernels the two agree within 1 %; for k_backbone the controllers see 165-168 of the 198 B/residue -- the Infinity "
                                     "Cache absorbs a sixth of its ring traffic, the rest is real HBM traffic (forward atoms and torsion trig of a segment, written "
                                     "once and read back once by the reverse pass: 120 B/residue by construction of the two-sweep algorithm, 17x the algorithmic bytes)",
                     "secondary_bound": valu,

@@ -433,12 +433,16 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
             struct fld { uint32_t w[4]; uint32_t n; };
             auto ch_at = [](const fld& f, int i) -> uint32_t { return (f.w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
             auto is_null = [&](const fld& f) -> bool { return f.n == 1u && ((f.w[0] & 0xffu) == '?' || (f.w[0] & 0xffu) == '.'); };
-            auto integer = [&](const fld& f, int32_t* out) -> bool {                  // [+-]digits, at most nine of them
+            // the numeric readers come in two widths: every numeric field of the step at most eight characters (what coordinate files
+            // hold: the wavefront decides it from the token bounds before a character is loaded) -> two dwords and a 32-bit mantissa;
+            // otherwise sixteen characters and the 64-bit one. Same value either way: the digits are exact in both.
+            auto integer = [&](const fld& f, int32_t* out, auto NC) -> bool {        // [+-]digits, at most nine of them
+                constexpr int N = decltype(NC)::value;
                 const uint32_t c0 = f.w[0] & 0xffu;
                 const bool sg = (c0 == '-') | (c0 == '+');
-                uint32_t v = 0, nd = 0; bool ok = f.n <= 10u;
+                uint32_t v = 0, nd = 0; bool ok = f.n <= (uint32_t)N;
 #pragma unroll
-                for (int i = 0; i < 10; i++) {
+                for (int i = 0; i < N; i++) {
                     const uint32_t d = ch_at(f, i) - '0';
                     const bool in = (uint32_t)i < f.n && !(i == 0 && sg);
                     ok = ok & (!in | (d <= 9u));
@@ -447,17 +451,19 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 *out = c0 == '-' ? -(int32_t)v : (int32_t)v;
                 return ok & (nd >= 1u) & (nd <= 9u);
             };
-            auto decimal = [&](const fld& f, float* out) -> bool {                   // -digits.digits, at most 15 digits in 16 characters: cif::as_number's fast path
+            auto decimal = [&](const fld& f, float* out, auto NC) -> bool {          // -digits.digits, at most 15 digits in 16 characters: cif::as_number's fast path
+                constexpr int N = decltype(NC)::value;
+                using mant = typename std::conditional<(N <= 9), uint32_t, unsigned long long>::type;
                 const bool neg = (f.w[0] & 0xffu) == '-';
-                unsigned long long m = 0; uint32_t nd = 0, nf = 0; bool point = false, ok = f.n <= 16u;
+                mant m = 0; uint32_t nd = 0, nf = 0; bool point = false, ok = f.n <= (uint32_t)N;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
+                for (int i = 0; i < N; i++) {
                     const uint32_t c = ch_at(f, i), d = c - '0';
                     const bool in = (uint32_t)i < f.n && !(i == 0 && neg);
                     const bool dig = d <= 9u, pt = c == '.';
                     ok = ok & (!in | dig | (pt & !point));
                     const bool take = in & dig;
-                    m = take ? m * 10ull + d : m; nd += take ? 1u : 0u; nf += (take & point) ? 1u : 0u;
+                    m = take ? m * (mant)10 + (mant)d : m; nd += take ? 1u : 0u; nf += (take & point) ? 1u : 0u;
                     point = point | (in & pt);
                 }
                 const double v = (double)m / cif_pow10[nf & 15u];
@@ -480,30 +486,41 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
                 const int c = cols[q] >= 0 ? cols[q] : 0;
                 fs[q] = row ? (uint32_t)S.tok_s[c][lane] : 0u; fe[q] = row ? (uint32_t)S.tok_e[c][lane] : 0u;
             }
-            auto load = [&](int q) -> fld {
+            auto load = [&](int q, auto NW) -> fld {
+                constexpr int W = decltype(NW)::value;
                 fld f; f.n = fe[q] - fs[q];
                 const int at = row ? lo + (int)fs[q] : 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) f.w[k] = ldw(at + 4 * k);
+                for (int k = 0; k < 4; k++) f.w[k] = k < W ? ldw(at + 4 * k) : 0u;
                 return f;
             };
-            {
-                const fld f0 = load(0), f1 = load(1), f2 = load(2), f3 = load(3), f4 = load(4);
-                rbad = rbad | !integer(f0, &serial) | !integer(f1, &num) | !decimal(f2, &x) | !decimal(f3, &y) | !decimal(f4, &z);
-            }
-            {
-                const fld f5 = load(5), f6 = load(6), f7 = load(7), f8 = load(8), f9 = load(9);
-                rbad = rbad | !decimal(f5, &bf) | !pack(f6, &an) | !pack(f7, &rn) | (f8.n != 1u) | is_null(f8) | (!is_null(f9) & (f9.n != 1u));
-                ch = f8.w[0] & 0xffu;
-            }
-            {
-                const fld f10 = load(10), f11 = load(11), f12 = load(12), f13 = load(13);
-                int32_t dummy;
-                if (cols[10] >= 0) rbad = rbad | !is_null(f10);
-                if (cols[11] >= 0) rbad = rbad | (!is_null(f11) & !integer(f11, &dummy));
-                if (cols[12] >= 0) rbad = rbad | (!is_null(f12) & !integer(f12, &dummy));
-                if (cols[13] >= 0) { rbad = rbad | (f13.n > 8u); const unsigned long long v8 = (unsigned long long)f13.w[0] | ((unsigned long long)f13.w[1] << 32); mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull)); }
-            }
+            using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+            using I8 = std::integral_constant<int, 8>; using I10 = std::integral_constant<int, 10>; using I16 = std::integral_constant<int, 16>;
+            uint32_t widest = 0;
+            { const int numeric[8] = {0, 1, 2, 3, 4, 5, 11, 12};
+#pragma unroll
+              for (int q = 0; q < 8; q++) widest = max(widest, fe[numeric[q]] - fs[numeric[q]]); }
+            const bool narrow = !__any(widest > 8u);
+            auto fields = [&](auto NI, auto ND, auto NWD) {
+                {
+                    const fld f0 = load(0, NWD), f1 = load(1, NWD), f2 = load(2, NWD), f3 = load(3, NWD), f4 = load(4, NWD);
+                    rbad = rbad | !integer(f0, &serial, NI) | !integer(f1, &num, NI) | !decimal(f2, &x, ND) | !decimal(f3, &y, ND) | !decimal(f4, &z, ND);
+                }
+                {
+                    const fld f5 = load(5, NWD), f6 = load(6, I1{}), f7 = load(7, I1{}), f8 = load(8, I1{}), f9 = load(9, I1{});
+                    rbad = rbad | !decimal(f5, &bf, ND) | !pack(f6, &an) | !pack(f7, &rn) | (f8.n != 1u) | is_null(f8) | (!is_null(f9) & (f9.n != 1u));
+                    ch = f8.w[0] & 0xffu;
+                }
+                {
+                    const fld f10 = load(10, I1{}), f11 = load(11, NWD), f12 = load(12, NWD), f13 = load(13, I2{});
+                    int32_t dummy;
+                    if (cols[10] >= 0) rbad = rbad | !is_null(f10);
+                    if (cols[11] >= 0) rbad = rbad | (!is_null(f11) & !integer(f11, &dummy, NI));
+                    if (cols[12] >= 0) rbad = rbad | (!is_null(f12) & !integer(f12, &dummy, NI));
+                    if (cols[13] >= 0) { rbad = rbad | (f13.n > 8u); const unsigned long long v8 = (unsigned long long)f13.w[0] | ((unsigned long long)f13.w[1] << 32); mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull)); }
+                }
+            };
+            if (narrow) fields(I8{}, I8{}, I2{}); else fields(I10{}, I16{}, I4{});
             rbad = rbad & row;
         }
         // one model; residues of a chain run in rising order (the reader regroups anything else); keep rule of removeAlternativePosition

@@ -291,6 +291,42 @@ def test_device_mmcif_equals_host_reader_on_plain_files(codec, golden, ing):
     assert rec == ref[:len(rec)] or _same_but_title(rec, ref)
 
 
+def test_device_mmcif_numeric_field_widths(codec, golden):
+    """the row readers of k_ingest_parse_cif come in two widths, chosen per step from the token bounds (every numeric field at most
+    eight characters -> two dwords and a 32-bit mantissa, otherwise sixteen characters and a 64-bit one): files whose rows are all
+    narrow, files with ONE wide field among narrow rows (padded zeros, fifteen digits, a nine-digit serial), and fields beyond what
+    the device reads (handed back, never parsed differently) -- the taken files equal the host reader's batch bit for bit"""
+    from test_host_cpp import _cif_text
+    z, _ = golden
+    syn = _cif_text(z, "pdb:test_af")
+    lines = syn.split("\n")
+    rows = [i for i, l in enumerate(lines) if l.startswith("ATOM")]
+
+    def with_row(k, col, fn):
+        out = list(lines); t = out[rows[k]].split(" "); t[col] = fn(t[col]); out[rows[k]] = " ".join(t)
+        return "\n".join(out).encode()
+    # columns of _cif_text's rows: 1 = id, 8 = auth_seq_id, 9..11 = Cartn_x/y/z, 13 = B
+    taken = [syn.encode(),
+             with_row(3, 9, lambda v: v + "000000"),                       # 12.345000000: nine decimals
+             with_row(70, 10, lambda v: ("-" if v.startswith("-") else "") + "0000" + v.lstrip("-")),
+             with_row(5, 11, lambda v: v.split(".")[0] + ".12345678901"),  # fifteen or fewer digits in sixteen characters
+             with_row(2, 13, lambda v: v + "0000000"),
+             with_row(100, 1, lambda v: "%09d" % int(v)),                   # nine digits
+             with_row(0, 9, lambda v: "+" + v.lstrip("-"))]                 # a plus sign: not the reader's fast path, the host decides
+    beyond = [with_row(4, 9, lambda v: v + "0" * 14),                      # seventeen characters and more
+              with_row(4, 1, lambda v: "%011d" % int(v))]
+    texts = taken + beyond
+    names = [f"w{i}.cif" for i in range(len(texts))]
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    assert list(fstat[:6]) == [0] * 6, fstat
+    assert all(int(v) != 0 for v in fstat[len(taken):]), fstat
+    ok = [i for i in range(len(texts)) if fstat[i] == 0]
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok], reader=_read_any)
+    assert not failed
+    _same_batch(b, exp)
+    assert [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)] == exp_names
+
+
 def _same_but_title(a, b):
     def no_title(f):
         na, tl = f[12], int.from_bytes(f[24:28], "little")

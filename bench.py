@@ -1233,7 +1233,7 @@ def main():
                 _lib.check(lib.fcz_ingest_pdb_dev(codec.ctx, ctext.data_ptr(), coff.data_ptr(), nf, int(ctext.numel()), cnames.data_ptr(), cname_off.data_ptr(),
                                                   cstem.data_ptr(), args.anchor, 0, ctypes.byref(resc)), "fcz_ingest_pdb_dev (mmCIF)")
             codec.synchronize()
-            cms = {k: codec.kernel_time(k)[0] / reps_i for k in ("ingest_parse", "ingest_parse_cif", "ingest_frags", "ingest_fill")}
+            cms = {k: codec.kernel_time(k)[0] / reps_i for k in ("ingest_parse", "ingest_parse_cif", "ingest_rows_cif", "ingest_frags", "ingest_fill")}
             ctot = sum(cms.values())
             n_rc = int(res_off_dev[n_src]) * reps_t
             pdb["ingest_of_the_same_chains_as_mmcif"] = {

@@ -576,7 +576,7 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
     int rc;
     enum { B_CAP, B_ABASE, B_NAME, B_RESN, B_SERIAL, B_RESSEQ, B_X, B_Y, B_Z, B_B, B_CHAIN, B_ACODE, B_RCODE, B_RFIRST, B_RBFAC, B_RCODE2,
            B_TITLES, B_TLEN, B_NKEPT, B_STATUS, B_FRAGS, B_NFRAGS, B_TOTC, B_TOTR, B_TOTA, B_TOTT, B_USESTEM, B_OFFC, B_OFFR, B_OFFA, B_OFFT,
-           B_REFUSED, B_NREF, B_OUT_A, B_OUT_R, B_OUT_C, B_OUT_T };
+           B_REFUSED, B_NREF, B_OUT_A, B_OUT_R, B_OUT_C, B_OUT_T, B_CIFROWS };
     auto need = [&](int i, size_t bytes) { return ctx->ig[i].ensure(std::max<size_t>(bytes, 16)); };
     if ((rc = need(B_CAP, 8 * F)) || (rc = need(B_ABASE, 8 * (F + 1))) || (rc = need(B_NAME, 4 * cap)) || (rc = need(B_RESN, 4 * cap)) ||
         (rc = need(B_SERIAL, 4 * cap)) || (rc = need(B_RESSEQ, 4 * cap)) || (rc = need(B_X, 4 * cap)) || (rc = need(B_Y, 4 * cap)) ||
@@ -585,7 +585,7 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
         (rc = need(B_TLEN, 4 * F)) || (rc = need(B_NKEPT, 4 * F)) || (rc = need(B_STATUS, 4 * F)) || (rc = need(B_FRAGS, sizeof(ingest_frag) * IG_MAX_FRAGS * F)) ||
         (rc = need(B_NFRAGS, 4 * F)) || (rc = need(B_TOTC, 4 * F)) || (rc = need(B_TOTR, 4 * F)) || (rc = need(B_TOTA, 4 * F)) || (rc = need(B_TOTT, 4 * F)) ||
         (rc = need(B_USESTEM, 4 * F)) || (rc = need(B_OFFC, 4 * (F + 1))) || (rc = need(B_OFFR, 4 * (F + 1))) || (rc = need(B_OFFA, 4 * (F + 1))) ||
-        (rc = need(B_OFFT, 4 * (F + 1))) || (rc = need(B_REFUSED, 8 * (size_t)IG_MAX_FRAGS * F)) || (rc = need(B_NREF, 16)))
+        (rc = need(B_OFFT, 4 * (F + 1))) || (rc = need(B_REFUSED, 8 * (size_t)IG_MAX_FRAGS * F)) || (rc = need(B_NREF, 16)) || (rc = need(B_CIFROWS, 4 * F)))
         return rc;
     auto P = [&](int i) { return ctx->ig[i].p; };
     ingest_scratch T;
@@ -605,7 +605,13 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
         // at once); what this kernel cannot promise to read as the reference's reader would stays handed back
         span_guard g(ctx, "ingest_parse_cif");
         hipLaunchKernelGGL(k_ingest_parse_cif, dim3(n_files), dim3(WAVE), 0, ctx->stream, text_dev, file_off_dev, n_files,
-                           (const uint64_t*)P(B_ABASE), T, (uint8_t*)P(B_TITLES), (uint32_t*)P(B_TLEN), (uint32_t*)P(B_NKEPT), (int32_t*)P(B_STATUS));
+                           (const uint64_t*)P(B_ABASE), T, (uint8_t*)P(B_TITLES), (uint32_t*)P(B_TLEN), (const int32_t*)P(B_STATUS), (uint32_t*)P(B_CIFROWS));
+    }
+    {
+        // ... and the rows it marked, read by a kernel of their own (fcz_ingest_cif.h: the register file)
+        span_guard g(ctx, "ingest_rows_cif");
+        hipLaunchKernelGGL(k_ingest_rows_cif, dim3(n_files), dim3(WAVE), 0, ctx->stream, text_dev, file_off_dev, n_files, text_bytes,
+                           (const uint64_t*)P(B_ABASE), T, (uint32_t*)P(B_NKEPT), (int32_t*)P(B_STATUS), (const uint32_t*)P(B_CIFROWS));
     }
     ingest_counts tot{(uint32_t*)P(B_TOTC), (uint32_t*)P(B_TOTR), (uint32_t*)P(B_TOTA), (uint32_t*)P(B_TOTT)};
     {

@@ -10,9 +10,17 @@
 //        loop_ tag+ value+; lib/gemmi/cif.hpp:37-148 as host/foldcomp_hip.cpp cif_items restates it): pairs complete, loops
 //        have tags and whole rows, no tag twice (hashes in LDS), the `_atom_site` loop's column map (23 names, any case),
 //        `_entry.id` (the title), `_cell.angle_*` (the zero-angle rule); it marks the lines that are `_atom_site` rows;
-//     3. the marked rows are parsed by their lanes: columns by token ordinal, decimals as (double)digits / 10^f (exact operands,
-//        IEEE division = strtod's result for <= 15 digits = gemmi's fast_float), names packed, codes through the LDS hash,
-//        removeAlternativePosition by the keep rule of the PDB kernel, kept atoms appended to the file's scratch slice.
+//     3. every marked row leaves as a 32-byte ROW RECORD in the file's slice of the scratch table (the eight dword columns, entry =
+//        row ordinal): where its line starts in the file, and the bounds of the fourteen fields the reader looks at (by token
+//        ordinal through the column map; an absent optional column has no characters).
+//   k_ingest_rows_cif    wavefront = file, lane = row record: the fields' characters straight from the text, decimals as
+//                        (double)digits / 10^f (exact operands, IEEE division = strtod's result for <= 15 digits = gemmi's
+//                        fast_float), names packed, codes through the LDS hash, removeAlternativePosition by the keep rule of the
+//                        PDB kernel, kept atoms written over the records (a row's atom never lands behind its own record).
+//                        A kernel of its own because of the register file: the lexer and the automaton hold ~230 VGPRs and two
+//                        dozen more of spilled scalars, which leaves two wavefronts per SIMD; the readers in the same kernel
+//                        cost either the second wavefront or scratch (profiles/r4_ab_cif_readers.txt). Here they run at the PDB
+//                        kernel's register count with every row of the step in flight.
 //   The same k_ingest_frags / k_ingest_fill then build the batch.
 //
 // The device never guesses. It takes the shape every predicted-structure file has -- one data_ block, items one per line (or
@@ -67,11 +75,12 @@ __device__ __forceinline__ uint32_t cif_lower(uint32_t c) { return (c - 'A' < 26
 __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __restrict__ text, const uint64_t* __restrict__ file_off, uint32_t n_files,
                                                            const uint64_t* __restrict__ abase, ingest_scratch T,
                                                            uint8_t* __restrict__ titles, uint32_t* __restrict__ title_len,
-                                                           uint32_t* __restrict__ n_kept, int32_t* __restrict__ file_status) {
+                                                           const int32_t* __restrict__ file_status, uint32_t* __restrict__ cif_rows) {
     __shared__ cif_lds S;
     const int lane = threadIdx.x;
     const uint32_t f = blockIdx.x;
     if (f >= n_files) return;
+    if (lane == 0) cif_rows[f] = 0;                               // (rows + 1 of a file this kernel takes: k_ingest_rows_cif's work list)
     if (file_status[f] != FCZ_INGEST_HOST_FIELD) return;          // only what the PDB kernel handed back can be mmCIF
     const uint64_t f0 = file_off[f], f1 = file_off[f + 1];
     const uint8_t* base = text + f0;
@@ -88,32 +97,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         }
         if (!cif) return;
     }
-    // name -> code tables (as in k_ingest_parse), the tag table, the column map
-    S.akey[lane] = 0; if (lane < 32) S.rkey[lane] = 0;
+    // the tag table, the column map
     for (int k = lane; k < CIF_TAGSET; k += WAVE) S.tagset[k] = 0;
     if (lane <= CIF_NCOL) S.pos[lane] = -1;
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        for (int i = 0; i < FCZ_N_ATOM_CODES; i++) {
-            uint32_t k; __builtin_memcpy(&k, fcz_atom_name[i], 4);
-            uint32_t h = ig_hash(k) & 63u; while (S.akey[h]) h = (h + 1) & 63u;
-            S.akey[h] = k; S.aval[h] = (uint8_t)i;
-        }
-        for (int i = 0; i < FCZ_N_RES_CODES; i++) {
-            uint32_t k; __builtin_memcpy(&k, fcz_res3[i], 4);
-            uint32_t h = ig_hash(k) & 31u; while (S.rkey[h]) h = (h + 1) & 31u;
-            S.rkey[h] = k; S.rval[h] = (uint8_t)i;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    auto atom_code_of = [&](uint32_t k) -> uint32_t {
-        for (uint32_t h = ig_hash(k) & 63u; S.akey[h]; h = (h + 1) & 63u) if (S.akey[h] == k) return S.aval[h];
-        return (uint32_t)FCZ_ATOM_OTHER;
-    };
-    auto res_code_of = [&](uint32_t k) -> int {
-        for (uint32_t h = ig_hash(k) & 31u; S.rkey[h]; h = (h + 1) & 31u) if (S.rkey[h] == k) { const int c = S.rval[h]; return (c < 20 || c == 23) ? c : -1; }
-        return -1;
-    };
 
 #ifdef FCZ_CIF_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -131,10 +118,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
     bool in_text = false;                  // inside a text field
     uint32_t tlen = 0; bool have_title = false;
     int kAsym = -1, kComp = -1, kAtom = -1;
-    // ---- row state (uniform) ----
-    uint32_t kept = 0;
-    bool have_last = false; uint32_t last_name = 0, last_comp = 0, last_ch = 0; int32_t last_num = 0;
-    unsigned long long model0 = 0; bool have_model = false;
+    uint32_t nrows = 0;                    // row records written
     uint64_t line_start = 0;
 
     // exact compare of a staged line's bytes [at, at + n) with a lower-case word, case folded; uniform arguments
@@ -423,138 +407,30 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         }
         CIF_STAMP(6)
         if (dead) return;
-        // ---- 3. the _atom_site rows of the step, every lane its own: a field's characters come into registers as four dwords, the
-        //         readers are boolean arithmetic over their (at most sixteen) characters ----
+        // ---- 3. the _atom_site rows of the step leave as row records: where the line starts, the bounds of the fourteen fields ----
         if (rowmask == 0ull) return;
         const bool row = ((rowmask >> lane) & 1ull) != 0;
-        bool rbad = false;
-        uint32_t an = 0, rn = 0, ch = ' '; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
+        // no quoted value anywhere in a row (the host strips the quotes): such a line went through the character lexer
+        if (__any(row && slow)) { dead = true; return; }
+        const uint32_t n_new = (uint32_t)__builtin_popcountll(rowmask);
+        if (nrows + n_new > cap || (flen >> 32) != 0ull) { dead = true; return; }
         {
-            struct fld { uint32_t w[4]; uint32_t n; };
-            auto ch_at = [](const fld& f, int i) -> uint32_t { return (f.w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
-            auto is_null = [&](const fld& f) -> bool { return f.n == 1u && ((f.w[0] & 0xffu) == '?' || (f.w[0] & 0xffu) == '.'); };
-            // the numeric readers come in two widths: every numeric field of the step at most eight characters (what coordinate files
-            // hold: the wavefront decides it from the token bounds before a character is loaded) -> two dwords and a 32-bit mantissa;
-            // otherwise sixteen characters and the 64-bit one. Same value either way: the digits are exact in both.
-            auto integer = [&](const fld& f, int32_t* out, auto NC) -> bool {        // [+-]digits, at most nine of them
-                constexpr int N = decltype(NC)::value;
-                const uint32_t c0 = f.w[0] & 0xffu;
-                const bool sg = (c0 == '-') | (c0 == '+');
-                uint32_t v = 0, nd = 0; bool ok = f.n <= (uint32_t)N;
-#pragma unroll
-                for (int i = 0; i < N; i++) {
-                    const uint32_t d = ch_at(f, i) - '0';
-                    const bool in = (uint32_t)i < f.n && !(i == 0 && sg);
-                    ok = ok & (!in | (d <= 9u));
-                    v = in ? v * 10u + d : v; nd += in ? 1u : 0u;
-                }
-                *out = c0 == '-' ? -(int32_t)v : (int32_t)v;
-                return ok & (nd >= 1u) & (nd <= 9u);
-            };
-            auto decimal = [&](const fld& f, float* out, auto NC) -> bool {          // -digits.digits, at most 15 digits in 16 characters: cif::as_number's fast path
-                constexpr int N = decltype(NC)::value;
-                using mant = typename std::conditional<(N <= 9), uint32_t, unsigned long long>::type;
-                const bool neg = (f.w[0] & 0xffu) == '-';
-                mant m = 0; uint32_t nd = 0, nf = 0; bool point = false, ok = f.n <= (uint32_t)N;
-#pragma unroll
-                for (int i = 0; i < N; i++) {
-                    const uint32_t c = ch_at(f, i), d = c - '0';
-                    const bool in = (uint32_t)i < f.n && !(i == 0 && neg);
-                    const bool dig = d <= 9u, pt = c == '.';
-                    ok = ok & (!in | dig | (pt & !point));
-                    const bool take = in & dig;
-                    m = take ? m * (mant)10 + (mant)d : m; nd += take ? 1u : 0u; nf += (take & point) ? 1u : 0u;
-                    point = point | (in & pt);
-                }
-                const double v = (double)m / cif_pow10[nf & 15u];
-                *out = (float)(neg ? -v : v);
-                return ok & (nd >= 1u) & (nd <= 15u);
-            };
-            auto pack = [&](const fld& f, uint32_t* out) -> bool {                   // a name of one to four characters
-                *out = f.n >= 4u ? f.w[0] : (f.w[0] & ((1u << (8u * f.n)) - 1u));
-                return (f.n >= 1u) & (f.n <= 4u) & !is_null(f);
-            };
-            // no quoted value anywhere in the row (the host strips the quotes): such a line went through the character lexer
-            if (row && slow) rbad = true;
-            // the fourteen fields: first every field's bounds, then their characters, four dwords each -- the loads of a group leave
-            // together (one round trip to the LDS per group instead of two per field)
             const int cols[14] = {S.pos[CK_ID], S.pos[CK_ASEQ], S.pos[CK_X], S.pos[CK_Y], S.pos[CK_Z], S.pos[CK_B], S.pos[kAtom], S.pos[kComp], S.pos[kAsym],
                                   S.pos[CK_ALT], S.pos[CK_INS], S.pos[CK_LSEQ], S.pos[CK_CHARGE], S.pos[CK_MODEL]};
-            uint32_t fs[14], fe[14];
+            uint32_t w[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 14; q++) {
                 const int c = cols[q] >= 0 ? cols[q] : 0;
-                fs[q] = row ? (uint32_t)S.tok_s[c][lane] : 0u; fe[q] = row ? (uint32_t)S.tok_e[c][lane] : 0u;
+                const uint32_t ts = (row && cols[q] >= 0) ? (uint32_t)S.tok_s[c][lane] : 0u, te = (row && cols[q] >= 0) ? (uint32_t)S.tok_e[c][lane] : 0u;
+                w[q >> 1] |= (ts | (te << 8)) << (16 * (q & 1));
             }
-            auto load = [&](int q, auto NW) -> fld {
-                constexpr int W = decltype(NW)::value;
-                fld f; f.n = fe[q] - fs[q];
-                const int at = row ? lo + (int)fs[q] : 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) f.w[k] = k < W ? ldw(at + 4 * k) : 0u;
-                return f;
-            };
-            using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
-            using I8 = std::integral_constant<int, 8>; using I10 = std::integral_constant<int, 10>; using I16 = std::integral_constant<int, 16>;
-            uint32_t widest = 0;
-            { const int numeric[8] = {0, 1, 2, 3, 4, 5, 11, 12};
-#pragma unroll
-              for (int q = 0; q < 8; q++) widest = max(widest, fe[numeric[q]] - fs[numeric[q]]); }
-            const bool narrow = !__any(widest > 8u);
-            auto fields = [&](auto NI, auto ND, auto NWD) {
-                {
-                    const fld f0 = load(0, NWD), f1 = load(1, NWD), f2 = load(2, NWD), f3 = load(3, NWD), f4 = load(4, NWD);
-                    rbad = rbad | !integer(f0, &serial, NI) | !integer(f1, &num, NI) | !decimal(f2, &x, ND) | !decimal(f3, &y, ND) | !decimal(f4, &z, ND);
-                }
-                {
-                    const fld f5 = load(5, NWD), f6 = load(6, I1{}), f7 = load(7, I1{}), f8 = load(8, I1{}), f9 = load(9, I1{});
-                    rbad = rbad | !decimal(f5, &bf, ND) | !pack(f6, &an) | !pack(f7, &rn) | (f8.n != 1u) | is_null(f8) | (!is_null(f9) & (f9.n != 1u));
-                    ch = f8.w[0] & 0xffu;
-                }
-                {
-                    const fld f10 = load(10, I1{}), f11 = load(11, NWD), f12 = load(12, NWD), f13 = load(13, I2{});
-                    int32_t dummy;
-                    if (cols[10] >= 0) rbad = rbad | !is_null(f10);
-                    if (cols[11] >= 0) rbad = rbad | (!is_null(f11) & !integer(f11, &dummy, NI));
-                    if (cols[12] >= 0) rbad = rbad | (!is_null(f12) & !integer(f12, &dummy, NI));
-                    if (cols[13] >= 0) { rbad = rbad | (f13.n > 8u); const unsigned long long v8 = (unsigned long long)f13.w[0] | ((unsigned long long)f13.w[1] << 32); mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull)); }
-                }
-            };
-            if (narrow) fields(I8{}, I8{}, I2{}); else fields(I10{}, I16{}, I4{});
-            rbad = rbad & row;
-        }
-        // one model; residues of a chain run in rising order (the reader regroups anything else); keep rule of removeAlternativePosition
-        const uint32_t pl = ig_prev_lane(rowmask, lane);
-        {
-            const int src = pl < 64u ? (int)pl : 0;
-            const int32_t s_num = __shfl(num, src, WAVE);
-            const uint32_t s_rn = (uint32_t)__shfl((int)rn, src, WAVE), s_ch = (uint32_t)__shfl((int)ch, src, WAVE), s_an = (uint32_t)__shfl((int)an, src, WAVE);
-            const bool has_p = pl < 64u ? true : have_last;
-            const int32_t p_num = pl < 64u ? s_num : last_num;
-            const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name;
-            const int fl = __builtin_ctzll(rowmask);
-            const unsigned long long m_first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mdl >> 32), fl) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mdl, fl);
-            const unsigned long long m0 = have_model ? model0 : m_first;
-            if (row && mdl != m0) rbad = true;
-            if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_rn == rn) && !(num > p_num)) rbad = true;
-            if (__any(row && rbad)) { dead = true; return; }
-            if (!have_model) { model0 = m0; have_model = true; }
-            const bool keep = row && !(has_p && p_an == an);
-            const unsigned long long m_keep = __ballot(keep);
-            const uint32_t n_new = (uint32_t)__builtin_popcountll(m_keep);
-            if (kept + n_new > cap) { dead = true; return; }
-            if (keep) {
-                const size_t o = (size_t)A0 + kept + (uint32_t)__builtin_popcountll(m_keep & ((1ull << lane) - 1ull));
-                T.name[o] = an; T.resn[o] = rn; T.serial[o] = serial; T.resseq[o] = num;
-                T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = (uint8_t)ch;
-                T.acode[o] = (uint8_t)atom_code_of(an);
-                T.rcode[o] = (int8_t)res_code_of(rn);
+            if (row) {
+                const size_t o = (size_t)A0 + nrows + (uint32_t)__builtin_popcountll(rowmask & ((1ull << lane) - 1ull));
+                T.name[o] = (uint32_t)ls; T.resn[o] = w[0]; T.serial[o] = (int32_t)w[1]; T.resseq[o] = (int32_t)w[2];
+                T.x[o] = __uint_as_float(w[3]); T.y[o] = __uint_as_float(w[4]); T.z[o] = __uint_as_float(w[5]); T.b[o] = __uint_as_float(w[6]);
             }
-            kept += n_new;
-            const int hl = 63 - __builtin_clzll(rowmask);
-            last_name = (uint32_t)__builtin_amdgcn_readlane((int)an, hl); last_comp = (uint32_t)__builtin_amdgcn_readlane((int)rn, hl); last_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, hl);
-            last_num = __builtin_amdgcn_readlane(num, hl); have_last = true;
         }
+        nrows += n_new;
         CIF_STAMP(7)
     };
 
@@ -646,16 +522,202 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         if (in_text) dead = true;
         if (ctx == CX_LOOP_BODY) { if (ntags == 0 || nvals % ntags != 0) dead = true; if (in_as) as_done = true; }
         else if (ctx != CX_NONE) dead = true;
-        if (!as_done || !have_title || kept == 0) dead = true;              // no atoms, no title: the host reports what the reference reports
+        if (!as_done || !have_title || nrows == 0) dead = true;             // no atoms, no title: the host reports what the reference reports
     }
     if (lane == 0 && !dead) {
         title_len[f] = tlen;
-        n_kept[f] = kept;
-        file_status[f] = FCZ_OK;
+        cif_rows[f] = nrows + 1u;                                          // the file's status stays "to the host" until its rows are read
     }
 #ifdef FCZ_CIF_TIMING
     if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_ig_timing[i], tacc[i]);
 #endif
+}
+
+// ---- the rows of the files k_ingest_parse_cif took: wavefront = file, lane = row record ----
+struct cif_rows_lds { uint32_t akey[64], rkey[32]; uint8_t aval[64], rval[32]; };
+
+__global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restrict__ text, const uint64_t* __restrict__ file_off, uint32_t n_files,
+                                                          uint64_t text_bytes, const uint64_t* __restrict__ abase, ingest_scratch T,
+                                                          uint32_t* __restrict__ n_kept, int32_t* __restrict__ file_status,
+                                                          const uint32_t* __restrict__ cif_rows) {
+    __shared__ cif_rows_lds S;
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_files) return;
+    const uint32_t rows1 = cif_rows[f];
+    if (rows1 == 0u) return;                                       // not a file the lexer took
+    const uint32_t nrows = rows1 - 1u;
+    const uint8_t* base = text + file_off[f];
+    const uint8_t* lim = text + text_bytes;
+    // name -> code tables (as in k_ingest_parse)
+    S.akey[lane] = 0; if (lane < 32) S.rkey[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        for (int i = 0; i < FCZ_N_ATOM_CODES; i++) {
+            uint32_t k; __builtin_memcpy(&k, fcz_atom_name[i], 4);
+            uint32_t h = ig_hash(k) & 63u; while (S.akey[h]) h = (h + 1) & 63u;
+            S.akey[h] = k; S.aval[h] = (uint8_t)i;
+        }
+        for (int i = 0; i < FCZ_N_RES_CODES; i++) {
+            uint32_t k; __builtin_memcpy(&k, fcz_res3[i], 4);
+            uint32_t h = ig_hash(k) & 31u; while (S.rkey[h]) h = (h + 1) & 31u;
+            S.rkey[h] = k; S.rval[h] = (uint8_t)i;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto atom_code_of = [&](uint32_t k) -> uint32_t {
+        for (uint32_t h = ig_hash(k) & 63u; S.akey[h]; h = (h + 1) & 63u) if (S.akey[h] == k) return S.aval[h];
+        return (uint32_t)FCZ_ATOM_OTHER;
+    };
+    auto res_code_of = [&](uint32_t k) -> int {
+        for (uint32_t h = ig_hash(k) & 31u; S.rkey[h]; h = (h + 1) & 31u) if (S.rkey[h] == k) { const int c = S.rval[h]; return (c < 20 || c == 23) ? c : -1; }
+        return -1;
+    };
+    const uint64_t A0 = abase[f];
+    uint32_t kept = 0;
+    bool have_last = false; uint32_t last_name = 0, last_comp = 0, last_ch = 0; int32_t last_num = 0;
+    unsigned long long model0 = 0; bool have_model = false;
+    bool dead = false;
+
+    struct fld { uint32_t w[4]; uint32_t n; };
+    auto ch_at = [](const fld& fd, int i) -> uint32_t { return (fd.w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+    auto is_null = [&](const fld& fd) -> bool { return fd.n == 1u && ((fd.w[0] & 0xffu) == '?' || (fd.w[0] & 0xffu) == '.'); };
+    // the numeric readers come in two widths: every numeric field of the step at most eight characters (what coordinate files
+    // hold: the wavefront decides it from the field bounds before a character is loaded) -> two dwords and a 32-bit mantissa;
+    // otherwise sixteen characters and the 64-bit one. Same value either way: the digits are exact in both.
+    auto lt = [](uint32_t a, uint32_t b) -> uint32_t { return (a - b) >> 31; };            // a < b for a, b < 2^31
+    auto is_digit = [](uint32_t d) -> uint32_t { return ((d | (9u - d)) >> 31) ^ 1u; };    // d = c - '0' as two's complement, |d| < 2^31
+    auto eq = [](uint32_t a, uint32_t b) -> uint32_t { const uint32_t x = a ^ b; return ((x | (0u - x)) >> 31) ^ 1u; };
+    auto integer = [&](const fld& f, int32_t* out, auto NC) -> bool {        // [+-]digits, at most nine of them
+        constexpr int N = decltype(NC)::value;
+        const uint32_t c0 = f.w[0] & 0xffu;
+        const uint32_t neg = eq(c0, '-'), sg = neg | eq(c0, '+');
+        uint32_t v = 0, nd = 0, ok = lt(f.n, (uint32_t)N + 1u);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t d = ch_at(f, i) - '0';
+            const uint32_t in = i == 0 ? (lt(0u, f.n) & (sg ^ 1u)) : lt((uint32_t)i, f.n);
+            const uint32_t dig = is_digit(d);
+            ok &= (in ^ 1u) | dig;
+            const uint32_t t = 0u - in;                                            // all ones where the character counts
+            v = ((v * 10u + d) & t) | (v & ~t); nd += in;
+        }
+        *out = (int32_t)((v ^ (0u - neg)) + neg);
+        return (ok & lt(0u, nd) & lt(nd, 10u)) != 0u;
+    };
+    auto decimal = [&](const fld& f, float* out, auto NC) -> bool {          // -digits.digits, at most 15 digits in 16 characters: cif::as_number's fast path
+        constexpr int N = decltype(NC)::value;
+        using mant = typename std::conditional<(N <= 9), uint32_t, unsigned long long>::type;
+        const uint32_t neg = eq(f.w[0] & 0xffu, '-');
+        mant m = 0; uint32_t nd = 0, nf = 0, point = 0, ok = lt(f.n, (uint32_t)N + 1u);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t c = ch_at(f, i), d = c - '0';
+            const uint32_t in = i == 0 ? (lt(0u, f.n) & (neg ^ 1u)) : lt((uint32_t)i, f.n);
+            const uint32_t dig = is_digit(d), pt = eq(c, '.');
+            ok &= (in ^ 1u) | dig | (pt & (point ^ 1u));
+            const uint32_t take = in & dig;
+            const mant t = (mant)0 - (mant)take;
+            m = ((m * (mant)10 + (mant)d) & t) | (m & ~t); nd += take; nf += take & point;
+            point |= in & pt;
+        }
+        const double v = (double)m / cif_pow10[nf & 15u];
+        *out = (float)(neg ? -v : v);
+        return (ok & lt(0u, nd) & lt(nd, 16u)) != 0u;
+    };
+    auto pack = [&](const fld& fd, uint32_t* out) -> bool {                   // a name of one to four characters
+        *out = fd.n >= 4u ? fd.w[0] : (fd.w[0] & ((1u << (8u * fd.n)) - 1u));
+        return (fd.n >= 1u) & (fd.n <= 4u) & !is_null(fd);
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>; using I10 = std::integral_constant<int, 10>; using I16 = std::integral_constant<int, 16>;
+
+    for (uint32_t s0 = 0; s0 < nrows; s0 += WAVE) {
+        const bool row = s0 + (uint32_t)lane < nrows;
+        const unsigned long long rowmask = __ballot(row);
+        const size_t at = (size_t)A0 + s0 + (uint32_t)lane;
+        // the record: line start, fourteen (start, end) byte pairs
+        uint32_t ls = 0, w[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (row) {
+            ls = T.name[at]; w[0] = T.resn[at]; w[1] = (uint32_t)T.serial[at]; w[2] = (uint32_t)T.resseq[at];
+            w[3] = __float_as_uint(T.x[at]); w[4] = __float_as_uint(T.y[at]); w[5] = __float_as_uint(T.z[at]); w[6] = __float_as_uint(T.b[at]);
+        }
+        uint32_t fs[14], fn[14];
+#pragma unroll
+        for (int q = 0; q < 14; q++) { const uint32_t p2 = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu; fs[q] = p2 & 0xffu; fn[q] = (p2 >> 8) - (p2 & 0xffu); }
+        const uint8_t* lp = base + ls;
+        auto load = [&](int q, auto NW) -> fld {
+            constexpr int W = decltype(NW)::value;
+            fld fd; fd.n = fn[q];
+            const uint8_t* p = lp + fs[q];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t v = 0;
+                if (k < W && row) {
+                    if (p + 4 * k + 4 <= lim) v = ld_u32(p + 4 * k);
+                    else for (int b = 0; b < 4; b++) if (p + 4 * k + b < lim) v |= (uint32_t)p[4 * k + b] << (8 * b);
+                }
+                fd.w[k] = v;
+            }
+            return fd;
+        };
+        uint32_t widest = 0;
+        { const int numeric[8] = {0, 1, 2, 3, 4, 5, 11, 12};
+#pragma unroll
+          for (int q = 0; q < 8; q++) widest = max(widest, fn[numeric[q]]); }
+        const bool narrow = !__any(widest > 8u);
+        bool rbad = false;
+        uint32_t an = 0, rn = 0, ch = ' '; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
+        auto fields = [&](auto NI, auto ND, auto NWD) {
+            const fld f0 = load(0, NWD), f1 = load(1, NWD), f2 = load(2, NWD), f3 = load(3, NWD), f4 = load(4, NWD), f5 = load(5, NWD);
+            const fld f6 = load(6, I1{}), f7 = load(7, I1{}), f8 = load(8, I1{}), f9 = load(9, I1{}), f10 = load(10, I1{});
+            const fld f11 = load(11, NWD), f12 = load(12, NWD), f13 = load(13, I2{});
+            rbad = rbad | !integer(f0, &serial, NI) | !integer(f1, &num, NI) | !decimal(f2, &x, ND) | !decimal(f3, &y, ND) | !decimal(f4, &z, ND);
+            rbad = rbad | !decimal(f5, &bf, ND) | !pack(f6, &an) | !pack(f7, &rn) | (f8.n != 1u) | is_null(f8) | (!is_null(f9) & (f9.n != 1u));
+            ch = f8.w[0] & 0xffu;
+            int32_t dummy;
+            // an optional column that the loop does not have has no characters
+            rbad = rbad | ((f10.n != 0u) & !is_null(f10));
+            rbad = rbad | ((f11.n != 0u) & !is_null(f11) & !integer(f11, &dummy, NI));
+            rbad = rbad | ((f12.n != 0u) & !is_null(f12) & !integer(f12, &dummy, NI));
+            rbad = rbad | (f13.n > 8u);
+            const unsigned long long v8 = (unsigned long long)f13.w[0] | ((unsigned long long)f13.w[1] << 32);
+            mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull));
+        };
+        if (narrow) fields(I8{}, I8{}, I2{}); else fields(I10{}, I16{}, I4{});
+        rbad = rbad & row;
+        // one model; residues of a chain run in rising order (the reader regroups anything else); keep rule of removeAlternativePosition
+        const uint32_t pl = ig_prev_lane(rowmask, lane);
+        const int src = pl < 64u ? (int)pl : 0;
+        const int32_t s_num = __shfl(num, src, WAVE);
+        const uint32_t s_rn = (uint32_t)__shfl((int)rn, src, WAVE), s_ch = (uint32_t)__shfl((int)ch, src, WAVE), s_an = (uint32_t)__shfl((int)an, src, WAVE);
+        const bool has_p = pl < 64u ? true : have_last;
+        const int32_t p_num = pl < 64u ? s_num : last_num;
+        const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name;
+        const unsigned long long m_first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mdl >> 32), 0) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mdl, 0);
+        const unsigned long long m0 = have_model ? model0 : m_first;
+        if (row && mdl != m0) rbad = true;
+        if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_rn == rn) && !(num > p_num)) rbad = true;
+        if (__any(row && rbad)) { dead = true; break; }
+        if (!have_model) { model0 = m0; have_model = true; }
+        const bool keep = row && !(has_p && p_an == an);
+        const unsigned long long m_keep = __ballot(keep);
+        if (keep) {
+            const size_t o = (size_t)A0 + kept + (uint32_t)__builtin_popcountll(m_keep & ((1ull << lane) - 1ull));   // <= `at`: never a record still to be read
+            T.name[o] = an; T.resn[o] = rn; T.serial[o] = serial; T.resseq[o] = num;
+            T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = (uint8_t)ch;
+            T.acode[o] = (uint8_t)atom_code_of(an);
+            T.rcode[o] = (int8_t)res_code_of(rn);
+        }
+        kept += (uint32_t)__builtin_popcountll(m_keep);
+        const int hl = 63 - __builtin_clzll(rowmask);
+        last_name = (uint32_t)__builtin_amdgcn_readlane((int)an, hl); last_comp = (uint32_t)__builtin_amdgcn_readlane((int)rn, hl); last_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, hl);
+        last_num = __builtin_amdgcn_readlane(num, hl); have_last = true;
+    }
+    if (lane == 0 && !dead && kept != 0u) {
+        n_kept[f] = kept;
+        file_status[f] = FCZ_OK;
+    }
 }
 
 }  // namespace fcz

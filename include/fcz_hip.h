@@ -240,7 +240,7 @@ int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
  * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order or with a second one
  * of them, a last atom that carries another residue name than its residue, chain beyond the header's counts,
  * --skip-discontinuous). Gzip stays on the host (its read threads inflate; the inflated text is parsed here).
- * mmCIF text (round 4, k_ingest_parse_cif): a file that opens with data_ (gemmi::coor_format_from_content, lib/gemmi/mmread.hpp:31-47)
+ * mmCIF text (round 4, k_ingest_parse_cif + k_ingest_rows_cif): a file that opens with data_ (gemmi::coor_format_from_content, lib/gemmi/mmread.hpp:31-47)
  * is read by gemmi's mmCIF rules (cif.hpp:37-148 grammar, mmcif.hpp:560-680 make_structure: the _atom_site loop's 23 columns by any
  * case, chain = auth_asym_id else label_asym_id, residue = auth_seq_id + comp id, atom name = auth_atom_id else label_atom_id,
  * title = _entry.id) when it has the shape every predicted-structure file has: one block, one item per line (or a tag line and its
@@ -308,7 +308,7 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
  * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
  * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format", "extract_sizes", "extract",
- * "ingest_parse", "ingest_parse_cif", "ingest_frags", "ingest_fill". */
+ * "ingest_parse", "ingest_parse_cif", "ingest_rows_cif", "ingest_frags", "ingest_fill". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

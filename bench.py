@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gen-chunk", type=int, default=32768)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="chains timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--parity-chains", type=int, default=4096,
+    ap.add_argument("--parity-chains", type=int, default=65536,
                     help="chains of the GPU result compared with the oracle bit for bit after the timed region (FCZ bytes and coordinates)")
     ap.add_argument("--seed-base", type=int, default=0,
                     help="first chain id of rank 0's batch (chain c of rank r is seeded with seed-base + r x chains + c): another value = another batch")
@@ -187,9 +187,12 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(hb, anchor):
+def cpu_baseline(hb, anchor, gpu=None):
     """the reference's CPU path on this host (oracle/_ref, OpenMP over chains like `foldcomp -t`);
-    falls back to the C port (oracle/) only as a *baseline*, never as part of the product path."""
+    falls back to the C port (oracle/) only as a *baseline*, never as part of the product path.
+    `gpu` (the product's results for the same chains: records, offsets, decoded arrays): the LIVE reference's records and decoded
+    atoms are compared with them chain by chain (64-bit FNV-1a of the pad-masked record and of the x / y / z / B-factor bit patterns,
+    computed by the checker library for both sides) -> `live_reference` in the returned dict."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _harness as H
     from foldcomp_amd._aa_tables import ATOM_NAMES, RES3
@@ -201,14 +204,36 @@ def cpu_baseline(hb, anchor):
         an = np.zeros((37, 4), np.uint8); rn = np.zeros((24, 4), np.uint8)
         for i, n in enumerate(ATOM_NAMES): an[i, :len(n)] = np.frombuffer(n.encode(), np.uint8)
         for i, n in enumerate(RES3): rn[i, :3] = np.frombuffer(n.encode(), np.uint8)
-        lib.ref_bench_roundtrip.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+        lib.ref_bench_roundtrip.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 11
         tc = ctypes.c_double(); td = ctypes.c_double(); fb = ctypes.c_ulonglong(); ao = ctypes.c_ulonglong()
-        fail = lib.ref_bench_roundtrip(hb.n_chains, hb.res_off.ctypes.data, hb.atom_off.ctypes.data, hb.x.ctypes.data, hb.y.ctypes.data,
+        n = hb.n_chains
+        h_fcz = np.zeros(n, np.uint64); h_xyz = np.zeros(n, np.uint64)
+        titles = np.ascontiguousarray(hb.titles, dtype=np.uint8); toff = np.ascontiguousarray(hb.title_off, dtype=np.uint32)
+        fres = np.ascontiguousarray(hb.first_res_index, dtype=np.int32); fatom = np.ascontiguousarray(hb.first_atom_index, dtype=np.int32)
+        cid = np.ascontiguousarray(hb.chain_id, dtype=np.uint8)
+        fail = lib.ref_bench_roundtrip(n, hb.res_off.ctypes.data, hb.atom_off.ctypes.data, hb.x.ctypes.data, hb.y.ctypes.data,
                                        hb.z.ctypes.data, hb.atom_code.ctypes.data, hb.res_code.ctypes.data, hb.bfac_ca.ctypes.data,
                                        an.ctypes.data, rn.ctypes.data, anchor, cores, ctypes.byref(tc), ctypes.byref(td),
-                                       ctypes.byref(fb), ctypes.byref(ao))
-        return {"value": R / (tc.value + td.value), "unit": "residues/s", "cores": cores, "hardware_threads": os.cpu_count(), "kind": "reference", "sample": sample,
-                "compress_residues_per_s": R / tc.value, "decompress_residues_per_s": R / td.value, "failed_chains": int(fail)}
+                                       ctypes.byref(fb), ctypes.byref(ao), titles.ctypes.data, toff.ctypes.data, fres.ctypes.data, fatom.ctypes.data,
+                                       cid.ctypes.data, h_fcz.ctypes.data, h_xyz.ctypes.data)
+        out = {"value": R / (tc.value + td.value), "unit": "residues/s", "cores": cores, "hardware_threads": os.cpu_count(), "kind": "reference", "sample": sample,
+               "compress_residues_per_s": R / tc.value, "decompress_residues_per_s": R / td.value, "failed_chains": int(fail)}
+        if gpu is not None:
+            # the product's records and decoded atoms of the same chains, hashed by the same checker functions
+            lib.ref_hash_records.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+            lib.ref_hash_atoms.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_long, ctypes.c_void_p]
+            g_fcz = np.zeros(n, np.uint64); g_xyz = np.zeros(n, np.uint64)
+            lib.ref_hash_records(gpu["blob"].ctypes.data, gpu["off"].ctypes.data, n, g_fcz.ctypes.data)
+            lib.ref_hash_atoms(gpu["x"].ctypes.data, gpu["y"].ctypes.data, gpu["z"].ctypes.data, gpu["atom_off"].ctypes.data,
+                               gpu["bfac_res"].ctypes.data, gpu["res_off"].ctypes.data, n, g_xyz.ctypes.data)
+            ne_f = np.nonzero(g_fcz != h_fcz)[0]; ne_x = np.nonzero(g_xyz != h_xyz)[0]
+            out["live_reference"] = {"chains": int(n), "records_equal": int(n - len(ne_f)), "coords_equal": int(n - len(ne_x)),
+                                     "first_record_mismatch_chain": int(ne_f[0]) if len(ne_f) else None,
+                                     "first_coords_mismatch_chain": int(ne_x[0]) if len(ne_x) else None,
+                                     "digest_records": f"{int(np.bitwise_xor.reduce(h_fcz)):016x}", "digest_coords": f"{int(np.bitwise_xor.reduce(h_xyz)):016x}",
+                                     "what": "Foldcomp::compress + writeStream / read + decompress of oracle/_ref on these chains (own titles, numbering, chain ids) "
+                                             "against the GPU's records (header bytes 14, 15, 22, 23 masked) and decoded x / y / z / B-factor bits, chain by chain"}
+        return out
     t0 = time.perf_counter(); blob, off, st = H.oracle_compress(hb, n_threads=cores)
     t1 = time.perf_counter(); H.oracle_decompress(blob, off, n_threads=cores); t2 = time.perf_counter()
     return {"value": R / (t2 - t0), "unit": "residues/s", "cores": cores, "kind": "port", "sample": sample,
@@ -621,11 +646,11 @@ def end_to_end_leg(args, codec, w, dev):
         # ---- the sharded driver at N = 1 (what `--gpus 8` runs per rank): `python -m foldcomp_amd <mode> -d --gpus 1`
         #      = a 1-rank RCCL group around the same engine (`foldcomp-hip --shard 0/1`) + the count exchange + the splice, on the
         #      same inputs as gpu_host above: what the process group, the second process and the exchange cost beside the bare engine
-        def run_sharded(mode, inp_list, out_db):
+        def run_sharded(mode, inp_list, out_db, ranks=1):
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
             env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
             t0 = time.perf_counter()
-            r = subprocess.run([sys.executable, "-m", "foldcomp_amd", mode, "-d", "-y", "--gpus", "1", "-t", str(eff), "--json-stats", "-f", inp_list, out_db],
+            r = subprocess.run([sys.executable, "-m", "foldcomp_amd", mode, "-d", "-y", "--gpus", str(ranks), "-t", str(max(1, eff // ranks)), "--json-stats", "-f", inp_list, out_db],
                                capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
             wall = time.perf_counter() - t0
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -649,6 +674,31 @@ def end_to_end_leg(args, codec, w, dev):
                             "steady_over_gpu_host": round(st["steady_residues_per_s"] / max(ref_leg["steady_residues_per_s"], 1), 3),
                             "database_equals_gpu_host": bool(same)}
                 os.remove(os.path.join(tmp, f"sharded_{mode}"))
+            # ---- TEST MODE: two ranks on this ONE GPU (gloo group; on a node every rank has its own GPU and the group is RCCL). What it
+            #      shows is the file side of the sharded decompress: the ranks exchange {records, text bytes} BEFORE they write (sizes
+            #      pre-pass of the engine), every job is written once at its final offset of the final data file, and what is left
+            #      after the engines end is the concatenation of the ranks' index lines (reference: every record
+            #      appended once, src/main.cpp:656-664, src/database_writer.cpp:36-58)
+            try:
+                st = run_sharded("decompress", dlist, os.path.join(tmp, "sharded_two"), ranks=2)
+                same = all(open(os.path.join(tmp, "sharded_two") + ext, "rb").read() == open(os.path.join(tmp, "pdbdb") + ext, "rb").read() for ext in (".index", ".lookup", ".dbtype"))
+                same = same and os.path.getsize(os.path.join(tmp, "sharded_two")) == os.path.getsize(os.path.join(tmp, "pdbdb"))
+                with open(os.path.join(tmp, "sharded_two"), "rb") as fa, open(os.path.join(tmp, "pdbdb"), "rb") as fb:
+                    while same:
+                        ba, bb_ = fa.read(1 << 26), fb.read(1 << 26)
+                        same = ba == bb_
+                        if not ba:
+                            break
+                sh["decompress_two_ranks"] = {"mode": "TEST MODE: 2 ranks share the one GPU of this box (gloo group, half the host threads each)",
+                                              "world": st["world"], "backend": st["backend"], "records": st["records"], "records_per_rank": st["records_per_rank"],
+                                              "wall_s": st["wall_s"], "engine_s": st["engine_s"], "sizes_pass_s": st.get("sizes_pass_s_max"),
+                                              "exchange_and_splice_s": st["exchange_and_splice_s"],
+                                              "exchange_and_splice_over_engine": round(st["exchange_and_splice_s"] / max(st["engine_s"], 1e-9), 4),
+                                              "data_written_once": st.get("data_written_once"),
+                                              "steady_residues_per_s": st["steady_residues_per_s"], "database_equals_gpu_host": bool(same)}
+                os.remove(os.path.join(tmp, "sharded_two"))
+            except (RuntimeError, subprocess.TimeoutExpired, OSError, KeyError) as e:
+                sh["decompress_two_ranks"] = {"failed": str(e)[-400:]}
             out["sharded"] = sh
         except (RuntimeError, subprocess.TimeoutExpired, OSError, KeyError) as e:
             out["sharded"] = {"failed": str(e)[-400:]}
@@ -1302,8 +1352,22 @@ def main():
         note(f"parity check done: {parity['chains_checked']} chains, fcz {parity['fcz_bit_exact']}, coords {parity['coords_bit_exact']}")
     # ---- CPU baseline: rank 0, at any world size, with an explicit thread count (a launcher exports OMP_NUM_THREADS=1; the
     #      reference loop takes num_threads(cores) itself); the other ranks sleep on the store meanwhile, off the host cores ----
-    cpu = comm.wait_for_rank0("cpu_baseline_done", (lambda: cpu_baseline(host_sample(d, args.cpu_sample), args.anchor)) if args.cpu_sample else None)
+    def gpu_sample(n):
+        """the product's records and decoded arrays of the rank's first n chains, on the host (default atom order)"""
+        n = min(n, w.C)
+        goff = w.off_dev[:n + 1].cpu().numpy().astype(np.uint64)
+        a1 = _u32(w.atom_off_dev[n]); r1 = _u32(w.res_off_dev[n])
+        return {"blob": np.ascontiguousarray(w.blob_dev[:int(goff[-1])].cpu().numpy()), "off": np.ascontiguousarray(goff),
+                "x": w.out_t["x"][:a1].cpu().numpy(), "y": w.out_t["y"][:a1].cpu().numpy(), "z": w.out_t["z"][:a1].cpu().numpy(),
+                "atom_off": np.ascontiguousarray(w.atom_off_dev[:n + 1].cpu().numpy().view(np.uint32)),
+                "bfac_res": w.out_t["bfac_res"][:r1].cpu().numpy(), "res_off": np.ascontiguousarray(w.res_off_dev[:n + 1].cpu().numpy().view(np.uint32))}
+    cpu = comm.wait_for_rank0("cpu_baseline_done", (lambda: cpu_baseline(host_sample(d, args.cpu_sample), args.anchor,
+                                                                         gpu=None if (args.no_parity or args.numerics == "fast") else gpu_sample(args.cpu_sample))) if args.cpu_sample else None)
     note("cpu baseline done")
+    if parity is not None and cpu and cpu.get("live_reference"):
+        lr = cpu["live_reference"]
+        parity["live_reference_chains"] = lr["chains"]
+        parity["live_reference_equal"] = bool(lr["records_equal"] == lr["chains"] and lr["coords_equal"] == lr["chains"])
 
     if rank == 0:
         A = M / R                                   # atoms per residue

@@ -68,6 +68,7 @@ def load():
         "fcz_pdb_format_dev": (i32, [vp, vp, vp, u32, vp, vp, PO, i32, vp, vp]),
         "fcz_decompress_pdb_begin": (i32, [vp, vp, vp, u32, i32, vp, vp]),
         "fcz_decompress_pdb_fetch": (i32, [vp, vp]),
+        "fcz_decompress_pdb_sizes": (i32, [vp, vp, vp, u32, i32, vp, vp]),
         "fcz_extract_sizes": (i32, [vp, vp, u32, i32, i32, vp]),
         "fcz_extract": (i32, [vp, vp, vp, u32, i32, i32, vp, vp]),
         "fcz_extract_sizes_dev": (i32, [vp, vp, vp, u32, i32, i32, vp]),
@@ -96,7 +97,7 @@ EXPORTS = ["fcz_ctx_create", "fcz_ctx_destroy", "fcz_ctx_stream", "fcz_ctx_synch
            "fcz_res_code_natoms", "fcz_res_code_atom", "fcz_compress_sizes", "fcz_compress_batch",
            "fcz_compress_angles", "fcz_compress_sizes_dev", "fcz_compress_batch_dev", "fcz_decompress_sizes", "fcz_decompress_batch",
            "fcz_decompress_sizes_dev", "fcz_decompress_batch_dev", "fcz_pdb_sizes_dev", "fcz_pdb_format_dev",
-           "fcz_decompress_pdb_begin", "fcz_decompress_pdb_fetch", "fcz_extract_sizes", "fcz_extract",
+           "fcz_decompress_pdb_begin", "fcz_decompress_pdb_fetch", "fcz_decompress_pdb_sizes", "fcz_extract_sizes", "fcz_extract",
            "fcz_extract_sizes_dev", "fcz_extract_dev", "fcz_ingest_pdb_dev", "fcz_ingest_pdb_begin", "fcz_ingest_pdb_fetch",
            "fcz_compress_pdb_begin", "fcz_compress_pdb_fetch", "fcz_check", "fcz_ctx_enable_timing",
            "fcz_ctx_kernel_time", "fcz_ctx_reset_timing", "fcz_selftest_math"]

@@ -290,8 +290,8 @@ int fcz_pdb_format_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* of
 
 // Host-pointer convenience: FCZ entries in, PDB text out, everything in between on the device. begin() leaves the text in
 // the ctx and reports the per-entry text offsets; fetch() copies it out.
-int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order, uint64_t* text_off,
-                             int32_t* status) {
+static int pdb_begin_impl(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order, uint64_t* text_off,
+                          int32_t* status, bool format) {
     if (!ctx || !blob || !off || !text_off) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t pad = (alt_order & FCZ_PDB_NUL_TERMINATED) ? 1u : 0u;   // every entry followed by one NUL (a database record)
@@ -332,11 +332,22 @@ int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(text_off, ctx->pdb_off.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!format) return FCZ_OK;           // sizes only: nothing is kept for a fetch
     ctx->pdb_bytes = text_off[n];
     if ((rc = ctx->pdb_text.ensure(std::max<uint64_t>(ctx->pdb_bytes, 16)))) return rc;
     if (pad && ctx->pdb_bytes) HIP_TRY(hipMemsetAsync(ctx->pdb_text.p, 0, ctx->pdb_bytes, ctx->stream));   // the terminators: the format pass writes the text around them
     return fcz_pdb_format_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->stage[1].as<uint64_t>(), n, ctx->stage[2].as<uint32_t>(),
                               ctx->stage[3].as<uint32_t>(), &dv, alt_order, ctx->pdb_off.as<uint64_t>(), ctx->pdb_text.as<uint8_t>());
+}
+
+int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order, uint64_t* text_off,
+                             int32_t* status) {
+    return pdb_begin_impl(ctx, blob, off, n, alt_order, text_off, status, true);
+}
+
+int fcz_decompress_pdb_sizes(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order, uint64_t* text_off,
+                             int32_t* status) {
+    return pdb_begin_impl(ctx, blob, off, n, alt_order, text_off, status, false);
 }
 
 int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out) {
@@ -948,7 +959,13 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
     rc = ctx->bb.ensure(sizeof(v3) * 3 * (size_t)R); if (rc) return rc;
     const uint32_t* perm = ctx->len_perm.as<uint32_t>();
     const bool fast_bb = ctx->numerics == FCZ_NUMERICS_FAST, fast_sc = fast_bb;
+#ifdef FCZ_PROFILING
+    // measurement builds only (tools/hbm_busy_probe.py builds its own library with -DFCZ_PROFILING): FCZ_PROFILE_STAGES=<mask> leaves
+    // stages out. The product library never reads the environment here -- a leaked variable must not turn a decompress into a no-op.
     { const char* ps = getenv("FCZ_PROFILE_STAGES"); ctx->profile_stages = ps ? ((unsigned)strtoul(ps, nullptr, 0) & 7u) : 7u; }
+#else
+    ctx->profile_stages = 7u;
+#endif
     if (!(ctx->profile_stages & 1u)) { /* profiling aid: no backbone launch */ }
     else if (fast_bb) {
         // plain-float backbone: 8 chains per wavefront, the forward atoms of a segment stay in LDS; only segments longer than
@@ -989,21 +1006,28 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
                 const uint32_t g = std::min(chunk, groups_long_all - g0);
                 const uint32_t slots = std::min<uint32_t>(n_long - g0 * WAVE, g * WAVE);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<1>), dim3(g), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
-                                   perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
+                                   perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>(), 0u, (uint32_t*)nullptr);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<2>), dim3(g * max_nseg), dim3(WAVE), 0, ctx->stream2, blob_dev, off_dev, n, slots, res_off_dev,
-                                   perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>());
+                                   perm + (size_t)g0 * WAVE, ctx->fwd_long.as<v3>(), ctx->wring_long.as<float>(), ring_rows, max_nseg, ctx->bb.as<v3>(), 0u, (uint32_t*)nullptr);
             }
             HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
         }
         const uint32_t n_fused = n - n_split;
         const uint32_t groups = grid_for(n_fused, WAVE);
-        rc = ctx->fwd.ensure(sizeof(v3) * (size_t)std::max<uint32_t>(groups, 1) * slot_atoms); if (rc) return rc;
-        rc = ctx->wring.ensure(sizeof(float) * (size_t)std::max<uint32_t>(groups, 1) * slot_trig); if (rc) return rc;
+        // persistent grid: as many wavefronts as the chip keeps in flight (FCZ_BACKBONE_MIN_WAVES per SIMD), one ring slot each --
+        // 2 048 x 107.5 KB = 220 MB at the headline batch whatever its size, and a slot is rewritten by the wavefront's next
+        // group instead of being left behind dirty (one slot per group was 1.68 GB at 1 M chains)
+        const uint32_t resident = FCZ_BB_PERSIST ? (uint32_t)ctx->n_cu * 4u * FCZ_BACKBONE_MIN_WAVES : groups;
+        const uint32_t blocks0 = std::min(groups, resident);
+        rc = ctx->fwd.ensure(sizeof(v3) * (size_t)std::max<uint32_t>(blocks0, 1) * slot_atoms + 64); if (rc) return rc;
+        rc = ctx->wring.ensure(sizeof(float) * (size_t)std::max<uint32_t>(blocks0, 1) * slot_trig); if (rc) return rc;
+        uint32_t* next_group = (uint32_t*)(ctx->fwd.as<uint8_t>() + sizeof(v3) * (size_t)std::max<uint32_t>(blocks0, 1) * slot_atoms);
+        if (FCZ_BB_PERSIST && groups) HIP_TRY(hipMemsetAsync(next_group, 0, sizeof(uint32_t), ctx->stream));
         {
             span_guard g(ctx, "decompress_backbone");
             if (groups)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<0>), dim3(groups), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, n_fused, res_off_dev,
-                                   perm + n_split, ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, 1u, ctx->bb.as<v3>());
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_backbone<0>), dim3(blocks0), dim3(WAVE), 0, ctx->stream, blob_dev, off_dev, n, n_fused, res_off_dev,
+                                   perm + n_split, ctx->fwd.as<v3>(), ctx->wring.as<float>(), ring_rows, 1u, ctx->bb.as<v3>(), groups, next_group);
             if (split_long) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     }

@@ -533,6 +533,9 @@ __global__ __launch_bounds__(1024) void k_sizes_apply(const uint32_t* __restrict
 #ifndef FCZ_BACKBONE_MIN_WAVES
 #define FCZ_BACKBONE_MIN_WAVES 2
 #endif
+#ifndef FCZ_BB_PERSIST
+#define FCZ_BB_PERSIST 1
+#endif
 // Backbone reconstruction, one wavefront per group of 64 consecutive entries, lane = chain.
 // Reference: segment loop of Foldcomp::decompress (src/foldcomp.cpp:814-858): per anchor segment a forward
 // NeRF (reconstructBackboneAtoms :167-246), then reconstructBackboneReverse (:248-273: bond angles re-measured
@@ -565,24 +568,24 @@ __device__ unsigned long long g_bb_timing[8];
 #else
 #define BB_STAMP(i)
 #endif
+// one group of 64 chains (lane = chain) of k_backbone; `home` = the ring slot of a MODE 0 wavefront (its block index: the grid is
+// persistent, so the ring is as large as the wavefronts in flight, not as the batch)
 template <int MODE>
-__global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
+__device__ __forceinline__ void backbone_group(
+        backbone_lds& S, const uint32_t grp, const uint32_t seg_only, const uint32_t home,
         const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries, uint32_t n_slots,
         const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ perm, v3* __restrict__ ring,
         float* __restrict__ tring, uint32_t ring_rows, uint32_t seg_slots, v3* __restrict__ bb) {
-    __shared__ backbone_lds S;
     const int lane = threadIdx.x;
 #ifdef FCZ_BB_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
-    const uint32_t grp = (MODE == 2) ? blockIdx.x / seg_slots : blockIdx.x;
-    const uint32_t seg_only = (MODE == 2) ? blockIdx.x - grp * seg_slots : 0u;
     const uint32_t slot = grp * WAVE + lane;
     const uint32_t c = slot < n_slots ? perm[slot] : n_entries;   // chains grouped by length, longest first
     const bool valid = c < n_entries && res_off[c + 1] != res_off[c];
     // ring slot of segment sg: atom row j at Rg[j * WAVE]; cos/sin of the three torsions of word i at Tg rows 6i .. 6i+5
     // (the reverse pass needs nothing else of the word)
-    auto ring_slot = [&](uint32_t sg) -> size_t { return (MODE == 0) ? (size_t)grp : (size_t)grp * seg_slots + sg; };
+    auto ring_slot = [&](uint32_t sg) -> size_t { return (MODE == 0) ? (size_t)home : (size_t)grp * seg_slots + sg; };
     v3* Rg = ring + ring_slot(seg_only) * ring_rows * WAVE + lane;
     float* Tg = tring + ring_slot(seg_only) * (ring_rows / 3) * 6 * WAVE + lane;
     const uint8_t* e = blob + (valid ? off[c] : off[0]);
@@ -760,6 +763,31 @@ __global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
 #ifdef FCZ_BB_TIMING
     if (MODE == 0 && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_bb_timing[i], tacc[i]);
 #endif
+}
+
+// MODE 0 runs as a persistent grid (FCZ_BB_PERSIST): n_cu x 8 wavefronts, the first round of groups by block index, every later
+// one from a counter (groups are in length order, longest first), ring slot = block index. MODE 1 / 2: one block per group /
+// (group, segment). n_groups and next_group are only read by MODE 0.
+template <int MODE>
+__global__ __launch_bounds__(WAVE, FCZ_BACKBONE_MIN_WAVES) void k_backbone(
+        const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint32_t n_entries, uint32_t n_slots,
+        const uint32_t* __restrict__ res_off, const uint32_t* __restrict__ perm, v3* __restrict__ ring,
+        float* __restrict__ tring, uint32_t ring_rows, uint32_t seg_slots, v3* __restrict__ bb,
+        uint32_t n_groups, uint32_t* __restrict__ next_group) {
+    __shared__ backbone_lds S;
+    if (MODE == 0 && FCZ_BB_PERSIST) {
+        uint32_t grp = blockIdx.x;
+        while (grp < n_groups) {
+            backbone_group<MODE>(S, grp, 0u, blockIdx.x, blob, off, n_entries, n_slots, res_off, perm, ring, tring, ring_rows, seg_slots, bb);
+            uint32_t nx = 0;
+            if (threadIdx.x == 0) nx = atomicAdd(next_group, 1u);
+            grp = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+        }
+    } else {
+        const uint32_t grp = (MODE == 2) ? blockIdx.x / seg_slots : blockIdx.x;
+        const uint32_t seg_only = (MODE == 2) ? blockIdx.x - grp * seg_slots : 0u;
+        backbone_group<MODE>(S, grp, seg_only, grp, blob, off, n_entries, n_slots, res_off, perm, ring, tring, ring_rows, seg_slots, bb);
+    }
 }
 
 }  // namespace fcz

@@ -8,9 +8,12 @@ keys and offsets counted from 0 (rank 0 straight into the final files). Then, on
   1. `exchange_counts`: ONE all_gather of {records, data bytes, failed} over the process group (backend "nccl" = RCCL over xGMI
      with device tensors; "gloo" in the CPU tests) -> every rank knows key0 = records of the ranks before it and off0 = their
      bytes (the reference numbers keys in arrival order under `omp critical`, src/main.cpp:514-518: here input order);
-  2. `splice`: rank r > 0 moves its data into the final file at off0 and rewrites its index / lookup lines with key0 / off0 added
-     (`foldcomp-hip db-splice`: in-kernel copy, line streaming); after a barrier rank 0 appends those line files to its own
-     (.index / .lookup sorted by key as free_writer leaves them, src/database_writer.cpp:59-73; .dbtype = int32 12).
+  2. compress -- `splice`: rank r > 0 moves its data into the final file at off0 and rewrites its index / lookup lines with key0 /
+     off0 added (`foldcomp-hip db-splice`: in-kernel copy, line streaming); after a barrier rank 0 appends those line files to its
+     own (.index / .lookup sorted by key as free_writer leaves them, src/database_writer.cpp:59-73; .dbtype = int32 12). The data
+     moved is the FCZ output (2.5 % of the bytes the run reads).
+     decompress -- the exchange comes FIRST (the engines measure their ranges before they write, foldcomp_amd/sharded_cli.py), every
+     rank writes its records once at off0 in the final file with final index lines, and `join_lines` only appends line files.
 
 No rank holds a per-record Python object or another rank's rows: memory is O(one job of the engine) whatever the shard size.
 """
@@ -68,6 +71,35 @@ def remove_db(path: str) -> None:
             os.remove(path + ext)
         except OSError:
             pass
+
+
+def remove_rank_files(output: str, rank: int) -> None:
+    """what rank `rank` may have left beside the output: its partial database and its index / lookup line files"""
+    if rank > 0:
+        remove_db(f"{output}.part{rank}")
+        for ext in (".index", ".lookup"):
+            try:
+                os.remove(f"{output}{ext}.{rank}")
+            except OSError:
+                pass
+
+
+def join_lines(output: str, device=None, host: str = HOST) -> bool:
+    """file side of a PLACED run (decompress): every rank has already written its records into `output` at their final offsets and
+    its index / lookup lines with final keys (rank 0: output.index, rank r: output.index.r). After a barrier rank 0 appends the
+    line files in rank order (`foldcomp-hip db-splice --shard 0/N`) -- the only bytes moved after the engines end. -> success on
+    every rank"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ok = True
+    dist.barrier()
+    if rank == 0 and world > 1:
+        r = subprocess.run([host, "db-splice", "--shard", f"0/{world}", output, output])
+        ok = r.returncode == 0
+    if world == 1:
+        return ok
+    t = torch.tensor([0 if ok else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item()) == 0
 
 
 def splice(output: str, part: str, key0: int, off0: int, device=None, host: str = HOST) -> bool:

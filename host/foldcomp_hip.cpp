@@ -1263,6 +1263,8 @@ struct Options {
     bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
     int shard_rank = 0, shard_world = 1;   // --shard R/N: this process is rank R of N of a sharded database run (see InputPlan)
     int device = 0;             // --device D: first HIP device of this process (a rank of a sharded run drives device LOCAL_RANK)
+    bool place = false;         // --place: decompress -d as a rank of a sharded run: sizes pass over the range, counts on stdout, then the
+                                // placement (`key0 off0 total` on stdin) and ONE write of every record at its final offset (see run_decompress)
 };
 
 // ---- the inputs of a run, as a stream ------------------------------------------------------------------------------------------
@@ -1507,13 +1509,17 @@ struct InputPlan {
     }
 
     // the bytes of a database entry into dst (exactly it.len); false: the entry lies outside the data file
+    // does the entry lie inside its data file? (asked BEFORE a buffer is sized from the index's numbers: one corrupt line must not
+    // become a bad_alloc that ends the run; off + len cannot wrap this way -- an index number may have 19 digits)
+    bool entry_in_range(const InputItem& it) const {
+        const Src& s = *srcs[(size_t)it.src];
+        const uint64_t size = s.kind == 2 ? (uint64_t)s.db->size : s.dsize;
+        return it.len <= size && it.off <= size - it.len;
+    }
     bool read_entry(const InputItem& it, uint8_t* dst) const {
         const Src& s = *srcs[(size_t)it.src];
-        if (s.kind == 2) {
-            if (it.off + it.len > s.db->size) return false;
-            memcpy(dst, s.db->data + it.off, it.len); return true;
-        }
-        if (it.off + it.len > s.dsize) return false;
+        if (!entry_in_range(it)) return false;
+        if (s.kind == 2) { memcpy(dst, s.db->data + it.off, it.len); return true; }
         uint64_t got = 0;
         while (got < it.len) { const ssize_t k = pread(s.dfd, dst + got, it.len - got, (off_t)(it.off + got)); if (k <= 0) return false; got += (uint64_t)k; }
         return true;
@@ -1651,8 +1657,8 @@ template <class T> struct JobQueue {           // bounded hand-over between the 
 struct Sequencer {
     std::mutex m; std::condition_variable cv; size_t next = 0; uint64_t pos = 0; long long key = 0;
     FILE* fi = nullptr; FILE* fl = nullptr;
-    bool open_index(const std::string& db) {
-        fi = fopen((db + ".index").c_str(), "w"); fl = fopen((db + ".lookup").c_str(), "w");
+    bool open_index(const std::string& db, const std::string& tag = "") {      // tag ".R": rank R > 0 of a placed run writes its own line files
+        fi = fopen((db + ".index" + tag).c_str(), "w"); fl = fopen((db + ".lookup" + tag).c_str(), "w");
         return fi && fl;
     }
     // lens / names: the job's records in the order they lie in its byte range (both null: a job without records)
@@ -2243,136 +2249,218 @@ int run_decompress(const Options& o) {
     const int gpus = o.gpus <= 0 ? n_dev - o.device : o.gpus;
     if (gpus < 1 || o.device + gpus > n_dev) { fprintf(stderr, "[Error] --gpus %d from device %d but only %d device(s) are visible\n", gpus, o.device, n_dev); return 1; }
     const int n_workers = single ? 1 : gpus * std::max(1, o.workers_per_gpu);
+    // A rank of a sharded run (--place, database output): the record and byte counts of every rank must be known before any rank
+    // writes, so that every record is appended ONCE, at its final offset of the final data file (the reference appends every record
+    // once: writer_append, src/database_writer.cpp:36-58, from src/main.cpp:656-664). The text of a record is ~40x its FCZ bytes and
+    // its exact size needs the decoded numbers (printf widens a column that overflows), so the range is walked twice:
+    //   sizes pass   the same producer and workers, fcz_decompress_pdb_sizes instead of _begin / _fetch: entries read (16.5 B per
+    //                residue), decoded and measured on the device, nothing formatted, copied back or written; --check and entries
+    //                that do not decode are decided here exactly as the real pass decides them, so the count is final;
+    //   exchange     {"phase": "sizes", records, data_bytes} on stdout; the caller (foldcomp_amd/sharded_cli.py) does the run's one
+    //                all_gather and answers `key0 off0 total` on stdin (or `abort`);
+    //   real pass    the sequencer starts at key0 / off0: every job pwrites into <output> itself, index / lookup lines carry final
+    //                keys and offsets (rank 0: <output>.index, rank R: <output>.index.R -- rank 0 only concatenates line files).
+    const bool place = o.place && o.db && !single;
     pinned_enabled() = true;
     int db_fd = -1;
-    if (o.db) {
-        db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
-        if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
-    } else if (!single) make_dir(output);
+    if (!o.db && !single) make_dir(output);
 
-    JobQueue<DecompressJob> queue((size_t)n_workers + 2);
     InputPlan plan;
     Sequencer seq;
-    if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
     std::atomic<uint64_t> n_ok{0}, n_text{0}, n_fcz{0}, n_res{0};
     std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0), wait_s(n_workers, 0.0), write_s(n_workers, 0.0), alloc_s(n_workers, 0.0);
-    std::vector<std::thread> workers;
-    for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
-        fcz_ctx* ctx = nullptr;
-        if (fcz_ctx_create(o.device + w % gpus, &ctx) != FCZ_OK) { hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", o.device + w % gpus); }
-        ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
-        pvec<uint8_t> text, packed;
-        DecompressJob job;
-        for (;;) {
-            const auto tw = clk::now();
-            const bool more = queue.get(job);
-            wait_s[w] += std::chrono::duration<double>(clk::now() - tw).count();
-            if (!more) break;
-            const uint32_t n = job.ents.n();
-            std::vector<uint64_t> text_off(n + 1, 0);
-            std::vector<int32_t> status(n, 0);
-            const auto t0 = clk::now();
-            // a database record is the text + the MMseqs terminator (src/main.cpp:659): the device leaves the NULs in place, so a job's
-            // records are one contiguous range of the data file
-            const int flags = (o.alt ? FCZ_PDB_ALT_ORDER : 0) | (o.db ? FCZ_PDB_NUL_TERMINATED : 0);
-            int rc = ctx ? fcz_decompress_pdb_begin(ctx, job.ents.blob.data(), job.ents.off.data(), n, flags, text_off.data(), status.data()) : FCZ_E_NO_DEVICE;
-            gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
-            uint32_t n_good = 0;
-            if (rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) n_good += status[i] == FCZ_OK ? 1u : 0u;
-            const uint64_t bytes = rc == FCZ_OK ? text_off[n] : 0;
-            std::vector<uint64_t> lens; std::vector<std::string> dbnames;
-            if (o.db && rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) {
-                if (status[i] != FCZ_OK) continue;
-                std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
-                lens.push_back(text_off[i + 1] - text_off[i]); dbnames.push_back(stem);
+    std::vector<fcz_ctx*> ctxs(n_workers, nullptr);
+    std::vector<char> ctx_tried(n_workers, 0);
+    // what the sizes pass found per job (records that decode, bytes incl. their terminators): the real pass must find the same
+    std::mutex planned_m; std::vector<std::pair<uint64_t, uint64_t>> planned;
+    std::atomic<uint64_t> planned_records{0}, planned_bytes{0};
+    bool plan_built = false;
+    double t_queued = 0.0;
+
+    auto run_pass = [&](const bool sizes_only) {
+        JobQueue<DecompressJob> queue((size_t)n_workers + 2);
+        std::vector<std::thread> workers;
+        for (int w = 0; w < n_workers; w++) workers.emplace_back([&, w]() {
+            if (!ctx_tried[w]) {
+                ctx_tried[w] = 1;
+                if (fcz_ctx_create(o.device + w % gpus, &ctxs[w]) != FCZ_OK) { ctxs[w] = nullptr; hard_fail = true; fprintf(stderr, "[Error] no ctx on device %d\n", o.device + w % gpus); }
+                ctx_ready[w] = std::chrono::duration<double>(clk::now() - t_start).count();
             }
-            const uint64_t at = o.db ? seq.claim(job.index, bytes, &lens, &dbnames) : 0;     // every job claims, also a failed one
-            if (rc == FCZ_OK) {
-                const auto ta = clk::now();
-                if (text.size() < text_off[n]) text.resize(text_off[n] + text_off[n] / 8);     // grows, never shrinks (a resize zero-fills what it adds)
-                alloc_s[w] += std::chrono::duration<double>(clk::now() - ta).count();
-                const auto t1 = clk::now();
-                rc = fcz_decompress_pdb_fetch(ctx, text.data());
-                gpu_busy[w] += std::chrono::duration<double>(clk::now() - t1).count();
-                for (uint32_t i = 0; i < n; i++) if (status[i] == FCZ_OK) { const uint8_t* e = job.ents.blob.data() + job.ents.off[i]; n_res += (uint32_t)e[4] | ((uint32_t)e[5] << 8); }
-            }
-            if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s\n", fcz_status_string(rc)); hard_fail = true; continue; }
-            const auto t_write = clk::now();
-            try {
-                if (o.db) {
-                    // the job's records lie in the fetched buffer exactly as in the data file: one run of large writes. (The copy into
-                    // the page cache is the cost of this direction -- the text is 40x the FCZ bytes -- and writes to ONE file
-                    // serialise on its inode lock: large writes from one thread reach what the file system gives,
-                    // tools/dbg/write_bench.cpp; more writer threads only add contention.)
-                    for (uint32_t i = 0; i < n; i++) if (status[i] != FCZ_OK) fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str());
-                    pwrite_all(db_fd, text.data(), bytes, at);
-                } else {
-                    // one file per entry, written by several threads (open / write / close per file is what takes the time)
-                    const int pieces = (int)std::min<size_t>(std::max<size_t>(n / 64, 1), (size_t)std::max(1, o.write_threads));
-                    std::vector<std::thread> wt;
-                    for (int pc = 0; pc < pieces; pc++) wt.emplace_back([&, pc]() {
-                        for (uint32_t i = (uint32_t)((uint64_t)n * pc / pieces); i < (uint32_t)((uint64_t)n * (pc + 1) / pieces); i++) {
-                            if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
-                            std::string stem, ext;
-                            file_parts(base_name(job.ents.names[i]), stem, ext);
-                            const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
-                            write_out(single ? output : output + "/" + fname, (const char*)text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
-                        }
-                    });
-                    for (std::thread& t : wt) t.join();
+            fcz_ctx* ctx = ctxs[w];
+            pvec<uint8_t> text, packed;
+            DecompressJob job;
+            for (;;) {
+                const auto tw = clk::now();
+                const bool more = queue.get(job);
+                if (!sizes_only) wait_s[w] += std::chrono::duration<double>(clk::now() - tw).count();
+                if (!more) break;
+                const uint32_t n = job.ents.n();
+                std::vector<uint64_t> text_off(n + 1, 0);
+                std::vector<int32_t> status(n, 0);
+                const auto t0 = clk::now();
+                // a database record is the text + the MMseqs terminator (src/main.cpp:659): the device leaves the NULs in place, so a job's
+                // records are one contiguous range of the data file
+                const int flags = (o.alt ? FCZ_PDB_ALT_ORDER : 0) | (o.db ? FCZ_PDB_NUL_TERMINATED : 0);
+                int rc = !ctx ? FCZ_E_NO_DEVICE
+                       : sizes_only ? fcz_decompress_pdb_sizes(ctx, job.ents.blob.data(), job.ents.off.data(), n, flags, text_off.data(), status.data())
+                                    : fcz_decompress_pdb_begin(ctx, job.ents.blob.data(), job.ents.off.data(), n, flags, text_off.data(), status.data());
+                if (!sizes_only) gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
+                uint32_t n_good = 0;
+                if (rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) n_good += status[i] == FCZ_OK ? 1u : 0u;
+                const uint64_t bytes = rc == FCZ_OK ? text_off[n] : 0;
+                if (sizes_only) {
+                    if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s\n", fcz_status_string(rc)); hard_fail = true; continue; }
+                    std::lock_guard<std::mutex> l(planned_m);
+                    if (planned.size() <= job.index) planned.resize(job.index + 1, {0, 0});
+                    planned[job.index] = {n_good, bytes};
+                    planned_records += n_good; planned_bytes += bytes;
+                    continue;
                 }
-                n_ok += n_good; n_text += text_off[n] - (o.db ? n_good : 0); n_fcz += job.ents.off.back();
+                if (place) {
+                    // the placement rests on the sizes pass: a job that measures differently now (the input changed under the run) would
+                    // write into another job's -- or another rank's -- range
+                    std::pair<uint64_t, uint64_t> want{0, 0};
+                    { std::lock_guard<std::mutex> l(planned_m); if (job.index < planned.size()) want = planned[job.index]; }
+                    if (rc == FCZ_OK && (want.first != n_good || want.second != bytes)) {
+                        fprintf(stderr, "[Error] job %zu measures %llu bytes now, %llu in the sizes pass: the input changed during the run\n", job.index, (unsigned long long)bytes, (unsigned long long)want.second);
+                        rc = FCZ_E_INVALID_ARG;
+                    }
+                }
+                std::vector<uint64_t> lens; std::vector<std::string> dbnames;
+                if (o.db && rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) {
+                    if (status[i] != FCZ_OK) continue;
+                    std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
+                    lens.push_back(text_off[i + 1] - text_off[i]); dbnames.push_back(stem);
+                }
+                const uint64_t at = o.db ? seq.claim(job.index, rc == FCZ_OK ? bytes : 0, &lens, &dbnames) : 0;     // every job claims, also a failed one
+                if (rc == FCZ_OK) {
+                    const auto ta = clk::now();
+                    if (text.size() < text_off[n]) text.resize(text_off[n] + text_off[n] / 8);     // grows, never shrinks (a resize zero-fills what it adds)
+                    alloc_s[w] += std::chrono::duration<double>(clk::now() - ta).count();
+                    const auto t1 = clk::now();
+                    rc = fcz_decompress_pdb_fetch(ctx, text.data());
+                    gpu_busy[w] += std::chrono::duration<double>(clk::now() - t1).count();
+                    for (uint32_t i = 0; i < n; i++) if (status[i] == FCZ_OK) { const uint8_t* e = job.ents.blob.data() + job.ents.off[i]; n_res += (uint32_t)e[4] | ((uint32_t)e[5] << 8); }
+                }
+                if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s\n", fcz_status_string(rc)); hard_fail = true; continue; }
+                const auto t_write = clk::now();
+                try {
+                    if (o.db) {
+                        // the job's records lie in the fetched buffer exactly as in the data file: one run of large writes. (The copy into
+                        // the page cache is the cost of this direction -- the text is 40x the FCZ bytes -- and writes to ONE file
+                        // serialise on its inode lock: large writes from one thread reach what the file system gives,
+                        // tools/dbg/write_bench.cpp; more writer threads only add contention.)
+                        for (uint32_t i = 0; i < n; i++) if (status[i] != FCZ_OK) fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str());
+                        pwrite_all(db_fd, text.data(), bytes, at);
+                    } else {
+                        // one file per entry, written by several threads (open / write / close per file is what takes the time)
+                        const int pieces = (int)std::min<size_t>(std::max<size_t>(n / 64, 1), (size_t)std::max(1, o.write_threads));
+                        std::vector<std::thread> wt;
+                        for (int pc = 0; pc < pieces; pc++) wt.emplace_back([&, pc]() {
+                            for (uint32_t i = (uint32_t)((uint64_t)n * pc / pieces); i < (uint32_t)((uint64_t)n * (pc + 1) / pieces); i++) {
+                                if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
+                                std::string stem, ext;
+                                file_parts(base_name(job.ents.names[i]), stem, ext);
+                                const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
+                                write_out(single ? output : output + "/" + fname, (const char*)text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
+                            }
+                        });
+                        for (std::thread& t : wt) t.join();
+                    }
+                    n_ok += n_good; n_text += text_off[n] - (o.db ? n_good : 0); n_fcz += job.ents.off.back();
+                } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
+                write_s[w] += std::chrono::duration<double>(clk::now() - t_write).count();
+            }
+        });
+        {
+            const size_t JOB = 2048;            // ~0.5 GB of text per job: page-locked buffers of that size, several jobs in flight
+            size_t job_index = 0;
+            Entries ents;
+            auto flush = [&]() {
+                if (!ents.n()) return;
+                if (o.check) {
+                    // --check: entries that fail Foldcomp::checkValidity are reported and left out (src/main.cpp:629-636)
+                    Entries ok;
+                    for (uint32_t i = 0; i < ents.n(); i++) {
+                        const uint64_t len = ents.off[i + 1] - ents.off[i];
+                        const int rc = len ? fcz_check(ents.blob.data() + ents.off[i], len) : FCZ_E_TRUNCATED;
+                        if (rc != 0) { if (!sizes_only) fprintf(stderr, "[Error] invalid FCZ entry skipped: %s\n", ents.names[i].c_str()); continue; }
+                        ok.add(ents.names[i], std::string((const char*)ents.blob.data() + ents.off[i], len));
+                    }
+                    ents = std::move(ok);
+                    if (!ents.n()) { ents = Entries(); return; }
+                }
+                DecompressJob j; j.index = job_index++; j.ents = std::move(ents);
+                ents = Entries();
+                queue.put(std::move(j));
+            };
+            if (single) for_each_entry(o, ents, flush, JOB);
+            else try {
+                // this process's range of the listing (all of it unless --shard), database entries streamed from their files
+                if (!plan_built) { plan.build(o); plan_built = true; }
+                plan.for_each([&](const InputItem& it) {
+                    if (it.kind == 0) { try { ents.add(it.name, read_file(it.name)); } catch (const std::exception& e) { if (!sizes_only) fprintf(stderr, "[Error] %s\n", e.what()); } }
+                    else if (!plan.entry_in_range(it)) { if (!sizes_only) fprintf(stderr, "[Error] database entry out of range: %s\n", it.name.c_str()); }   // (checked before anything is sized from it)
+                    else {
+                        const size_t at = ents.blob.size();
+                        ents.blob.resize(at + it.len);
+                        if (!plan.read_entry(it, ents.blob.data() + at)) { ents.blob.resize(at); if (!sizes_only) fprintf(stderr, "[Error] database entry out of range: %s\n", it.name.c_str()); }
+                        else { ents.names.push_back(it.name); ents.off.push_back(ents.blob.size()); }
+                    }
+                    if (ents.n() >= JOB) flush();
+                });
+                flush();
             } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
-            write_s[w] += std::chrono::duration<double>(clk::now() - t_write).count();
+            queue.close();
         }
-        if (ctx) fcz_ctx_destroy(ctx);
-    });
-    {
-        const size_t JOB = 2048;            // ~0.5 GB of text per job: page-locked buffers of that size, several jobs in flight
-        size_t job_index = 0;
-        Entries ents;
-        auto flush = [&]() {
-            if (!ents.n()) return;
-            if (o.check) {
-                // --check: entries that fail Foldcomp::checkValidity are reported and left out (src/main.cpp:629-636)
-                Entries ok;
-                for (uint32_t i = 0; i < ents.n(); i++) {
-                    const uint64_t len = ents.off[i + 1] - ents.off[i];
-                    const int rc = len ? fcz_check(ents.blob.data() + ents.off[i], len) : FCZ_E_TRUNCATED;
-                    if (rc != 0) { fprintf(stderr, "[Error] invalid FCZ entry skipped: %s\n", ents.names[i].c_str()); continue; }
-                    ok.add(ents.names[i], std::string((const char*)ents.blob.data() + ents.off[i], len));
-                }
-                ents = std::move(ok);
-                if (!ents.n()) { ents = Entries(); return; }
-            }
-            DecompressJob j; j.index = job_index++; j.ents = std::move(ents);
-            ents = Entries();
-            queue.put(std::move(j));
-        };
-        if (single) for_each_entry(o, ents, flush, JOB);
-        else try {
-            // this process's range of the listing (all of it unless --shard), database entries streamed from their files
-            plan.build(o);
-            plan.for_each([&](const InputItem& it) {
-                if (it.kind == 0) { try { ents.add(it.name, read_file(it.name)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); } }
-                else {
-                    const size_t at = ents.blob.size();
-                    ents.blob.resize(at + it.len);
-                    if (!plan.read_entry(it, ents.blob.data() + at)) { ents.blob.resize(at); fprintf(stderr, "[Error] database entry out of range\n"); }
-                    else { ents.names.push_back(it.name); ents.off.push_back(ents.blob.size()); }
-                }
-                if (ents.n() >= JOB) flush();
-            });
-            flush();
-        } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
-        queue.close();
+        if (!sizes_only) t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
+        for (std::thread& t : workers) t.join();
+    };
+
+    double sizes_pass_s = 0.0, placed_wait_s = 0.0;
+    unsigned long long total_bytes = 0;
+    if (place) {
+        run_pass(true);
+        sizes_pass_s = std::chrono::duration<double>(clk::now() - t_start).count();
+        printf("{\"phase\": \"sizes\", \"records\": %llu, \"data_bytes\": %llu, \"failed\": %s, \"sizes_pass_s\": %.4f}\n", (unsigned long long)planned_records.load(),
+               (unsigned long long)planned_bytes.load(), hard_fail ? "true" : "false", sizes_pass_s);
+        fflush(stdout);
+        const auto tp = clk::now();
+        char line[256]; long long key0 = 0; unsigned long long off0 = 0;
+        const bool got = fgets(line, sizeof line, stdin) != nullptr && sscanf(line, "%lld %llu %llu", &key0, &off0, &total_bytes) == 3;
+        placed_wait_s = std::chrono::duration<double>(clk::now() - tp).count();
+        if (!got || hard_fail) {
+            if (hard_fail) fprintf(stderr, "[Error] the sizes pass failed: nothing was written\n");
+            for (fcz_ctx* c : ctxs) if (c) fcz_ctx_destroy(c);
+            return 1;                                                    // (`abort`, or the caller went away: nothing was written)
+        }
+        seq.key = key0; seq.pos = off0;
     }
-    const double t_queued = std::chrono::duration<double>(clk::now() - t_start).count();
-    for (std::thread& t : workers) t.join();
     if (o.db) {
+        // a placed rank writes into the final file beside the other ranks: created, never truncated (the caller removed what was there)
+        db_fd = open(output.c_str(), place ? (O_CREAT | O_WRONLY) : (O_CREAT | O_TRUNC | O_WRONLY), 0666);
+        if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
+        if (!seq.open_index(output, place && o.shard_rank > 0 ? "." + std::to_string(o.shard_rank) : "")) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
+    }
+    const uint64_t pos0 = seq.pos;
+    run_pass(false);
+    for (fcz_ctx* c : ctxs) if (c) fcz_ctx_destroy(c);
+    if (o.db) {
+        if (place && !hard_fail && seq.pos - pos0 != planned_bytes.load()) { fprintf(stderr, "[Error] wrote %llu bytes, planned %llu\n", (unsigned long long)(seq.pos - pos0), (unsigned long long)planned_bytes.load()); hard_fail = true; }
+        // (a pre-existing longer file cannot be: the caller removed it; rank 0 still pins the size, which also covers ranks without records)
+        if (place && !hard_fail && o.shard_rank == 0 && ftruncate(db_fd, (off_t)total_bytes) != 0) hard_fail = true;
         close(db_fd);
-        seq.finish(output, !hard_fail);
+        if (place) {
+            // the data file and the dbtype belong to the whole run: on failure this rank removes only its own line files, the caller
+            // removes the rest once every rank has reported
+            if (seq.fi) fclose(seq.fi);
+            if (seq.fl) fclose(seq.fl);
+            seq.fi = seq.fl = nullptr;
+            const std::string tag = o.shard_rank > 0 ? "." + std::to_string(o.shard_rank) : "";
+            if (hard_fail) { unlink((output + ".index" + tag).c_str()); unlink((output + ".lookup" + tag).c_str()); }
+            else if (o.shard_rank == 0) { std::ofstream t(output + ".dbtype", std::ios::binary); const int32_t twelve = 12; t.write((const char*)&twelve, 4); }
+        } else seq.finish(output, !hard_fail);
         if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
     }
     if (o.json_stats) {
@@ -2385,10 +2473,12 @@ int run_decompress(const Options& o) {
         printf("{\"mode\": \"decompress\", \"gpus\": %d, \"workers\": %d, \"records\": %llu, \"residues\": %llu, \"fcz_bytes\": %llu, \"text_bytes\": %llu, "
                "\"wall_s\": %.4f, \"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_queued_s\": %.4f, \"residues_per_s\": %.1f, \"text_MB_per_s\": %.1f, "
                "\"pinned_blocks\": %llu, \"queue_wait_s_sum\": %.4f, \"write_s_sum\": %.4f, \"buffer_alloc_s_sum\": %.4f, \"host_threads\": %d, "
-               "\"shard\": \"%d/%d\", \"items\": %llu, \"items_total\": %llu, \"data_bytes\": %llu, \"streamed_inputs\": %s, \"max_rss_kb\": %ld}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
+               "\"shard\": \"%d/%d\", \"items\": %llu, \"items_total\": %llu, \"data_bytes\": %llu, \"streamed_inputs\": %s, \"max_rss_kb\": %ld, "
+               "\"placed\": %s, \"sizes_pass_s\": %.4f, \"placement_wait_s\": %.4f}\n", gpus, n_workers, (unsigned long long)n_ok.load(), (unsigned long long)n_res.load(), (unsigned long long)n_fcz.load(),
                (unsigned long long)n_text.load(), wall, busy, *std::max_element(ctx_ready.begin(), ctx_ready.end()), t_queued,
                wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? n_text.load() / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load(), waited, wrote, alloc, o.write_threads * n_workers,
-               o.shard_rank, o.shard_world, (unsigned long long)plan.n_mine, (unsigned long long)plan.n_items, (unsigned long long)seq.pos, plan.streamed_all ? "true" : "false", max_rss_kb());
+               o.shard_rank, o.shard_world, (unsigned long long)plan.n_mine, (unsigned long long)plan.n_items, (unsigned long long)(seq.pos - pos0), plan.streamed_all ? "true" : "false", max_rss_kb(),
+               place ? "true" : "false", sizes_pass_s, placed_wait_s);
     }
     return hard_fail ? 1 : 0;
 }
@@ -2691,6 +2781,7 @@ int main(int argc, char** argv) {
         else if (a == "--workers-per-gpu") next_int(o.workers_per_gpu);
         else if (a == "--json-stats") o.json_stats = true;
         else if (a == "--device") next_int(o.device);
+        else if (a == "--place") o.place = true;               // decompress -d of a sharded run: sizes pass, placement on stdin, one write (run_decompress)
         else if (a == "--device-mod") device_mod = true;     // the device number wraps at the device count (ranks of a test run that share GPUs)
         else if (a == "--key0") { if (i + 1 < argc) g_key0 = atoll(argv[++i]); }
         else if (a == "--off0") { if (i + 1 < argc) g_off0 = strtoull(argv[++i], nullptr, 10); }

@@ -215,6 +215,13 @@ int fcz_pdb_format_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64_t* of
 int fcz_decompress_pdb_begin(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order,
                              uint64_t* text_off, int32_t* status);
 int fcz_decompress_pdb_fetch(fcz_ctx* ctx, uint8_t* text_out);
+/* The sizes half of begin(): the entries are decoded on the device and text_off[n+1] / status[n] filled exactly as begin() fills
+ * them (a line's width depends on the decoded numbers: printf widens a column that overflows), but no text is formatted or kept.
+ * What a rank of a sharded `decompress --db` run calls over its range BEFORE it writes, so that the ranks exchange their record
+ * and byte counts first and every record is appended once at its final offset -- writer_append, src/database_writer.cpp:36-58,
+ * called once per record from src/main.cpp:656-664. */
+int fcz_decompress_pdb_sizes(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off, uint32_t n, int alt_order,
+                             uint64_t* text_off, int32_t* status);
 
 /* ---- structure ingest: PDB / mmCIF text -> fcz_chain_batch on the device ----------------------------- */
 /* What the reference's driver does to every input file before Foldcomp::compress (src/main.cpp:455-508): StructureReader

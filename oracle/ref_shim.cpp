@@ -177,22 +177,57 @@ long ref_extract(const unsigned char* fcz, long len, int type, int digits, char*
 //   compress leg:   Foldcomp::compress + writeStream   (src/foldcomp.cpp:562, :1038)
 //   decompress leg: Foldcomp::read + decompress          (src/foldcomp.cpp:904, :779)
 // parallelised over chains with OpenMP exactly like the reference's `-t` (src/input_processor.h:85-89).
+// With the chains' own titles / numbering / chain ids (all five `meta` pointers given) the records are the ones the product writes
+// for the same batch, and hash_fcz[c] / hash_xyz[c] (may be null) return what the LIVE reference produced per chain: FNV-1a of the
+// record with the 4 uninitialised header bytes zeroed, and of the bit patterns of the decoded x, y, z of every atom followed by the
+// tempFactor of every CA atom (a third, untimed pass). ref_hash_records / ref_hash_atoms below hash a caller's arrays the same way.
+static inline unsigned long long fnv_bytes(const unsigned char* p, size_t n, unsigned long long h) {
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+static inline unsigned long long fnv_word(unsigned w, unsigned long long h) { h ^= w; h *= 0x100000001b3ull; return h; }
+static inline unsigned fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static const unsigned long long FNV0 = 0xcbf29ce484222325ull;
+static unsigned long long hash_record_masked(const unsigned char* p, size_t n) {
+    unsigned long long h = FNV0;
+    for (size_t i = 0; i < n; i++) { const unsigned char b = (i == 14 || i == 15 || i == 22 || i == 23) ? 0 : p[i]; h ^= b; h *= 0x100000001b3ull; }
+    return h;
+}
+void ref_hash_records(const unsigned char* blob, const unsigned long long* off, long n, unsigned long long* out) {
+    for (long i = 0; i < n; i++) out[i] = hash_record_masked(blob + off[i], (size_t)(off[i + 1] - off[i]));
+}
+// chain c: atoms [atom_off[c], atom_off[c+1]) of x / y / z, residues [res_off[c], res_off[c+1]) of bfac_res
+void ref_hash_atoms(const float* x, const float* y, const float* z, const unsigned* atom_off, const float* bfac_res, const unsigned* res_off,
+                    long n, unsigned long long* out) {
+    for (long c = 0; c < n; c++) {
+        unsigned long long h = FNV0;
+        for (unsigned a = atom_off[c]; a < atom_off[c + 1]; a++) { h = fnv_word(fbits(x[a]), h); h = fnv_word(fbits(y[a]), h); h = fnv_word(fbits(z[a]), h); }
+        for (unsigned r = res_off[c]; r < res_off[c + 1]; r++) h = fnv_word(fbits(bfac_res[r]), h);
+        out[c] = h;
+    }
+}
+
 int ref_bench_roundtrip(int n_chains, const unsigned* res_off, const unsigned* atom_off,
                         const float* x, const float* y, const float* z,
                         const unsigned char* atom_code, const unsigned char* res_code, const float* bfac_ca,
                         const char* atom_names /*37 x 4, NUL padded*/, const char* res_names /*24 x 4*/,
                         int anchor_threshold, int n_threads, double* t_compress, double* t_decompress,
-                        unsigned long long* fcz_bytes, unsigned long long* atoms_out) {
+                        unsigned long long* fcz_bytes, unsigned long long* atoms_out,
+                        const char* titles, const unsigned* title_off, const int* first_res, const int* first_atom, const char* chain_id,
+                        unsigned long long* hash_fcz, unsigned long long* hash_xyz) {
+    const bool meta = titles && title_off && first_res && first_atom && chain_id;
     std::vector<std::vector<AtomCoordinate>> chains(n_chains);
 #pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads)
     for (int c = 0; c < n_chains; c++) {
         unsigned r0 = res_off[c], r1 = res_off[c + 1];
-        int serial = 1;
+        int serial = meta ? first_atom[c] : 1;
+        const int res0 = meta ? first_res[c] : 1;
+        const std::string chain = meta ? std::string(1, chain_id[c]) : std::string("A");
         for (unsigned r = r0; r < r1; r++)
             for (unsigned a = atom_off[r]; a < atom_off[r + 1]; a++) {
                 int code = atom_code[a];
                 chains[c].emplace_back(std::string(code < 37 ? atom_names + 4 * code : "H"), std::string(res_names + 4 * res_code[r]),
-                                       std::string("A"), serial++, (int)(r - r0) + 1, x[a], y[a], z[a], 1.0f, bfac_ca[r]);
+                                       chain, serial++, (int)(r - r0) + res0, x[a], y[a], z[a], 1.0f, bfac_ca[r]);
             }
     }
     std::vector<std::string> fcz(n_chains);
@@ -203,7 +238,7 @@ int ref_bench_roundtrip(int n_chains, const unsigned* res_off, const unsigned* a
     for (int c = 0; c < n_chains; c++) {
         try {
             Foldcomp comp;
-            comp.strTitle = "synth_0000000000";
+            comp.strTitle = meta ? std::string(titles + title_off[c], title_off[c + 1] - title_off[c]) : std::string("synth_0000000000");
             comp.anchorThreshold = anchor_threshold;
             tcb::span<AtomCoordinate> sp(chains[c].data(), chains[c].size());
             comp.compress(sp);
@@ -232,6 +267,24 @@ int ref_bench_roundtrip(int n_chains, const unsigned* res_off, const unsigned* a
         }
     }
     double t2 = now();
+    if (hash_fcz) for (int c = 0; c < n_chains; c++) hash_fcz[c] = hash_record_masked((const unsigned char*)fcz[c].data(), fcz[c].size());
+    if (hash_xyz) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads)
+        for (int c = 0; c < n_chains; c++) {
+            hash_xyz[c] = 0;
+            try {
+                std::istringstream iss(fcz[c]);
+                Foldcomp comp;
+                if (comp.read(iss) != 0) continue;
+                std::vector<AtomCoordinate> atoms;
+                comp.decompress(atoms);
+                unsigned long long h = FNV0;
+                for (const AtomCoordinate& a : atoms) { h = fnv_word(fbits(a.coordinate.x), h); h = fnv_word(fbits(a.coordinate.y), h); h = fnv_word(fbits(a.coordinate.z), h); }
+                for (const AtomCoordinate& a : atoms) if (a.atom == "CA") h = fnv_word(fbits(a.tempFactor), h);
+                hash_xyz[c] = h;
+            } catch (...) {}
+        }
+    }
     unsigned long long bytes = 0;
     for (auto& s : fcz) bytes += s.size();
     *t_compress = t1 - t0; *t_decompress = t2 - t1; *fcz_bytes = bytes; *atoms_out = total_atoms;
@@ -325,8 +378,10 @@ long ref_db_lookup(const char* data_path, const char* index_path, const char* na
 // `omp parallel for` (src/input_processor.h:85-101): read the file, StructureReader::loadFromBuffer, removeAlternativePosition,
 // identifyChains / identifyDiscontinousResInd, Foldcomp::compress + writeStream per fragment (the bytes are kept in memory as the
 // --db path does before writer_append). Wall time of the whole loop; returns the number of files that failed to load.
+// file_hash (may be null): per file, the hashes (hash_record_masked) of its fragments' records chained in fragment order; 0 = failed.
 int ref_compress_files(const char* paths, int n_files, int n_threads, int anchor_threshold, double* seconds,
-                       unsigned long long* residues, unsigned long long* fcz_bytes, unsigned char* first_out, long first_cap, long* first_len) {
+                       unsigned long long* residues, unsigned long long* fcz_bytes, unsigned char* first_out, long first_cap, long* first_len,
+                       unsigned long long* file_hash) {
     std::vector<std::string> files;
     const char* p = paths;
     for (int i = 0; i < n_files; i++) { files.emplace_back(p); p += files.back().size() + 1; }
@@ -352,6 +407,7 @@ int ref_compress_files(const char* paths, int n_files, int n_threads, int anchor
         const std::string title = reader.title == base ? stem : reader.title;
         removeAlternativePosition(atoms);
         std::vector<std::pair<size_t, size_t>> chains = identifyChains(atoms);
+        unsigned long long fh = 0;
         for (size_t c = 0; c < chains.size(); c++) {
             std::vector<std::pair<size_t, size_t>> fr = identifyDiscontinousResInd(atoms, chains[c].first, chains[c].second);
             for (size_t j = 0; j < fr.size(); j++) {
@@ -364,6 +420,8 @@ int ref_compress_files(const char* paths, int n_files, int n_threads, int anchor
                 comp.writeStream(oss);
                 const std::string os = oss.str();
                 res += comp.nResidue; bytes += os.size();
+                fh = fnv_word((unsigned)(hash_record_masked((const unsigned char*)os.data(), os.size()) >> 32),
+                              fnv_word((unsigned)hash_record_masked((const unsigned char*)os.data(), os.size()), fh ? fh : FNV0));
                 if (i == 0 && c == 0 && j == 0 && (long)os.size() <= first_cap) {
                     memcpy(first_out, os.data(), os.size());
                     if (os.size() >= 24) first_out[14] = first_out[15] = first_out[22] = first_out[23] = 0;
@@ -371,6 +429,7 @@ int ref_compress_files(const char* paths, int n_files, int n_threads, int anchor
                 }
             }
         }
+        if (file_hash) file_hash[i] = fh;
     }
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *residues = res; *fcz_bytes = bytes;

@@ -26,6 +26,10 @@ def _cli(*args):
     return subprocess.run([sys.executable, "-m", "foldcomp_amd", *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
 
 
+def _stats(r):
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def _same_db(a, b):
     for ext in ("", ".index", ".lookup", ".dbtype"):
         assert open(str(a) + ext, "rb").read() == open(str(b) + ext, "rb").read(), ext
@@ -70,17 +74,44 @@ def test_two_ranks_compress_and_decompress_equal_the_single_process(tmp_path, go
     w.close(); rd.close()
     r = _cli("decompress", "-d", "-y", str(tmp_path / "big"), str(tmp_path / "d0"))
     assert r.returncode == 0, r.stderr
-    r = _cli("decompress", "-d", "-y", "--gpus", "2", str(tmp_path / "big"), str(tmp_path / "d2"))
+    # two ranks: counts exchanged BEFORE the writes (the engines' sizes pass), every record written once at its final offset of d2
+    # itself -- no partial database exists at any time (a watcher thread lists the directory while the run is going)
+    import threading
+    seen, stop = set(), threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            seen.update(f for f in os.listdir(tmp_path) if ".part" in f)
+            stop.wait(0.005)
+    th = threading.Thread(target=watch); th.start()
+    (tmp_path / "d2").write_bytes(b"x" * 10_000_000)          # what an earlier run left: longer than the new output, and gone afterwards
+    r = _cli("decompress", "-d", "-y", "--gpus", "2", "--json-stats", str(tmp_path / "big"), str(tmp_path / "d2"))
+    stop.set(); th.join()
     assert r.returncode == 0, r.stderr[-2000:]
+    st = _stats(r)
+    assert st["world"] == 2 and st["data_written_once"] is True and st["engine"].endswith("--place") and st["records"] == 2412
+    assert not seen, seen
     _same_db(tmp_path / "d0", tmp_path / "d2")
+    assert not [f for f in os.listdir(tmp_path) if ".index." in f or ".lookup." in f]
+    # --check and an id list go through the placed run as well: the sizes pass leaves out exactly what the real pass leaves out
+    bad = bytearray(open(tmp_path / "big", "rb").read())
+    idx = [l.split("\t") for l in open(str(tmp_path / "big") + ".index").read().splitlines()]
+    for k in (5, 1300):                                        # two records lose their magic: refused by --check / by the decoder
+        bad[int(idx[k][1])] = ord("X")
+    for ext in (".index", ".lookup", ".dbtype"):
+        (tmp_path / ("bad" + ext)).write_bytes(open(str(tmp_path / "big") + ext, "rb").read())
+    (tmp_path / "bad").write_bytes(bytes(bad))
+    for flags in ((), ("--check",)):
+        r = _cli("decompress", "-d", "-y", "--gpus", "1", *flags, str(tmp_path / "bad"), str(tmp_path / "b1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = _cli("decompress", "-d", "-y", "--gpus", "2", "--json-stats", *flags, str(tmp_path / "bad"), str(tmp_path / "b2"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert _stats(r)["records"] == 2410
+        _same_db(tmp_path / "b1", tmp_path / "b2")
 
     # --gpus without -d is refused
     r = _cli("compress", "-y", "--gpus", "2", str(d), str(tmp_path / "dir"))
     assert r.returncode != 0 and "add -d" in r.stderr
-
-
-def _stats(r):
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
 def test_shard_memory_is_independent_of_the_shard_size_and_databases_round_trip(tmp_path, golden):

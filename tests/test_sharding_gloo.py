@@ -202,3 +202,51 @@ def _fail_worker(rank, world, port, tmp):
     assert failed
     shard.remove_db(part)
     dist.destroy_process_group()
+
+
+def _placed_worker(rank, world, port, tmp):
+    """the decompress shape of the exchange: counts FIRST, then every rank writes its records once at its final offset of the
+    final file with final index lines (what `foldcomp-hip decompress --place` does after its sizes pass), rank 0 joins the lines"""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from foldcomp_amd import shard
+    files = sorted(os.listdir(os.path.join(tmp, "files")))
+    cuts = shard.shard_cuts([os.path.getsize(os.path.join(tmp, "files", f)) for f in files], world)
+    mine = files[cuts[rank]:cuts[rank + 1]]
+    recs = [open(os.path.join(tmp, "files", f), "rb").read() for f in mine]
+    out = os.path.join(tmp, f"placed{world}")
+    if rank == 0:
+        shard.remove_db(out)
+    key0, off0, failed, rows = shard.exchange_counts(len(recs), sum(len(r) for r in recs), False)     # before any byte is written
+    assert not failed and key0 == cuts[rank]
+    assert not [f for f in os.listdir(tmp) if f.startswith(f"placed{world}")]
+    dist.barrier()
+    fd = os.open(out, os.O_CREAT | os.O_WRONLY, 0o666)
+    tag = "" if rank == 0 else f".{rank}"
+    with open(out + ".index" + tag, "w") as fi, open(out + ".lookup" + tag, "w") as fl:
+        o = off0
+        for k, (f, r) in enumerate(zip(mine, recs)):
+            os.pwrite(fd, r, o)
+            fi.write(f"{key0 + k}\t{o}\t{len(r)}\n"); fl.write(f"{key0 + k}\t{os.path.splitext(f)[0]}\t0\n"); o += len(r)
+    os.close(fd)
+    if rank == 0:
+        open(out + ".dbtype", "wb").write((12).to_bytes(4, "little"))
+    assert shard.join_lines(out)
+    dist.barrier()
+    assert not [f for f in os.listdir(tmp) if ".part" in f]                      # no partial database ever existed
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_placed_ranks_write_once_into_the_final_database(tmp_path, world):
+    rng = np.random.default_rng(4)
+    (tmp_path / "files").mkdir()
+    for i in range(47):
+        (tmp_path / "files" / f"e{i:03d}.fcz").write_bytes(bytes(rng.integers(0, 256, int(rng.integers(0, 3000)), dtype=np.uint8)))
+    mp.spawn(_placed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _host("db-pack", str(tmp_path / "files"), str(tmp_path / "single"))
+    for suffix in ("", ".index", ".lookup", ".dbtype"):
+        assert open(str(tmp_path / f"placed{world}") + suffix, "rb").read() == open(str(tmp_path / "single") + suffix, "rb").read(), suffix
+    assert not [f for f in os.listdir(tmp_path) if ".index." in f or ".lookup." in f]

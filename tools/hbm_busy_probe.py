@@ -12,7 +12,9 @@ looks as if it moved those bytes through HBM. The only memory-controller-side si
      as a whole) for a few seconds, median mem_busy_percent -> HBM bytes/s -> bytes per residue of that stage.
 
 It is a coarse instrument (integer percent, firmware-averaged) and says so in its output; it complements the counters, it does not
-replace them.  usage (GPU box): python tools/hbm_busy_probe.py [--chains 1000000] [--seconds 3] > gpurun_out/hbm_busy.json
+replace them. The stage mask is only read by a library built with -DFCZ_PROFILING (the product library ignores the variable):
+  hipcc <flags of foldcomp_amd/csrc/Makefile> -DFCZ_PROFILING -shared -o build/libfcz_prof.so foldcomp_amd/csrc/fcz_abi.hip
+usage (GPU box): FCZ_HIP_LIB=$PWD/build/libfcz_prof.so python tools/hbm_busy_probe.py [--chains 1000000] [--seconds 3] [--probes k_backbone] > gpurun_out/hbm_busy.json
 """
 from __future__ import annotations
 
@@ -119,6 +121,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--stage-fn", default=None)
     ap.add_argument("--mask", default="7")
+    ap.add_argument("--probes", default="", help="comma-separated subset of the probes (default: all)")
     args = ap.parse_args()
     if args.stage_fn:
         return stage_child(args)
@@ -167,6 +170,8 @@ def main():
         probes = {}
         for name, fnname, mask in (("k_backbone", "decompress", "1"), ("k_res_index", "decompress", "2"), ("k_sidechain", "decompress", "4"),
                                    ("decompress_all", "decompress", "7"), ("compress_all", "compress", "7")):
+            if args.probes and name not in args.probes.split(","):
+                continue
             env = {k: v for k, v in os.environ.items() if k != "FCZ_PROFILE_STAGES"}
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--stage-fn", fnname, "--mask", mask, "--chains", str(args.chains), "--seconds", str(args.seconds)],
                                env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)

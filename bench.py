@@ -709,14 +709,16 @@ def end_to_end_leg(args, codec, w, dev):
             rl = H.load_ref()
             rl.ref_compress_files.restype = ctypes.c_int
             rl.ref_compress_files.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+                                              ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
             rpasses = min(passes, 4)
             blob = b"".join(p_.encode() + b"\0" for p_ in paths) * rpasses
             secs = ctypes.c_double(); rres = ctypes.c_ulonglong(); rbytes = ctypes.c_ulonglong(); flen = ctypes.c_long()
             first = ctypes.create_string_buffer(1 << 20)
             ref_runs = {}
+            file_hash = np.zeros(n * rpasses, np.uint64)          # per file: the live reference's record(s), pad-masked, hashed
             for t in tcounts:
-                fail = rl.ref_compress_files(blob, n * rpasses, t, args.anchor, ctypes.byref(secs), ctypes.byref(rres), ctypes.byref(rbytes), first, 1 << 20, ctypes.byref(flen))
+                fail = rl.ref_compress_files(blob, n * rpasses, t, args.anchor, ctypes.byref(secs), ctypes.byref(rres), ctypes.byref(rbytes), first, 1 << 20, ctypes.byref(flen),
+                                             file_hash.ctypes.data)
                 ref_runs[t] = (secs.value, int(fail))
             bt = min(ref_runs, key=lambda k: ref_runs[k][0])
             comp["cpu_reference"] = {"what": "the reference's driver loop on the same files (oracle/_ref: StructureReader + Foldcomp::compress, omp parallel for), best thread count",
@@ -729,7 +731,28 @@ def end_to_end_leg(args, codec, w, dev):
             for k in (14, 15, 22, 23):
                 e0[k] = 0
             comp["first_record_equals_reference"] = bytes(e0) == first.raw[:flen.value]
-            comp["fcz_bytes_equal_reference_total"] = runs[0]["fcz_bytes"] * rpasses == int(rbytes.value) * passes
+            # every record of the GPU database against the live reference's record of the same file (by lookup name = the file's stem;
+            # the 4 uninitialised header bytes masked), hashed on both sides by the checker's FNV-1a
+            rl.ref_hash_records.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+            rd = DatabaseReader(os.path.join(tmp, f"db{tcounts[0]}"))
+            nrec = len(rd)
+            recs = [rd.data(i) for i in range(nrec)]
+            names = [rd.name(i) for i in range(nrec)]
+            rd.close()
+            roff = np.zeros(nrec + 1, np.uint64); roff[1:] = np.cumsum([len(r_) for r_ in recs], dtype=np.uint64)
+            rblob = np.frombuffer(b"".join(recs), np.uint8)
+            gh = np.zeros(nrec, np.uint64)
+            rl.ref_hash_records(rblob.ctypes.data, roff.ctypes.data, nrec, gh.ctypes.data)
+            M64 = (1 << 64) - 1
+            def chain1(h):                      # ref_compress_files chains a file's fragment hashes; these files hold one fragment
+                x = 0xcbf29ce484222325
+                for wd in (h & 0xFFFFFFFF, h >> 32):
+                    x = ((x ^ wd) * 0x100000001b3) & M64
+                return x
+            want = {os.path.splitext(os.path.basename(p_))[0]: int(file_hash[i]) for i, p_ in enumerate(paths)}
+            equal = sum(1 for nm_, h in zip(names, gh) if want.get(nm_) == chain1(int(h)))
+            comp["records_equal_reference"] = f"{equal}/{nrec}"
+            comp["records_equal_reference_all"] = bool(equal == nrec and nrec == n * passes)
             comp["speedup_vs_cpu_reference"] = round(comp["gpu_host"]["residues_per_s"] / comp["cpu_reference"]["residues_per_s"], 2)
             comp["steady_speedup_vs_cpu_reference"] = round(comp["gpu_host"]["steady_residues_per_s"] / comp["cpu_reference"]["residues_per_s"], 2)
             comp["speedup_note"] = (f"per-residue rates: the GPU host walks the files {passes} times, the reference's loop {rpasses} times (it has no start-up to amortise); "
@@ -752,7 +775,19 @@ def end_to_end_leg(args, codec, w, dev):
                                     "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in dref.items()}}
             rd = DatabaseReader(os.path.join(tmp, "pdbdb"))
             dec["first_text_equals_reference"] = rd.data(0) == first_t.raw[:flen.value]
-            dec["text_bytes_equal_reference_total"] = runs_d[0]["text_bytes"] + runs_d[0]["records"] == int(tb.value)
+            # every text of the GPU database against the reference writer's database (its last run above wrote refpdbdb), by lookup name
+            rr = DatabaseReader(os.path.join(tmp, "refpdbdb"))
+            ref_by_name = {}
+            for i in range(len(rr)):
+                ref_by_name.setdefault(rr.name(i), i)
+            equal_t = 0
+            n_cmp = min(len(rd), n)                 # one walk over the input database = every distinct entry (the later walks repeat it)
+            for i in range(n_cmp):
+                j = ref_by_name.get(rd.name(i))
+                equal_t += 1 if (j is not None and rd.data(i) == rr.data(j)) else 0
+            dec["texts_equal_reference"] = f"{equal_t}/{n_cmp}"
+            dec["texts_equal_reference_all"] = bool(equal_t == n_cmp and n_cmp == n and len(rd) == n * dpasses)
+            rr.close()
             rd.close()
             dec["speedup_vs_cpu_reference"] = round(dref[bt][0] / dec["gpu_host"]["wall_s"], 2)
             dec["steady_speedup_vs_cpu_reference"] = round(dref[bt][0] / dec["gpu_host"]["steady_wall_s"], 2)

@@ -23,7 +23,7 @@ from typing import Iterable, Iterator, List, Optional, Tuple
 
 import numpy as np
 
-from . import fczfile
+from . import _lib, fczfile
 from .api import decompress_many, default_codec
 from .database import DatabaseReader, DatabaseWriter
 from .structure import (AtomTable, Chain, StructureError, build_batch, identify_chains, identify_discontinuous, parse_pdb, parse_structure_gemmi,
@@ -183,7 +183,7 @@ def run_compress(a, inputs, output, kind, single):
         blob, off, st = default_codec().compress_batch(batch, strict=False)
         for i, (fname, dbname, _) in enumerate(pending):
             if st[i] != 0:
-                print(f"[Error] compressing {fname}", file=sys.stderr); continue
+                print(f"[Error] compressing {fname}: {_lib.load().fcz_status_string(int(st[i])).decode()}", file=sys.stderr); continue
             sink.put(fname, blob[off[i]:off[i + 1]].tobytes(), db_name=dbname)
         pending.clear()
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FCZ_HIP_LIB") or os.path.join(_HERE, "libfcz_hip.so")
 
 FCZ_OK = 0
 STATUS = {0: "FCZ_OK", -1: "FCZ_E_INVALID_ARG", -2: "FCZ_E_NO_DEVICE", -3: "FCZ_E_HIP", -4: "FCZ_E_BAD_MAGIC",
-          -5: "FCZ_E_TRUNCATED", -6: "FCZ_E_RESIDUE", -7: "FCZ_E_TOO_SHORT", -8: "FCZ_E_NOMEM"}
+          -5: "FCZ_E_TRUNCATED", -6: "FCZ_E_RESIDUE", -7: "FCZ_E_TOO_SHORT", -8: "FCZ_E_NOMEM", -9: "FCZ_E_NONFINITE"}
 
 _lib = None
 

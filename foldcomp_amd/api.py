@@ -19,6 +19,7 @@ import numpy as np
 
 from . import fczfile
 from ._aa_tables import RES1, RES3
+from . import _lib
 from .codec import Codec
 from .database import DatabaseReader
 from .structure import (Chain, StructureError, build_batch, parse_pdb, remove_alternative_position)
@@ -70,7 +71,10 @@ def compress_many(items: Sequence[Tuple[str, str]], *, anchor_residue_threshold:
     c = codec or default_codec()
     blob, off, st = c.compress_batch(batch, strict=False)
     if (st != 0).any():
-        raise error("Error compressing")
+        # (a refused chain: residue names the reference cannot process, fewer than two residues, a NaN / infinite coordinate or
+        # B-factor -- FCZ_E_NONFINITE, include/fcz_hip.h)
+        bad = int(st[st != 0][0])
+        raise error("Error compressing: " + _lib.load().fcz_status_string(bad).decode())
     return [blob[off[i]:off[i + 1]].tobytes() for i in range(len(chains))]
 
 

@@ -175,6 +175,7 @@ const char* fcz_status_string(int s) {
         case FCZ_E_RESIDUE: return "residue code not supported by the codec";
         case FCZ_E_TOO_SHORT: return "chain shorter than 2 residues";
         case FCZ_E_NOMEM: return "out of device memory";
+        case FCZ_E_NONFINITE: return "a coordinate or B-factor of the chain is not a finite number";
         default: return "unknown status";
     }
 }
@@ -473,6 +474,8 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
     rc = ctx->res_sc_addr.ensure(sizeof(uint64_t) * (size_t)std::max<uint32_t>(in->n_residues, 1));
     if (rc) return rc;
     const dim3 per_chain(grid_for(in->n_chains, WAVES_PER_BLOCK));
+    const size_t nf_words = ((size_t)in->n_chains + 31) / 32;
+    uint32_t* nonfinite = nullptr;
     {
         span_guard g(ctx, "compress_index");
         hipLaunchKernelGGL(k_compress_index, dim3(grid_for(in->n_chains, GROUPS_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, ctx->res_sc_addr.as<uint64_t>());
@@ -483,20 +486,25 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
         span_guard g(ctx, "compress_angles");
         const uint32_t n_tiles = grid_for(in->n_residues, CK_TILE);
         const uint32_t n_wtiles = grid_for(in->n_residues, CW_RES);
-        rc = ctx->tile_work.ensure(sizeof(uint32_t) * (2 * (size_t)n_tiles + 4)); if (rc) return rc;
+        rc = ctx->tile_work.ensure(sizeof(uint32_t) * (2 * (size_t)n_tiles + 4 + nf_words)); if (rc) return rc;
         uint32_t* flags = ctx->tile_work.as<uint32_t>(); uint32_t* list = flags + n_tiles; uint32_t* count = list + n_tiles;
-        HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (2 * (size_t)n_tiles + 4), ctx->stream));
+        nonfinite = count + 4;             // one bit per chain: a named atom with a NaN / infinite coordinate (set by the angle kernels)
+        HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (2 * (size_t)n_tiles + 4 + nf_words), ctx->stream));
         const uint32_t blocks_w = std::min<uint32_t>(grid_for(n_wtiles, WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 3u * FCZ_CW_GRID_FACTOR);
         hipLaunchKernelGGL(k_compress_angles_w, dim3(blocks_w), dim3(BLOCK), 0, ctx->stream, *in, n_wtiles, ctx->res_sc_addr.as<uint64_t>(), out_dev,
-                           ctx->ang.as<float>(), flags, list, count);
+                           ctx->ang.as<float>(), flags, list, count, nonfinite);
         const uint32_t blocks = std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * FCZ_COMPRESS_MIN_BLOCKS);
         hipLaunchKernelGGL(k_compress_angles, dim3(blocks), dim3(BLOCK), 0, ctx->stream, *in, n_tiles, (const uint32_t*)list, (const uint32_t*)count,
-                           ctx->res_sc_addr.as<uint64_t>(), out_dev, ctx->ang.as<float>());
+                           ctx->res_sc_addr.as<uint64_t>(), out_dev, ctx->ang.as<float>(), nonfinite);
+    } else {
+        rc = ctx->tile_work.ensure(sizeof(uint32_t) * (4 + nf_words)); if (rc) return rc;
+        nonfinite = ctx->tile_work.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(nonfinite, 0, sizeof(uint32_t) * nf_words, ctx->stream));
     }
     {
         span_guard g(ctx, "compress_pack");
         hipLaunchKernelGGL(k_compress_pack, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
-                           ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0);
+                           ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
     }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;

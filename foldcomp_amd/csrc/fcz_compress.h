@@ -114,6 +114,23 @@ __device__ __forceinline__ unsigned long long sc_addr_get(const uint64_t* base, 
     return (unsigned long long)lo | ((unsigned long long)(hi & 0x7fu) << 32) | ((unsigned long long)(hi >> 7) << 63);
 }
 
+// ---- non-finite input ----------------------------------------------------------------------------------------------
+// A chain with a NaN or an infinity in a coordinate of a named atom, or in a CA B-factor, is REFUSED (FCZ_E_NONFINITE). The
+// reference's readers can produce such values (gemmi: mmCIF `?` / `.` -> NaN, lib/gemmi/numb.hpp:19-40; "nan" in a PDB column,
+// lib/gemmi/pdb.hpp:49-54) and its compressor then writes a record whose quantiser parameters are NaNs with the input's sign and
+// payload carried through SSE arithmetic (src/discretizer.cpp:22-33) -- a record that decodes to no structure. Here the angle
+// kernels test every coordinate they stage (one v_cmp_class per value; the values are in registers anyway) and, only when one
+// fires, find the atom's chain by two binary searches and set its bit; k_compress_pack refuses the flagged chains.
+__device__ __forceinline__ bool nonfinite_f32(float v) { return __builtin_amdgcn_classf(v, 0x207); }   // sNaN | qNaN | -inf | +inf
+__device__ __forceinline__ void flag_nonfinite_atom(const fcz_chain_batch& in, uint32_t atom, uint32_t* __restrict__ chain_bits) {
+    uint32_t lo = 0, hi = in.n_residues;          // residue of the atom: the last r with atom_off[r] <= atom
+    while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (in.atom_off[mid] <= atom) lo = mid; else hi = mid; }
+    const uint32_t r = lo;
+    lo = 0; hi = in.n_chains;                     // chain of the residue: the last c with res_off[c] <= r
+    while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (in.res_off[mid] <= r) lo = mid; else hi = mid; }
+    atomicOr(&chain_bits[lo >> 5], 1u << (lo & 31u));
+}
+
 // =====================================================================================================================
 // k_compress_index
 // =====================================================================================================================
@@ -200,7 +217,7 @@ __device__ __noinline__ atom_quad load_atoms_tail(const float* __restrict__ x, c
 
 __global__ __launch_bounds__(BLOCK, FCZ_COMPRESS_MIN_BLOCKS)
 void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles_all, const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ tile_count,
-                       const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out, float* __restrict__ ang) {
+                       const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out, float* __restrict__ ang, uint32_t* __restrict__ nonfinite) {
     // tile_list != null: only the listed 256-residue tiles (the ones k_compress_angles_w left to this kernel); else all of them
     const uint32_t n_tiles = tile_list ? *tile_count : n_tiles_all;
     auto tile_of = [&](uint32_t k) -> uint32_t { return tile_list ? tile_list[k < n_tiles ? k : (n_tiles ? n_tiles - 1 : 0)] : k; };
@@ -329,7 +346,7 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles_all, const uint32_t*
         // ---- passes: residues [s, e) whose atoms (plus the successor of e-1) are parked; one pass for a normal tile ----
         uint32_t s = 0;
         while (s < nres) {
-            uint32_t e = nres, A0 = A0s;
+            uint32_t e = nres, A0 = A0s, staged = simple ? cnts : 0u;
             bool tail_succ = true;
             if (!simple) {
                 A0 = L.olo[s];
@@ -366,8 +383,16 @@ void k_compress_angles(fcz_chain_batch in, uint32_t n_tiles_all, const uint32_t*
                     L.atom[i4 + 3] = float4{qx.w, qy.w, qz.w, __uint_as_float(qc >> 24)};
                 }
                 __syncthreads();
+                staged = cnt;
             } else {
                 tail_succ = r_lo + nres < R;   // row nres exists in the batch
+            }
+            // non-finite coordinates of named atoms among the records of this pass (this kernel only sees the atom-rich tiles and
+            // the tail of the batch: a plain walk over the parked records)
+            for (uint32_t i = (uint32_t)t; i < staged; i += BLOCK) {
+                const float4 a = L.atom[i];
+                if (__builtin_expect((nonfinite_f32(a.x) | nonfinite_f32(a.y) | nonfinite_f32(a.z)) && __float_as_uint(a.w) != 255u, 0))
+                    flag_nonfinite_atom(in, A0 + i, nonfinite);
             }
 
             // ---- slot index table: first atom of each canonical name; one thread per residue row ----
@@ -598,7 +623,8 @@ __device__ unsigned long long g_cw_timing[8];
 #endif
 __global__ __launch_bounds__(BLOCK, 3)
 void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* __restrict__ res_sc_addr, uint8_t* __restrict__ out,
-                         float* __restrict__ ang, uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_count) {
+                         float* __restrict__ ang, uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ tile_list, uint32_t* __restrict__ tile_count,
+                         uint32_t* __restrict__ nonfinite) {
     __shared__ compress_wave_lds WL[WAVES_PER_BLOCK];
     __shared__ compress_tables_lds T;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -675,6 +701,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
         W.sc_rel[lane] = (uint32_t)((sa & ~CK_LAST) - base0);
         const bool is_last = (sa & CK_LAST) != 0;
         if (lane == 0) W.atom[CW_ZERO] = cw_f4{0.f, 0.f, 0.f, 0.f};
+        bool odd = false;                        // a NaN or an infinity among this lane's coordinates (lanes past the end read zero)
         {
             float px[CW_NA], py[CW_NA], pz[CW_NA];
             uint32_t pc[CW_NC];
@@ -701,6 +728,7 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             for (int u = 0; u < CW_NA; u++) {
                 const uint32_t i = (uint32_t)u * WAVE + (uint32_t)lane;
                 if (i < cnt) W.atom[i] = cw_f4{px[u], py[u], pz[u], 0.f};
+                odd |= nonfinite_f32(px[u]) | nonfinite_f32(py[u]) | nonfinite_f32(pz[u]);
             }
 #pragma unroll
             for (int u = 0; u < CW_NC; u++) {
@@ -709,6 +737,14 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
             }
         }
         wave_sync();          // LDS operations of a wavefront execute in issue order: rows read what was staged
+        if (__builtin_expect(__any(odd), 0)) {
+            // never on a real file: which atoms, are they named ones (code != 255), whose chain -- read back from the staged records
+            const uint8_t* code8 = reinterpret_cast<const uint8_t*>(&W.code4[0]);
+            for (uint32_t i = (uint32_t)lane; i < cnt; i += WAVE) {
+                const cw_f4 a = W.atom[i];
+                if ((nonfinite_f32(a.x) | nonfinite_f32(a.y) | nonfinite_f32(a.z)) && code8[i] != 255u) flag_nonfinite_atom(in, a0 + i, nonfinite);
+            }
+        }
         CW_STAMP(1)
         // ---- slot table row of this lane's residue ----
         const uint32_t na = T.natoms[rc];
@@ -822,7 +858,8 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
 // k_compress_pack
 // =====================================================================================================================
 __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                                                         int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle) {
+                                                         int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                         const uint32_t* __restrict__ nonfinite) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= in.n_chains) return;
@@ -877,18 +914,21 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     // whose layout uses the full values and whose header holds wrapped ones (the reference writes exactly that, unreadable)
     if (!bad && (n > 65535u || n / thr + 2u > 255u)) bad = FCZ_E_INVALID_ARG;
     uint32_t nsc = 0;
-    auto check = [&](uint32_t rc, uint32_t span) {
+    // a non-finite coordinate of a named atom (found by the angle kernels) or CA B-factor: refused, see flag_nonfinite_atom
+    if (!bad && ((nonfinite[c >> 5] >> (c & 31u)) & 1u)) bad = FCZ_E_NONFINITE;
+    auto check = [&](uint32_t rc, uint32_t span, float bf) {
         if (!res_code_ok(rc)) bad = bad ? bad : FCZ_E_RESIDUE;
         // a residue and its successor must fit the staging buffer of k_compress_angles (not a protein otherwise)
         if (span > (uint32_t)CK_CAP) bad = bad ? bad : FCZ_E_INVALID_ARG;
+        if (nonfinite_f32(bf)) bad = bad ? bad : FCZ_E_NONFINITE;
         nsc += fcz_res_natoms[rc < 24 ? rc : 23] - 3;
     };
     if (small) {
 #pragma unroll
-        for (int u = 0; u < U; u++) if ((uint32_t)(u * WAVE + lane) < n) check(rcs[u], o2[u] - o0[u]);
+        for (int u = 0; u < U; u++) if ((uint32_t)(u * WAVE + lane) < n) check(rcs[u], o2[u] - o0[u], va[6][u]);
     } else {
         for (uint32_t k = lane; k < n; k += WAVE)
-            check(in.res_code[r0 + k], in.atom_off[r0 + (k + 2 < n ? k + 2 : n)] - in.atom_off[r0 + k]);
+            check(in.res_code[r0 + k], in.atom_off[r0 + (k + 2 < n ? k + 2 : n)] - in.atom_off[r0 + k], in.bfac_ca[r0 + k]);
     }
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) { int o = __shfl_xor(bad, d, WAVE); bad = o < bad ? o : bad; }

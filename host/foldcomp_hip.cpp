@@ -1795,7 +1795,7 @@ int run_compress(const Options& o) {
                 if (o.db && packed) pwrite_all(db_fd, blob.data(), packed, at);
                 for (size_t q = 0; q < kept.size(); q++) {
                     const Fragment& f = job.frags[kept[q]];
-                    if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
+                    if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), fcz_status_string(status[q])); continue; }
                     n_frag_ok++; n_res += v.res_off[q + 1] - v.res_off[q]; n_bytes += off[q + 1] - off[q];
                     n_atoms += v.atom_off[v.res_off[q + 1]] - v.atom_off[v.res_off[q]];
                     if (o.db) continue;
@@ -1962,7 +1962,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                 for (uint32_t c = 0; c < counts[0]; c++) {
                     const size_t file = text_file[chain_file[c]];
                     const std::string nm = frag_name(file, chain_meta[c]);
-                    if (status[c] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s.fcz\n", nm.c_str()); continue; }
+                    if (status[c] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s.fcz: %s\n", nm.c_str(), fcz_status_string(status[c])); continue; }
                     recs.push_back({file, (chain_meta[c] >> 8) & 0xffu, blob.data() + off[c], off[c + 1] - off[c], nm + suffix_of(file), stem_of(file), 0, 0});
                     // (sub: the order of a file's records is the order the device emitted them; see the stable sort below)
                     recs.back().sub = c;
@@ -2010,7 +2010,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     if (call_failed) { fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size()); failed = true; }
                     for (size_t q = 0; q < kept.size() && !failed; q++) {
                         const Fragment& f = job.host_frags[kept[q].first][kept[q].second];
-                        if (hstatus[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s\n", f.out_name.c_str()); continue; }
+                        if (hstatus[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), fcz_status_string(hstatus[q])); continue; }
                         recs.push_back({kept[q].first, (uint32_t)kept[q].second, blob_host.data() + hoff[q], hoff[q + 1] - hoff[q], f.out_name, f.db_name, 0, 0});
                     }
                 }

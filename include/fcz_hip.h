@@ -41,7 +41,13 @@ enum fcz_status {
     FCZ_E_TRUNCATED = -5,       /* FCZ entry shorter than its header promises */
     FCZ_E_RESIDUE = -6,         /* residue code the reference cannot process (AAS.at throws, src/sidechain.cpp:177) */
     FCZ_E_TOO_SHORT = -7,       /* chain with < 2 residues: undefined in the reference */
-    FCZ_E_NOMEM = -8
+    FCZ_E_NOMEM = -8,
+    FCZ_E_NONFINITE = -9        /* compress: a NaN or an infinity in a coordinate of a named atom (atom_code != 255) or in a CA
+                                 * B-factor of the chain. The reference's readers can produce them (mmCIF `?` / `.` -> NaN,
+                                 * lib/gemmi/numb.hpp:19-40; "nan" in a PDB column, lib/gemmi/pdb.hpp:49-54) and its compressor
+                                 * then writes NaN quantiser parameters carrying the input's sign and payload
+                                 * (src/discretizer.cpp:22-33): a record that decodes to no structure. Refused here, at every
+                                 * level (C-ABI status, `[Error]` line of the hosts, foldcomp.error in Python). */
 };
 
 /* ---- vocabulary --------------------------------------------------------------------------- */

@@ -625,6 +625,46 @@ def end_to_end_leg(args, codec, w, dev):
             shutil.rmtree(cdir, ignore_errors=True)
         except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
             comp["mmcif"] = {"failed": str(e)[-300:]}
+        # ---- gzipped input (AFDB ships .pdb.gz / .cif.gz): MEASUREMENT ONLY of where it stands. The host's reader threads inflate
+        #      (zlib, reference: uncompressBuffer src/structure_reader.cpp:156-203), the inflated text takes the device route. The same
+        #      2 048 files gzipped, both formats; the reference's loop on the same files is timed in the cpu_reference block below ----
+        gz_sets = {}
+        try:
+            import gzip as _gzip
+            n_gz = min(n, 2048)
+            gzo = {}
+            for kind in ("pdb", "cif"):
+                gdir = os.path.join(tmp, "gz_" + kind); os.mkdir(gdir)
+                def make_gz(i, kind=kind, gdir=gdir):                     # (zlib releases the GIL: the files are made on all host cores)
+                    tb_ = text[toff[i]:toff[i + 1]].tobytes()
+                    if kind == "cif":
+                        tb_ = cif_from_pdb_text(tb_, f"S{i:07d}")
+                    zb = _gzip.compress(tb_, 6)
+                    gp = os.path.join(gdir, f"s{i:07d}.{kind}.gz")
+                    with open(gp, "wb") as fh:
+                        fh.write(zb)
+                    return gp, len(tb_), len(zb)
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max(1, eff)) as ex:
+                    made = list(ex.map(make_gz, range(n_gz)))
+                gpaths = [m_[0] for m_ in made]; raw_b = sum(m_[1] for m_ in made); gz_b = sum(m_[2] for m_ in made)
+                glst = os.path.join(tmp, f"gz_{kind}.txt")
+                with open(glst, "w") as fh:
+                    fh.write((gdir + "\n") * passes)
+                runs_g = [run_host(["compress", "-d", "-y", "-t", str(t), "--gpus", "1", *wpg, "--json-stats", "-f", glst, os.path.join(tmp, f"dbgz_{kind}_{t}")]) for t in tcounts]
+                sm = summarise(runs_g, "input_bytes", f"host/foldcomp-hip compress -d -f <list of .{kind}.gz> <db>   (inflate on the host threads, parse + codec on the device)")
+                res_pass = int(w.res_off_dev[n_gz]) & 0xFFFFFFFF
+                gzo[kind + "_gz"] = {"files": n_gz, "passes": passes, "gz_bytes_per_pass": gz_b, "text_bytes_per_pass": raw_b, "residues_per_pass": res_pass,
+                                     "gpu_host": sm, "records_per_pass": runs_g[0]["records"] // passes,
+                                     "steady_inflated_text_GB_per_s": round(raw_b * passes / max(sm["steady_wall_s"], 1e-9) / 1e9, 2)}
+                gz_sets[kind] = gpaths
+            plain = comp["gpu_host"]["steady_residues_per_s"]
+            gzo["pdb_gz"]["steady_over_plain_pdb"] = round(gzo["pdb_gz"]["gpu_host"]["steady_residues_per_s"] / max(plain, 1), 3)
+            if isinstance(comp.get("mmcif"), dict) and "gpu_host" in comp["mmcif"]:
+                gzo["cif_gz"]["steady_over_plain_cif"] = round(gzo["cif_gz"]["gpu_host"]["steady_residues_per_s"] / max(comp["mmcif"]["gpu_host"]["steady_residues_per_s"], 1), 3)
+            comp["gz"] = gzo
+        except (RuntimeError, subprocess.TimeoutExpired, OSError, KeyError) as e:
+            comp["gz"] = {"failed": str(e)[-300:]}
         # one pass as the decompress leg's input
         db1 = os.path.join(tmp, "db_one")
         run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", "--json-stats", src, db1])
@@ -725,6 +765,20 @@ def end_to_end_leg(args, codec, w, dev):
                                      "cores": bt, "passes": rpasses, "wall_s": round(ref_runs[bt][0], 4), "residues_per_s": round(rres.value / ref_runs[bt][0]) if ref_runs[bt][0] else None,
                                      "failed_files": ref_runs[bt][1], "fcz_bytes": int(rbytes.value),
                                      "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in ref_runs.items()}}
+            # the reference's loop on the gzipped sets (one walk each)
+            for kind, gpaths in gz_sets.items():
+                gblob = b"".join(p_.encode() + b"\0" for p_ in gpaths)
+                gr = {}
+                for t in tcounts:
+                    fail = rl.ref_compress_files(gblob, len(gpaths), t, args.anchor, ctypes.byref(secs), ctypes.byref(rres), ctypes.byref(rbytes), first, 1 << 20, ctypes.byref(flen), None)
+                    gr[t] = (secs.value, int(fail), int(rres.value))
+                bt_ = min(gr, key=lambda k: gr[k][0])
+                g_ = comp["gz"][kind + "_gz"]
+                g_["cpu_reference"] = {"what": "the reference's driver loop on the same .gz files (oracle/_ref: inflate + StructureReader + Foldcomp::compress, omp parallel for), best thread count",
+                                       "cores": bt_, "wall_s": round(gr[bt_][0], 4), "residues_per_s": round(gr[bt_][2] / gr[bt_][0]) if gr[bt_][0] else None, "failed_files": gr[bt_][1],
+                                       "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in gr.items()}}
+                if g_["cpu_reference"]["residues_per_s"]:
+                    g_["steady_speedup_vs_cpu_reference"] = round(g_["gpu_host"]["steady_residues_per_s"] / g_["cpu_reference"]["residues_per_s"], 2)
             from foldcomp_amd.database import DatabaseReader
             rd = DatabaseReader(os.path.join(tmp, f"db{tcounts[0]}"))
             e0 = bytearray(rd.data(0)); rd.close()

@@ -518,6 +518,9 @@ int fcz_compress_batch(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* 
     if (C == 0) return FCZ_OK;
     const uint32_t TL = in->title_off[C];
     const uint64_t out_bytes = out_off[C];
+    // the side-chain byte addresses handed from k_compress_index to the angle kernels keep 39 bits (fcz_compress.h, sc_addr_put):
+    // a blob of 512 GB or more is refused, not truncated (no device holds one: a device-resident out_dev cannot reach the limit)
+    if (out_bytes >= (1ull << 39)) return FCZ_E_INVALID_ARG;
     struct item { const void* src; size_t bytes; };
     const item items[] = {
         {in->res_off, sizeof(uint32_t) * (C + 1)}, {in->atom_off, sizeof(uint32_t) * (R + 1)},
@@ -924,6 +927,7 @@ int fcz_decompress_sizes_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
                              uint32_t* res_off_dev, uint32_t* atom_off_dev, uint32_t* total_res, uint32_t* total_atoms) {
     if (!ctx || !blob_dev || !off_dev || !res_off_dev || !atom_off_dev) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    ctx->sizes_fresh = false;   // the pass below overwrites what an earlier sizes call left; set again only when it succeeds
     {
         span_guard g(ctx, "decompress_sizes");
         int rc = run_entry_sizes(ctx, blob_dev, off_dev, n, res_off_dev, atom_off_dev);

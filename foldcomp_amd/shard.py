@@ -87,14 +87,25 @@ def remove_rank_files(output: str, rank: int) -> None:
 def join_lines(output: str, device=None, host: str = HOST) -> bool:
     """file side of a PLACED run (decompress): every rank has already written its records into `output` at their final offsets and
     its index / lookup lines with final keys (rank 0: output.index, rank r: output.index.r). After a barrier rank 0 appends the
-    line files in rank order (`foldcomp-hip db-splice --shard 0/N`) -- the only bytes moved after the engines end. -> success on
-    every rank"""
+    line files in rank order -- the only bytes moved after the engines end. -> success on every rank"""
     world, rank = dist.get_world_size(), dist.get_rank()
     ok = True
     dist.barrier()
     if rank == 0 and world > 1:
-        r = subprocess.run([host, "db-splice", "--shard", f"0/{world}", output, output])
-        ok = r.returncode == 0
+        # (in this process: the lines are a few tens of bytes per record, starting the engine binary for them costs more than the copy)
+        import shutil
+        try:
+            for ext in (".index", ".lookup"):
+                with open(output + ext, "ab") as dst:
+                    for r in range(1, world):
+                        with open(f"{output}{ext}.{r}", "rb") as src:
+                            shutil.copyfileobj(src, dst, 8 << 20)
+            for ext in (".index", ".lookup"):
+                for r in range(1, world):
+                    os.remove(f"{output}{ext}.{r}")
+        except OSError as e:
+            print(f"[Error] joining the index lines: {e}", flush=True)
+            ok = False
     if world == 1:
         return ok
     t = torch.tensor([0 if ok else 1], dtype=torch.int64, device=device)

@@ -2068,6 +2068,8 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                 if (it.kind == 1) {
                     // a database entry: gzipped by its NAME, PDB or mmCIF by its CONTENT (StructureReader::loadFromBuffer)
                     try {
+                        // (before anything is sized from the index's numbers: a corrupt line is this entry's error, not a bad_alloc)
+                        if (!plan.entry_in_range(it)) throw std::runtime_error("database entry out of range");
                         if (ends_with(nm, ".gz")) {
                             std::string z(it.len, '\0');
                             if (!plan.read_entry(it, (uint8_t*)&z[0])) throw std::runtime_error("database entry out of range");

@@ -160,7 +160,9 @@ int  fcz_res_code_atom(int res_code, int j, int alt_order);
 int fcz_compress_sizes(const fcz_chain_batch* in, uint64_t* out_off);
 
 /* Host-pointer convenience: copies the batch to the GPU, runs the kernels, copies FCZ bytes back
- * into out[out_off[c] .. out_off[c+1]). status[c] (may be NULL) receives a per-chain fcz_status. */
+ * into out[out_off[c] .. out_off[c+1]). status[c] (may be NULL) receives a per-chain fcz_status.
+ * Limit: the records of one batch total less than 2^39 bytes (512 GB; more than any device holds) -- a larger out_off[C] is
+ * refused with FCZ_E_INVALID_ARG (the kernels hand side-chain byte addresses on in 39 bits). */
 int fcz_compress_batch(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64_t* out_off,
                        uint8_t* out, int32_t* status);
 

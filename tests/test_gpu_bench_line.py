@@ -75,8 +75,31 @@ def test_end_to_end_both_directions(line):
     assert c["gpu_host"]["page_locked_blocks"] > 0 and c["gpu_host_parse"]["page_locked_blocks"] > 0
     assert c["gpu_host"]["steady_residues_per_s"] > 0 and d["gpu_host"]["steady_residues_per_s"] > 0
     if "cpu_reference" in c:      # oracle/_ref travels to the GPU box
-        assert c["first_record_equals_reference"] and c["fcz_bytes_equal_reference_total"] and c["cpu_reference"]["failed_files"] == 0
-        assert d["first_text_equals_reference"] and d["text_bytes_equal_reference_total"] and d["cpu_reference"]["failed_entries"] == 0
+        # EVERY record / text against the live reference's of the same name (pad bytes masked), not totals
+        assert c["first_record_equals_reference"] and c["records_equal_reference_all"] and c["cpu_reference"]["failed_files"] == 0
+        assert c["records_equal_reference"] == f"{384 * 8}/{384 * 8}"
+        assert d["first_text_equals_reference"] and d["texts_equal_reference_all"] and d["cpu_reference"]["failed_entries"] == 0
+        assert d["texts_equal_reference"] == "384/384"
+
+
+def test_live_reference_hashes_in_the_line(line):
+    """the chains the CPU baseline runs through the reference are compared with the GPU's, record by record and atom by atom"""
+    if line["cpu_baseline"].get("kind") != "reference":
+        pytest.skip("oracle/_ref not on this box")
+    lr = line["cpu_baseline"]["live_reference"]
+    assert lr["chains"] > 0 and lr["records_equal"] == lr["chains"] and lr["coords_equal"] == lr["chains"]
+    assert line["parity"]["live_reference_equal"] is True and line["parity"]["live_reference_chains"] == lr["chains"]
+
+
+def test_gz_leg_and_two_rank_decompress(line):
+    """the measurement-only .gz rows, and the two-rank sharded decompress (TEST MODE) that writes its output once"""
+    g = line["end_to_end"]["compress"]["gz"]
+    assert "failed" not in g, g
+    for k in ("pdb_gz", "cif_gz"):
+        assert g[k]["gpu_host"]["steady_residues_per_s"] > 0 and g[k]["records_per_pass"] == g[k]["files"]
+    t = line["end_to_end"]["sharded"]["decompress_two_ranks"]
+    assert "failed" not in t, t
+    assert t["world"] == 2 and t["data_written_once"] is True and t["database_equals_gpu_host"] and sum(t["records_per_rank"]) == t["records"]
 
 
 def test_mmcif_leg(line):

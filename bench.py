@@ -734,6 +734,9 @@ def end_to_end_leg(args, codec, w, dev):
                                               "wall_s": st["wall_s"], "engine_s": st["engine_s"], "sizes_pass_s": st.get("sizes_pass_s_max"),
                                               "exchange_and_splice_s": st["exchange_and_splice_s"],
                                               "exchange_and_splice_over_engine": round(st["exchange_and_splice_s"] / max(st["engine_s"], 1e-9), 4),
+                                              "exchange_wait_for_slowest_rank_s": st.get("exchange_wait_for_slowest_rank_s"),
+                                              "file_work_after_exchange_s": st.get("file_work_after_exchange_s"),
+                                              "before_this_change": {"exchange_and_splice_s": 1.5273, "engine_s": 1.1591, "note": "round 4's partial database + splice on the same box class (gpurun_out/r5_ring/e2e_before.json, kept as profiles/r5_sharded_decompress_before_after.json)"},
                                               "data_written_once": st.get("data_written_once"),
                                               "steady_residues_per_s": st["steady_residues_per_s"], "database_equals_gpu_host": bool(same)}
                 os.remove(os.path.join(tmp, "sharded_two"))
@@ -765,6 +768,7 @@ def end_to_end_leg(args, codec, w, dev):
                                      "cores": bt, "passes": rpasses, "wall_s": round(ref_runs[bt][0], 4), "residues_per_s": round(rres.value / ref_runs[bt][0]) if ref_runs[bt][0] else None,
                                      "failed_files": ref_runs[bt][1], "fcz_bytes": int(rbytes.value),
                                      "wall_s_by_threads": {str(k): round(v[0], 4) for k, v in ref_runs.items()}}
+            first_ref_record = first.raw[:flen.value]              # (the calls below reuse the buffer)
             # the reference's loop on the gzipped sets (one walk each)
             for kind, gpaths in gz_sets.items():
                 gblob = b"".join(p_.encode() + b"\0" for p_ in gpaths)
@@ -784,7 +788,7 @@ def end_to_end_leg(args, codec, w, dev):
             e0 = bytearray(rd.data(0)); rd.close()
             for k in (14, 15, 22, 23):
                 e0[k] = 0
-            comp["first_record_equals_reference"] = bytes(e0) == first.raw[:flen.value]
+            comp["first_record_equals_reference"] = bytes(e0) == first_ref_record
             # every record of the GPU database against the live reference's record of the same file (by lookup name = the file's stem;
             # the 4 uninitialised header bytes masked), hashed on both sides by the checker's FNV-1a
             rl.ref_hash_records.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]

@@ -505,6 +505,10 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
         span_guard g(ctx, "compress_pack");
         hipLaunchKernelGGL(k_compress_pack, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+        // chains of 2 .. 64 residues (k_compress_pack leaves them): a persistent grid over chunks of 32 chains
+        const uint32_t short_blocks = std::min<uint32_t>(grid_for(grid_for(in->n_chains, CP_CHUNK), WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * FCZ_PACK_SHORT_WAVES);
+        hipLaunchKernelGGL(k_compress_pack_short, dim3(short_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
+                           ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
     }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;

@@ -84,7 +84,7 @@ template <int Q> __device__ __forceinline__ float dec_angle(float e) { return Q 
 
 struct lo_hi { float lo, hi; };
 // mode 0: src holds values; 1: encoded dihedrals; 2: bond-angle cosines
-__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, int mode) {
+__device__ __forceinline__ lo_hi first_extrema_body(const float* __restrict__ src, uint32_t cnt, int lane, int mode) {
     const float kInf = __builtin_huge_valf();
     ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
     for (uint32_t k = lane; k < cnt; k += WAVE) {
@@ -94,6 +94,7 @@ __device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint3
     }
     return lo_hi{wave_ext_min(mn), wave_ext_max(mx)};
 }
+__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, int mode) { return first_extrema_body(src, cnt, lane, mode); }
 
 constexpr uint64_t CK_LAST = 1ull << 63;   // res_sc_addr flag: last residue of its chain
 constexpr int CK_TILE = BLOCK;              // residues per tile
@@ -857,13 +858,15 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
 // =====================================================================================================================
 // k_compress_pack
 // =====================================================================================================================
-__global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                                                         int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
-                                                         const uint32_t* __restrict__ nonfinite) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (c >= in.n_chains) return;
-    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
+// One chain by one wavefront. U = rounds of 64 residues whose values stay in registers (chains of up to U x 64 residues take the
+// register path; U = 6 covers the 350-residue headline, U = 1 is the short-chain kernel below: a seventh of the loads, a third of
+// the registers, more wavefronts in flight).
+template <int U>
+__device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, const uint32_t c, const uint32_t r0, const uint32_t n,
+                                                    const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                    int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                    const uint32_t* __restrict__ nonfinite) {
+    const int lane = threadIdx.x & 63;
     const uint32_t title_len = in.title_off[c + 1] - in.title_off[c];
     const uint32_t thr = (uint32_t)in.anchor_threshold;
     uint8_t* rec = out + out_off[c];
@@ -875,7 +878,6 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
 
     // ---- every load of a normal chain (<= 384 residues) is issued here, unconditionally and from clamped indices, so
     //      that validation, anchors and quantisation do not each pay a memory round trip ----
-    constexpr int U = 6;
     const bool small = n >= 2 && n <= (uint32_t)(U * WAVE);
     const size_t R = in.n_residues;
     const uint32_t m = n ? n - 1 : 0;
@@ -903,6 +905,17 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if ((uint32_t)(u * WAVE) >= m) continue;      // a round no residue of this chain falls into (wave-uniform): short chains
+            if (U == 1) {
+                // the short-chain kernel lives on wavefronts in flight, not on instruction-level parallelism: one acos at a time
+                // keeps its registers at a third of the interleaved form's
+                va[0][u] = dec_angle<0>(va[0][u]); __builtin_amdgcn_sched_barrier(0);
+                va[1][u] = dec_angle<1>(va[1][u]); __builtin_amdgcn_sched_barrier(0);
+                va[2][u] = dec_angle<2>(va[2][u]); __builtin_amdgcn_sched_barrier(0);
+                va[3][u] = dec_angle<3>(va[3][u]); __builtin_amdgcn_sched_barrier(0);
+                va[4][u] = dec_angle<4>(va[4][u]); __builtin_amdgcn_sched_barrier(0);
+                va[5][u] = dec_angle<5>(va[5][u]); __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             va[0][u] = dec_angle<0>(va[0][u]); va[1][u] = dec_angle<1>(va[1][u]); va[2][u] = dec_angle<2>(va[2][u]);
             va[3][u] = dec_angle<3>(va[3][u]); va[4][u] = dec_angle<4>(va[4][u]); va[5][u] = dec_angle<5>(va[5][u]);
         }
@@ -926,7 +939,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     if (small) {
 #pragma unroll
         for (int u = 0; u < U; u++) if ((uint32_t)(u * WAVE + lane) < n) check(rcs[u], o2[u] - o0[u], va[6][u]);
-    } else {
+    } else if (U > 1) {
         for (uint32_t k = lane; k < n; k += WAVE)
             check(in.res_code[r0 + k], in.atom_off[r0 + (k + 2 < n ? k + 2 : n)] - in.atom_off[r0 + k], in.bfac_ca[r0 + k]);
     }
@@ -1010,9 +1023,16 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     // comparison says so: a NaN there stays (nothing compares below or above it), a NaN anywhere else is never picked -- which is
     // what the fminf / fmaxf reductions give
     auto finish_q = [&](int q, float first, float lo, float hi, const float* src, uint32_t cntq, int mode) {
-        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
+        // (a call reserves the callee's registers in the caller's budget: the short-chain kernel, which lives on occupancy, inlines it)
+        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = (U == 1) ? first_extrema_body(src, cntq, lane, mode) : first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
         if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+        if (U == 1) {
+            // wave-uniform values: held in scalar registers by the short-chain kernel (21 vector registers less per wavefront)
+            qmin[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qmin[q])));
+            qdisc[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qdisc[q])));
+            qcont[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qcont[q])));
+        }
     };
     if (small) {
         // everything of the chain is in registers already: no reload for the quantisation pass
@@ -1044,7 +1064,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
             if (k < n) pack_store(k, rcs[u], va[0][u], va[1][u], va[2][u], va[3][u], va[4][u], va[5][u], va[6][u]);
             __builtin_amdgcn_sched_barrier(0);   // one word at a time: interleaving all of them only inflates the live set
         }
-    } else {
+    } else if (U > 1) {
         // longer chains: all seven arrays advance together, 128 residues per memory round trip (clamped, unconditional
         // loads), first for the extrema, then again (from the L2) for the words
         float lo[7], hi[7], first[7];
@@ -1130,6 +1150,63 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
         st_f32(rec + RL.o_tmp, qmin[6]);
         st_f32(rec + RL.o_tmp + 4, qcont[6]);
         if (status) status[c] = FCZ_OK;
+    }
+}
+
+
+// Chains of 2 .. CP_SHORT residues belong to k_compress_pack_short, everything else (incl. what is refused) to k_compress_pack.
+constexpr uint32_t CP_SHORT = WAVE;
+#ifndef FCZ_PACK_CLASSES
+#define FCZ_PACK_CLASSES 1
+#endif
+
+__global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                         int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                         const uint32_t* __restrict__ nonfinite) {
+    const int wave = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (c >= in.n_chains) return;
+    const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
+    if (n >= 2 && n <= CP_SHORT) return;                      // k_compress_pack_short's
+#if FCZ_PACK_CLASSES
+    // rounds of 64 residues held in registers, by length class (wave-uniform): a 100-residue chain does not issue the loads,
+    // reductions and stores of a 350-residue one
+    if (n <= 2u * WAVE) compress_pack_chain<2>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
+    else if (n <= 4u * WAVE) compress_pack_chain<4>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
+    else
+#endif
+    compress_pack_chain<6>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
+}
+
+// Short chains (2 .. 64 residues: peptides, fragments, the low end of a metagenomic set). One wavefront per chain costs a short
+// chain what it costs a long one -- a handful of dependent memory round trips (offsets -> codes -> anchor atoms -> record) with the
+// wavefront idle in between -- so what matters is how many chains are in flight: this kernel keeps a third of the registers
+// (one round of values instead of six) and therefore more than twice the wavefronts per SIMD. A persistent grid: wavefront w takes
+// the chunks of CP_CHUNK consecutive chains w, w + W, ...; one coalesced load gives the chunk's lengths, a ballot the short ones.
+// A batch without short chains costs one load per 16 chains.
+constexpr int CP_CHUNK = 16;
+#ifndef FCZ_PACK_SHORT_WAVES
+#define FCZ_PACK_SHORT_WAVES 5
+#endif
+__global__ __launch_bounds__(BLOCK, FCZ_PACK_SHORT_WAVES) void k_compress_pack_short(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                               int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                               const uint32_t* __restrict__ nonfinite) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t n_chunks = (in.n_chains + CP_CHUNK - 1) / CP_CHUNK;
+    for (uint32_t ch = blockIdx.x * WAVES_PER_BLOCK + wave; ch < n_chunks; ch += n_waves) {
+        const uint32_t c0 = ch * CP_CHUNK;
+        const uint32_t ci = c0 + (uint32_t)lane;
+        const uint32_t ro = in.res_off[ci <= in.n_chains ? ci : in.n_chains];          // lanes 0 .. CP_CHUNK: the chunk's offsets
+        const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
+        unsigned long long todo = __ballot(lane < CP_CHUNK && ci < in.n_chains && nn >= 2u && nn <= CP_SHORT);
+        if (!todo) continue;
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), n = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+            compress_pack_chain<1>(in, c0 + (uint32_t)l, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
+        }
     }
 }
 

@@ -62,10 +62,12 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
     };
     // Torsion bytes of a residue: atoms before it minus 3 per residue = torsion bytes before it. The dwords read at most 11
     // bytes past the residue's last torsion byte: still inside the record (8-byte B-factor header + n bytes follow).
-    constexpr int U = 6;
-    if (n <= (uint32_t)(U * WAVE)) {
-        // a normal chain: every load of a dependency level is in flight at once (two memory round trips per chain
-        // instead of two per 64 residues)
+    // a chain of up to 384 residues: every load of a dependency level is in flight at once (two memory round trips per chain
+    // instead of two per 64 residues). The rounds are a compile-time count chosen by the chain's length (1, 2, 4 or 6 rounds of 64
+    // residues): a 37-residue chain does not pay the loads, scans and stores of five empty rounds (round 5; the fixed six rounds
+    // were 2.2 ms per 2 M short chains).
+    auto rounds = [&](auto U_) {
+        constexpr int U = decltype(U_)::value;
         uint32_t wb[U], tq[U], rc[U], na[U], ex[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -101,7 +103,12 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
             const uint32_t k = u * WAVE + lane;
             if (k < n) emit(k, rc[u], tq[u], ex[u], q0[u], q1[u], na[u] > 11 ? q2[u] : 0u);
         }
-    } else {
+    };
+    if (n <= (uint32_t)WAVE) rounds(std::integral_constant<int, 1>{});
+    else if (n <= 2u * WAVE) rounds(std::integral_constant<int, 2>{});
+    else if (n <= 4u * WAVE) rounds(std::integral_constant<int, 4>{});
+    else if (n <= 6u * WAVE) rounds(std::integral_constant<int, 6>{});
+    else {
         for (uint32_t base = 0; base < n; base += WAVE) {
             const uint32_t k = base + lane;
             const bool act = k < n;

@@ -171,6 +171,7 @@ def run(a, inputs: List[str], output: str) -> int:
         extra = [st.get("residues", 0), int(st.get("wall_s", 0.0) * 1e6), int(st.get("ctx_ready_s", 0.0) * 1e6), st.get("max_rss_kb", 0),
                  st.get("items", st.get("files", 0)), st.get("input_bytes", st.get("fcz_bytes", 0)), int(st.get("sizes_pass_s", 0.0) * 1e6)]
         key0, off0, any_failed, rows = shard.exchange_counts(st.get("records", 0), st.get("data_bytes", 0), failed, tdev, extra)
+        t_exchanged = time.perf_counter()             # (a collective: it returns when the SLOWEST rank's engine has ended)
         if any_failed:
             # a database without one rank's records looks complete: nothing is left behind
             shard.remove_db(part)
@@ -210,6 +211,8 @@ def run(a, inputs: List[str], output: str) -> int:
                               "wall_s": round(t_done - t_start, 4), "torch_and_group_s_beside_engine": round(t_group - t_spawn, 4), "communicator_s_beside_engine": round(t_comm - t_group, 4),
                               "engine_s": round(t_engine - t_spawn, 4), "engine_wall_s_max": round(eng_wall, 4),
                               "engine_steady_s_max": round(steady, 4), "exchange_and_splice_s": round(t_done - t_engine, 4),
+                              # ... of which: rank 0 waiting in the all_gather for the slowest rank's engine, and the file work after it
+                              "exchange_wait_for_slowest_rank_s": round(t_exchanged - t_engine, 4), "file_work_after_exchange_s": round(t_done - t_exchanged, 4),
                               "residues_per_s": round(res / (t_done - t_start), 1) if t_done > t_start else None,
                               # the steady rate: without the group's and the engines' start-up (HIP context), WITH the exchange
                               "steady_residues_per_s": round(res / (steady + (t_done - t_engine)), 1) if steady + (t_done - t_engine) > 0 else None}))

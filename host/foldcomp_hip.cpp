@@ -1775,7 +1775,7 @@ int run_compress(const Options& o) {
             gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
             // rc is the worst per-chain status or a failure of the call itself; FCZ_E_INVALID_ARG is both (a refused chain, or
             // refused arguments -- then no per-chain status was written). Nothing may be emitted unless every chain has one.
-            bool call_failed = rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG;
+            bool call_failed = rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_NONFINITE && rc != FCZ_E_INVALID_ARG;
             for (uint32_t q = 0; q < v.n_chains && !call_failed; q++) if (status[q] == UNSET) call_failed = true;
             if (call_failed) {
                 fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size());
@@ -2005,7 +2005,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     const auto t0 = clk::now();
                     const int rc = fcz_compress_batch(ctx, &v, hoff.data(), blob_host.data(), hstatus.data());
                     gpu_busy[w] += std::chrono::duration<double>(clk::now() - t0).count();
-                    bool call_failed = rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_INVALID_ARG;
+                    bool call_failed = rc != FCZ_OK && rc != FCZ_E_RESIDUE && rc != FCZ_E_TOO_SHORT && rc != FCZ_E_NONFINITE && rc != FCZ_E_INVALID_ARG;
                     for (uint32_t q = 0; q < v.n_chains && !call_failed; q++) if (hstatus[q] == UNSET) call_failed = true;
                     if (call_failed) { fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size()); failed = true; }
                     for (size_t q = 0; q < kept.size() && !failed; q++) {

@@ -1544,7 +1544,13 @@ def main():
                        "chains_per_gpu": C, "residues_per_chain": round(R / C, 1) if args.mixed else n_res, "atoms_per_residue": round(A, 3),
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective",
                        "index_exchange": group_note or f"record lengths gathered on rank 0 over RCCL inside every step ({world}-rank group)",
-                       "seed_base": args.seed_base, "backend": backend},
+                       "seed_base": args.seed_base, "backend": backend,
+                       # how to read a --gpus N line of this bench, and of the product drivers, on a CPU quota that does not grow with N
+                       "expected_bound_at_n_gpus": ("this step: inputs resident in HBM, no host stage, one small gather per step -> weak scaling, per-rank rate = the 1-GPU rate; "
+                                                    "the CPU baseline and the parity checkers run on rank 0's host cores only. The product drivers (end_to_end / "
+                                                    "python -m foldcomp_amd --gpus N) divide the host's CPU quota between the ranks' reader threads (sharded_cli.host_threads): "
+                                                    "one engine needs ~16 threads to fill one GPU's link, so on a 16-CPU quota an 8-rank directory -> database run is "
+                                                    "reader-thread-bound (2 threads per engine), not GPU- or xGMI-bound")},
             "compress_residues_per_s": R / (ktime["compress"] * 1e-3) if ktime["compress"] else None,
             "decompress_residues_per_s": R / (dec_ms * 1e-3) if dec_ms else None,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "properties": props,

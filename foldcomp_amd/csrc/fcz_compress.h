@@ -905,17 +905,6 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if ((uint32_t)(u * WAVE) >= m) continue;      // a round no residue of this chain falls into (wave-uniform): short chains
-            if (U == 1) {
-                // the short-chain kernel lives on wavefronts in flight, not on instruction-level parallelism: one acos at a time
-                // keeps its registers at a third of the interleaved form's
-                va[0][u] = dec_angle<0>(va[0][u]); __builtin_amdgcn_sched_barrier(0);
-                va[1][u] = dec_angle<1>(va[1][u]); __builtin_amdgcn_sched_barrier(0);
-                va[2][u] = dec_angle<2>(va[2][u]); __builtin_amdgcn_sched_barrier(0);
-                va[3][u] = dec_angle<3>(va[3][u]); __builtin_amdgcn_sched_barrier(0);
-                va[4][u] = dec_angle<4>(va[4][u]); __builtin_amdgcn_sched_barrier(0);
-                va[5][u] = dec_angle<5>(va[5][u]); __builtin_amdgcn_sched_barrier(0);
-                continue;
-            }
             va[0][u] = dec_angle<0>(va[0][u]); va[1][u] = dec_angle<1>(va[1][u]); va[2][u] = dec_angle<2>(va[2][u]);
             va[3][u] = dec_angle<3>(va[3][u]); va[4][u] = dec_angle<4>(va[4][u]); va[5][u] = dec_angle<5>(va[5][u]);
         }
@@ -1154,6 +1143,224 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
 }
 
 
+// =====================================================================================================================
+// Several short chains per wavefront: one chain per G-lane group (G = 16: a DPP row, four chains; G = 32: two)
+// =====================================================================================================================
+// A chain costs k_compress_pack ~1 250 VALU wave-instructions before its first residue (validation, anchors, seven min / max
+// reductions, record layout, title, header: profiles/r5_short_chains.txt), all of it executed by a whole wavefront whatever the
+// chain's length. Here the lanes of a group carry their own chain's scalars, so that cost is shared by the 2 or 4 chains of the
+// wavefront; the reductions stay inside a group (four DPP steps cover a row of 16; one more exchange joins two rows).
+// Same arithmetic, same order, same first-occurrence rules as compress_pack_chain (the results are the same bits).
+template <int G> __device__ __forceinline__ float grp_min_f32(float v) {
+    v = __builtin_fminf(v, dpp_f32<0xB1, 0xf>(v)); v = __builtin_fminf(v, dpp_f32<0x4E, 0xf>(v));
+    v = __builtin_fminf(v, dpp_f32<0x141, 0xf>(v)); v = __builtin_fminf(v, dpp_f32<0x140, 0xf>(v));
+    if (G == 32) v = __builtin_fminf(v, __shfl_xor(v, 16, WAVE));
+    return v;
+}
+template <int G> __device__ __forceinline__ float grp_max_f32(float v) {
+    v = __builtin_fmaxf(v, dpp_f32<0xB1, 0xf>(v)); v = __builtin_fmaxf(v, dpp_f32<0x4E, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x141, 0xf>(v)); v = __builtin_fmaxf(v, dpp_f32<0x140, 0xf>(v));
+    if (G == 32) v = __builtin_fmaxf(v, __shfl_xor(v, 16, WAVE));
+    return v;
+}
+template <int G> __device__ __forceinline__ int grp_min_i32(int v) {
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) { const int o = __shfl_xor(v, d, WAVE); v = o < v ? o : v; }
+    return v;
+}
+template <int G> __device__ __forceinline__ uint32_t grp_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, WAVE);
+    return v;
+}
+// std::min_element / max_element over the group's values with their positions (first occurrence wins): only when an extremum is a zero
+template <int G> __device__ __forceinline__ lo_hi grp_first_extrema(float v, bool act, uint32_t k) {
+    const float kInf = __builtin_huge_valf();
+    ext mn{act ? v : kInf, act ? k : 0xffffffffu}, mx{act ? v : -kInf, act ? k : 0xffffffffu};
+    // (an inactive lane's value must never win a tie against an active one: its position is the largest)
+    if (!act) { mn.v = kInf; mx.v = -kInf; }
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) {
+        const float v1 = __shfl_xor(mn.v, d, WAVE); const uint32_t i1 = (uint32_t)__shfl_xor((int)mn.i, d, WAVE);
+        const float v2 = __shfl_xor(mx.v, d, WAVE); const uint32_t i2 = (uint32_t)__shfl_xor((int)mx.i, d, WAVE);
+        ext_min_upd(mn, v1, i1); ext_max_upd(mx, v2, i2);
+    }
+    return lo_hi{mn.v, mx.v};
+}
+
+template <int G>
+__device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, const uint32_t c_in, const bool live, const uint32_t r0_in, const uint32_t n_in,
+                                                   const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                   int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                   const uint32_t* __restrict__ nonfinite) {
+    const uint32_t sub = (uint32_t)(threadIdx.x & (G - 1));
+    // a group without a chain runs along on chain 0's addresses with everything it would write switched off
+    const uint32_t c = live ? c_in : 0u, r0 = live ? r0_in : 0u, n = live ? n_in : 0u;
+    const uint32_t title_len = in.title_off[c + 1] - in.title_off[c];
+    const uint32_t thr = (uint32_t)in.anchor_threshold;
+    uint8_t* rec = out + out_off[c];
+    const uint32_t rec_size = (uint32_t)(out_off[c + 1] - out_off[c]);
+    const int32_t h_first_res = in.first_res_index[c], h_first_atom = in.first_atom_index[c];
+    const char h_chain = in.chain_id[c];
+    const size_t R = in.n_residues;
+    const uint32_t a_first = in.atom_off[r0], a_end = in.atom_off[r0 + n];
+    const uint32_t rl = r0 + (n ? n - 1 : 0);
+    const uint32_t h_rc_first = in.res_code[r0 < R ? r0 : R - 1], h_rc_last = in.res_code[rl < R ? rl : R - 1];
+    const uint32_t m = n ? n - 1 : 0;
+    float* a_arr = ang + (r0 < R ? r0 : (R ? R - 1 : 0));
+    // ---- the group's one round of values: lane = residue ----
+    float va[7];
+    const uint32_t k = sub;
+    const uint32_t kw = k < m ? k : (m ? m - 1 : 0), kr = k < n ? k : (n ? n - 1 : 0);
+    const size_t rr = (size_t)r0 + kr < R ? (size_t)r0 + kr : R - 1;
+#pragma unroll
+    for (int q = 0; q < 6; q++) va[q] = a_arr[(size_t)q * R + kw];
+    va[6] = in.bfac_ca[rr];
+    const uint32_t rcs = in.res_code[rr];
+    const uint32_t o0 = in.atom_off[rr];
+    const uint32_t o2 = in.atom_off[r0 + (k + 2 < n ? k + 2 : n)];
+    va[0] = dec_angle<0>(va[0]); va[1] = dec_angle<1>(va[1]); va[2] = dec_angle<2>(va[2]);
+    va[3] = dec_angle<3>(va[3]); va[4] = dec_angle<4>(va[4]); va[5] = dec_angle<5>(va[5]);
+
+    // ---- validation, as compress_pack_chain orders it ----
+    int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
+    if (!bad && (n > 65535u || n / thr + 2u > 255u)) bad = FCZ_E_INVALID_ARG;
+    if (!bad && ((nonfinite[c >> 5] >> (c & 31u)) & 1u)) bad = FCZ_E_NONFINITE;
+    uint32_t nsc = 0;
+    if (k < n) {
+        if (!res_code_ok(rcs)) bad = bad ? bad : FCZ_E_RESIDUE;
+        if (o2 - o0 > (uint32_t)CK_CAP) bad = bad ? bad : FCZ_E_INVALID_ARG;
+        if (nonfinite_f32(va[6])) bad = bad ? bad : FCZ_E_NONFINITE;
+        nsc = fcz_res_natoms[rcs < 24 ? rcs : 23] - 3;
+    }
+    bad = grp_min_i32<G>(bad);
+    nsc = grp_sum_u32<G>(nsc);
+    {
+        const uint32_t zlim = (live && bad) ? rec_size : 0u;         // a refused chain leaves zeros
+        for (uint32_t i = sub; __any(i < zlim); i += G) if (i < zlim) rec[i] = 0;
+        if (live && bad && sub == 0 && status) status[c] = bad;
+    }
+    const bool on = live && !bad;
+
+    const uint32_t n_anchor = n / (thr ? thr : 1u) + 2;
+    const uint32_t interval = n / (n_anchor - 1);
+    const rec_layout RL = make_layout(n, n_anchor, title_len, nsc);
+
+    // ---- anchors (Foldcomp::_setAnchor src/foldcomp.cpp:745-761, written :1045-1059): one lane per anchor ----
+    for (uint32_t sl = sub; __any(on && sl < n_anchor); sl += G) {
+        if (!(on && sl < n_anchor)) continue;
+        const uint32_t ka = (sl + 1 < n_anchor) ? sl * interval : n - 1;
+        const uint32_t lo = in.atom_off[r0 + ka], hi = in.atom_off[r0 + ka + 1];
+        uint32_t at[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint32_t codes[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) codes[j] = (lo + j < hi) ? (uint32_t)in.atom_code[lo + j] : 255u;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            at[0] = codes[j] == 0u ? lo + j : at[0];
+            at[1] = codes[j] == 1u ? lo + j : at[1];
+            at[2] = codes[j] == 2u ? lo + j : at[2];
+        }
+        if (__builtin_expect(at[0] == 0xffffffffu || at[1] == 0xffffffffu || at[2] == 0xffffffffu, 0)) {
+            for (uint32_t i = lo + 8; i < hi; i++) {
+                const uint32_t code = in.atom_code[i];
+                if (code == 0u && at[0] == 0xffffffffu) at[0] = i;
+                if (code == 1u && at[1] == 0xffffffffu) at[1] = i;
+                if (code == 2u && at[2] == 0xffffffffu) at[2] = i;
+            }
+        }
+        v3 p[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const bool have = at[q] != 0xffffffffu;
+            const uint32_t i = have ? at[q] : lo;
+            const bool ok = have && lo < hi;
+            p[q] = ok ? v3{in.x[i], in.y[i], in.z[i]} : v3{0.f, 0.f, 0.f};
+        }
+        uint8_t* q = rec + RL.o_anchor + 36 * sl;
+        st_f32(q, p[0].x); st_f32(q + 4, p[0].y); st_f32(q + 8, p[0].z);
+        st_f32(q + 12, p[1].x); st_f32(q + 16, p[1].y); st_f32(q + 20, p[1].z);
+        st_f32(q + 24, p[2].x); st_f32(q + 28, p[2].y); st_f32(q + 32, p[2].z);
+        st_u32(rec + RL.o_aidx + 4 * sl, ka);
+        if (keep_first_angle && sl == 0) a_arr[3 * R + (n - 1)] = bond_angle_deg(p[0], p[1], p[2]);
+    }
+
+    // ---- per-chain quantiser parameters (Discretizer::Discretizer src/discretizer.cpp:22-33) ----
+    const float kInf = __builtin_huge_valf();
+    float qmin[7], qdisc[7], qcont[7];
+    const float nbins[7] = {4095.0f, 4095.0f, 2047.0f, 255.0f, 255.0f, 255.0f, 255.0f};
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        const uint32_t cntq = (q < 6) ? m : n;
+        const bool act = k < cntq;
+        float lo = grp_min_f32<G>(act ? va[q] : kInf), hi = grp_max_f32<G>(act ? va[q] : -kInf);
+        const float first = __shfl(va[q], (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), WAVE);     // element 0 of the group's array
+        if (__builtin_expect(__any(on && (lo == 0.0f || hi == 0.0f)), 0)) {
+            const lo_hi e = grp_first_extrema<G>(va[q], act, k);
+            if (lo == 0.0f || hi == 0.0f) { lo = e.lo; hi = e.hi; }
+        }
+        if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
+        qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+    }
+    if (keep_first_angle && on && k < m) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) a_arr[(size_t)q * R + k] = va[q];
+    }
+    // ---- the packed word (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52) + B-factor byte ----
+    if (on && k < n) {
+        uint32_t om = 0, ps = 0, ph = 0, b1 = 0, b2 = 0, b3 = 0;
+        if (k < m) {
+            ph = quant_round(va[0], qmin[0], qdisc[0]) & 0xfffu;
+            ps = quant_round(va[1], qmin[1], qdisc[1]) & 0xfffu;
+            om = quant_round(va[2], qmin[2], qdisc[2]) & 0x7ffu;
+            b3 = quant_round(va[3], qmin[3], qdisc[3]) & 0xffu;
+            b1 = quant_round(va[4], qmin[4], qdisc[4]) & 0xffu;
+            b2 = quant_round(va[5], qmin[5], qdisc[5]) & 0xffu;
+        }
+        const uint32_t w0 = ((rcs & 0x1fu) << 3) | (om >> 8), w1 = om & 0xffu, w2 = ps >> 4,
+                       w3 = ((ps & 0xfu) << 4) | (ph >> 8), w4 = ph & 0xffu;
+        const uint64_t word = (uint64_t)w0 | ((uint64_t)w1 << 8) | ((uint64_t)w2 << 16) | ((uint64_t)w3 << 24) |
+                              ((uint64_t)w4 << 32) | ((uint64_t)b1 << 40) | ((uint64_t)b2 << 48) | ((uint64_t)b3 << 56);
+        st_u64(rec + RL.o_words + 8 * (size_t)k, word);
+        rec[RL.o_tbytes + k] = (uint8_t)quant_round(va[6], qmin[6], qdisc[6]);
+    }
+    {
+        const uint32_t tlim = on ? title_len : 0u;
+        const uint32_t t0 = in.title_off[c];
+        for (uint32_t i = sub; __any(i < tlim); i += G) if (i < tlim) rec[RL.o_title + i] = (uint8_t)in.titles[t0 + i];
+    }
+    // ---- header (CompressedFileHeader src/foldcomp.h:118-136; get_header src/foldcomp.cpp:1340) ----
+    if (on && sub == 0) {
+        rec[0] = 'F'; rec[1] = 'C'; rec[2] = 'M'; rec[3] = 'P';
+        uint8_t* h = rec + 4;
+        st_u16(h + 0, n);
+        st_u16(h + 2, a_end - a_first);
+        st_u16(h + 4, (uint32_t)h_first_res);
+        st_u16(h + 6, (uint32_t)h_first_atom);
+        h[8] = (uint8_t)n_anchor;
+        h[9] = (uint8_t)h_chain;
+        h[10] = 0; h[11] = 0;
+        st_u32(h + 12, nsc);
+        h[16] = (uint8_t)fcz_res1[h_rc_first];
+        h[17] = (uint8_t)fcz_res1[h_rc_last];
+        h[18] = 0; h[19] = 0;
+        st_u32(h + 20, title_len);
+        auto x86_nan = [](float v) { return v != v ? __uint_as_float(0xFFC00000u) : v; };
+#pragma unroll
+        for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, x86_nan(qmin[q])); st_f32(h + 48 + 4 * q, x86_nan(qcont[q])); }
+        const uint32_t la = a_end - 1;
+        const bool has_oxt = a_end > a_first && in.atom_code[la] == FCZ_ATOM_OXT;
+        uint8_t* o = rec + RL.o_oxt;
+        o[0] = has_oxt ? 1 : 0;
+        st_f32(o + 1, has_oxt ? in.x[la] : 0.0f);
+        st_f32(o + 5, has_oxt ? in.y[la] : 0.0f);
+        st_f32(o + 9, has_oxt ? in.z[la] : 0.0f);
+        st_f32(rec + RL.o_tmp, qmin[6]);
+        st_f32(rec + RL.o_tmp + 4, qcont[6]);
+        if (status) status[c] = FCZ_OK;
+    }
+}
+
 // Chains of 2 .. CP_SHORT residues belong to k_compress_pack_short, everything else (incl. what is refused) to k_compress_pack.
 constexpr uint32_t CP_SHORT = WAVE;
 #ifndef FCZ_PACK_CLASSES
@@ -1185,9 +1392,14 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
 // the chunks of CP_CHUNK consecutive chains w, w + W, ...; one coalesced load gives the chunk's lengths, a ballot the short ones.
 // A batch without short chains costs one load per 16 chains.
 constexpr int CP_CHUNK = 16;
+constexpr uint32_t CP_ROWS = 32;           // chains of up to this many residues go several to a wavefront (k_compress_pack_rows)
 #ifndef FCZ_PACK_SHORT_WAVES
 #define FCZ_PACK_SHORT_WAVES 5
 #endif
+#ifndef FCZ_PACK_ROWS_WAVES
+#define FCZ_PACK_ROWS_WAVES 4
+#endif
+// chains of CP_ROWS + 1 .. CP_SHORT residues, one at a time
 __global__ __launch_bounds__(BLOCK, FCZ_PACK_SHORT_WAVES) void k_compress_pack_short(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                                int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
                                                                const uint32_t* __restrict__ nonfinite) {
@@ -1199,13 +1411,55 @@ __global__ __launch_bounds__(BLOCK, FCZ_PACK_SHORT_WAVES) void k_compress_pack_s
         const uint32_t ci = c0 + (uint32_t)lane;
         const uint32_t ro = in.res_off[ci <= in.n_chains ? ci : in.n_chains];          // lanes 0 .. CP_CHUNK: the chunk's offsets
         const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
-        unsigned long long todo = __ballot(lane < CP_CHUNK && ci < in.n_chains && nn >= 2u && nn <= CP_SHORT);
-        if (!todo) continue;
+        unsigned long long todo = __ballot(lane < CP_CHUNK && ci < in.n_chains && nn > CP_ROWS && nn <= CP_SHORT);
         while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), n = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
             compress_pack_chain<1>(in, c0 + (uint32_t)l, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
+        }
+    }
+}
+
+// chains of 2 .. 16 residues four to a wavefront, 17 .. 32 two to a wavefront (compress_pack_rows); a kernel of its own because the
+// per-lane chain scalars want other registers than the one-chain form (together they spilled and the 33 .. 64 class lost 8 %)
+__global__ __launch_bounds__(BLOCK, FCZ_PACK_ROWS_WAVES) void k_compress_pack_rows(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                             int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                             const uint32_t* __restrict__ nonfinite) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t n_chunks = (in.n_chains + CP_CHUNK - 1) / CP_CHUNK;
+    const uint32_t g16 = (uint32_t)lane >> 4, g32 = (uint32_t)lane >> 5;
+    for (uint32_t ch = blockIdx.x * WAVES_PER_BLOCK + wave; ch < n_chunks; ch += n_waves) {
+        const uint32_t c0 = ch * CP_CHUNK;
+        const uint32_t ci = c0 + (uint32_t)lane;
+        const uint32_t ro = in.res_off[ci <= in.n_chains ? ci : in.n_chains];
+        const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
+        const bool mine = lane < CP_CHUNK && ci < in.n_chains;
+        unsigned long long t16 = __ballot(mine && nn >= 2u && nn <= 16u), t32 = __ballot(mine && nn > 16u && nn <= CP_ROWS);
+        while (t16) {
+            uint32_t cc = 0, rr0 = 0, rn = 0; bool live = false;
+#pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                if (!t16) break;
+                const int l = __builtin_ctzll(t16);
+                t16 &= t16 - 1;
+                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+                if (g16 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
+            }
+            compress_pack_rows<16>(in, cc, live, rr0, rn, out_off, out, status, ang, keep_first_angle, nonfinite);
+        }
+        while (t32) {
+            uint32_t cc = 0, rr0 = 0, rn = 0; bool live = false;
+#pragma unroll
+            for (uint32_t g = 0; g < 2; g++) {
+                if (!t32) break;
+                const int l = __builtin_ctzll(t32);
+                t32 &= t32 - 1;
+                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+                if (g32 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
+            }
+            compress_pack_rows<32>(in, cc, live, rr0, rn, out_off, out, status, ang, keep_first_angle, nonfinite);
         }
     }
 }

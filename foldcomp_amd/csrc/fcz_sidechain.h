@@ -33,6 +33,7 @@ namespace fcz {
 //                 whatever follows in the record and are never used)
 // plus the per-residue outputs that need nothing else: B-factor (src/foldcomp.cpp:884-892), residue code, and the
 // chain's OXT atom (:893-900).
+constexpr uint32_t RI_ROWS = 32;           // entries of up to this many residues are k_res_index_rows'
 __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                      uint32_t n_entries, const uint32_t* __restrict__ res_off,
                                                      const uint32_t* __restrict__ atom_off, uint32_t n_res,
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= n_entries) return;
     const uint32_t r0 = res_off[c], n = res_off[c + 1] - r0;
-    if (n == 0) return;   // skipped entry
+    if (n <= RI_ROWS) return;   // skipped entry (n = 0), or k_res_index_rows' (several short chains to a wavefront)
     const uint8_t* e = blob + off[c];
     const entry_view v = view_entry(e);
     const uint32_t abase = atom_off[c];
@@ -136,6 +137,103 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
             if (out.atom_code) out.atom_code[a] = FCZ_ATOM_OXT;
         }
         if (r0 + n == n_res) res_aoff[n_res] = abase + run + (oxt ? 1u : 0u);   // closes the array: total atoms
+    }
+}
+
+// Entries of 1 .. 32 residues: one entry per G-lane group (16 lanes: four entries to a wavefront, 32: two), a persistent grid over
+// chunks of 16 consecutive entries. What k_res_index does per wavefront -- header, layout, the B-factor parameters, the OXT -- is
+// done once per group here; a 16-residue chain filled a quarter of the lanes before (1.3 ms per 2 M of them).
+template <int G>
+__device__ __forceinline__ void res_index_rows(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, const uint32_t c, const bool live,
+                                               const uint32_t r0, const uint32_t n, const uint32_t* __restrict__ atom_off, uint32_t n_res,
+                                               uint32_t* __restrict__ res_aoff, uint8_t* __restrict__ res_rc, uint32_t* __restrict__ res_sc,
+                                               const fcz_atoms_out& out, const uint8_t* __restrict__ codes) {
+    const uint32_t k = (uint32_t)(threadIdx.x & (G - 1));
+    // (a group without an entry runs along on a live group's entry -- same addresses, nothing written)
+    const uint8_t* e = blob + off[c];
+    const entry_view v = view_entry(e);
+    const uint32_t abase = atom_off[c];
+    const float tmin = ld_f32(e + v.L.o_tmp), tcf = ld_f32(e + v.L.o_tmp + 4);
+    const uint8_t* rcs = codes + (off[c] >> 3);
+    const uint8_t* scb = e + v.L.o_sc;
+    const bool act = k < n;
+    const uint32_t kc = act ? k : n - 1;
+    uint32_t rc = rcs[kc];
+    const uint32_t tq = e[v.L.o_tbytes + kc];
+    if (rc >= 24) rc = 23;
+    const uint32_t na = act ? (uint32_t)fcz_res_natoms[rc] : 0u;
+    uint32_t inc = na;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, G); if (k >= (uint32_t)d) inc += t; }
+    const uint32_t run = (uint32_t)__shfl((int)inc, G - 1, G);
+    const uint32_t ex = inc - na;
+    const uint8_t* sp = scb + (act ? ex - 3 * k : 0u);
+    const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = ld_u32((act && na > 11) ? sp + 8 : sp);
+    if (live && act) {
+        const size_t r = (size_t)r0 + k;
+        res_aoff[r] = abase + ex;
+        res_rc[r] = (uint8_t)rc;
+        res_sc[r] = q0; res_sc[(size_t)n_res + r] = q1; res_sc[2 * (size_t)n_res + r] = na > 11 ? q2 : 0u;
+        out.bfac_res[r] = dequant(tq, tmin, tcf);
+        if (out.res_code) out.res_code[r] = (uint8_t)rc;
+    }
+    if (live && k == 0) {
+        const bool oxt = e[v.L.o_oxt] != 0;
+        if (oxt) {
+            const uint32_t a = abase + run;
+            const v3 o = ld_v3(e + v.L.o_oxt + 1);
+            out.x[a] = o.x; out.y[a] = o.y; out.z[a] = o.z;
+            if (out.atom_code) out.atom_code[a] = FCZ_ATOM_OXT;
+        }
+        if (r0 + n == n_res) res_aoff[n_res] = abase + run + (oxt ? 1u : 0u);
+    }
+}
+
+constexpr int RI_CHUNK = 16;
+__global__ __launch_bounds__(BLOCK) void k_res_index_rows(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
+                                                          uint32_t n_entries, const uint32_t* __restrict__ res_off,
+                                                          const uint32_t* __restrict__ atom_off, uint32_t n_res,
+                                                          uint32_t* __restrict__ res_aoff, uint8_t* __restrict__ res_rc,
+                                                          uint32_t* __restrict__ res_sc, fcz_atoms_out out, const uint8_t* __restrict__ codes) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t n_chunks = (n_entries + RI_CHUNK - 1) / RI_CHUNK;
+    const uint32_t g16 = (uint32_t)lane >> 4, g32 = (uint32_t)lane >> 5;
+    for (uint32_t ch = blockIdx.x * WAVES_PER_BLOCK + wave; ch < n_chunks; ch += n_waves) {
+        const uint32_t c0 = ch * RI_CHUNK;
+        const uint32_t ci = c0 + (uint32_t)lane;
+        const uint32_t ro = res_off[ci <= n_entries ? ci : n_entries];
+        const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
+        const bool mine = lane < RI_CHUNK && ci < n_entries;
+        unsigned long long t16 = __ballot(mine && nn >= 1u && nn <= 16u), t32 = __ballot(mine && nn > 16u && nn <= RI_ROWS);
+        while (t16) {
+            const int l0 = __builtin_ctzll(t16);
+            uint32_t cc = c0 + (uint32_t)l0, rr0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l0), rn = (uint32_t)__builtin_amdgcn_readlane((int)nn, l0);
+            bool live = g16 == 0;
+            t16 &= t16 - 1;
+#pragma unroll
+            for (uint32_t g = 1; g < 4; g++) {
+                if (!t16) break;
+                const int l = __builtin_ctzll(t16);
+                t16 &= t16 - 1;
+                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+                if (g16 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
+            }
+            res_index_rows<16>(blob, off, cc, live, rr0, rn, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+        }
+        while (t32) {
+            const int l0 = __builtin_ctzll(t32);
+            uint32_t cc = c0 + (uint32_t)l0, rr0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l0), rn = (uint32_t)__builtin_amdgcn_readlane((int)nn, l0);
+            bool live = g32 == 0;
+            t32 &= t32 - 1;
+            if (t32) {
+                const int l = __builtin_ctzll(t32);
+                t32 &= t32 - 1;
+                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+                if (g32 == 1) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
+            }
+            res_index_rows<32>(blob, off, cc, live, rr0, rn, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+        }
     }
 }
 

@@ -102,6 +102,44 @@ def test_many_tiny_chains(codec):
     _check(codec, b)
 
 
+def test_length_classes_in_one_batch_with_refused_neighbours(codec):
+    """The compress side sorts a batch's chains into length classes handled by different kernels (round 5): 2..16 residues four
+    to a wavefront, 17..32 two to a wavefront (compress_pack_rows: a 16- / 32-lane group per chain), 33..64 one at a time with one
+    round of values, 65..128 / ..256 / ..384 with 2 / 4 / 6 rounds, longer ones in two passes -- and the decompress side's
+    k_res_index / k_res_index_rows likewise. Every length from 2 to 70 and the class edges beyond, in random order, so that the
+    groups of one wavefront hold chains of different lengths, partly filled wavefronts occur, and refused chains (a residue name
+    the reference cannot process, a NaN B-factor, a NaN coordinate) sit in groups next to good ones: statuses as expected, refused
+    records zero, every other record and its decode equal to the oracle's. Both anchor thresholds 25 and 3 (many anchors per
+    chain: the per-lane anchor loop of a group takes several rounds)."""
+    rng = np.random.default_rng(77)
+    lens = list(range(2, 71)) * 3 + [127, 128, 129, 255, 256, 257, 383, 384, 385, 600] + [16] * 37 + [32] * 21 + [17, 33, 64, 65] * 5
+    rng.shuffle(lens)
+    for thr in (25, 3):
+        b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=4242, anchor_threshold=thr))
+        _check(codec, b)
+        # refuse every 9th chain one way or another
+        rc, bf, x = b.res_code.copy(), b.bfac_ca.copy(), b.x.copy()
+        want = np.zeros(len(lens), np.int32)
+        for c in range(0, len(lens), 9):
+            r0, n = int(b.res_off[c]), int(b.res_off[c + 1] - b.res_off[c])
+            how = (c // 9) % 3
+            if how == 0:
+                rc[r0 + n // 2] = 21; want[c] = -6                       # FCZ_E_RESIDUE
+            elif how == 1:
+                bf[r0 + n - 1] = np.nan; want[c] = -9                    # FCZ_E_NONFINITE (CA B-factor)
+            else:
+                x[int(b.atom_off[r0 + n // 2])] = np.inf; want[c] = -9   # FCZ_E_NONFINITE (coordinate of the residue's N)
+        b2 = ChainBatch(res_off=b.res_off, atom_off=b.atom_off, x=x, y=b.y, z=b.z, atom_code=b.atom_code, res_code=rc, bfac_ca=bf,
+                        first_res_index=b.first_res_index, first_atom_index=b.first_atom_index, chain_id=b.chain_id, titles=b.titles,
+                        title_off=b.title_off, anchor_threshold=b.anchor_threshold)
+        good_blob, good_off, _ = codec.compress_batch(b)
+        blob, off, st = codec.compress_batch(b2, strict=False)
+        assert np.array_equal(st, want), (thr, np.nonzero(st != want)[0][:10], st[st != want][:10])
+        for c in range(len(lens)):                                  # (a changed residue name changes that record's size: own offsets)
+            rec = blob[off[c]:off[c + 1]].tobytes()
+            assert rec == (bytes(len(rec)) if want[c] else good_blob[good_off[c]:good_off[c + 1]].tobytes()), (thr, c, lens[c])
+
+
 def test_roundtrip_properties_at_scale(codec):
     """size-independent properties on 20k chains: idempotence (compress(decompress(compress(x))) keeps the
     words' residue codes, side-chain byte count and sizes), determinism, and round-trip accuracy"""

@@ -188,6 +188,16 @@ def test_more_ranks_than_work_and_mixed_input_lists(tmp_path, golden):
     assert st["world"] == 3 and st["records"] == 2 and sorted(st["records_per_rank"]) in ([0, 0, 2], [0, 1, 1])
     _same_db(tmp_path / "t1", tmp_path / "t3")
     assert not [f for f in os.listdir(tmp_path) if ".part" in f or ".index." in f or ".lookup." in f]
+    # ... and back: three ranks over the two records (placed run: one rank's sizes pass finds nothing, it still takes part in the
+    # exchange and writes nothing), the output of one rank
+    r = _cli("decompress", "-d", "-y", "--gpus", "1", str(tmp_path / "t1"), str(tmp_path / "u1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _cli("decompress", "-d", "-y", "--gpus", "3", "--json-stats", str(tmp_path / "t1"), str(tmp_path / "u3"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = _stats(r)
+    assert st["world"] == 3 and st["records"] == 2 and st["data_written_once"] is True and sorted(st["records_per_rank"]) in ([0, 0, 2], [0, 1, 1])
+    _same_db(tmp_path / "u1", tmp_path / "u3")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f or ".index." in f or ".lookup." in f]
     # a database of PDB texts + a directory of files, listed in one -f file
     w = DatabaseWriter(str(tmp_path / "texts"))
     for k, n in enumerate(["syn:len26", "syn:len64", "pdb:test", "syn:len350", "syn:len129"] * 8):

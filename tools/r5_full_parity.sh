@@ -8,6 +8,7 @@ python bench.py --mixed --chains 542000 --parity-chains 542000 --cpu-sample 3276
 python bench.py --residues 37 --chains 2000000 --seed-base 11000000000 --parity-chains 2000000 --cpu-sample 65536 $OFF >> gpurun_out/r5_parity_sweeps.jsonl 2> gpurun_out/r5_parity_sweeps.err
 python bench.py --residues 129 --chains 1000000 --seed-base 55000000000 --parity-chains 1000000 --cpu-sample 32768 $OFF >> gpurun_out/r5_parity_sweeps.jsonl 2>> gpurun_out/r5_parity_sweeps.err
 python bench.py --residues 16 --chains 2000000 --seed-base 66000000000 --parity-chains 2000000 --cpu-sample 65536 $OFF >> gpurun_out/r5_parity_sweeps.jsonl 2>> gpurun_out/r5_parity_sweeps.err
+python bench.py --residues 32 --chains 2000000 --seed-base 99000000000 --parity-chains 2000000 --cpu-sample 65536 $OFF >> gpurun_out/r5_parity_sweeps.jsonl 2>> gpurun_out/r5_parity_sweeps.err
 python bench.py --residues 64 --chains 1000000 --seed-base 77000000000 --parity-chains 1000000 --cpu-sample 32768 $OFF >> gpurun_out/r5_parity_sweeps.jsonl 2>> gpurun_out/r5_parity_sweeps.err
 python bench.py --residues 65 --chains 1000000 --seed-base 88000000000 --parity-chains 1000000 --cpu-sample 32768 $OFF >> gpurun_out/r5_parity_sweeps.jsonl 2>> gpurun_out/r5_parity_sweeps.err
 python - <<'PY'

@@ -1054,52 +1054,56 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
             __builtin_amdgcn_sched_barrier(0);   // one word at a time: interleaving all of them only inflates the live set
         }
     } else if (U > 1) {
-        // longer chains: all seven arrays advance together, 128 residues per memory round trip (clamped, unconditional
-        // loads), first for the extrema, then again (from the L2) for the words
+        // longer chains: blocks of U x 64 residues in the register path's shape -- every load of a block in flight at once, the
+        // rounds past the chain's end skipped (wave-uniform) -- first for the extrema, the finished angles written back in place
+        // (each lane its own entries), then again (from the L2) for the words. (Round 4 walked 128 residues per memory round trip;
+        // this form is 2 % faster on 1 000-residue chains: the path is as VALU-bound as the rest, profiles/r5_short_chains.txt.)
         float lo[7], hi[7], first[7];
 #pragma unroll
         for (int q = 0; q < 7; q++) { lo[q] = kInf; hi[q] = -kInf; first[q] = 0.f; }
-        for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
-            float tv[7][2];
+        for (uint32_t b0 = 0; b0 < n; b0 += (uint32_t)(U * WAVE)) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t k = k0 + u * WAVE + lane, kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
+            for (int u = 0; u < U; u++) {
+                if (b0 + (uint32_t)(u * WAVE) >= n) continue;
+                const uint32_t k = b0 + u * WAVE + lane, kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
 #pragma unroll
-                for (int q = 0; q < 6; q++) tv[q][u] = a_arr[(size_t)q * R + kw];
-                tv[6][u] = in.bfac_ca[r0 + kr];
+                for (int q = 0; q < 6; q++) va[q][u] = a_arr[(size_t)q * R + kw];
+                va[6][u] = in.bfac_ca[r0 + kr];
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t k = k0 + u * WAVE + lane;
-                // finished here and written back in place (each lane its own entries): the second pass reads angles
-                tv[0][u] = dec_angle<0>(tv[0][u]); tv[1][u] = dec_angle<1>(tv[1][u]); tv[2][u] = dec_angle<2>(tv[2][u]);
-                tv[3][u] = dec_angle<3>(tv[3][u]); tv[4][u] = dec_angle<4>(tv[4][u]); tv[5][u] = dec_angle<5>(tv[5][u]);
+            for (int u = 0; u < U; u++) {
+                if (b0 + (uint32_t)(u * WAVE) >= n) continue;
+                const uint32_t k = b0 + u * WAVE + lane;
+                va[0][u] = dec_angle<0>(va[0][u]); va[1][u] = dec_angle<1>(va[1][u]); va[2][u] = dec_angle<2>(va[2][u]);
+                va[3][u] = dec_angle<3>(va[3][u]); va[4][u] = dec_angle<4>(va[4][u]); va[5][u] = dec_angle<5>(va[5][u]);
 #pragma unroll
                 for (int q = 0; q < 7; q++) {
-                    if (k0 == 0 && u == 0) first[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tv[q][0])));
+                    if (u == 0 && b0 == 0) first[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(va[q][0])));
                     const bool on = k < ((q < 6) ? m : n);
-                    if (q < 6 && on) a_arr[(size_t)q * R + k] = tv[q][u];
-                    lo[q] = __builtin_fminf(lo[q], on ? tv[q][u] : kInf); hi[q] = __builtin_fmaxf(hi[q], on ? tv[q][u] : -kInf);
+                    if (q < 6 && on) a_arr[(size_t)q * R + k] = va[q][u];
+                    lo[q] = __builtin_fminf(lo[q], on ? va[q][u] : kInf); hi[q] = __builtin_fmaxf(hi[q], on ? va[q][u] : -kInf);
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < 7; q++)
             finish_q(q, first[q], wave_min_f32(lo[q]), wave_max_f32(hi[q]), (q < 6) ? (a_arr + (size_t)q * R) : (in.bfac_ca + r0), (q < 6) ? m : n, 0);
-        for (uint32_t k0 = 0; k0 < n; k0 += 2 * WAVE) {
-            float tv[7][2]; uint32_t rc2[2];
+        for (uint32_t b0 = 0; b0 < n; b0 += (uint32_t)(U * WAVE)) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t k = k0 + u * WAVE + lane, kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
+            for (int u = 0; u < U; u++) {
+                if (b0 + (uint32_t)(u * WAVE) >= n) continue;
+                const uint32_t k = b0 + u * WAVE + lane, kw = k < m ? k : m - 1, kr = k < n ? k : n - 1;
 #pragma unroll
-                for (int q = 0; q < 6; q++) tv[q][u] = a_arr[(size_t)q * R + kw];
-                tv[6][u] = in.bfac_ca[r0 + kr];
-                rc2[u] = in.res_code[r0 + kr];
+                for (int q = 0; q < 6; q++) va[q][u] = a_arr[(size_t)q * R + kw];
+                va[6][u] = in.bfac_ca[r0 + kr];
+                rcs[u] = in.res_code[r0 + kr];
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t k = k0 + u * WAVE + lane;
-                if (k < n) pack_store(k, rc2[u], tv[0][u], tv[1][u], tv[2][u], tv[3][u], tv[4][u], tv[5][u], tv[6][u]);
+            for (int u = 0; u < U; u++) {
+                if (b0 + (uint32_t)(u * WAVE) >= n) continue;
+                const uint32_t k = b0 + u * WAVE + lane;
+                if (k < n) pack_store(k, rcs[u], va[0][u], va[1][u], va[2][u], va[3][u], va[4][u], va[5][u], va[6][u]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -1366,6 +1370,7 @@ constexpr uint32_t CP_SHORT = WAVE;
 #ifndef FCZ_PACK_CLASSES
 #define FCZ_PACK_CLASSES 1
 #endif
+
 
 __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                          int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,

@@ -505,14 +505,19 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
         span_guard g(ctx, "compress_pack");
         hipLaunchKernelGGL(k_compress_pack, per_chain, dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
-        // chains of 33 .. 64 residues (k_compress_pack leaves them): a persistent grid over chunks of 16 chains
-        const uint32_t short_blocks = std::min<uint32_t>(grid_for(grid_for(in->n_chains, CP_CHUNK), WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * FCZ_PACK_SHORT_WAVES);
-        hipLaunchKernelGGL(k_compress_pack_short, dim3(short_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
+        // chains of 2 .. 128 residues (k_compress_pack leaves them): four to a wavefront, a persistent grid over chunks of 16 chains
+        // (one launch per length class -- 2..16, 17..32, 33..64, 65..128 residues in 1, 2, 4, 8 rounds of 16 -- each a scan of the chunks' lengths)
+        const uint32_t rows_blocks = std::min<uint32_t>(grid_for(grid_for(in->n_chains, CP_CHUNK), WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 4u);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<1>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
-        // ... and those of 2 .. 32 residues: four / two chains to a wavefront
-        const uint32_t rows_blocks = std::min<uint32_t>(grid_for(grid_for(in->n_chains, CP_CHUNK), WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * FCZ_PACK_ROWS_WAVES);
-        hipLaunchKernelGGL(k_compress_pack_rows, dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<2>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<4>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
+                           ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+#if FCZ_PACK_ROWS_MAX_ROUNDS >= 8
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<8>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
+                           ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+#endif
     }
     HIP_TRY(hipGetLastError());
     return FCZ_OK;
@@ -1059,7 +1064,7 @@ int fcz_decompress_batch_dev(fcz_ctx* ctx, const uint8_t* blob_dev, const uint64
         hipLaunchKernelGGL(k_res_index, dim3(grid_for(n, WAVES_PER_BLOCK)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
                            res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
                            ctx->res_sc.as<uint32_t>(), *out_dev, ctx->codes.as<uint8_t>());
-        // entries of up to 32 residues (k_res_index leaves them): four / two to a wavefront, a persistent grid over chunks of 16 entries
+        // entries of up to 64 residues (k_res_index leaves them): four to a wavefront, a persistent grid over chunks of 16 entries
         hipLaunchKernelGGL(k_res_index_rows, dim3(std::min<uint32_t>(grid_for(grid_for(n, RI_CHUNK), WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 8u)), dim3(BLOCK), 0, ctx->stream, blob_dev, off_dev, n,
                            res_off_dev, atom_off_dev, R, ctx->res_aoff.as<uint32_t>(), ctx->res_rc.as<uint8_t>(),
                            ctx->res_sc.as<uint32_t>(), *out_dev, ctx->codes.as<uint8_t>());

@@ -84,7 +84,7 @@ template <int Q> __device__ __forceinline__ float dec_angle(float e) { return Q 
 
 struct lo_hi { float lo, hi; };
 // mode 0: src holds values; 1: encoded dihedrals; 2: bond-angle cosines
-__device__ __forceinline__ lo_hi first_extrema_body(const float* __restrict__ src, uint32_t cnt, int lane, int mode) {
+__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, int mode) {
     const float kInf = __builtin_huge_valf();
     ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
     for (uint32_t k = lane; k < cnt; k += WAVE) {
@@ -94,7 +94,6 @@ __device__ __forceinline__ lo_hi first_extrema_body(const float* __restrict__ sr
     }
     return lo_hi{wave_ext_min(mn), wave_ext_max(mx)};
 }
-__device__ __noinline__ lo_hi first_extrema(const float* __restrict__ src, uint32_t cnt, int lane, int mode) { return first_extrema_body(src, cnt, lane, mode); }
 
 constexpr uint64_t CK_LAST = 1ull << 63;   // res_sc_addr flag: last residue of its chain
 constexpr int CK_TILE = BLOCK;              // residues per tile
@@ -859,8 +858,8 @@ void k_compress_angles_w(fcz_chain_batch in, uint32_t n_wtiles, const uint64_t* 
 // k_compress_pack
 // =====================================================================================================================
 // One chain by one wavefront. U = rounds of 64 residues whose values stay in registers (chains of up to U x 64 residues take the
-// register path; U = 6 covers the 350-residue headline, U = 1 is the short-chain kernel below: a seventh of the loads, a third of
-// the registers, more wavefronts in flight).
+// register path; U = 6 covers the 350-residue headline, 2 and 4 the shorter classes; chains of up to 64 residues are
+// compress_pack_rows' below).
 template <int U>
 __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, const uint32_t c, const uint32_t r0, const uint32_t n,
                                                     const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
@@ -1012,16 +1011,9 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
     // comparison says so: a NaN there stays (nothing compares below or above it), a NaN anywhere else is never picked -- which is
     // what the fminf / fmaxf reductions give
     auto finish_q = [&](int q, float first, float lo, float hi, const float* src, uint32_t cntq, int mode) {
-        // (a call reserves the callee's registers in the caller's budget: the short-chain kernel, which lives on occupancy, inlines it)
-        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = (U == 1) ? first_extrema_body(src, cntq, lane, mode) : first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
+        if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
         if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
-        if (U == 1) {
-            // wave-uniform values: held in scalar registers by the short-chain kernel (21 vector registers less per wavefront)
-            qmin[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qmin[q])));
-            qdisc[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qdisc[q])));
-            qcont[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qcont[q])));
-        }
     };
     if (small) {
         // everything of the chain is in registers already: no reload for the quantisation pass
@@ -1148,12 +1140,13 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
 
 
 // =====================================================================================================================
-// Several short chains per wavefront: one chain per G-lane group (G = 16: a DPP row, four chains; G = 32: two)
+// Several short chains per wavefront: one chain per G-lane group (G = 16: a DPP row, four chains to a wavefront)
 // =====================================================================================================================
 // A chain costs k_compress_pack ~1 250 VALU wave-instructions before its first residue (validation, anchors, seven min / max
 // reductions, record layout, title, header: profiles/r5_short_chains.txt), all of it executed by a whole wavefront whatever the
-// chain's length. Here the lanes of a group carry their own chain's scalars, so that cost is shared by the 2 or 4 chains of the
-// wavefront; the reductions stay inside a group (four DPP steps cover a row of 16; one more exchange joins two rows).
+// chain's length. Here the lanes of a group carry their own chain's scalars, so that cost is shared by the four chains of the
+// wavefront; the reductions stay inside a group (four DPP steps cover a row of 16). A chain longer than the group takes several
+// rounds of G residues (lane sub holds residues sub, sub + G, ...): every chain of up to 64 residues goes four to a wavefront.
 // Same arithmetic, same order, same first-occurrence rules as compress_pack_chain (the results are the same bits).
 template <int G> __device__ __forceinline__ float grp_min_f32(float v) {
     v = __builtin_fminf(v, dpp_f32<0xB1, 0xf>(v)); v = __builtin_fminf(v, dpp_f32<0x4E, 0xf>(v));
@@ -1178,11 +1171,8 @@ template <int G> __device__ __forceinline__ uint32_t grp_sum_u32(uint32_t v) {
     return v;
 }
 // std::min_element / max_element over the group's values with their positions (first occurrence wins): only when an extremum is a zero
-template <int G> __device__ __forceinline__ lo_hi grp_first_extrema(float v, bool act, uint32_t k) {
-    const float kInf = __builtin_huge_valf();
-    ext mn{act ? v : kInf, act ? k : 0xffffffffu}, mx{act ? v : -kInf, act ? k : 0xffffffffu};
-    // (an inactive lane's value must never win a tie against an active one: its position is the largest)
-    if (!act) { mn.v = kInf; mx.v = -kInf; }
+// std::min_element / max_element over the group's values with their positions (first occurrence wins): only when an extremum is a zero
+template <int G> __device__ __forceinline__ lo_hi grp_first_extrema(ext mn, ext mx) {
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) {
         const float v1 = __shfl_xor(mn.v, d, WAVE); const uint32_t i1 = (uint32_t)__shfl_xor((int)mn.i, d, WAVE);
@@ -1192,13 +1182,15 @@ template <int G> __device__ __forceinline__ lo_hi grp_first_extrema(float v, boo
     return lo_hi{mn.v, mx.v};
 }
 
-template <int G>
+// One chain per G-lane group, U rounds of G residues each (a chain of up to G x U residues): lane `sub` of the group holds residues
+// sub, sub + G, ... The group's scalars live in its lanes; `live` false = a group without a chain (it runs along on chain 0's
+// addresses with everything it would write switched off).
+template <int G, int U>
 __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, const uint32_t c_in, const bool live, const uint32_t r0_in, const uint32_t n_in,
                                                    const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                    int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
                                                    const uint32_t* __restrict__ nonfinite) {
     const uint32_t sub = (uint32_t)(threadIdx.x & (G - 1));
-    // a group without a chain runs along on chain 0's addresses with everything it would write switched off
     const uint32_t c = live ? c_in : 0u, r0 = live ? r0_in : 0u, n = live ? n_in : 0u;
     const uint32_t title_len = in.title_off[c + 1] - in.title_off[c];
     const uint32_t thr = (uint32_t)in.anchor_threshold;
@@ -1212,30 +1204,42 @@ __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, co
     const uint32_t h_rc_first = in.res_code[r0 < R ? r0 : R - 1], h_rc_last = in.res_code[rl < R ? rl : R - 1];
     const uint32_t m = n ? n - 1 : 0;
     float* a_arr = ang + (r0 < R ? r0 : (R ? R - 1 : 0));
-    // ---- the group's one round of values: lane = residue ----
-    float va[7];
-    const uint32_t k = sub;
-    const uint32_t kw = k < m ? k : (m ? m - 1 : 0), kr = k < n ? k : (n ? n - 1 : 0);
-    const size_t rr = (size_t)r0 + kr < R ? (size_t)r0 + kr : R - 1;
+    // ---- the group's values: every load issued up front from clamped indices ----
+    float va[7][U];
+    uint32_t rcs[U], o0[U], o2[U];
 #pragma unroll
-    for (int q = 0; q < 6; q++) va[q] = a_arr[(size_t)q * R + kw];
-    va[6] = in.bfac_ca[rr];
-    const uint32_t rcs = in.res_code[rr];
-    const uint32_t o0 = in.atom_off[rr];
-    const uint32_t o2 = in.atom_off[r0 + (k + 2 < n ? k + 2 : n)];
-    va[0] = dec_angle<0>(va[0]); va[1] = dec_angle<1>(va[1]); va[2] = dec_angle<2>(va[2]);
-    va[3] = dec_angle<3>(va[3]); va[4] = dec_angle<4>(va[4]); va[5] = dec_angle<5>(va[5]);
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub;
+        const uint32_t kw = k < m ? k : (m ? m - 1 : 0), kr = k < n ? k : (n ? n - 1 : 0);
+        const size_t rr = (size_t)r0 + kr < R ? (size_t)r0 + kr : R - 1;
+#pragma unroll
+        for (int q = 0; q < 6; q++) va[q][u] = a_arr[(size_t)q * R + kw];
+        va[6][u] = in.bfac_ca[rr];
+        rcs[u] = in.res_code[rr];
+        o0[u] = in.atom_off[rr];
+        o2[u] = in.atom_off[r0 + (k + 2 < n ? k + 2 : n)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (!__any((uint32_t)u * G < m)) continue;        // a round none of the wavefront's chains reaches
+        va[0][u] = dec_angle<0>(va[0][u]); va[1][u] = dec_angle<1>(va[1][u]); va[2][u] = dec_angle<2>(va[2][u]);
+        va[3][u] = dec_angle<3>(va[3][u]); va[4][u] = dec_angle<4>(va[4][u]); va[5][u] = dec_angle<5>(va[5][u]);
+    }
 
     // ---- validation, as compress_pack_chain orders it ----
     int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
     if (!bad && (n > 65535u || n / thr + 2u > 255u)) bad = FCZ_E_INVALID_ARG;
     if (!bad && ((nonfinite[c >> 5] >> (c & 31u)) & 1u)) bad = FCZ_E_NONFINITE;
     uint32_t nsc = 0;
-    if (k < n) {
-        if (!res_code_ok(rcs)) bad = bad ? bad : FCZ_E_RESIDUE;
-        if (o2 - o0 > (uint32_t)CK_CAP) bad = bad ? bad : FCZ_E_INVALID_ARG;
-        if (nonfinite_f32(va[6])) bad = bad ? bad : FCZ_E_NONFINITE;
-        nsc = fcz_res_natoms[rcs < 24 ? rcs : 23] - 3;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub;
+        if (k < n) {
+            if (!res_code_ok(rcs[u])) bad = bad ? bad : FCZ_E_RESIDUE;
+            if (o2[u] - o0[u] > (uint32_t)CK_CAP) bad = bad ? bad : FCZ_E_INVALID_ARG;
+            if (nonfinite_f32(va[6][u])) bad = bad ? bad : FCZ_E_NONFINITE;
+            nsc += fcz_res_natoms[rcs[u] < 24 ? rcs[u] : 23] - 3;
+        }
     }
     bad = grp_min_i32<G>(bad);
     nsc = grp_sum_u32<G>(nsc);
@@ -1296,37 +1300,52 @@ __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, co
 #pragma unroll
     for (int q = 0; q < 7; q++) {
         const uint32_t cntq = (q < 6) ? m : n;
-        const bool act = k < cntq;
-        float lo = grp_min_f32<G>(act ? va[q] : kInf), hi = grp_max_f32<G>(act ? va[q] : -kInf);
-        const float first = __shfl(va[q], (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), WAVE);     // element 0 of the group's array
+        float lo = kInf, hi = -kInf;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool act = (uint32_t)u * G + sub < cntq;
+            lo = __builtin_fminf(lo, act ? va[q][u] : kInf); hi = __builtin_fmaxf(hi, act ? va[q][u] : -kInf);
+        }
+        lo = grp_min_f32<G>(lo); hi = grp_max_f32<G>(hi);
+        const float first = __shfl(va[q][0], (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), WAVE);     // element 0 of the group's array
         if (__builtin_expect(__any(on && (lo == 0.0f || hi == 0.0f)), 0)) {
-            const lo_hi e = grp_first_extrema<G>(va[q], act, k);
+            ext mn{kInf, 0xffffffffu}, mx{-kInf, 0xffffffffu};
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t k = (uint32_t)u * G + sub;
+                if (k < cntq) { ext_min_upd(mn, va[q][u], k); ext_max_upd(mx, va[q][u], k); }
+            }
+            const lo_hi e = grp_first_extrema<G>(mn, mx);
             if (lo == 0.0f || hi == 0.0f) { lo = e.lo; hi = e.hi; }
         }
         if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
     }
-    if (keep_first_angle && on && k < m) {
+    // ---- the packed words (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52) + B-factor bytes ----
 #pragma unroll
-        for (int q = 0; q < 6; q++) a_arr[(size_t)q * R + k] = va[q];
-    }
-    // ---- the packed word (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52) + B-factor byte ----
-    if (on && k < n) {
-        uint32_t om = 0, ps = 0, ph = 0, b1 = 0, b2 = 0, b3 = 0;
-        if (k < m) {
-            ph = quant_round(va[0], qmin[0], qdisc[0]) & 0xfffu;
-            ps = quant_round(va[1], qmin[1], qdisc[1]) & 0xfffu;
-            om = quant_round(va[2], qmin[2], qdisc[2]) & 0x7ffu;
-            b3 = quant_round(va[3], qmin[3], qdisc[3]) & 0xffu;
-            b1 = quant_round(va[4], qmin[4], qdisc[4]) & 0xffu;
-            b2 = quant_round(va[5], qmin[5], qdisc[5]) & 0xffu;
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub;
+        if (keep_first_angle && on && k < m) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) a_arr[(size_t)q * R + k] = va[q][u];
         }
-        const uint32_t w0 = ((rcs & 0x1fu) << 3) | (om >> 8), w1 = om & 0xffu, w2 = ps >> 4,
-                       w3 = ((ps & 0xfu) << 4) | (ph >> 8), w4 = ph & 0xffu;
-        const uint64_t word = (uint64_t)w0 | ((uint64_t)w1 << 8) | ((uint64_t)w2 << 16) | ((uint64_t)w3 << 24) |
-                              ((uint64_t)w4 << 32) | ((uint64_t)b1 << 40) | ((uint64_t)b2 << 48) | ((uint64_t)b3 << 56);
-        st_u64(rec + RL.o_words + 8 * (size_t)k, word);
-        rec[RL.o_tbytes + k] = (uint8_t)quant_round(va[6], qmin[6], qdisc[6]);
+        if (on && k < n) {
+            uint32_t om = 0, ps = 0, ph = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (k < m) {
+                ph = quant_round(va[0][u], qmin[0], qdisc[0]) & 0xfffu;
+                ps = quant_round(va[1][u], qmin[1], qdisc[1]) & 0xfffu;
+                om = quant_round(va[2][u], qmin[2], qdisc[2]) & 0x7ffu;
+                b3 = quant_round(va[3][u], qmin[3], qdisc[3]) & 0xffu;
+                b1 = quant_round(va[4][u], qmin[4], qdisc[4]) & 0xffu;
+                b2 = quant_round(va[5][u], qmin[5], qdisc[5]) & 0xffu;
+            }
+            const uint32_t w0 = ((rcs[u] & 0x1fu) << 3) | (om >> 8), w1 = om & 0xffu, w2 = ps >> 4,
+                           w3 = ((ps & 0xfu) << 4) | (ph >> 8), w4 = ph & 0xffu;
+            const uint64_t word = (uint64_t)w0 | ((uint64_t)w1 << 8) | ((uint64_t)w2 << 16) | ((uint64_t)w3 << 24) |
+                                  ((uint64_t)w4 << 32) | ((uint64_t)b1 << 40) | ((uint64_t)b2 << 48) | ((uint64_t)b3 << 56);
+            st_u64(rec + RL.o_words + 8 * (size_t)k, word);
+            rec[RL.o_tbytes + k] = (uint8_t)quant_round(va[6][u], qmin[6], qdisc[6]);
+        }
     }
     {
         const uint32_t tlim = on ? title_len : 0u;
@@ -1365,8 +1384,11 @@ __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, co
     }
 }
 
-// Chains of 2 .. CP_SHORT residues belong to k_compress_pack_short, everything else (incl. what is refused) to k_compress_pack.
-constexpr uint32_t CP_SHORT = WAVE;
+// Chains of 2 .. CP_SHORT residues belong to k_compress_pack_rows, everything else (incl. what is refused) to k_compress_pack.
+#ifndef FCZ_PACK_ROWS_MAX_ROUNDS
+#define FCZ_PACK_ROWS_MAX_ROUNDS 8     // chains of up to 16 x this many residues go four to a wavefront (8: up to 128; 202 VGPRs for that class)
+#endif
+constexpr uint32_t CP_SHORT = 16u * FCZ_PACK_ROWS_MAX_ROUNDS;
 #ifndef FCZ_PACK_CLASSES
 #define FCZ_PACK_CLASSES 1
 #endif
@@ -1379,12 +1401,11 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     const uint32_t c = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (c >= in.n_chains) return;
     const uint32_t r0 = in.res_off[c], n = in.res_off[c + 1] - r0;
-    if (n >= 2 && n <= CP_SHORT) return;                      // k_compress_pack_short's
+    if (n >= 2 && n <= CP_SHORT) return;                      // k_compress_pack_rows'
 #if FCZ_PACK_CLASSES
     // rounds of 64 residues held in registers, by length class (wave-uniform): a 100-residue chain does not issue the loads,
     // reductions and stores of a 350-residue one
-    if (n <= 2u * WAVE) compress_pack_chain<2>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
-    else if (n <= 4u * WAVE) compress_pack_chain<4>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
+    if (n <= 4u * WAVE) compress_pack_chain<4>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
     else
 #endif
     compress_pack_chain<6>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
@@ -1397,75 +1418,44 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
 // the chunks of CP_CHUNK consecutive chains w, w + W, ...; one coalesced load gives the chunk's lengths, a ballot the short ones.
 // A batch without short chains costs one load per 16 chains.
 constexpr int CP_CHUNK = 16;
-constexpr uint32_t CP_ROWS = 32;           // chains of up to this many residues go several to a wavefront (k_compress_pack_rows)
-#ifndef FCZ_PACK_SHORT_WAVES
-#define FCZ_PACK_SHORT_WAVES 5
-#endif
-#ifndef FCZ_PACK_ROWS_WAVES
-#define FCZ_PACK_ROWS_WAVES 4
-#endif
-// chains of CP_ROWS + 1 .. CP_SHORT residues, one at a time
-__global__ __launch_bounds__(BLOCK, FCZ_PACK_SHORT_WAVES) void k_compress_pack_short(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                                                               int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
-                                                               const uint32_t* __restrict__ nonfinite) {
+// Chains of 2 .. 64 residues, FOUR to a wavefront: one chain per 16-lane DPP row, in 1, 2 or 4 rounds of 16 residues by length class
+// (2..16, 17..32, 33..64). A persistent grid: wavefront w takes the chunks of CP_CHUNK consecutive chains w, w + W, ...; one
+// coalesced load gives the chunk's lengths, a ballot per class the chains, which are handed to the rows four at a time. A batch
+// without short chains costs one load per 16 chains.
+template <int U>
+__device__ __forceinline__ void pack_rows_class(unsigned long long todo, const uint32_t c0, const uint32_t ro, const uint32_t nn, const fcz_chain_batch& in,
+                                                const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out, int32_t* __restrict__ status,
+                                                float* __restrict__ ang, int keep_first_angle, const uint32_t* __restrict__ nonfinite) {
+    const uint32_t g16 = (uint32_t)(threadIdx.x & 63) >> 4;
+    while (todo) {
+        uint32_t cc = 0, rr0 = 0, rn = 0; bool live = false;
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            if (!todo) break;
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+            if (g16 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
+        }
+        compress_pack_rows<16, U>(in, cc, live, rr0, rn, out_off, out, status, ang, keep_first_angle, nonfinite);
+    }
+}
+// (one kernel per length class: the one-round form fits four wavefronts per SIMD, the four-round form three)
+template <int U>
+__global__ __launch_bounds__(BLOCK, (U >= 8 ? 2 : (U >= 4 ? 3 : 4))) void k_compress_pack_rows(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
+                                                                      int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
+                                                                      const uint32_t* __restrict__ nonfinite) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t n_chunks = (in.n_chains + CP_CHUNK - 1) / CP_CHUNK;
+    constexpr uint32_t LO = U == 1 ? 2u : (uint32_t)(U / 2) * 16u + 1u, HI = (uint32_t)U * 16u;     // 2..16, 17..32, 33..64
     for (uint32_t ch = blockIdx.x * WAVES_PER_BLOCK + wave; ch < n_chunks; ch += n_waves) {
         const uint32_t c0 = ch * CP_CHUNK;
         const uint32_t ci = c0 + (uint32_t)lane;
         const uint32_t ro = in.res_off[ci <= in.n_chains ? ci : in.n_chains];          // lanes 0 .. CP_CHUNK: the chunk's offsets
         const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
-        unsigned long long todo = __ballot(lane < CP_CHUNK && ci < in.n_chains && nn > CP_ROWS && nn <= CP_SHORT);
-        while (todo) {
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), n = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
-            compress_pack_chain<1>(in, c0 + (uint32_t)l, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
-        }
-    }
-}
-
-// chains of 2 .. 16 residues four to a wavefront, 17 .. 32 two to a wavefront (compress_pack_rows); a kernel of its own because the
-// per-lane chain scalars want other registers than the one-chain form (together they spilled and the 33 .. 64 class lost 8 %)
-__global__ __launch_bounds__(BLOCK, FCZ_PACK_ROWS_WAVES) void k_compress_pack_rows(fcz_chain_batch in, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                                                             int32_t* __restrict__ status, float* __restrict__ ang, int keep_first_angle,
-                                                             const uint32_t* __restrict__ nonfinite) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
-    const uint32_t n_chunks = (in.n_chains + CP_CHUNK - 1) / CP_CHUNK;
-    const uint32_t g16 = (uint32_t)lane >> 4, g32 = (uint32_t)lane >> 5;
-    for (uint32_t ch = blockIdx.x * WAVES_PER_BLOCK + wave; ch < n_chunks; ch += n_waves) {
-        const uint32_t c0 = ch * CP_CHUNK;
-        const uint32_t ci = c0 + (uint32_t)lane;
-        const uint32_t ro = in.res_off[ci <= in.n_chains ? ci : in.n_chains];
-        const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
-        const bool mine = lane < CP_CHUNK && ci < in.n_chains;
-        unsigned long long t16 = __ballot(mine && nn >= 2u && nn <= 16u), t32 = __ballot(mine && nn > 16u && nn <= CP_ROWS);
-        while (t16) {
-            uint32_t cc = 0, rr0 = 0, rn = 0; bool live = false;
-#pragma unroll
-            for (uint32_t g = 0; g < 4; g++) {
-                if (!t16) break;
-                const int l = __builtin_ctzll(t16);
-                t16 &= t16 - 1;
-                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
-                if (g16 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
-            }
-            compress_pack_rows<16>(in, cc, live, rr0, rn, out_off, out, status, ang, keep_first_angle, nonfinite);
-        }
-        while (t32) {
-            uint32_t cc = 0, rr0 = 0, rn = 0; bool live = false;
-#pragma unroll
-            for (uint32_t g = 0; g < 2; g++) {
-                if (!t32) break;
-                const int l = __builtin_ctzll(t32);
-                t32 &= t32 - 1;
-                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
-                if (g32 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
-            }
-            compress_pack_rows<32>(in, cc, live, rr0, rn, out_off, out, status, ang, keep_first_angle, nonfinite);
-        }
+        const unsigned long long todo = __ballot(lane < CP_CHUNK && ci < in.n_chains && nn >= LO && nn <= HI);
+        if (todo) pack_rows_class<U>(todo, c0, ro, nn, in, out_off, out, status, ang, keep_first_angle, nonfinite);
     }
 }
 

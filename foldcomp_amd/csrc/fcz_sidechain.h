@@ -33,7 +33,10 @@ namespace fcz {
 //                 whatever follows in the record and are never used)
 // plus the per-residue outputs that need nothing else: B-factor (src/foldcomp.cpp:884-892), residue code, and the
 // chain's OXT atom (:893-900).
-constexpr uint32_t RI_ROWS = 32;           // entries of up to this many residues are k_res_index_rows'
+#ifndef FCZ_INDEX_ROWS_MAX_ROUNDS
+#define FCZ_INDEX_ROWS_MAX_ROUNDS 4    // (8 = entries of up to 128 residues: measured slower here, the rows kernel loses two wavefronts per SIMD)
+#endif
+constexpr uint32_t RI_ROWS = 16u * FCZ_INDEX_ROWS_MAX_ROUNDS;   // entries of up to this many residues are k_res_index_rows' (four to a wavefront)
 __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                      uint32_t n_entries, const uint32_t* __restrict__ res_off,
                                                      const uint32_t* __restrict__ atom_off, uint32_t n_res,
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
     // bytes past the residue's last torsion byte: still inside the record (8-byte B-factor header + n bytes follow).
     // a chain of up to 384 residues: every load of a dependency level is in flight at once (two memory round trips per chain
     // instead of two per 64 residues). The rounds are a compile-time count chosen by the chain's length (1, 2, 4 or 6 rounds of 64
-    // residues): a 37-residue chain does not pay the loads, scans and stores of five empty rounds (round 5; the fixed six rounds
-    // were 2.2 ms per 2 M short chains).
+    // residues; chains of up to 64 are k_res_index_rows'): a 100-residue chain does not pay the loads, scans and stores of four empty
+    // rounds.
     auto rounds = [&](auto U_) {
         constexpr int U = decltype(U_)::value;
         uint32_t wb[U], tq[U], rc[U], na[U], ex[U];
@@ -105,8 +108,7 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
             if (k < n) emit(k, rc[u], tq[u], ex[u], q0[u], q1[u], na[u] > 11 ? q2[u] : 0u);
         }
     };
-    if (n <= (uint32_t)WAVE) rounds(std::integral_constant<int, 1>{});
-    else if (n <= 2u * WAVE) rounds(std::integral_constant<int, 2>{});
+    if (n <= 2u * WAVE) rounds(std::integral_constant<int, 2>{});
     else if (n <= 4u * WAVE) rounds(std::integral_constant<int, 4>{});
     else if (n <= 6u * WAVE) rounds(std::integral_constant<int, 6>{});
     else {
@@ -140,15 +142,16 @@ __global__ __launch_bounds__(BLOCK) void k_res_index(const uint8_t* __restrict__
     }
 }
 
-// Entries of 1 .. 32 residues: one entry per G-lane group (16 lanes: four entries to a wavefront, 32: two), a persistent grid over
-// chunks of 16 consecutive entries. What k_res_index does per wavefront -- header, layout, the B-factor parameters, the OXT -- is
-// done once per group here; a 16-residue chain filled a quarter of the lanes before (1.3 ms per 2 M of them).
-template <int G>
+// Entries of 1 .. 64 residues FOUR to a wavefront: one entry per 16-lane group, in 1, 2 or 4 rounds of 16 residues by length class
+// (lane `sub` of a group holds residues sub, sub + 16, ...); a persistent grid over chunks of 16 consecutive entries. What k_res_index
+// does per wavefront -- header, layout, the B-factor parameters, the OXT -- is done once per group here; a 16-residue chain filled a
+// quarter of the lanes before (1.3 ms per 2 M of them).
+template <int G, int U>
 __device__ __forceinline__ void res_index_rows(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, const uint32_t c, const bool live,
                                                const uint32_t r0, const uint32_t n, const uint32_t* __restrict__ atom_off, uint32_t n_res,
                                                uint32_t* __restrict__ res_aoff, uint8_t* __restrict__ res_rc, uint32_t* __restrict__ res_sc,
                                                const fcz_atoms_out& out, const uint8_t* __restrict__ codes) {
-    const uint32_t k = (uint32_t)(threadIdx.x & (G - 1));
+    const uint32_t sub = (uint32_t)(threadIdx.x & (G - 1));
     // (a group without an entry runs along on a live group's entry -- same addresses, nothing written)
     const uint8_t* e = blob + off[c];
     const entry_view v = view_entry(e);
@@ -156,28 +159,46 @@ __device__ __forceinline__ void res_index_rows(const uint8_t* __restrict__ blob,
     const float tmin = ld_f32(e + v.L.o_tmp), tcf = ld_f32(e + v.L.o_tmp + 4);
     const uint8_t* rcs = codes + (off[c] >> 3);
     const uint8_t* scb = e + v.L.o_sc;
-    const bool act = k < n;
-    const uint32_t kc = act ? k : n - 1;
-    uint32_t rc = rcs[kc];
-    const uint32_t tq = e[v.L.o_tbytes + kc];
-    if (rc >= 24) rc = 23;
-    const uint32_t na = act ? (uint32_t)fcz_res_natoms[rc] : 0u;
-    uint32_t inc = na;
+    uint32_t rc[U], tq[U], na[U], ex[U];
 #pragma unroll
-    for (int d = 1; d < G; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, G); if (k >= (uint32_t)d) inc += t; }
-    const uint32_t run = (uint32_t)__shfl((int)inc, G - 1, G);
-    const uint32_t ex = inc - na;
-    const uint8_t* sp = scb + (act ? ex - 3 * k : 0u);
-    const uint32_t q0 = ld_u32(sp), q1 = ld_u32(sp + 4), q2 = ld_u32((act && na > 11) ? sp + 8 : sp);
-    if (live && act) {
-        const size_t r = (size_t)r0 + k;
-        res_aoff[r] = abase + ex;
-        res_rc[r] = (uint8_t)rc;
-        res_sc[r] = q0; res_sc[(size_t)n_res + r] = q1; res_sc[2 * (size_t)n_res + r] = na > 11 ? q2 : 0u;
-        out.bfac_res[r] = dequant(tq, tmin, tcf);
-        if (out.res_code) out.res_code[r] = (uint8_t)rc;
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub, kc = k < n ? k : n - 1;
+        rc[u] = rcs[kc];
+        tq[u] = e[v.L.o_tbytes + kc];
     }
-    if (live && k == 0) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub;
+        if (rc[u] >= 24) rc[u] = 23;
+        na[u] = k < n ? (uint32_t)fcz_res_natoms[rc[u]] : 0u;
+        uint32_t inc = na[u];
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, G); if (sub >= (uint32_t)d) inc += t; }
+        ex[u] = run + inc - na[u];
+        run += (uint32_t)__shfl((int)inc, G - 1, G);
+    }
+    uint32_t q0[U], q1[U], q2[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub;
+        const bool act = k < n;
+        const uint8_t* sp = scb + (act ? ex[u] - 3 * k : 0u);
+        q0[u] = ld_u32(sp); q1[u] = ld_u32(sp + 4); q2[u] = ld_u32((act && na[u] > 11) ? sp + 8 : sp);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = (uint32_t)u * G + sub;
+        if (live && k < n) {
+            const size_t r = (size_t)r0 + k;
+            res_aoff[r] = abase + ex[u];
+            res_rc[r] = (uint8_t)rc[u];
+            res_sc[r] = q0[u]; res_sc[(size_t)n_res + r] = q1[u]; res_sc[2 * (size_t)n_res + r] = na[u] > 11 ? q2[u] : 0u;
+            out.bfac_res[r] = dequant(tq[u], tmin, tcf);
+            if (out.res_code) out.res_code[r] = (uint8_t)rc[u];
+        }
+    }
+    if (live && sub == 0) {
         const bool oxt = e[v.L.o_oxt] != 0;
         if (oxt) {
             const uint32_t a = abase + run;
@@ -190,6 +211,28 @@ __device__ __forceinline__ void res_index_rows(const uint8_t* __restrict__ blob,
 }
 
 constexpr int RI_CHUNK = 16;
+template <int U>
+__device__ __forceinline__ void res_index_class(unsigned long long todo, const uint32_t c0, const uint32_t ro, const uint32_t nn,
+                                                const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, const uint32_t* __restrict__ atom_off,
+                                                uint32_t n_res, uint32_t* __restrict__ res_aoff, uint8_t* __restrict__ res_rc, uint32_t* __restrict__ res_sc,
+                                                const fcz_atoms_out& out, const uint8_t* __restrict__ codes) {
+    const uint32_t g16 = (uint32_t)(threadIdx.x & 63) >> 4;
+    while (todo) {
+        const int l0 = __builtin_ctzll(todo);
+        uint32_t cc = c0 + (uint32_t)l0, rr0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l0), rn = (uint32_t)__builtin_amdgcn_readlane((int)nn, l0);
+        bool live = g16 == 0;
+        todo &= todo - 1;
+#pragma unroll
+        for (uint32_t g = 1; g < 4; g++) {
+            if (!todo) break;
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
+            if (g16 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
+        }
+        res_index_rows<16, U>(blob, off, cc, live, rr0, rn, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_res_index_rows(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                           uint32_t n_entries, const uint32_t* __restrict__ res_off,
                                                           const uint32_t* __restrict__ atom_off, uint32_t n_res,
@@ -198,42 +241,21 @@ __global__ __launch_bounds__(BLOCK) void k_res_index_rows(const uint8_t* __restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t n_chunks = (n_entries + RI_CHUNK - 1) / RI_CHUNK;
-    const uint32_t g16 = (uint32_t)lane >> 4, g32 = (uint32_t)lane >> 5;
     for (uint32_t ch = blockIdx.x * WAVES_PER_BLOCK + wave; ch < n_chunks; ch += n_waves) {
         const uint32_t c0 = ch * RI_CHUNK;
         const uint32_t ci = c0 + (uint32_t)lane;
         const uint32_t ro = res_off[ci <= n_entries ? ci : n_entries];
         const uint32_t nn = (uint32_t)__shfl_down((int)ro, 1, WAVE) - ro;
         const bool mine = lane < RI_CHUNK && ci < n_entries;
-        unsigned long long t16 = __ballot(mine && nn >= 1u && nn <= 16u), t32 = __ballot(mine && nn > 16u && nn <= RI_ROWS);
-        while (t16) {
-            const int l0 = __builtin_ctzll(t16);
-            uint32_t cc = c0 + (uint32_t)l0, rr0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l0), rn = (uint32_t)__builtin_amdgcn_readlane((int)nn, l0);
-            bool live = g16 == 0;
-            t16 &= t16 - 1;
-#pragma unroll
-            for (uint32_t g = 1; g < 4; g++) {
-                if (!t16) break;
-                const int l = __builtin_ctzll(t16);
-                t16 &= t16 - 1;
-                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
-                if (g16 == g) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
-            }
-            res_index_rows<16>(blob, off, cc, live, rr0, rn, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
-        }
-        while (t32) {
-            const int l0 = __builtin_ctzll(t32);
-            uint32_t cc = c0 + (uint32_t)l0, rr0 = (uint32_t)__builtin_amdgcn_readlane((int)ro, l0), rn = (uint32_t)__builtin_amdgcn_readlane((int)nn, l0);
-            bool live = g32 == 0;
-            t32 &= t32 - 1;
-            if (t32) {
-                const int l = __builtin_ctzll(t32);
-                t32 &= t32 - 1;
-                const uint32_t r0g = (uint32_t)__builtin_amdgcn_readlane((int)ro, l), ng = (uint32_t)__builtin_amdgcn_readlane((int)nn, l);
-                if (g32 == 1) { cc = c0 + (uint32_t)l; rr0 = r0g; rn = ng; live = true; }
-            }
-            res_index_rows<32>(blob, off, cc, live, rr0, rn, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
-        }
+        const unsigned long long t1 = __ballot(mine && nn >= 1u && nn <= 16u), t2 = __ballot(mine && nn > 16u && nn <= 32u),
+                                 t4 = __ballot(mine && nn > 32u && nn <= 64u);
+        if (t1) res_index_class<1>(t1, c0, ro, nn, blob, off, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+        if (t2) res_index_class<2>(t2, c0, ro, nn, blob, off, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+        if (t4) res_index_class<4>(t4, c0, ro, nn, blob, off, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+#if FCZ_INDEX_ROWS_MAX_ROUNDS >= 8
+        const unsigned long long t8 = __ballot(mine && nn > 64u && nn <= 128u);
+        if (t8) res_index_class<8>(t8, c0, ro, nn, blob, off, atom_off, n_res, res_aoff, res_rc, res_sc, out, codes);
+#endif
     }
 }
 

@@ -104,15 +104,15 @@ def test_many_tiny_chains(codec):
 
 def test_length_classes_in_one_batch_with_refused_neighbours(codec):
     """The compress side sorts a batch's chains into length classes handled by different kernels (round 5): 2..16 residues four
-    to a wavefront, 17..32 two to a wavefront (compress_pack_rows: a 16- / 32-lane group per chain), 33..64 one at a time with one
-    round of values, 65..128 / ..256 / ..384 with 2 / 4 / 6 rounds, longer ones in two passes -- and the decompress side's
+    to a wavefront in one round of 16 lanes, 17..32 / 33..64 / 65..128 four to a wavefront in 2 / 4 / 8 rounds (compress_pack_rows: a
+    16-lane group per chain), ..256 / ..384 a wavefront each with 4 / 6 rounds of 64, longer ones in two passes -- and the decompress side's
     k_res_index / k_res_index_rows likewise. Every length from 2 to 70 and the class edges beyond, in random order, so that the
     groups of one wavefront hold chains of different lengths, partly filled wavefronts occur, and refused chains (a residue name
     the reference cannot process, a NaN B-factor, a NaN coordinate) sit in groups next to good ones: statuses as expected, refused
     records zero, every other record and its decode equal to the oracle's. Both anchor thresholds 25 and 3 (many anchors per
     chain: the per-lane anchor loop of a group takes several rounds)."""
     rng = np.random.default_rng(77)
-    lens = list(range(2, 71)) * 3 + [127, 128, 129, 255, 256, 257, 383, 384, 385, 600] + [16] * 37 + [32] * 21 + [17, 33, 64, 65] * 5
+    lens = list(range(2, 71)) * 3 + list(range(71, 131, 3)) + [127, 128, 129, 255, 256, 257, 383, 384, 385, 600] + [16] * 37 + [32] * 21 + [17, 33, 64, 65, 128] * 5
     rng.shuffle(lens)
     for thr in (25, 3):
         b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=4242, anchor_threshold=thr))

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5: chains of <= 32 residues several to a wavefront (compress_pack_rows). usage: tools/r5_rows_ab.sh <tag> <lib>...
+# round 5: should chains of 65..128 residues go four to a wavefront too (8 rounds of 16)? usage: tools/r5_rows8_ab.sh <tag> <lib>...
 TAG=$1; shift
-OUT=gpurun_out/rows_$TAG.txt; : > $OUT
-run() { # lib, label, bench args...
+OUT=gpurun_out/rows8_$TAG.txt; : > $OUT
+run() {
   local lib=$1 label=$2; shift 2
   FCZ_HIP_LIB=$PWD/$lib python bench.py "$@" --steps 3 --warmup 1 --cpu-sample 0 --pdb-sample 0 --mixed-chains 0 --e2e-files 0 --host-chains 0 > /tmp/ab.json 2> /tmp/ab.err || { echo "$lib $label FAILED" >> $OUT; tail -3 /tmp/ab.err >> $OUT; return; }
   python - "$lib" "$label" >> $OUT <<'PY'
@@ -12,11 +12,11 @@ print(sys.argv[1], sys.argv[2], "Gres/s=%.3f" % (d["value"] / 1e9), "step_ms=%.2
 PY
 }
 for lib in "$@"; do
-  run $lib res16 --residues 16 --chains 2000000 --parity-chains 262144 --seed-base 66000000000
-  run $lib res32 --residues 32 --chains 2000000 --parity-chains 262144 --seed-base 99000000000
-  run $lib res37 --residues 37 --chains 2000000 --parity-chains 262144
-  run $lib res64 --residues 64 --chains 1000000 --parity-chains 131072 --seed-base 77000000000
-  run $lib mixed --mixed --chains 542000 --parity-chains 16384
+  run $lib res16 --residues 16 --chains 2000000 --parity-chains 131072 --seed-base 66000000000
+  run $lib res37 --residues 37 --chains 2000000 --parity-chains 131072
+  run $lib res100 --residues 100 --chains 1000000 --parity-chains 131072 --seed-base 44000000000
+  run $lib res129 --residues 129 --chains 1000000 --parity-chains 65536 --seed-base 55000000000
+  run $lib mixed --mixed --chains 542000 --parity-chains 65536
   run $lib res350 --chains 262144 --parity-chains 8192
 done
 cat $OUT

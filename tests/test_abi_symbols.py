@@ -108,6 +108,34 @@ def test_no_cpu_fallback_without_gpu():
         Codec(0)
 
 
+def test_engine_and_status_strings_fail_loudly_without_gpu(tmp_path):
+    """the C++ engine in every mode a sharded run starts it in -- also the placed decompress (sizes pass first) -- refuses to run
+    without a HIP device instead of computing anything on the CPU, and prints no counts a driver could mistake for a sizes pass;
+    the status added in round 5 has its text"""
+    import subprocess
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    lib = _lib.load()
+    lib.fcz_status_string.restype = ctypes.c_char_p
+    assert b"finite" in lib.fcz_status_string(-9) and _lib.STATUS[-9] == "FCZ_E_NONFINITE"
+    if has_gpu:
+        pytest.skip("GPU present")
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "host", "foldcomp-hip")
+    if not os.path.exists(host):
+        pytest.skip("host/foldcomp-hip not built")
+    for ext in ("", ".index", ".lookup"):
+        (tmp_path / ("db" + ext)).write_bytes(b"")
+    (tmp_path / "db.dbtype").write_bytes((12).to_bytes(4, "little"))
+    for extra in ([], ["--place"]):
+        r = subprocess.run([host, "decompress", "-d", "-y", "--shard", "0/2", *extra, str(tmp_path / "db"), str(tmp_path / "out")],
+                           input="0 0 0\n", capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "no HIP device" in r.stderr and '"phase"' not in r.stdout, (extra, r.stdout, r.stderr)
+        assert not os.path.exists(tmp_path / "out")
+
+
 def test_host_extract_sizes_match_reference_strings(golden):
     """fcz_extract_sizes is pure host code: the data sizes must equal the lengths of the reference's extract strings"""
     z, index = golden

@@ -25,7 +25,13 @@
 //                      (src/torsion_angle.cpp:74-94, src/float3d.h:55-65), per-chain quantiser parameters (min/max with
 //                      std::min_element semantics, src/discretizer.cpp:22-33), the packed 8-byte words
 //                      (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52), B-factor bytes, anchors
-//                      (_setAnchor :745-761), OXT (:474-482), title and header (:1038-1109).
+//                      (_setAnchor :745-761), OXT (:474-482), title and header (:1038-1109). Chains beyond 128 residues
+//                      (4 or 6 rounds of 64 residues in registers by length class; beyond 384 in blocks of 384).
+//   k_compress_pack_rows<U>  the same work for chains of up to 128 residues, FOUR to a wavefront: one chain per 16-lane DPP
+//                      row, U = 1 / 2 / 4 / 8 rounds of 16 residues by length class -- what a chain costs before its first
+//                      residue is shared by the four chains of the wavefront (round 5).
+//   Non-finite input (a NaN / infinity in a coordinate of a named atom or a CA B-factor) is found by the angle kernels on the
+//   values they stage and refused by the pack kernels (FCZ_E_NONFINITE).
 #pragma once
 #include "fcz_kernels.h"
 

@@ -69,9 +69,9 @@ def host_threads(world: int) -> int:
     return max(1, n // max(1, world))
 
 
-def engine_command(a, rank: int, world: int, device_index: int, out_path: str, host: str = ENGINE, place: bool = False) -> List[str]:
+def engine_command(a, rank: int, world: int, device_index: int, out_path: str, host: str = None, place: bool = False) -> List[str]:
     """the rank's engine: the C++ host on its range of the inputs (same option letters as the reference's command line)"""
-    cmd = [host, a.mode, "-d", "-y", "--gpus", "1", "--device", str(device_index), "--device-mod", "--shard", f"{rank}/{world}", "--json-stats",
+    cmd = [host or ENGINE, a.mode, "-d", "-y", "--gpus", "1", "--device", str(device_index), "--device-mod", "--shard", f"{rank}/{world}", "--json-stats",
            "-t", str(a.threads if a.threads and a.threads > 1 else host_threads(world)), "-b", str(a.brk)]
     if a.recursive:
         cmd.append("-r")

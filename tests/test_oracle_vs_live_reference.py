@@ -3,7 +3,7 @@ fresh chains of the bench generator -- the uniform 350-residue shape of configs[
 record by record and atom by atom: every large-scale bit-exact claim of the GPU path is made against the restatement, this pins
 the restatement on the workload itself.
 
-Default size: 1 500 + 1 500 chains (seconds). FCZ_SLOW_CHAINS=100000 runs the full-size check (minutes; the line it prints is kept
+Default size: 600 + 600 chains (seconds; the mixed-length generator is dense in chains x longest chain on the CPU). FCZ_SLOW_CHAINS=100000 runs the full-size check (minutes; the line it prints is kept
 under profiles/ per round)."""
 import json
 import os
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built 
 @pytest.mark.parametrize("mixed", [False, True])
 def test_restatement_equals_live_reference_on_bench_chains(mixed):
     import bench
-    n = int(os.environ.get("FCZ_SLOW_CHAINS", "3000")) // 2
+    n = int(os.environ.get("FCZ_SLOW_CHAINS", "1200")) // 2
     seed_base = int(os.environ.get("FCZ_SLOW_SEED", "777000"))
     d = bench.generate_resident(n, 350, 25, 8192, "cpu", seed_base, mixed=mixed)
     hb = bench.host_slice(d, 0, n)

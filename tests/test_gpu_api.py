@@ -86,7 +86,10 @@ def test_get_data_fcz(golden):
 def test_get_data_pdb_angles_bit_exact(golden):
     z, _ = golden
     # syn:len700 / syn:len1400: chains beyond the register path of the pack kernel (angles finished in place, two passes)
-    for name in ("pdb:test_af", "pdb:test", "syn:len129", "syn:len351", "syn:len700", "syn:len1400"):
+    # ... and every length class of the rows kernels (four chains to a wavefront: 1 / 2 / 4 / 8 rounds of 16 residues; the finished
+    # angles and the first residue's N-CA-C angle are left in the scratch by a 16-lane group there)
+    for name in ("pdb:test_af", "pdb:test", "syn:len129", "syn:len351", "syn:len700", "syn:len1400",
+                 "syn:len2", "syn:len3", "syn:len7", "syn:len24", "syn:len26", "syn:len49", "syn:len64", "syn:len65", "syn:len127", "syn:len128", "syn:thr10"):
         text, _ = _input_pdb_text(z, name)
         d = foldcomp.get_data(text)
         for k in ("phi", "psi", "omega"):

@@ -192,6 +192,45 @@ class Codec:
         return dict(blob=blob[:int(nbytes.value)], off=off, status=st, chain_file=chain_file, chain_meta=chain_meta,
                     file_status=file_status, refused=refused, counts=counts)
 
+    # ---- gzip members on the device ----------------------------------------------------------------
+    INFLATE_STATUS = {0: "ok", 1: "header", 2: "block", 3: "code", 4: "size", 5: "input", 6: "check"}
+
+    def inflate(self, members, kind=None):
+        """gzip members (bytes each) -> (list of texts, status[n]): fcz_inflate_sizes + fcz_inflate. A member with a non-zero status
+        was NOT inflated on the device (the caller's zlib decides about it); its text is returned as blanks of the ISIZE it claims."""
+        n = len(members)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(m) for m in members])
+        raw = np.frombuffer(b"".join(members) or b"\0", np.uint8)
+        kd = None if kind is None else np.ascontiguousarray(kind, np.uint8)
+        toff = np.zeros(n + 1, np.uint64)
+        _lib.check(self.lib.fcz_inflate_sizes(raw.ctypes.data, off.ctypes.data, n, None if kd is None else kd.ctypes.data, toff.ctypes.data),
+                   "fcz_inflate_sizes")
+        text = np.zeros(max(int(toff[n]), 1), np.uint8); st = np.zeros(n, np.int32)
+        _lib.check(self.lib.fcz_inflate(self.ctx, raw.ctypes.data, off.ctypes.data, n, None if kd is None else kd.ctypes.data, toff.ctypes.data,
+                                        text.ctypes.data, st.ctypes.data), "fcz_inflate")
+        tb = text.tobytes()
+        return [tb[int(toff[i]):int(toff[i + 1])] for i in range(n)], st
+
+    def compress_gz(self, files, names, is_gz=None, anchor_threshold: int = 25, skip_discontinuous: bool = False):
+        """Structure files as they lie on disk (gzip members where is_gz, by default where the name ends in .gz) -> FCZ records:
+        inflate, parse and codec on the GPU. Same dict as compress_pdb; file_status 5 = the member is left to the caller's zlib."""
+        data, file_off, name_blob, name_off, stem_len = self._pack_files(files, names)
+        gz = np.asarray([n.endswith(".gz") for n in names] if is_gz is None else is_gz, np.uint8)
+        counts = np.zeros(5, np.uint32); nbytes = ctypes.c_uint64(0)
+        _lib.check(self.lib.fcz_compress_gz_begin(self.ctx, data.ctypes.data, file_off.ctypes.data, len(files), gz.ctypes.data, name_blob.ctypes.data,
+                                                  name_off.ctypes.data, stem_len.ctypes.data, int(anchor_threshold),
+                                                  1 if skip_discontinuous else 0, counts.ctypes.data, ctypes.byref(nbytes)),
+                   "fcz_compress_gz_begin")
+        C, NR = int(counts[0]), int(counts[4])
+        off = np.zeros(C + 1, np.uint64); st = np.zeros(C, np.int32); blob = np.zeros(max(int(nbytes.value), 1), np.uint8)
+        chain_file = np.zeros(C, np.uint32); chain_meta = np.zeros(C, np.uint32)
+        file_status = np.zeros(len(files), np.int32); refused = np.zeros((NR, 2), np.uint32)
+        _lib.check(self.lib.fcz_compress_pdb_fetch(self.ctx, off.ctypes.data, st.ctypes.data, chain_file.ctypes.data, chain_meta.ctypes.data,
+                                                   file_status.ctypes.data, refused.ctypes.data, blob.ctypes.data), "fcz_compress_pdb_fetch")
+        return dict(blob=blob[:int(nbytes.value)], off=off, status=st, chain_file=chain_file, chain_meta=chain_meta,
+                    file_status=file_status, refused=refused, counts=counts)
+
     # ---- timing ---------------------------------------------------------------------------------
     def enable_timing(self, on: bool = True):
         self.lib.fcz_ctx_enable_timing(self.ctx, int(on))

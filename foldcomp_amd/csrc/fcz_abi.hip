@@ -28,6 +28,7 @@
 #include "fcz_extract.h"
 #include "fcz_ingest.h"
 #include "fcz_ingest_cif.h"
+#include "fcz_inflate.h"
 
 // second, host-side instance of the generated tables (integer metadata for sizes/validation)
 namespace host_tab {
@@ -115,6 +116,8 @@ struct fcz_ctx {
     fcz_ingest_result ig_res{};
     uint32_t ig_counts[5] = {0, 0, 0, 0, 0};
     uint64_t ig_fcz_bytes = 0;
+    // inflate in front of the ingest: the files' bytes as they came over the link, their offsets / kinds / text offsets / statuses
+    dev_buf gz_raw, gz_off, gz_kind, gz_toff, gz_status;
     std::vector<timed_span> spans;
     std::map<std::string, std::pair<double, uint64_t>> acc;
 };
@@ -234,6 +237,7 @@ void fcz_ctx_destroy(fcz_ctx* c) {
     c->ang.release(); c->res_sc_addr.release(); c->tile_work.release(); c->sizes.release(); c->scan_tmp.release(); c->codes.release(); c->cnt.release(); c->fwd.release(); c->bb.release(); c->wring.release(); c->fwd_long.release(); c->wring_long.release(); c->res_aoff.release(); c->len_perm.release(); c->pdb_size.release(); c->pdb_off.release(); c->pdb_text.release(); c->res_rc.release(); c->res_sc.release(); c->fast_scratch.release();
     for (auto& b : c->stage) b.release();
     for (auto& b : c->ig) b.release();
+    c->gz_raw.release(); c->gz_off.release(); c->gz_kind.release(); c->gz_toff.release(); c->gz_status.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -770,12 +774,126 @@ int fcz_ingest_pdb_fetch(fcz_ctx* ctx, const fcz_chain_batch* hb, uint32_t* chai
     return FCZ_OK;
 }
 
+// the compress half of fcz_compress_pdb_begin / fcz_compress_gz_begin: sizes, then the codec, on the batch the ingest left in the ctx
+static int compress_resident_batch(fcz_ctx* ctx, uint64_t* fcz_bytes);
+
 int fcz_compress_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* file_off, uint32_t n_files, const char* names, const uint32_t* name_off,
                            const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5], uint64_t* fcz_bytes) {
     if (!fcz_bytes) return FCZ_E_INVALID_ARG;
     *fcz_bytes = 0; if (ctx) ctx->ig_fcz_bytes = 0;
     int rc = fcz_ingest_pdb_begin(ctx, text, file_off, n_files, names, name_off, stem_len, anchor_threshold, flags, counts);
     if (rc) return rc;
+    return compress_resident_batch(ctx, fcz_bytes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inflate: gzip members -> text on the device (fcz_inflate.h)
+// ------------------------------------------------------------------------------------------------
+int fcz_inflate_sizes(const uint8_t* gz, const uint64_t* gz_off, uint32_t n, const uint8_t* kind, uint64_t* text_off) {
+    if (!text_off || (n && (!gz || !gz_off))) return FCZ_E_INVALID_ARG;
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        text_off[i] = pos;
+        if (gz_off[i + 1] < gz_off[i]) return FCZ_E_INVALID_ARG;
+        const uint64_t len = gz_off[i + 1] - gz_off[i];
+        if (kind && kind[i] == 0) { pos += len; continue; }
+        if (len < 18) continue;
+        const uint8_t* t = gz + gz_off[i + 1] - 4;
+        const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+        // DEFLATE expands by at most 1032 : 1 (258 bytes per two bits, zlib's documented bound); an ISIZE beyond that is not this
+        // member's text size (a corrupt trailer, several members, > 4 GB of text): zlib's to read
+        if (isize > (len - 18) * 1032 + 1024 || isize >= (1ull << 31)) continue;
+        pos += isize;
+    }
+    text_off[n] = pos;
+    return FCZ_OK;
+}
+
+int fcz_inflate_dev(fcz_ctx* ctx, const uint8_t* gz_dev, const uint64_t* gz_off_dev, uint32_t n, const uint8_t* kind_dev,
+                    const uint64_t* text_off_dev, uint8_t* text_dev, int32_t* status_dev) {
+    if (!ctx) return FCZ_E_INVALID_ARG;
+    if (n == 0) return FCZ_OK;
+    if (!gz_dev || !gz_off_dev || !text_off_dev || !text_dev || !status_dev) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    {
+        span_guard g(ctx, "inflate");
+        hipLaunchKernelGGL(inflate::k_inflate, dim3(n), dim3(WAVE), 0, ctx->stream, gz_dev, gz_off_dev, n, kind_dev, text_off_dev, text_dev, status_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return FCZ_OK;
+}
+
+// the files' bytes -> ctx->gz_raw, their text -> ctx->stage[0] (text offsets in ctx->gz_toff, statuses in ctx->gz_status)
+static int inflate_into_stage(fcz_ctx* ctx, const uint8_t* data, const uint64_t* file_off, uint32_t n, const uint8_t* kind, const uint64_t* text_off) {
+    const uint64_t raw_bytes = file_off[n], text_bytes = text_off[n];
+    int rc;
+    if ((rc = ctx->gz_raw.ensure(std::max<uint64_t>(raw_bytes, 16))) || (rc = ctx->gz_off.ensure(8 * ((size_t)n + 1))) || (rc = ctx->gz_kind.ensure(std::max<size_t>(n, 16))) ||
+        (rc = ctx->gz_toff.ensure(8 * ((size_t)n + 1))) || (rc = ctx->gz_status.ensure(4 * (size_t)n + 16)) || (rc = ctx->stage[0].ensure(std::max<uint64_t>(text_bytes, 16))))
+        return rc;
+    if (raw_bytes) HIP_TRY(hipMemcpyAsync(ctx->gz_raw.p, data, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->gz_off.p, file_off, 8 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->gz_toff.p, text_off, 8 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (kind) HIP_TRY(hipMemcpyAsync(ctx->gz_kind.p, kind, n, hipMemcpyHostToDevice, ctx->stream));
+    return fcz_inflate_dev(ctx, ctx->gz_raw.as<uint8_t>(), ctx->gz_off.as<uint64_t>(), n, kind ? ctx->gz_kind.as<uint8_t>() : nullptr,
+                           ctx->gz_toff.as<uint64_t>(), ctx->stage[0].as<uint8_t>(), ctx->gz_status.as<int32_t>());
+}
+
+int fcz_inflate(fcz_ctx* ctx, const uint8_t* gz, const uint64_t* gz_off, uint32_t n, const uint8_t* kind, const uint64_t* text_off,
+                uint8_t* text, int32_t* status) {
+    if (!ctx) return FCZ_E_INVALID_ARG;
+    if (n == 0) return FCZ_OK;
+    if (!gz || !gz_off || !text_off || !status || (text_off[n] && !text)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->sizes_fresh = false;   // staging buffers are rewritten
+    int rc = inflate_into_stage(ctx, gz, gz_off, n, kind, text_off);
+    if (rc) return rc;
+    if (text_off[n]) HIP_TRY(hipMemcpyAsync(text, ctx->stage[0].p, text_off[n], hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(status, ctx->gz_status.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FCZ_OK;
+}
+
+int fcz_ingest_gz_begin(fcz_ctx* ctx, const uint8_t* data, const uint64_t* file_off, uint32_t n_files, const uint8_t* is_gz, const char* names,
+                        const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5]) {
+    if (!ctx || !counts || anchor_threshold <= 0) return FCZ_E_INVALID_ARG;
+    if (n_files && (!data || !file_off || !names || !name_off || !stem_len)) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->sizes_fresh = false;   // staging buffers are rewritten
+    memset(counts, 0, 5 * sizeof(uint32_t));
+    if (n_files == 0) { memset(&ctx->ig_res, 0, sizeof ctx->ig_res); memset(ctx->ig_counts, 0, sizeof ctx->ig_counts); return FCZ_OK; }
+    std::vector<uint64_t> text_off((size_t)n_files + 1);
+    int rc = fcz_inflate_sizes(data, file_off, n_files, is_gz, text_off.data());
+    if (rc) return rc;
+    if ((rc = inflate_into_stage(ctx, data, file_off, n_files, is_gz, text_off.data()))) return rc;
+    const uint32_t name_bytes = name_off[n_files];
+    if ((rc = ctx->stage[2].ensure(std::max<size_t>(name_bytes, 16))) || (rc = ctx->stage[3].ensure(4 * ((size_t)n_files + 1))) || (rc = ctx->stage[4].ensure(4 * (size_t)n_files)))
+        return rc;
+    if (name_bytes) HIP_TRY(hipMemcpyAsync(ctx->stage[2].p, names, name_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[3].p, name_off, 4 * ((size_t)n_files + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->stage[4].p, stem_len, 4 * (size_t)n_files, hipMemcpyHostToDevice, ctx->stream));
+    fcz_ingest_result res;
+    rc = fcz_ingest_pdb_dev(ctx, ctx->stage[0].as<uint8_t>(), ctx->gz_toff.as<uint64_t>(), n_files, text_off[n_files], ctx->stage[2].as<char>(),
+                            ctx->stage[3].as<uint32_t>(), ctx->stage[4].as<uint32_t>(), anchor_threshold, flags, &res);
+    if (rc) return rc;
+    // a member the device did not inflate left blanks (no atoms): the FILE goes back to the caller's zlib and reader
+    hipLaunchKernelGGL(inflate::k_inflate_merge_status, dim3(grid_for(n_files, 256)), dim3(256), 0, ctx->stream, ctx->gz_status.as<int32_t>(), n_files,
+                       (int32_t)FCZ_INGEST_HOST_GZIP, const_cast<int32_t*>(ctx->ig_res.file_status));
+    HIP_TRY(hipGetLastError());
+    memcpy(counts, ctx->ig_counts, sizeof ctx->ig_counts);
+    return FCZ_OK;
+}
+
+int fcz_compress_gz_begin(fcz_ctx* ctx, const uint8_t* data, const uint64_t* file_off, uint32_t n_files, const uint8_t* is_gz, const char* names,
+                          const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5], uint64_t* fcz_bytes) {
+    if (!fcz_bytes) return FCZ_E_INVALID_ARG;
+    *fcz_bytes = 0; if (ctx) ctx->ig_fcz_bytes = 0;
+    int rc = fcz_ingest_gz_begin(ctx, data, file_off, n_files, is_gz, names, name_off, stem_len, anchor_threshold, flags, counts);
+    if (rc) return rc;
+    return compress_resident_batch(ctx, fcz_bytes);
+}
+
+static int compress_resident_batch(fcz_ctx* ctx, uint64_t* fcz_bytes) {
+    int rc;
     const fcz_chain_batch& b = ctx->ig_res.batch;
     const uint32_t C = b.n_chains;
     if (C == 0) return FCZ_OK;

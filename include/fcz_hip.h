@@ -254,7 +254,7 @@ int fcz_decompress_pdb_sizes(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
  * repository restate every rule: foldcomp_amd/structure.py parse_pdb_gemmi, host/foldcomp_hip.cpp parse_pdb_gemmi). refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the
  * fragments that were left out (residue name the codec does not know, residue without N, CA, C in order or with a second one
  * of them, a last atom that carries another residue name than its residue, chain beyond the header's counts,
- * --skip-discontinuous). Gzip stays on the host (its read threads inflate; the inflated text is parsed here).
+ * --skip-discontinuous). Gzipped files: fcz_ingest_gz_begin below (inflated on the device in front of this stage).
  * mmCIF text (round 4, k_ingest_parse_cif + k_ingest_rows_cif): a file that opens with data_ (gemmi::coor_format_from_content, lib/gemmi/mmread.hpp:31-47)
  * is read by gemmi's mmCIF rules (cif.hpp:37-148 grammar, mmcif.hpp:560-680 make_structure: the _atom_site loop's 23 columns by any
  * case, chain = auth_asym_id else label_asym_id, residue = auth_seq_id + comp id, atom name = auth_atom_id else label_atom_id,
@@ -300,6 +300,51 @@ int fcz_compress_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* fi
 int fcz_compress_pdb_fetch(fcz_ctx* ctx, uint64_t* out_off, int32_t* status, uint32_t* chain_file, uint32_t* chain_meta,
                            int32_t* file_status, uint32_t* refused, uint8_t* blob);
 
+/* ---- inflate: gzip members -> text in HBM (round 6) -------------------------------------------------------- */
+/* What the reference's reader does with zlib before it parses a `.pdb.gz` / `.cif.gz` input: gemmi::MaybeGzipped
+ * (lib/gemmi/gz.hpp:105-133: gzread into a buffer sized from ISIZE, the member's last four bytes) for files, uncompressBuffer
+ * (src/structure_reader.cpp:156-203: inflateInit2(15 | 32), inflate()) for database / tar entries. Here: one wavefront per member
+ * (k_inflate, foldcomp_amd/csrc/fcz_inflate.h: RFC 1952 header and trailer, RFC 1951 stored / fixed / dynamic blocks, CRC-32 and ISIZE
+ * verified on the device), the text written where the structure ingest reads it.
+ * The device never guesses: status[i] != FCZ_INFLATE_OK means the member was NOT inflated here (its text range holds blanks) and
+ * the caller's zlib has to take it -- that covers every stream zlib's inflate() rejects (invalid block type / stored lengths /
+ * code-length set, over-subscribed or incomplete code, invalid literal/length or distance code, distance too far back, incorrect
+ * data or length check, truncation) and streams this decoder does not read although zlib does: a header CRC (FHCRC), a header
+ * beyond 252 bytes, an incomplete literal/length code, more than one member / bytes after the trailer, an ISIZE that is not the
+ * text's size. FCZ_INFLATE_OK: the bytes are what zlib's inflate() returns for the member, checked by CRC-32 and ISIZE. */
+enum fcz_inflate_status {
+    FCZ_INFLATE_OK = 0,
+    FCZ_INFLATE_HEADER = 1,     /* not a gzip member this decoder reads (magic, method, flags, header length, member < 18 bytes) */
+    FCZ_INFLATE_BLOCK = 2,      /* a block header zlib rejects (or an incomplete literal/length code: zlib's to judge) */
+    FCZ_INFLATE_CODE = 3,       /* invalid code / distance symbol, distance before the start of the text */
+    FCZ_INFLATE_SIZE = 4,       /* the text is not text_off[i + 1] - text_off[i] bytes long */
+    FCZ_INFLATE_INPUT = 5,      /* the stream runs past the member's end, or bytes are left before the trailer */
+    FCZ_INFLATE_CHECK = 6       /* CRC-32 or ISIZE of the trailer do not match */
+};
+/* Host: exclusive prefix of the text sizes in text_off[n + 1], member i sized from its ISIZE (gemmi estimate_uncompressed_size,
+ * lib/gemmi/gz.hpp:25-45). kind (may be NULL = every entry a gzip member): 1 gzip member, 0 plain bytes (size = length). A member
+ * shorter than 18 bytes, or whose ISIZE exceeds what DEFLATE can expand its bytes to (1032 : 1), is sized 0 and will be refused. */
+int fcz_inflate_sizes(const uint8_t* gz, const uint64_t* gz_off, uint32_t n, const uint8_t* kind, uint64_t* text_off);
+/* Device-resident: every pointer a device pointer (kind_dev may be NULL); enqueued on the ctx stream, no synchronisation.
+ * text_dev[text_off[i] .. text_off[i + 1]) receives member i's text (kind 0: a copy of its bytes), status_dev[i] its status. */
+int fcz_inflate_dev(fcz_ctx* ctx, const uint8_t* gz_dev, const uint64_t* gz_off_dev, uint32_t n, const uint8_t* kind_dev,
+                    const uint64_t* text_off_dev, uint8_t* text_dev, int32_t* status_dev);
+/* Host-pointer convenience (tests, small callers): members in, text + status out. */
+int fcz_inflate(fcz_ctx* ctx, const uint8_t* gz, const uint64_t* gz_off, uint32_t n, const uint8_t* kind, const uint64_t* text_off,
+                uint8_t* text, int32_t* status);
+/* Structure files as they lie on disk -> batch / FCZ records: fcz_ingest_pdb_begin / fcz_compress_pdb_begin with an inflate stage in
+ * front. data = the files' bytes back to back, is_gz[i] != 0: file i is a gzip member (the reference decides by the name's `.gz`,
+ * gemmi::MaybeGzipped::is_compressed) -- a fifth of the text's bytes cross the link. The results are fetched with
+ * fcz_ingest_pdb_fetch / fcz_compress_pdb_fetch; file_status[i] == FCZ_INGEST_HOST_GZIP: the member was not inflated here (see
+ * above), the caller inflates and reads the file itself. */
+#define FCZ_INGEST_HOST_GZIP 5
+int fcz_ingest_gz_begin(fcz_ctx* ctx, const uint8_t* data, const uint64_t* file_off, uint32_t n_files, const uint8_t* is_gz,
+                        const char* names, const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags,
+                        uint32_t counts[5]);
+int fcz_compress_gz_begin(fcz_ctx* ctx, const uint8_t* data, const uint64_t* file_off, uint32_t n_files, const uint8_t* is_gz,
+                          const char* names, const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags,
+                          uint32_t counts[5], uint64_t* fcz_bytes);
+
 /* ---- extract ---------------------------------------------------------------------------------- */
 /* Foldcomp::extract (src/foldcomp.cpp:1260-1336) straight from the FCZ bytes, no reconstruction.
  *   mode 0: pLDDT (B-factor) of every residue with `digits` in 1..4 characters ("d", "dd", "dd.d", "dd.dd"; digit rules
@@ -323,7 +368,7 @@ int fcz_check(const uint8_t* entry, uint64_t len);
 /* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named kernel
  * group since the last reset: "compress_sizes", "compress_index", "compress_angles", "compress_pack",
  * "decompress_sizes", "decompress_backbone", "decompress_index", "decompress_sidechain", "pdb_sizes", "pdb_format", "extract_sizes", "extract",
- * "ingest_parse", "ingest_parse_cif", "ingest_rows_cif", "ingest_frags", "ingest_fill". */
+ * "ingest_parse", "ingest_parse_cif", "ingest_rows_cif", "ingest_frags", "ingest_fill", "inflate". */
 int  fcz_ctx_enable_timing(fcz_ctx* ctx, int enable);
 int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* launches);
 void fcz_ctx_reset_timing(fcz_ctx* ctx);

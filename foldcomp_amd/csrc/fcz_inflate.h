@@ -26,7 +26,7 @@
 #include "fcz_kernels.h"
 
 #ifndef FCZ_INFLATE_RING_BITS
-#define FCZ_INFLATE_RING_BITS 14
+#define FCZ_INFLATE_RING_BITS 13
 #endif
 
 namespace fcz {
@@ -34,7 +34,10 @@ namespace inflate {
 
 constexpr uint32_t RING = 1u << FCZ_INFLATE_RING_BITS, RMASK = RING - 1u;
 constexpr uint32_t ROUND = 4096;                 // bytes per flush round (64 lanes x 64 bytes)
-constexpr int LBITS = 9, DBITS = 8;              // index bits of the literal/length and distance fast tables
+#ifndef FCZ_INFLATE_LBITS
+#define FCZ_INFLATE_LBITS 9
+#endif
+constexpr int LBITS = FCZ_INFLATE_LBITS, DBITS = 8;              // index bits of the literal/length and distance fast tables
 constexpr uint32_t CRC_POLY = 0xEDB88320u;       // CRC-32 (RFC 1952 section 8), reflected
 
 // status of a member (0 = inflated and verified); everything else: the caller's zlib decides (fcz_hip.h FCZ_INFLATE_*)
@@ -107,28 +110,39 @@ struct lds_t {
 // per-length view of a canonical code, lane l = code length l (lanes 1 .. 15)
 struct canon { uint32_t first, count, off; };
 
-// entry of a literal/length symbol: kind 0 literal, 1 length, 2 end of block, 3 invalid (286, 287)   (RFC 1951 section 3.2.5)
+// Fast-table words are laid out so that the scalar unit reads them without unpacking: bits [4:0] = code length L (bit 5 is zero: the
+// word itself is the shift count of s_lshr_b64) and bits [22:16] = number of extra bits, which makes the word the control operand
+// of s_bfe_u32 (offset [4:0], width [22:16], other bits ignored): the extra bits that follow the code come out of the low dword
+// of the bit buffer in ONE instruction. A word of 0 = "not in this table" (longer code, or no code).
+//   literal/length (RFC 1951 section 3.2.5): [7:6] kind (0 literal, 1 length, 2 end of block, 3 invalid: 286, 287),
+//                                            [15:8] the literal, [31:23] base length
 __device__ __forceinline__ uint32_t resolve_lit(uint32_t sym, uint32_t L) {
-    uint32_t kind, extra = 0, val;
-    if (sym < 256u) { kind = 0; val = sym; }
-    else if (sym == 256u) { kind = 2; val = 0; }
-    else if (sym > 285u) { kind = 3; val = 0; }
+    uint32_t kind, extra = 0, base = 0, lit = 0;
+    if (sym < 256u) { kind = 0; lit = sym; }
+    else if (sym == 256u) { kind = 2; }
+    else if (sym > 285u) { kind = 3; }
     else {
         const uint32_t i = sym - 257u;
         kind = 1;
-        if (i < 8u) val = i + 3u;
-        else if (i == 28u) val = 258u;
-        else { extra = (i - 4u) >> 2; val = ((4u + (i & 3u)) << extra) + 3u; }
+        if (i < 8u) base = i + 3u;
+        else if (i == 28u) base = 258u;
+        else { extra = (i - 4u) >> 2; base = ((4u + (i & 3u)) << extra) + 3u; }
     }
-    return L | (extra << 4) | (kind << 8) | (val << 16);
+    return L | (kind << 6) | (lit << 8) | (extra << 16) | (base << 23);
 }
-// entry of a distance symbol: bit 8 set = invalid (30, 31)
+//   distance: [6] invalid (30, 31), [9:8] m with base distance = (m << extra) + 1  (symbols 0 .. 3: m = symbol, no extra bits;
+//             from 4 on: m = 2 + (symbol & 1), extra = symbol / 2 - 1)
 __device__ __forceinline__ uint32_t resolve_dist(uint32_t sym, uint32_t L) {
-    uint32_t extra = 0, val, bad = 0;
-    if (sym < 4u) val = sym + 1u;
-    else if (sym < 30u) { extra = (sym >> 1) - 1u; val = ((2u + (sym & 1u)) << extra) + 1u; }
-    else { bad = 1; val = 0; }
-    return L | (extra << 4) | (bad << 8) | (val << 16);
+    uint32_t extra = 0, m, bad = 0;
+    if (sym < 4u) m = sym;
+    else if (sym < 30u) { extra = (sym >> 1) - 1u; m = 2u + (sym & 1u); }
+    else { bad = 1; m = 0; }
+    return L | (bad << 6) | (m << 8) | (extra << 16);
+}
+__device__ __forceinline__ uint32_t s_bfe(uint32_t src, uint32_t ctl) {      // src[ctl[4:0] +: ctl[22:16]] on the scalar unit
+    uint32_t r;
+    asm("s_bfe_u32 %0, %1, %2" : "=s"(r) : "s"(src), "s"(ctl) : "scc");
+    return r;
 }
 
 // code lengths lens[0 .. nsym) (LDS) -> sorted[] and the per-length view. Returns 0: complete code, 1: incomplete, 2: over-subscribed
@@ -217,7 +231,7 @@ struct bitreader {
     uint32_t lane;
     uint64_t bb; uint32_t bn; // bit buffer (wave-uniform): the next bn bits of the stream, first bit = bit 0; zeros beyond the end
     uint32_t w;               // next dword (from base) to enter the bit buffer
-    uint32_t blk, cur, nxt;   // cur / nxt: this lane's dword of block blk / blk + 1
+    uint32_t cur, nxt;        // this lane's dword of the 256-byte block dword w lies in / of the block after it
 
     __device__ __forceinline__ uint32_t load_block(uint32_t b) const {
         const uint32_t o = (b * 64u + lane) * 4u;
@@ -227,19 +241,18 @@ struct bitreader {
         return v;
     }
     __device__ __forceinline__ uint32_t word() {                    // dword w, then w++
-        const uint32_t b = w >> 6;
-        if (b != blk) { cur = nxt; blk = b; nxt = load_block(b + 1u); }
         const uint32_t d = rdl(cur, w & 63u);
         w++;
+        if ((w & 63u) == 0u) { cur = nxt; nxt = load_block((w >> 6) + 1u); }
         return d;
     }
     __device__ __forceinline__ void seek(uint32_t byte_off) {       // next bit = bit 0 of the byte at base + byte_off
-        w = byte_off >> 2; blk = w >> 6;
-        cur = load_block(blk); nxt = load_block(blk + 1u);
+        w = byte_off >> 2;
+        cur = load_block(w >> 6); nxt = load_block((w >> 6) + 1u);
         const uint32_t sk = (byte_off & 3u) * 8u;
         bb = (uint64_t)(word() >> sk); bn = 32u - sk;
     }
-    __device__ __forceinline__ void refill() { if (bn <= 32u) { bb |= (uint64_t)word() << bn; bn += 32u; } }   // -> at least 32 bits
+    __device__ __forceinline__ void refill() { if (bn <= 32u) { bb |= (uint64_t)word() << bn; bn += 32u; } }   // -> more than 32 bits
     __device__ __forceinline__ uint32_t bits(uint32_t n) { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); bb >>= n; bn -= n; return v; }   // n <= 16
     __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)w * 32u - bn; }    // bits consumed, counted from base
     __device__ __forceinline__ bool overrun() const { return bitpos() > (uint64_t)avail * 8u; }
@@ -397,76 +410,109 @@ __device__ __forceinline__ int32_t inflate_stream(bitreader& br, sink& sk, lds_t
             }
             fill_table<LBITS, false>(L.lit_tab, L.lit_sorted, cn_lit, lane);
             fill_table<DBITS, true>(L.dist_tab, L.dist_sorted, cn_dist, lane);
-            for (;;) {                                              // symbols
-                br.refill();
-                uint32_t e = rfl(L.lit_tab[(uint32_t)br.bb & LMASK]);
-                uint32_t cb = e & 15u;
-                if (cb == 0u) {
+            // symbols: one per turn, wave-uniform (the scalar unit does the bit work). The table word of the NEXT symbol is asked for
+            // as soon as the bits in front of it are known -- before the copy of the current match -- so that its LDS round trip
+            // runs beside the copy's (in-order LDS: it is back first). Text beyond the member's size only ever reaches the ring:
+            // the size is checked before a round leaves for HBM.
+            int32_t err = ST_OK;
+            br.refill();
+            uint32_t e_next = L.lit_tab[(uint32_t)br.bb & LMASK];
+            for (;;) {
+                uint32_t e = rfl(e_next);
+                if (__builtin_expect((e & 31u) == 0u, 0)) {
+                    uint32_t cb;
                     const int ix = canon_decode((uint32_t)br.bb & 0x7fffu, cn_lit, lane, &cb);
-                    if (ix < 0) return INF_FAIL(ST_CODE);
+                    if (ix < 0) { err = INF_FAIL(ST_CODE); break; }
                     e = resolve_lit(rfl(L.lit_sorted[ix]), cb);
+                    e_next = e;
                 }
-                br.bb >>= cb; br.bn -= cb;
-                const uint32_t kind = (e >> 8) & 3u;
-                if (kind == 0u) {
-                    if (sk.q >= sk.qcap) return INF_FAIL(ST_SIZE);
-                    L.ring[sk.q & RMASK] = (uint8_t)(e >> 16);      // (every lane the same byte to the same place)
-                    sk.q++;
-                } else if (kind == 1u) {
-                    const uint32_t len = (e >> 16) + br.bits((e >> 4) & 15u);
-                    br.refill();
-                    uint32_t de = rfl(L.dist_tab[(uint32_t)br.bb & DMASK]);
-                    uint32_t db = de & 15u;
-                    if (db == 0u) {
-                        const int ix = canon_decode((uint32_t)br.bb & 0x7fffu, cn_dist, lane, &db);
-                        if (ix < 0) return INF_FAIL(ST_CODE);
-                        de = resolve_dist(rfl(L.dist_sorted[ix]), db);
+                const uint32_t lo = (uint32_t)br.bb;
+                br.bb >>= (e & 63u); br.bn -= (e & 31u);
+                if ((e & 0xc0u) == 0u) {
+                    // literal
+                    if (br.bn <= 32u) {
+                        br.bb |= (uint64_t)br.word() << br.bn; br.bn += 32u;
+                        if (__builtin_expect(sk.q - sk.flushed >= ROUND, 0)) {            // (at most 32 literals between two refills)
+                            if (sk.q > sk.qcap) { err = INF_FAIL(ST_SIZE); break; }
+                            wave_fence(); sk.flush_one();
+                        }
                     }
-                    br.bb >>= db; br.bn -= db;
-                    if (de & 0x100u) return INF_FAIL(ST_CODE);                          // "invalid distance code"
-                    const uint32_t dist = (de >> 16) + br.bits((de >> 4) & 15u);
-                    if (dist > sk.q - sk.q0) return INF_FAIL(ST_CODE);                  // "invalid distance too far back"
-                    if (len > sk.qcap - sk.q) return INF_FAIL(ST_SIZE);
-                    const uint32_t src = sk.q - dist;
-                    wave_fence();
-                    if (dist <= RING) {
-                        if (dist >= len || dist >= 64u) {
-                            for (uint32_t j = 0; j < len; j += 64u) {
-                                const uint32_t k = j + lane;
-                                uint8_t v = 0;
-                                if (k < len) v = L.ring[(src + k) & RMASK];
-                                wave_fence();
-                                if (k < len) L.ring[(sk.q + k) & RMASK] = v;
-                                wave_fence();
-                            }
-                        } else {
-                            // the match overlaps its own output inside one chunk: every byte is one of the `dist` bytes before it
-                            for (uint32_t j = 0; j < len; j += 64u) {
-                                const uint32_t k = j + lane;
-                                uint8_t v = 0;
-                                if (k < len) v = L.ring[(src + (dist == 1u ? 0u : k % dist)) & RMASK];
-                                wave_fence();
-                                if (k < len) L.ring[(sk.q + k) & RMASK] = v;
-                                wave_fence();
-                            }
+                    const uint32_t ev = e_next;                       // (the word in every lane's register: the byte without scalar work)
+                    e_next = L.lit_tab[(uint32_t)br.bb & LMASK];
+                    L.ring[sk.q & RMASK] = (uint8_t)(ev >> 8);        // (every lane the same byte to the same place)
+                    sk.q++;
+                    continue;
+                }
+                if (__builtin_expect((e & 0x80u) != 0u, 0)) {           // end of block, or "invalid literal/length code"
+                    if (e & 0x40u) err = INF_FAIL(ST_CODE);
+                    break;
+                }
+                // length + distance
+                const uint32_t xb = (e >> 16) & 127u;
+                const uint32_t len = (e >> 23) + s_bfe(lo, e);
+                br.bb >>= xb; br.bn -= xb;
+                br.refill();
+                uint32_t de = rfl(L.dist_tab[(uint32_t)br.bb & DMASK]);
+                if (__builtin_expect((de & 31u) == 0u, 0)) {
+                    uint32_t db;
+                    const int ix = canon_decode((uint32_t)br.bb & 0x7fffu, cn_dist, lane, &db);
+                    if (ix < 0) { err = INF_FAIL(ST_CODE); break; }
+                    de = resolve_dist(rfl(L.dist_sorted[ix]), db);
+                }
+                if (__builtin_expect((de & 0x40u) != 0u, 0)) { err = INF_FAIL(ST_CODE); break; }   // "invalid distance code"
+                const uint32_t lo2 = (uint32_t)br.bb, dxb = (de >> 16) & 127u;
+                const uint32_t dist = (((de >> 8) & 3u) << dxb) + 1u + s_bfe(lo2, de);
+                br.bb >>= (de & 63u); br.bb >>= dxb; br.bn -= (de & 31u) + dxb;
+                if (__builtin_expect(dist > sk.q - sk.q0, 0)) { err = INF_FAIL(ST_CODE); break; }  // "invalid distance too far back"
+                br.refill();
+                e_next = L.lit_tab[(uint32_t)br.bb & LMASK];
+                const uint32_t src = sk.q - dist;
+                wave_fence();
+                if (__builtin_expect(dist <= RING, 1)) {
+                    if (__builtin_expect(len <= 64u && dist >= len, 1)) {
+                        uint8_t v = 0;
+                        if (lane < len) v = L.ring[(src + lane) & RMASK];
+                        wave_fence();
+                        if (lane < len) L.ring[(sk.q + lane) & RMASK] = v;
+                        wave_fence();
+                    } else if (dist >= 64u) {
+                        for (uint32_t j = 0; j < len; j += 64u) {     // (a later chunk reads what an earlier one wrote: in-order LDS)
+                            const uint32_t k = j + lane;
+                            uint8_t v = 0;
+                            if (k < len) v = L.ring[(src + k) & RMASK];
+                            wave_fence();
+                            if (k < len) L.ring[(sk.q + k) & RMASK] = v;
+                            wave_fence();
                         }
                     } else {
-                        // farther back than the ring holds: that text has left for HBM (dist > RING > ROUND + 258 >= q - flushed)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // the match overlaps its own output inside one chunk: every byte is one of the `dist` bytes before it
                         for (uint32_t j = 0; j < len; j += 64u) {
                             const uint32_t k = j + lane;
-                            if (k < len) L.ring[(sk.q + k) & RMASK] = *reinterpret_cast<const volatile uint8_t*>(sk.out + src + k);
+                            uint8_t v = 0;
+                            if (k < len) v = L.ring[(src + (dist == 1u ? 0u : k % dist)) & RMASK];
+                            wave_fence();
+                            if (k < len) L.ring[(sk.q + k) & RMASK] = v;
+                            wave_fence();
                         }
-                        wave_fence();
                     }
-                    sk.q += len;
-                } else if (kind == 2u) {
-                    break;
                 } else {
-                    return INF_FAIL(ST_CODE);                                           // "invalid literal/length code"
+                    // farther back than the ring holds: that text has left for HBM (dist > RING > ROUND + 258 >= q - flushed), in
+                    // whole rounds this wavefront stored itself (vmcnt(0): the stores are acknowledged; no line of it was read before)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (uint32_t j = 0; j < len; j += 64u) {
+                        const uint32_t k = j + lane;
+                        if (k < len) L.ring[(sk.q + k) & RMASK] = sk.out[src + k];
+                    }
+                    asm volatile("" ::: "memory");
+                    wave_fence();
                 }
-                if (sk.q - sk.flushed >= ROUND) { wave_fence(); sk.flush_one(); }
+                sk.q += len;
+                if (sk.q - sk.flushed >= ROUND) {
+                    if (sk.q > sk.qcap) { err = INF_FAIL(ST_SIZE); break; }
+                    wave_fence(); sk.flush_one();
+                }
             }
+            if (err != ST_OK) return err;
         }
         if (last) return ST_OK;
     }
@@ -511,7 +557,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate(const uint8_t* __restrict__ in
         br.lane = lane;
         const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
         br.base = src - mis; br.avail = (uint32_t)ilen + mis;
-        br.blk = 0; br.cur = br.load_block(0); br.nxt = 0; br.w = 0; br.bb = 0; br.bn = 0;
+        br.cur = br.load_block(0); br.nxt = 0; br.w = 0; br.bb = 0; br.bn = 0;
         // ---- member header (RFC 1952 section 2.3; zlib inflate.c HEAD .. HCRC) from the first 256 bytes ----
         auto hb = [&](uint32_t o) { const uint32_t p = mis + o; return (rdl(br.cur, (p >> 2) & 63u) >> (8u * (p & 3u))) & 0xffu; };
         const uint32_t hmax = umin((uint32_t)ilen, 256u - 4u);          // header bytes this parse can see
@@ -536,9 +582,9 @@ __global__ __launch_bounds__(WAVE) void k_inflate(const uint8_t* __restrict__ in
         br.seek(mis + pos);
         st = inflate_stream(br, sk, L, lane);
         if (st != ST_OK) break;
+        if (sk.q != sk.qcap) { st = INF_FAIL(ST_SIZE); break; }       // (before the last rounds leave: nothing is stored past the range)
         wave_fence();
         sk.finish();
-        if (sk.q != sk.qcap) { st = INF_FAIL(ST_SIZE); break; }
         // ---- trailer: CRC-32, ISIZE (zlib inflate.c CHECK, LENGTH); nothing may be left after it ----
         br.bits(br.bn & 7u);
         const uint64_t end = br.bitpos() >> 3;                                    // bytes consumed from br.base

@@ -507,6 +507,19 @@ std::string gunzip(const std::string& z) {
     return out;
 }
 
+// the first bytes of a gzip member's text (what decides PDB / mmCIF for a database entry whose member is inflated on the device);
+// -1: the stream does not start like a gzip member
+long gunzip_head(const uint8_t* z, size_t n, char* out, size_t cap) {
+    z_stream st{};
+    if (inflateInit2(&st, 16 + MAX_WBITS) != Z_OK) return -1;
+    st.next_in = (Bytef*)z; st.avail_in = (uInt)n;
+    st.next_out = (Bytef*)out; st.avail_out = (uInt)cap;
+    const int rc = inflate(&st, Z_NO_FLUSH);
+    const long got = (long)(cap - st.avail_out);
+    inflateEnd(&st);
+    return (rc == Z_OK || rc == Z_STREAM_END || (rc == Z_BUF_ERROR && got > 0)) ? got : -1;
+}
+
 // ---- minimal mmCIF reader: the _atom_site loop (what gemmi hands to StructureReader::updateStructure, reference
 //      src/structure_reader.cpp:31-61) and _entry.id ----
 // ---- mmCIF as the reference's reader takes it: gemmi 0.5.1's grammar (lib/gemmi/cif.hpp:37-148), its table look-ups
@@ -1251,6 +1264,7 @@ struct Options {
     bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
     bool single = false;        // one structure / FCZ file in, one file out
     bool host_parse = false;    // --host-parse: compress parses on the host threads even where the device could (A/B, debugging)
+    bool host_inflate = false;  // --host-inflate: gzipped inputs are inflated by the reader threads (zlib) instead of on the device (A/B)
     bool check = false;         // --check: decompress skips entries that fail Foldcomp::checkValidity (src/main.cpp:629-636)
     bool merge = true;          // --no-merge: extract writes one file per entry instead of one merged file (src/main.cpp:171-195)
     bool file_input = false;    // -f / --file: <input> is a text file that lists the inputs, one per line (src/main.cpp:304-325)
@@ -1877,6 +1891,8 @@ struct TextJob {
     pvec<uint8_t>* text = nullptr;             // page-locked: the text files back to back
     std::vector<uint64_t> file_off{0};
     std::string names; std::vector<uint32_t> name_off{0}, stem_len;
+    std::vector<uint8_t> is_gz;                // per text slot: the bytes are a gzip member the device inflates (fcz_compress_gz_begin)
+    bool any_gz = false;
     std::vector<std::vector<Fragment>> host_frags;   // per file of the job: fragments of the host-parsed ones
 };
 
@@ -1911,7 +1927,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
     Sequencer seq;
     if (o.db && !seq.open_index(output)) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
     std::atomic<bool> hard_fail{false};
-    std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0}, n_host_files{0};
+    std::atomic<uint64_t> n_res{0}, n_frag_ok{0}, n_bytes{0}, n_atoms{0}, n_host_files{0}, n_host_gz{0}, n_dev_gz{0};
     std::vector<double> gpu_busy(n_workers, 0.0), ctx_ready(n_workers, 0.0);
     std::vector<std::unique_ptr<pvec<uint8_t>>> text_bufs;
     TextPool pool;
@@ -1939,8 +1955,12 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
             if (!failed && n_text) {
                 uint64_t fcz_bytes = 0;
                 const auto t0 = clk::now();
-                int rc = fcz_compress_pdb_begin(ctx, job.text->data(), job.file_off.data(), n_text, job.names.data(), job.name_off.data(), job.stem_len.data(),
-                                                o.brk, o.skip_discontinuous ? FCZ_INGEST_SKIP_DISCONTINUOUS : 0, counts.data(), &fcz_bytes);
+                // (gzip members among the job's files are inflated on the device in front of the parser: a fifth of the text's bytes cross the link)
+                int rc = job.any_gz
+                    ? fcz_compress_gz_begin(ctx, job.text->data(), job.file_off.data(), n_text, job.is_gz.data(), job.names.data(), job.name_off.data(), job.stem_len.data(),
+                                            o.brk, o.skip_discontinuous ? FCZ_INGEST_SKIP_DISCONTINUOUS : 0, counts.data(), &fcz_bytes)
+                    : fcz_compress_pdb_begin(ctx, job.text->data(), job.file_off.data(), n_text, job.names.data(), job.name_off.data(), job.stem_len.data(),
+                                             o.brk, o.skip_discontinuous ? FCZ_INGEST_SKIP_DISCONTINUOUS : 0, counts.data(), &fcz_bytes);
                 if (rc == FCZ_OK) {
                     const uint32_t C = counts[0];
                     off.assign((size_t)C + 1, 0); status.assign(C, 0); chain_file.assign(C, 0); chain_meta.assign(C, 0);
@@ -1978,10 +1998,12 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                 for (uint32_t t = 0; t < n_text; t++) {
                     if (file_status[t] == FCZ_INGEST_NO_ATOMS) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base_name(job.paths[text_file[t]]).c_str()); continue; }
                     if (file_status[t] == FCZ_OK) continue;
-                    n_host_files++;
+                    if (file_status[t] != FCZ_INGEST_HOST_GZIP) n_host_files++;      // (a member zlib has to take is counted on its own below)
                     const size_t file = text_file[t];
                     std::string stem, ext; file_parts(base_name(job.paths[file]), stem, ext);
-                    try { fragments_from_memory((const char*)job.text->data() + job.file_off[t], job.file_off[t + 1] - job.file_off[t], base_name(job.paths[file]), stem, ext, !o.db, o, job.host_frags[file], /*inflated=*/true); }
+                    // (a member the device did not inflate, FCZ_INGEST_HOST_GZIP, or one whose text it handed back: zlib here, then the reader)
+                    if (file_status[t] == FCZ_INGEST_HOST_GZIP) n_host_gz++;
+                    try { fragments_from_memory((const char*)job.text->data() + job.file_off[t], job.file_off[t + 1] - job.file_off[t], base_name(job.paths[file]), stem, ext, !o.db, o, job.host_frags[file], /*inflated=*/!(job.any_gz && job.is_gz[t])); }
                     catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(job.paths[file]).c_str(), e.what()); }
                 }
             }
@@ -2058,7 +2080,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
             for (size_t i = 0; i < nf; i++) j.paths[i] = cur[i].name;
             j.slot.assign(nf, -1); j.host_frags.resize(nf);
             std::vector<uint64_t> size(nf, 0);
-            std::vector<int> cls(nf, 0);                              // 0: the host reader takes it, 1: text read straight into the job's buffer, 2: text that waits in unz[]
+            std::vector<int> cls(nf, 0);                              // 0: the host reader takes it, 1: text read straight into the job's buffer, 2: text that waits in unz[], 3: a gzip member read straight into the buffer (inflated on the device)
             std::vector<std::string> unz(nf);                         // inflated text of gzipped inputs; entries the host reader takes
             std::vector<std::string> err(nf);
 #pragma omp parallel for schedule(dynamic, 16)
@@ -2070,6 +2092,18 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     try {
                         // (before anything is sized from the index's numbers: a corrupt line is this entry's error, not a bad_alloc)
                         if (!plan.entry_in_range(it)) throw std::runtime_error("database entry out of range");
+                        if (ends_with(nm, ".gz") && !o.host_inflate && it.len >= 18) {
+                            // the member goes to the device as it is; PDB / mmCIF by the first bytes of its text (inflated here: microseconds)
+                            uint8_t zh[4096]; char head[4096];
+                            InputItem pre = it; pre.len = std::min<uint64_t>(it.len, sizeof zh);
+                            if (!plan.read_entry(pre, zh)) throw std::runtime_error("database entry out of range");
+                            InputItem tail = it; tail.off = it.off + it.len - 4; tail.len = 4; uint8_t t4[4];
+                            if (!plan.read_entry(tail, t4)) throw std::runtime_error("database entry out of range");
+                            const uint64_t isize = (uint64_t)t4[0] | ((uint64_t)t4[1] << 8) | ((uint64_t)t4[2] << 16) | ((uint64_t)t4[3] << 24);
+                            const long got = gunzip_head(zh, (size_t)pre.len, head, sizeof head);
+                            const int fz = got < 0 ? 0 : coor_format_from_prefix(head, (size_t)got, (size_t)std::max<uint64_t>(isize, (uint64_t)got));
+                            if (fz == 1 || fz == 2) { cls[i] = 3; size[i] = it.len; continue; }
+                        }
                         if (ends_with(nm, ".gz")) {
                             std::string z(it.len, '\0');
                             if (!plan.read_entry(it, (uint8_t*)&z[0])) throw std::runtime_error("database entry out of range");
@@ -2099,6 +2133,13 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     } catch (const std::exception& e) { err[i] = "[Error] " + base_name(nm) + ": " + e.what() + "\n"; size[i] = UINT64_MAX - 1; cls[i] = 2; }
                     continue;
                 }
+                if (is_gz_pdb(nm) && !o.host_inflate) {
+                    // the gzip member is read straight into the job's buffer and inflated on the device
+                    cls[i] = 3;
+                    struct stat st;
+                    if (stat(nm.c_str(), &st) == 0 && S_ISREG(st.st_mode)) size[i] = (uint64_t)st.st_size; else size[i] = UINT64_MAX;
+                    continue;
+                }
                 if (is_gz_pdb(nm)) {
                     cls[i] = 2;
                     try { const std::string z = read_file(nm); g_bytes_read += z.size(); unz[i] = gunzip(z); size[i] = unz[i].size(); }
@@ -2116,6 +2157,8 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                 if (size[i] == UINT64_MAX - 1) continue;               // a gzip stream that does not inflate, an entry outside its file (reported below)
                 if (size[i] == UINT64_MAX) { fprintf(stderr, "[Error] cannot open %s\n", j.paths[i].c_str()); continue; }
                 j.slot[i] = (int)n_text++;
+                j.is_gz.push_back(cls[i] == 3 ? 1 : 0);
+                if (cls[i] == 3) { j.any_gz = true; n_dev_gz++; }
                 j.file_off.push_back(j.file_off.back() + size[i]);
                 const std::string base = base_name(j.paths[i]);
                 std::string stem, ext; file_parts(base, stem, ext);
@@ -2178,11 +2221,12 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
         double busy = 0.0; for (double g : gpu_busy) busy += g;
         const double ready = *std::max_element(ctx_ready.begin(), ctx_ready.end());
         printf("{\"mode\": \"compress\", \"ingest\": \"device\", \"gpus\": %d, \"workers\": %d, \"host_threads\": %d, \"files\": %zu, \"input_bytes\": %llu, "
-               "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"host_parsed_files\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
+               "\"records\": %llu, \"residues\": %llu, \"atoms\": %llu, \"fcz_bytes\": %llu, \"host_parsed_files\": %llu, \"device_inflated_files\": %llu, \"host_inflated_after_device_refusal\": %llu, \"wall_s\": %.4f, \"parse_s\": %.4f, "
                "\"codec_call_s_sum\": %.4f, \"ctx_ready_s\": %.4f, \"all_parsed_s\": %.4f, \"workers_done_s\": %.4f, \"residues_per_s\": %.1f, "
                "\"input_MB_per_s\": %.1f, \"pinned_blocks\": %llu, \"shard\": \"%d/%d\", \"items_total\": %llu, \"data_bytes\": %llu, \"streamed_inputs\": %s, \"max_rss_kb\": %ld}\n",
                gpus, n_workers, omp_get_max_threads(), (size_t)plan.n_mine, (unsigned long long)in_bytes, (unsigned long long)n_frag_ok.load(),
-               (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), (unsigned long long)n_host_files.load(), wall, t_read, busy,
+               (unsigned long long)n_res.load(), (unsigned long long)n_atoms.load(), (unsigned long long)n_bytes.load(), (unsigned long long)n_host_files.load(),
+               (unsigned long long)(n_dev_gz.load() - n_host_gz.load()), (unsigned long long)n_host_gz.load(), wall, t_read, busy,
                ready, t_queued, t_joined, wall > 0 ? n_res.load() / wall : 0.0, wall > 0 ? in_bytes / wall / 1e6 : 0.0, (unsigned long long)pinned_blocks().load(),
                o.shard_rank, o.shard_world, (unsigned long long)plan.n_items, (unsigned long long)seq.pos, plan.streamed_all ? "true" : "false", max_rss_kb());
     }
@@ -2798,6 +2842,7 @@ int main(int argc, char** argv) {
         else if (a == "-d" || a == "--db") o.db = true;
         else if (a == "--check") o.check = true;
         else if (a == "--host-parse") o.host_parse = true;
+        else if (a == "--host-inflate") o.host_inflate = true;
         else if (a == "--no-merge") o.merge = false;
         else if (a == "-f" || a == "--file") o.file_input = true;
         else if (a == "-l" || a == "--id-list") { if (i + 1 < argc) o.id_list = argv[++i]; }

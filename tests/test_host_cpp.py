@@ -472,7 +472,7 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
     (d / "f0019_mse.pdb").write_text("\n".join(l[:17] + "MSE" + l[20:] if l.startswith("ATOM") and l[22:26] == ala else l for l in lines) + "\n")
     (d / "f0023_empty.pdb").write_text("HEADER    nothing\n")
     (d / "f0029_alt.pdb").write_text("\n".join(l for ln in lines for l in ([ln, ln[:30] + "   1.000   2.000   3.000" + ln[54:]] if ln.startswith("ATOM") and ln[12:16].strip() == "CB" else [ln])) + "\n")
-    # gzipped PDB text: inflated by the reader threads, parsed on the device; one of them holds a record the device hands back
+    # gzipped PDB text: inflated and parsed on the device; one of them holds a record the device hands back (zlib + the host reader then)
     (d / "f0331.ent.gz").write_bytes(gzip.compress(texts["syn:len129"].encode()))
     (d / "f0337_sci.pdb.gz").write_bytes(gzip.compress(("\n".join(lines[:k] + [lines[k][:30] + " 1.0e+01" + lines[k][38:]] + lines[k + 1:]) + "\n").encode()))
     (d / "f0341_bad.pdb.gz").write_bytes(b"not a gzip stream")
@@ -491,6 +491,8 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
         st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         outs[tag] = (st, r.stderr)
     assert outs["dev"][0].get("ingest") == "device" and outs["dev"][0]["host_parsed_files"] == 3      # the scientific-notation files, the quoted atom name
+    # gzip members are inflated on the device (k_inflate); the one that is no gzip stream goes back to zlib, which says so
+    assert outs["dev"][0]["device_inflated_files"] == 4 and outs["dev"][0]["host_inflated_after_device_refusal"] == 1
     assert outs["dev"][0]["records"] == outs["host"][0]["records"] == 300 + 1 + 1 + 1 + 3 + 1 + 2 + 2 + 2
     assert all("f0341_bad" in outs[tag][1] for tag in ("dev", "host"))
     for ext in ("", ".index", ".lookup", ".dbtype"):

@@ -96,15 +96,28 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
     return v;
 }
 
+// inclusive running maximum over the wavefront on the DPP network (zeros shift in)
+__device__ __forceinline__ uint32_t wave_incl_max_dpp(uint32_t v) {
+    v = umax(v, dpp_u32_or0<0x111, 0xf>(v));   // row_shr:1
+    v = umax(v, dpp_u32_or0<0x112, 0xf>(v));   // row_shr:2
+    v = umax(v, dpp_u32_or0<0x114, 0xf>(v));   // row_shr:4
+    v = umax(v, dpp_u32_or0<0x118, 0xf>(v));   // row_shr:8
+    v = umax(v, dpp_u32_or0<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3
+    v = umax(v, dpp_u32_or0<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 struct lds_t {
     alignas(16) uint8_t ring[RING];        // the newest RING bytes of output, byte p of the text at (p & RMASK)
-    uint32_t lit_tab[1 << LBITS];          // fast tables: code length | extra bits << 4 | kind << 8 | value << 16 (0: not here)
+    uint32_t lit_tab[1 << LBITS];          // fast tables (word layout: resolve_lit / resolve_dist below; 0: not in the table)
     uint32_t dist_tab[1 << DBITS];
     uint32_t crc_tab[256];
+    uint32_t in_ring[256];                 // the compressed stream around the read position: 256-byte block b at dwords (b & 3) * 64 ..
     uint16_t lit_sorted[288];              // symbols ordered by (code length, symbol)
     uint16_t dist_sorted[32];
     uint16_t cl_sorted[32];
     uint8_t lens[320 + 64];                // code lengths of the literal/length then the distance alphabet
+    uint8_t own[64];                       // a window's text: byte -> lane + 1 of the symbol that starts there
 };
 
 // per-length view of a canonical code, lane l = code length l (lanes 1 .. 15)
@@ -316,6 +329,9 @@ struct sink {
         crc = crc_mul(xr, crc) ^ r;                                 // (the first round multiplies a zero)
     }
     __device__ __forceinline__ void flush_one() {                   // q - flushed >= ROUND
+#ifdef FCZ_INFLATE_ABL_NOFLUSH
+        flushed += ROUND; return;     // measurement build: nothing leaves the ring, no CRC
+#endif
         if (flushed >= q0) round<true>(flushed, flushed + ROUND); else round<false>(flushed, flushed + ROUND);
         flushed += ROUND;
     }
@@ -325,9 +341,231 @@ struct sink {
     }
 };
 
+// one LZ77 copy of `len` bytes from `dist` bytes back to text position p (ring; beyond the ring's reach: the flushed text in HBM).
+// ahead = how far beyond p this turn has already written into the ring (literals of the same window): the ring's reach is shorter by it
+__device__ __forceinline__ void lz_copy(sink& sk, lds_t& L, uint32_t lane, uint32_t p, uint32_t len, uint32_t dist, uint32_t reach) {
+    const uint32_t src = p - dist;
+    wave_fence();
+#ifdef FCZ_INFLATE_ABL_NOFAR
+    reach = 0xffffffffu;              // measurement build: every match through the ring (wrong text beyond its reach; the time is the answer)
+#endif
+    if (__builtin_expect(dist <= reach, 1)) {
+        if (__builtin_expect(len <= 64u && dist >= len, 1)) {
+            uint8_t v = 0;
+            if (lane < len) v = L.ring[(src + lane) & RMASK];
+            wave_fence();
+            if (lane < len) L.ring[(p + lane) & RMASK] = v;
+        } else if (dist >= 64u) {
+            for (uint32_t j = 0; j < len; j += 64u) {                 // (a later chunk reads what an earlier one wrote: in-order LDS)
+                const uint32_t k = j + lane;
+                uint8_t v = 0;
+                if (k < len) v = L.ring[(src + k) & RMASK];
+                wave_fence();
+                if (k < len) L.ring[(p + k) & RMASK] = v;
+                wave_fence();
+            }
+        } else {
+            // the match overlaps its own output inside one chunk: every byte is one of the `dist` bytes before it
+            for (uint32_t j = 0; j < len; j += 64u) {
+                const uint32_t k = j + lane;
+                uint8_t v = 0;
+                if (k < len) v = L.ring[(src + (dist == 1u ? 0u : k % dist)) & RMASK];
+                wave_fence();
+                if (k < len) L.ring[(p + k) & RMASK] = v;
+                wave_fence();
+            }
+        }
+    } else {
+        // farther back than the ring reaches: that text has left for HBM, in whole rounds this wavefront stored itself
+        // (vmcnt(0): the stores are acknowledged; no line of it was read before it was complete)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t j = 0; j < len; j += 64u) {
+            const uint32_t k = j + lane;
+            if (k < len) L.ring[(p + k) & RMASK] = sk.out[src + k];
+        }
+        asm volatile("" ::: "memory");
+    }
+    wave_fence();
+}
+
+// The symbols of one Huffman-coded block. The stream is serial -- a symbol starts where the one before it ends -- but what a symbol
+// WOULD be if it started at a given bit does not depend on the others. So every turn lane k decodes the symbol that would start at bit
+// bp + k (two table gathers: literal/length, then distance; extra bits by v_bfe on a 64-bit view of the stream that starts at the
+// lane's bit), and the real symbols are the chain 0 -> 0 + used(0) -> ... that the scalar unit follows with one v_readlane per symbol.
+// Per window of about 4.4 symbols (14.5 bits each in PDB text at level 6) the scalar unit -- one per CU, the scarce issue port of the
+// serial loop this replaces -- spends a fifth of the instructions, and the four vector units do the rest.
+//   * text positions of the chain's symbols: a wave scan of their lengths; its literals are stored at once, its matches copied in order;
+//   * a lane whose symbol the tables do not settle (a code longer than the fast table, end of block, an invalid code) ends the
+//     chain: that ONE symbol is decoded by wave-uniform code below, then the next window starts behind it;
+//   * a turn writes at most WIN_OUT bytes (the chain is cut in front of the symbol that would exceed it), so that the ring keeps
+//     RING - WIN_OUT bytes of reach and an unflushed round.
+constexpr uint32_t WIN_OUT = 1024;
+__device__ __forceinline__ int32_t decode_body(const bitreader& br, sink& sk, lds_t& L, const canon& cn_lit, const canon& cn_dist,
+                                               uint32_t lane, uint32_t* bp_io) {
+    constexpr uint32_t LMASK = (1u << LBITS) - 1u, DMASK = (1u << DBITS) - 1u;
+    static_assert(RING >= ROUND + 2u * WIN_OUT + 512u, "ring too small for a round and a window");
+    uint32_t bp = *bp_io;
+    // the stream around bp in LDS: blocks cb and cb + 1; block cb + 2 on its way in a register
+    uint32_t cb = bp >> 11;
+    L.in_ring[(cb & 3u) * 64u + lane] = br.load_block(cb);
+    L.in_ring[((cb + 1u) & 3u) * 64u + lane] = br.load_block(cb + 1u);
+    uint32_t pf = br.load_block(cb + 2u);
+    wave_fence();
+    // text read from HBM in the last turn (lane = byte pend_pos + lane, lanes of pendm): stored into the ring at the next turn
+    constexpr uint32_t REACH = RING - WIN_OUT;
+    uint64_t pendm = 0;
+    uint32_t pend_pos = 0;
+    uint8_t pend_v = 0;
+    auto complete_pending = [&]() {
+        if (pendm) {
+            if ((pendm >> lane) & 1ull) L.ring[(pend_pos + lane) & RMASK] = pend_v;
+            pendm = 0;
+            wave_fence();
+        }
+    };
+    for (;;) {
+        // ---- every lane: the symbol that would start at bit bp + lane ----
+        const uint32_t o = (bp & 31u) + lane, j = (bp >> 5) + (o >> 5), sh = o & 31u;
+        const uint32_t d0 = L.in_ring[j & 255u], d1 = L.in_ring[(j + 1u) & 255u], d2 = L.in_ring[(j + 2u) & 255u];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);   // 64 bits from the lane's bit
+        const uint32_t e = L.lit_tab[lo & LMASK];
+        const uint32_t cl = e & 31u, kind = (e >> 6) & 3u, xb = (e >> 16) & 127u;
+        const uint32_t len = (e >> 23) + __builtin_amdgcn_ubfe(lo, cl, xb);
+        const uint32_t u1 = cl + xb;                                         // <= 20
+        const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, u1);
+        const uint32_t de = L.dist_tab[rest & DMASK];
+        const uint32_t dl = de & 31u, dxb = (de >> 16) & 127u;
+        const uint32_t dist = (((de >> 8) & 3u) << dxb) + 1u + __builtin_amdgcn_ubfe(rest, dl, dxb);
+        const bool is_len = kind == 1u;
+        const bool special = cl == 0u || kind >= 2u || (is_len && (dl == 0u || (de & 0x40u) != 0u));
+        const uint32_t nxt = special ? 128u + lane : lane + (is_len ? u1 + dl + dxb : cl);
+        // ---- the chain of real symbols ----
+        uint64_t on = 0;
+        uint32_t c = 0;
+        do { on |= 1ull << c; c = rdl(nxt, c); } while (c < 64u);
+        uint32_t sp = 64;                                                    // the lane of a symbol left to the uniform code, if any
+        if (c >= 128u) { sp = c - 128u; on &= ~(1ull << sp); c = sp; }
+        // ---- where their text goes ----
+        const bool onl = ((on >> lane) & 1ull) != 0ull;
+        uint32_t tot;
+        const uint32_t outn = is_len ? len : 1u;
+        const uint32_t ex = wave_excl_scan_dpp(onl ? outn : 0u, &tot);
+        if (__builtin_expect(tot > WIN_OUT, 0)) {
+            const uint64_t over = __ballot(onl && ex != 0u && ex + outn > WIN_OUT);      // (never the first symbol: a turn makes progress)
+            const uint32_t t = (uint32_t)__builtin_ctzll(over);
+            on &= (1ull << t) - 1ull; c = t; sp = 64; tot = rdl(ex, t);
+        }
+        const bool mine = ((on >> lane) & 1ull) != 0ull;
+        complete_pending();                                                  // (the ring was not looked at above)
+        // ---- its text. The usual window writes at most 64 bytes and its matches copy text from in front of the window: then lane =
+        //      byte. The owner of a byte (the symbol it belongs to) is the newest start marker at or before it (a max-scan over
+        //      markers the chain's lanes drop into LDS), its length / distance / literal come over the LDS crossbar, and ONE gather
+        //      and ONE store move every literal and every match of the window. Bytes that lie beyond the ring's reach are read from
+        //      the text in HBM and stored a turn later, behind that turn's table work. ----
+        const uint32_t ld = len | (dist << 9);
+        const uint32_t pos = sk.q + ex;
+        const bool okm = !is_len || (dist >= ex + len && dist <= pos - sk.q0);
+#ifdef FCZ_INFLATE_ABL_NOCOPY
+        if (false) {
+#else
+        if (__builtin_expect(tot <= 64u && __ballot(mine && !okm) == 0ull, 1)) {
+#endif
+            L.own[lane] = 0;
+            wave_fence();
+            if (mine) L.own[ex] = (uint8_t)(lane + 1u);
+            wave_fence();
+            const uint32_t k = wave_incl_max_dpp(L.own[lane]) - 1u;
+            const uint32_t old = (uint32_t)__shfl((int)ld, (int)k, WAVE), oe = (uint32_t)__shfl((int)e, (int)k, WAVE);
+            const uint32_t od = old >> 9;
+            const bool act = lane < tot, omatch = ((oe >> 6) & 3u) == 1u;
+#ifdef FCZ_INFLATE_ABL_NOFAR
+            const bool isfar = false;
+#else
+            const bool isfar = act && omatch && od > REACH;
+#endif
+            const uint64_t fm = __ballot(isfar);
+            if (fm) {
+                // (rounds this wavefront stored: acknowledged at vmcnt(0). Every lane loads -- the others the member's first byte --
+                //  so that the register is written by the load alone)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pend_v = sk.out[isfar ? sk.q + lane - od : sk.q0];
+                pendm = fm; pend_pos = sk.q;
+            }
+            uint8_t val = (uint8_t)(oe >> 8);
+            if (act && omatch && !isfar) val = L.ring[(sk.q + lane - od) & RMASK];
+            wave_fence();
+            if (act && !isfar) L.ring[(sk.q + lane) & RMASK] = val;
+            wave_fence();
+        } else {
+            if (mine && !is_len) L.ring[pos & RMASK] = (uint8_t)(e >> 8);
+            uint64_t mm = on & __ballot(is_len);
+#ifdef FCZ_INFLATE_ABL_NOCOPY
+            mm = 0;                   // measurement build: no match is copied (wrong text; the time is the answer)
+#endif
+            while (mm) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1ull;
+                const uint32_t v = rdl(ld, k), p = rdl(pos, k);
+                if (__builtin_expect((v >> 9) > p - sk.q0, 0)) return INF_FAIL(ST_CODE);  // "invalid distance too far back"
+                lz_copy(sk, L, lane, p, v & 511u, v >> 9, REACH);
+            }
+        }
+        sk.q += tot; bp += c;
+        // ---- the symbol the tables did not settle: wave-uniform, once ----
+        if (__builtin_expect(sp < 64u, 0)) {
+            complete_pending();
+            const uint32_t slo = rdl(lo, sp), shi = rdl(hi, sp);
+            uint32_t se = rdl(e, sp), cb2;
+            if ((se & 31u) == 0u) {
+                const int ix = canon_decode(slo & 0x7fffu, cn_lit, lane, &cb2);
+                if (ix < 0) return INF_FAIL(ST_CODE);
+                se = resolve_lit(rfl(L.lit_sorted[ix]), cb2);
+            }
+            const uint32_t sk_kind = (se >> 6) & 3u, scl = se & 31u;
+            if (sk_kind == 0u) {
+                L.ring[sk.q & RMASK] = (uint8_t)(se >> 8);
+                sk.q++; bp += scl;
+            } else if (sk_kind == 2u) {
+                *bp_io = bp + scl;
+                return ST_OK;                                                 // end of block
+            } else if (sk_kind == 3u) {
+                return INF_FAIL(ST_CODE);                                     // "invalid literal/length code"
+            } else {
+                const uint32_t sxb = (se >> 16) & 127u, su1 = scl + sxb;
+                const uint32_t slen = (se >> 23) + ((slo >> scl) & ((1u << sxb) - 1u));
+                const uint32_t srest = (uint32_t)((((uint64_t)shi << 32) | slo) >> su1);
+                uint32_t sde = rfl(L.dist_tab[srest & DMASK]);
+                if ((sde & 31u) == 0u) {
+                    uint32_t db;
+                    const int ix = canon_decode(srest & 0x7fffu, cn_dist, lane, &db);
+                    if (ix < 0) return INF_FAIL(ST_CODE);
+                    sde = resolve_dist(rfl(L.dist_sorted[ix]), db);
+                }
+                if (sde & 0x40u) return INF_FAIL(ST_CODE);                    // "invalid distance code"
+                const uint32_t sdl = sde & 31u, sdxb = (sde >> 16) & 127u;
+                const uint32_t sdist = (((sde >> 8) & 3u) << sdxb) + 1u + ((srest >> sdl) & ((1u << sdxb) - 1u));
+                if (sdist > sk.q - sk.q0) return INF_FAIL(ST_CODE);
+                lz_copy(sk, L, lane, sk.q, slen, sdist, REACH);
+                sk.q += slen; bp += su1 + sdl + sdxb;
+            }
+        }
+        // ---- a round of text leaves; the next block of the stream comes in ----
+        if (sk.q - sk.flushed >= ROUND) {
+            if (sk.q > sk.qcap) return INF_FAIL(ST_SIZE);
+            complete_pending();
+            wave_fence(); sk.flush_one();
+        }
+        while ((bp >> 11) > cb) {
+            cb++;
+            L.in_ring[((cb + 1u) & 3u) * 64u + lane] = pf;
+            pf = br.load_block(cb + 2u);
+            wave_fence();
+        }
+    }
+}
+
 // the DEFLATE stream of one member -> ring -> text. Returns ST_OK or why the member is left to zlib.
 __device__ __forceinline__ int32_t inflate_stream(bitreader& br, sink& sk, lds_t& L, uint32_t lane) {
-    constexpr uint32_t LMASK = (1u << LBITS) - 1u, DMASK = (1u << DBITS) - 1u;
     canon cl{}, cn_lit{}, cn_dist{};
     for (;;) {                                                      // blocks (RFC 1951 section 3.2.3)
         if (br.overrun()) return INF_FAIL(ST_INPUT);
@@ -410,108 +648,10 @@ __device__ __forceinline__ int32_t inflate_stream(bitreader& br, sink& sk, lds_t
             }
             fill_table<LBITS, false>(L.lit_tab, L.lit_sorted, cn_lit, lane);
             fill_table<DBITS, true>(L.dist_tab, L.dist_sorted, cn_dist, lane);
-            // symbols: one per turn, wave-uniform (the scalar unit does the bit work). The table word of the NEXT symbol is asked for
-            // as soon as the bits in front of it are known -- before the copy of the current match -- so that its LDS round trip
-            // runs beside the copy's (in-order LDS: it is back first). Text beyond the member's size only ever reaches the ring:
-            // the size is checked before a round leaves for HBM.
-            int32_t err = ST_OK;
-            br.refill();
-            uint32_t e_next = L.lit_tab[(uint32_t)br.bb & LMASK];
-            for (;;) {
-                uint32_t e = rfl(e_next);
-                if (__builtin_expect((e & 31u) == 0u, 0)) {
-                    uint32_t cb;
-                    const int ix = canon_decode((uint32_t)br.bb & 0x7fffu, cn_lit, lane, &cb);
-                    if (ix < 0) { err = INF_FAIL(ST_CODE); break; }
-                    e = resolve_lit(rfl(L.lit_sorted[ix]), cb);
-                    e_next = e;
-                }
-                const uint32_t lo = (uint32_t)br.bb;
-                br.bb >>= (e & 63u); br.bn -= (e & 31u);
-                if ((e & 0xc0u) == 0u) {
-                    // literal
-                    if (br.bn <= 32u) {
-                        br.bb |= (uint64_t)br.word() << br.bn; br.bn += 32u;
-                        if (__builtin_expect(sk.q - sk.flushed >= ROUND, 0)) {            // (at most 32 literals between two refills)
-                            if (sk.q > sk.qcap) { err = INF_FAIL(ST_SIZE); break; }
-                            wave_fence(); sk.flush_one();
-                        }
-                    }
-                    const uint32_t ev = e_next;                       // (the word in every lane's register: the byte without scalar work)
-                    e_next = L.lit_tab[(uint32_t)br.bb & LMASK];
-                    L.ring[sk.q & RMASK] = (uint8_t)(ev >> 8);        // (every lane the same byte to the same place)
-                    sk.q++;
-                    continue;
-                }
-                if (__builtin_expect((e & 0x80u) != 0u, 0)) {           // end of block, or "invalid literal/length code"
-                    if (e & 0x40u) err = INF_FAIL(ST_CODE);
-                    break;
-                }
-                // length + distance
-                const uint32_t xb = (e >> 16) & 127u;
-                const uint32_t len = (e >> 23) + s_bfe(lo, e);
-                br.bb >>= xb; br.bn -= xb;
-                br.refill();
-                uint32_t de = rfl(L.dist_tab[(uint32_t)br.bb & DMASK]);
-                if (__builtin_expect((de & 31u) == 0u, 0)) {
-                    uint32_t db;
-                    const int ix = canon_decode((uint32_t)br.bb & 0x7fffu, cn_dist, lane, &db);
-                    if (ix < 0) { err = INF_FAIL(ST_CODE); break; }
-                    de = resolve_dist(rfl(L.dist_sorted[ix]), db);
-                }
-                if (__builtin_expect((de & 0x40u) != 0u, 0)) { err = INF_FAIL(ST_CODE); break; }   // "invalid distance code"
-                const uint32_t lo2 = (uint32_t)br.bb, dxb = (de >> 16) & 127u;
-                const uint32_t dist = (((de >> 8) & 3u) << dxb) + 1u + s_bfe(lo2, de);
-                br.bb >>= (de & 63u); br.bb >>= dxb; br.bn -= (de & 31u) + dxb;
-                if (__builtin_expect(dist > sk.q - sk.q0, 0)) { err = INF_FAIL(ST_CODE); break; }  // "invalid distance too far back"
-                br.refill();
-                e_next = L.lit_tab[(uint32_t)br.bb & LMASK];
-                const uint32_t src = sk.q - dist;
-                wave_fence();
-                if (__builtin_expect(dist <= RING, 1)) {
-                    if (__builtin_expect(len <= 64u && dist >= len, 1)) {
-                        uint8_t v = 0;
-                        if (lane < len) v = L.ring[(src + lane) & RMASK];
-                        wave_fence();
-                        if (lane < len) L.ring[(sk.q + lane) & RMASK] = v;
-                        wave_fence();
-                    } else if (dist >= 64u) {
-                        for (uint32_t j = 0; j < len; j += 64u) {     // (a later chunk reads what an earlier one wrote: in-order LDS)
-                            const uint32_t k = j + lane;
-                            uint8_t v = 0;
-                            if (k < len) v = L.ring[(src + k) & RMASK];
-                            wave_fence();
-                            if (k < len) L.ring[(sk.q + k) & RMASK] = v;
-                            wave_fence();
-                        }
-                    } else {
-                        // the match overlaps its own output inside one chunk: every byte is one of the `dist` bytes before it
-                        for (uint32_t j = 0; j < len; j += 64u) {
-                            const uint32_t k = j + lane;
-                            uint8_t v = 0;
-                            if (k < len) v = L.ring[(src + (dist == 1u ? 0u : k % dist)) & RMASK];
-                            wave_fence();
-                            if (k < len) L.ring[(sk.q + k) & RMASK] = v;
-                            wave_fence();
-                        }
-                    }
-                } else {
-                    // farther back than the ring holds: that text has left for HBM (dist > RING > ROUND + 258 >= q - flushed), in
-                    // whole rounds this wavefront stored itself (vmcnt(0): the stores are acknowledged; no line of it was read before)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    for (uint32_t j = 0; j < len; j += 64u) {
-                        const uint32_t k = j + lane;
-                        if (k < len) L.ring[(sk.q + k) & RMASK] = sk.out[src + k];
-                    }
-                    asm volatile("" ::: "memory");
-                    wave_fence();
-                }
-                sk.q += len;
-                if (sk.q - sk.flushed >= ROUND) {
-                    if (sk.q > sk.qcap) { err = INF_FAIL(ST_SIZE); break; }
-                    wave_fence(); sk.flush_one();
-                }
-            }
+            // symbols, a WINDOW of 64 bit positions per turn (decode_body below)
+            uint32_t bp = (uint32_t)br.bitpos();
+            const int32_t err = decode_body(br, sk, L, cn_lit, cn_dist, lane, &bp);
+            if (err == ST_OK) { br.seek(bp >> 3); br.bits(bp & 7u); }
             if (err != ST_OK) return err;
         }
         if (last) return ST_OK;
@@ -551,7 +691,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate(const uint8_t* __restrict__ in
     }
     int32_t st = ST_OK;
     do {
-        if (ilen < 18u || ilen >= (1ull << 31) || cap >= (1ull << 31)) { st = INF_FAIL(ST_HEADER); break; }
+        if (ilen < 18u || ilen >= (1ull << 28) || cap >= (1ull << 31)) { st = INF_FAIL(ST_HEADER); break; }
         for (uint32_t i = lane; i < 256u; i += WAVE) L.crc_tab[i] = g_crc.tab[i];
         bitreader br;
         br.lane = lane;

@@ -625,13 +625,14 @@ def end_to_end_leg(args, codec, w, dev):
             shutil.rmtree(cdir, ignore_errors=True)
         except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
             comp["mmcif"] = {"failed": str(e)[-300:]}
-        # ---- gzipped input (AFDB ships .pdb.gz / .cif.gz): MEASUREMENT ONLY of where it stands. The host's reader threads inflate
-        #      (zlib, reference: uncompressBuffer src/structure_reader.cpp:156-203), the inflated text takes the device route. The same
-        #      2 048 files gzipped, both formats; the reference's loop on the same files is timed in the cpu_reference block below ----
+        # ---- gzipped input (AFDB ships .pdb.gz / .cif.gz): the gzip members cross the link as they are and are inflated on the
+        #      device (k_inflate, round 6; reference: zlib in gemmi::MaybeGzipped / uncompressBuffer src/structure_reader.cpp:156-203),
+        #      then parsed and compressed there. The first 4 096 files gzipped at level 6, both formats; `--host-inflate` (zlib on the
+        #      reader threads, round 5's route) beside it; the reference's loop on the same files is timed in the cpu_reference block ----
         gz_sets = {}
         try:
             import gzip as _gzip
-            n_gz = min(n, 2048)
+            n_gz = min(n, 4096)
             gzo = {}
             for kind in ("pdb", "cif"):
                 gdir = os.path.join(tmp, "gz_" + kind); os.mkdir(gdir)
@@ -652,11 +653,18 @@ def end_to_end_leg(args, codec, w, dev):
                 with open(glst, "w") as fh:
                     fh.write((gdir + "\n") * passes)
                 runs_g = [run_host(["compress", "-d", "-y", "-t", str(t), "--gpus", "1", *wpg, "--json-stats", "-f", glst, os.path.join(tmp, f"dbgz_{kind}_{t}")]) for t in tcounts]
-                sm = summarise(runs_g, "input_bytes", f"host/foldcomp-hip compress -d -f <list of .{kind}.gz> <db>   (inflate on the host threads, parse + codec on the device)")
+                sm = summarise(runs_g, "input_bytes", f"host/foldcomp-hip compress -d -f <list of .{kind}.gz> <db>   (inflate + parse + codec on the device)")
                 res_pass = int(w.res_off_dev[n_gz]) & 0xFFFFFFFF
                 gzo[kind + "_gz"] = {"files": n_gz, "passes": passes, "gz_bytes_per_pass": gz_b, "text_bytes_per_pass": raw_b, "residues_per_pass": res_pass,
                                      "gpu_host": sm, "records_per_pass": runs_g[0]["records"] // passes,
                                      "steady_inflated_text_GB_per_s": round(raw_b * passes / max(sm["steady_wall_s"], 1e-9) / 1e9, 2)}
+                # the same list with zlib on the reader threads (round 5's route), and the records of both routes compared
+                run_hi = run_host(["compress", "-d", "-y", "-t", str(eff), "--host-inflate", "--gpus", "1", *wpg, "--json-stats", "-f", glst, os.path.join(tmp, f"dbgz_{kind}_hi")])
+                hi = summarise([run_hi], "input_bytes", "... --host-inflate   (zlib on the reader threads, parse + codec on the device)")
+                gzo[kind + "_gz"]["host_inflate"] = {"steady_residues_per_s": hi["steady_residues_per_s"], "wall_s": hi["wall_s"], "host_threads": hi["host_threads"]}
+                gzo[kind + "_gz"]["device_over_host_inflate"] = round(sm["steady_residues_per_s"] / max(hi["steady_residues_per_s"], 1), 2)
+                gzo[kind + "_gz"]["device_inflated_files"] = runs_g[0].get("device_inflated_files"); gzo[kind + "_gz"]["host_inflated_after_device_refusal"] = runs_g[0].get("host_inflated_after_device_refusal")
+                gzo[kind + "_gz"]["databases_identical"] = all(open(os.path.join(tmp, f"dbgz_{kind}_{tcounts[0]}") + ext, "rb").read() == open(os.path.join(tmp, f"dbgz_{kind}_hi") + ext, "rb").read() for ext in ("", ".index", ".lookup"))
                 gz_sets[kind] = gpaths
             plain = comp["gpu_host"]["steady_residues_per_s"]
             gzo["pdb_gz"]["steady_over_plain_pdb"] = round(gzo["pdb_gz"]["gpu_host"]["steady_residues_per_s"] / max(plain, 1), 3)

@@ -158,3 +158,30 @@ def test_host_extract_sizes_match_reference_strings(golden):
     assert lib.fcz_extract_sizes(np.frombuffer(b"".join(bad), np.uint8).ctypes.data, off2.ctypes.data, 2, 0, 2, d2.ctypes.data) == 0
     assert d2[2] == 0
     assert lib.fcz_extract_sizes(blob.ctypes.data, off.ctypes.data, 1, 0, 7, d2.ctypes.data) == -1   # FCZ_E_INVALID_ARG
+
+
+def test_inflate_sizes_on_the_host():
+    """fcz_inflate_sizes (pure host work): text offsets from the members' ISIZE as the reference's reader sizes its buffer
+    (gemmi estimate_uncompressed_size, lib/gemmi/gz.hpp:25-45); plain entries by their length; what cannot be a member's text
+    size (member shorter than a header + trailer, an ISIZE beyond DEFLATE's 1032 : 1) is sized 0 -- and left to zlib later"""
+    import gzip, struct, zlib
+    lib = _lib.load()
+    texts = [b"ATOM      1  N   MET A   1\n" * k for k in (1, 40, 3000)]
+    members = [gzip.compress(t, 6) for t in texts]
+    lying = members[1][:-4] + struct.pack("<I", 1 << 30)            # a trailer that claims a gigabyte for a hundred bytes
+    entries = [members[0], texts[1], members[2], b"\x1f\x8b\x08", lying, members[1]]
+    kind = np.array([1, 0, 1, 1, 1, 1], np.uint8)
+    off = np.zeros(len(entries) + 1, np.uint64); off[1:] = np.cumsum([len(e) for e in entries])
+    raw = np.frombuffer(b"".join(entries), np.uint8)
+    toff = np.zeros(len(entries) + 1, np.uint64)
+    assert lib.fcz_inflate_sizes(raw.ctypes.data, off.ctypes.data, len(entries), kind.ctypes.data, toff.ctypes.data) == 0
+    assert list(np.diff(toff.astype(np.int64))) == [len(texts[0]), len(texts[1]), len(texts[2]), 0, 0, len(texts[1])]
+    # every entry a member when no kinds are given
+    toff2 = np.zeros(3, np.uint64); off2 = np.array([0, len(members[0]), len(members[0]) + len(members[2])], np.uint64)
+    raw2 = np.frombuffer(members[0] + members[2], np.uint8)
+    assert lib.fcz_inflate_sizes(raw2.ctypes.data, off2.ctypes.data, 2, None, toff2.ctypes.data) == 0
+    assert list(toff2) == [0, len(texts[0]), len(texts[0]) + len(texts[2])]
+    assert zlib.decompress(members[2], 31) == texts[2]
+    # the compute entry points refuse to run without a context (no CPU fallback behind them)
+    st = np.zeros(2, np.int32)
+    assert lib.fcz_inflate(None, raw2.ctypes.data, off2.ctypes.data, 2, None, toff2.ctypes.data, raw2.ctypes.data, st.ctypes.data) == -1

@@ -568,6 +568,19 @@ __device__ unsigned long long g_bb_timing[8];
 #else
 #define BB_STAMP(i)
 #endif
+// Measurement builds (results wrong by design, the time is the answer; profiles/r6_ab_ring_ablation.txt): the same instruction stream
+// with the ring rows folded into a window of a few rows per wavefront that stays in the L2 -- FCZ_ABL_NO_RING: forward atoms and
+// torsion trig; FCZ_ABL_NO_TRING: the trig ring only. What k_backbone would gain if its 120 B/residue of ring traffic cost nothing.
+#if defined(FCZ_ABL_NO_RING)
+#define BB_RROW(x) ((x) & 7)
+#define BB_TROW(x) ((x) & 15)
+#elif defined(FCZ_ABL_NO_TRING)
+#define BB_RROW(x) (x)
+#define BB_TROW(x) ((x) & 15)
+#else
+#define BB_RROW(x) (x)
+#define BB_TROW(x) (x)
+#endif
 // one group of 64 chains (lane = chain) of k_backbone; `home` = the ring slot of a MODE 0 wavefront (its block index: the grid is
 // persistent, so the ring is as large as the wavefronts in flight, not as the batch)
 template <int MODE>
@@ -680,13 +693,13 @@ __device__ __forceinline__ void backbone_group(
             sincosf_pair(deg2rad(w.psi), &s_psi, &c_psi);
             sincosf_pair(deg2rad(w.omega), &s_om, &c_om);
             sincosf_pair(deg2rad(w.phi), &s_phi, &c_phi);
-            float* Tw = Tg + (size_t)(6 * i) * WAVE;
+            float* Tw = Tg + (size_t)BB_TROW(6 * i) * WAVE;
             Tw[0] = c_psi; Tw[WAVE] = s_psi; Tw[2 * WAVE] = c_om; Tw[3 * WAVE] = s_om; Tw[4 * WAVE] = c_phi; Tw[5 * WAVE] = s_phi;
             const v3 N = place_atom_d2(p0, p1, p2, nerf_d2_trig((float)1.3311, w.can, c_psi, s_psi));
             const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
             const v3 CA = place_atom_d2(p1, p2, N, nerf_d2_trig(l_nca, w.cna, c_om, s_om));
             const v3 C = place_atom_d2(p2, N, CA, nerf_d2_trig((float)1.5281, w.nca, c_phi, s_phi));
-            Rg[(size_t)(3 * i + 3) * WAVE] = N; Rg[(size_t)(3 * i + 4) * WAVE] = CA; Rg[(size_t)(3 * i + 5) * WAVE] = C;
+            Rg[(size_t)BB_RROW(3 * i + 3) * WAVE] = N; Rg[(size_t)BB_RROW(3 * i + 4) * WAVE] = CA; Rg[(size_t)BB_RROW(3 * i + 5) * WAVE] = C;
             p0 = N; p1 = CA; p2 = C;
             w_cur = w_nxt; w_nxt = w_pre; wp += 8;
         }
@@ -714,8 +727,8 @@ __device__ __forceinline__ void backbone_group(
         v3 fa{0.f, 0.f, 0.f}, fb = fa, fc = fa;
         if (MODE != 1 && wi0 >= 0) {
 #pragma unroll
-            for (int u = 0; u < 6; u++) tq[u] = Tg[(size_t)(6 * wi0 + u) * WAVE];
-            fa = Rg[(size_t)(3 * wi0 + 2) * WAVE]; fb = Rg[(size_t)(3 * wi0 + 1) * WAVE]; fc = Rg[(size_t)(3 * wi0) * WAVE];
+            for (int u = 0; u < 6; u++) tq[u] = Tg[(size_t)(BB_TROW(6 * wi0) + u) * WAVE];
+            fa = Rg[(size_t)BB_RROW(3 * wi0 + 2) * WAVE]; fb = Rg[(size_t)BB_RROW(3 * wi0 + 1) * WAVE]; fc = Rg[(size_t)BB_RROW(3 * wi0) * WAVE];
         }
         for (int wi = maxlen - 2; MODE != 1 && wi >= 0; wi--) {       // wave-uniform trip count; lanes join when wi <= len-2
             const bool on = wi <= wi0;
@@ -726,8 +739,8 @@ __device__ __forceinline__ void backbone_group(
             if (on) {
                 const int wn = wi > 0 ? wi - 1 : 0;
 #pragma unroll
-                for (int u = 0; u < 6; u++) tn[u] = Tg[(size_t)(6 * wn + u) * WAVE];
-                na = Rg[(size_t)(3 * wn + 2) * WAVE]; nb = Rg[(size_t)(3 * wn + 1) * WAVE]; nc = Rg[(size_t)(3 * wn) * WAVE];
+                for (int u = 0; u < 6; u++) tn[u] = Tg[(size_t)(BB_TROW(6 * wn) + u) * WAVE];
+                na = Rg[(size_t)BB_RROW(3 * wn + 2) * WAVE]; nb = Rg[(size_t)BB_RROW(3 * wn + 1) * WAVE]; nc = Rg[(size_t)BB_RROW(3 * wn) * WAVE];
             }
 #pragma unroll
             for (int q = 2; q >= 0; q--) {

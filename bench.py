@@ -240,21 +240,51 @@ def cpu_baseline(hb, anchor, gpu=None):
             "compress_residues_per_s": R / (t1 - t0), "decompress_residues_per_s": R / (t2 - t1)}
 
 
-def measured_traffic(kernel, n_residues, n_res_per_chain):
+KERNEL_SOURCES = ("fcz_kernels.h", "fcz_math.h", "fcz_compress.h", "fcz_sidechain.h", "aa_tables.inc")   # the codec kernels' device code (fcz_abi.hip holds their launches among much host code: not hashed)
+
+
+def csrc_sha16():
+    """what the codec kernels are compiled from, hashed: a counter profile describes the kernels of ONE state of these files"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "foldcomp_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_profile():
+    """profiles/traffic.json if it describes the kernels this run timed (the hash of their sources, written when the passes were
+    collected by tools/pmc_summary.py, equals the tree's) -> (dict, None); else (None, why): a stale profile yields `traffic: null`,
+    never a number of other kernels"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None, "profiles/traffic.json missing"
+    now = csrc_sha16()
+    if t.get("csrc_sha16") != now:
+        return None, f"profiles/traffic.json describes csrc {t.get('csrc_sha16')}, this tree is {now}: counter passes have to be re-collected (tools/profile_gpu.sh)"
+    return t, None
+
+
+def measured_traffic(kernel, n_residues, n_res_per_chain, section="kernels"):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json, written by
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same workload,
     gfx950 corrections applied). PMC collection serialises dispatches and cannot run inside the timed region, so
-    the per-residue figure measured there is scaled to this launch; null when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    the per-residue figure measured there is scaled to this launch; null when no profile of THESE kernels (source hash) and
+    this workload shape exists. section: "kernels" (uniform chains of residues_per_chain) or "mixed" (the mixed-length generator)."""
+    t, why = traffic_profile()
+    if t is None:
+        return None, why
     try:
-        with open(path) as fh:
-            t = json.load(fh)
-        k = t["kernels"][kernel]
-        if int(t["residues_per_chain"]) != int(n_res_per_chain):
-            return None, None
-        return (k["fetch_bytes_per_residue"] + k["write_bytes_per_residue"]) * n_residues, t.get("source")
-    except (OSError, KeyError, ValueError):
-        return None, None
+        sec = t if section == "kernels" else t[section]
+        k = sec["kernels"][kernel]
+        if section == "kernels" and int(t["residues_per_chain"]) != int(n_res_per_chain):
+            return None, f"profiles/traffic.json holds {t['residues_per_chain']}-residue chains"
+        return (k["fetch_bytes_per_residue"] + k["write_bytes_per_residue"]) * n_residues, sec.get("source")
+    except (KeyError, ValueError):
+        return None, f"no counter pass of {kernel} ({section}) in profiles/traffic.json"
 
 
 def controller_side_traffic(kernel, n_residues, n_res_per_chain):
@@ -262,9 +292,8 @@ def controller_side_traffic(kernel, n_residues, n_res_per_chain):
     tools/hbm_busy_probe.py: the driver's mem_busy_percent during a seconds-long loop of that one kernel, calibrated on device
     copies); (bytes, fabric-side bytes of the same scope, source) or (None, None, None)"""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            t = json.load(fh)
-        if int(t["residues_per_chain"]) != int(n_res_per_chain):
+        t, _why = traffic_profile()
+        if t is None or int(t["residues_per_chain"]) != int(n_res_per_chain):
             return None, None, None
         c = t["controller_side"]
         return c["bytes_per_residue"][kernel] * n_residues, c["fabric_side_counters_same_scope"][kernel] * n_residues, c["source"]
@@ -272,8 +301,16 @@ def controller_side_traffic(kernel, n_residues, n_res_per_chain):
         return None, None, None
 
 
+def copy_ceiling_f4(codec, nbytes=1 << 30, reps=10):
+    """device copy by the kernel MI355X_MICROARCH.md quotes its 6.29 TB/s with (float4 per lane, grid-stride, a persistent grid):
+    read + write bytes per second, timed by HIP events on the ctx stream (fcz_selftest_copy)"""
+    gbs = ctypes.c_double(0.0)
+    rc = codec.lib.fcz_selftest_copy(codec.ctx, ctypes.c_uint64(nbytes), int(reps), ctypes.byref(gbs))
+    return gbs.value if rc == 0 else None
+
+
 def copy_ceiling(dev, nbytes=1 << 30, reps=5):
-    """measured device-to-device copy rate (read + write bytes) -- the practical HBM ceiling next to the 8 TB/s peak"""
+    """torch's device-to-device copy_ (rounds 1-5's calibration figure; kept beside the float4 kernel's): read + write bytes"""
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
     b.copy_(a); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -1075,7 +1112,8 @@ def secondary_legs(args, codec, dev, comm):
                 "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "residues_per_s": round(w.R * world * steps / dt),
                 "algorithmic_GBs": round(nbytes / (dt / steps) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4), "traffic": None},
+                             "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
+                             **dict(zip(("traffic", "traffic_source"), measured_traffic(dom, w.R, -1, "mixed")))},
                 "kernel_ms": {k: round(v, 4) for k, v in km.items() if v}}
 
     A = w.M / w.R; f = w.fcz_bytes / w.R
@@ -1501,8 +1539,7 @@ def main():
         # inside the timed region); the SIMD-cycles per VALU wave-instruction use this run's own kernel time.
         valu = None
         try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-                tk = json.load(fh)["kernels"][dom]
+            tk = (traffic_profile()[0] or {})["kernels"][dom]
             occ = {"k_backbone": 2, "k_compress_angles_w": 3, "k_compress_pack": 3, "k_sidechain": 4}.get(dom)
             n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
             valu = {"bound": "VALU issue", "valu_wave_insts_per_residue": tk["valu_wave_insts_per_residue"],
@@ -1527,7 +1564,11 @@ def main():
                     "kernel_ms": {k: round(v, 4) for k, v in ktime.items()},
                     "per_kernel_GBs": {k: round(b / (t * 1e-3) / 1e9, 1) if t else None for k, (b, t) in kern.items()},
                     "decompress_pair_GBs": round(bytes_decompress / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
-                    "hbm_copy_measured_GBs": round(copy_ceiling(dev), 1)}
+                    "traffic_profile_valid_for_these_kernels": traffic_profile()[0] is not None, "csrc_sha16": csrc_sha16(),
+                    "hbm_copy_measured_GBs": round(copy_ceiling_f4(codec) or 0.0, 1),
+                    "hbm_copy_note": "float4 grid-stride copy (fcz_selftest_copy: the kernel MI355X_MICROARCH.md measures 6.29 TB/s with), read + write bytes; "
+                                     "rounds 1-5 quoted torch's copy_ of the same 1 GiB, kept as hbm_copy_torch_GBs",
+                    "hbm_copy_torch_GBs": round(copy_ceiling(dev), 1)}
         hostb = None
         if args.host_chains and world == 1 and not args.mixed:
             try:

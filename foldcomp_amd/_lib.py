@@ -88,6 +88,7 @@ def load():
         "fcz_ctx_kernel_time": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]),
         "fcz_ctx_reset_timing": (None, [vp]),
         "fcz_selftest_math": (i32, [vp, i32, u32, u32, u32, vp]),
+        "fcz_selftest_copy": (i32, [vp, u64, i32, ctypes.POINTER(ctypes.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -106,7 +107,7 @@ EXPORTS = ["fcz_ctx_create", "fcz_ctx_destroy", "fcz_ctx_stream", "fcz_ctx_synch
            "fcz_extract_sizes_dev", "fcz_extract_dev", "fcz_ingest_pdb_dev", "fcz_ingest_pdb_begin", "fcz_ingest_pdb_fetch",
            "fcz_compress_pdb_begin", "fcz_compress_pdb_fetch", "fcz_inflate_sizes", "fcz_inflate_dev", "fcz_inflate",
            "fcz_ingest_gz_begin", "fcz_compress_gz_begin", "fcz_check", "fcz_ctx_enable_timing",
-           "fcz_ctx_kernel_time", "fcz_ctx_reset_timing", "fcz_selftest_math"]
+           "fcz_ctx_kernel_time", "fcz_ctx_reset_timing", "fcz_selftest_math", "fcz_selftest_copy"]
 
 
 def status_name(code: int) -> str:

@@ -1301,6 +1301,37 @@ __global__ void k_selftest_math(int mode, uint32_t start_bits, uint32_t stride, 
 }
 }  // namespace fcz
 
+namespace fcz {
+__global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace fcz
+extern "C" int fcz_selftest_copy(fcz_ctx* ctx, uint64_t bytes, int reps, double* gb_per_s) {
+    if (!ctx || !gb_per_s || bytes < 16 || reps < 1) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    *gb_per_s = 0.0;
+    const size_t n = (size_t)(bytes / 16);
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, n * 16) != hipSuccess) return FCZ_E_NOMEM;
+    if (hipMalloc(&b, n * 16) != hipSuccess) { (void)hipFree(a); return FCZ_E_NOMEM; }
+    (void)hipMemsetAsync(a, 1, n * 16, ctx->stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const unsigned grid = (unsigned)ctx->n_cu * 8u;             // 2 048 wavefronts of 64 lanes x 16 bytes in flight per sweep
+    hipLaunchKernelGGL(k_copy_f4, dim3(grid), dim3(256), 0, ctx->stream, (const float4*)a, (float4*)b, n);   // warm-up
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy_f4, dim3(grid), dim3(256), 0, ctx->stream, (const float4*)a, (float4*)b, n);
+    (void)hipEventRecord(e1, ctx->stream);
+    const hipError_t err = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (err != hipSuccess || ms <= 0.f) return FCZ_E_HIP;
+    *gb_per_s = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;
+    return FCZ_OK;
+}
+
 extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host) {
     if (!ctx || !out_host || mode < 0 || mode > 11) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -378,6 +378,10 @@ void fcz_ctx_reset_timing(fcz_ctx* ctx);
  * acos->degrees, glibc sinf / cosf restatements, norm, cosine, NeRF placement ...) on `count` inputs generated from
  * the float bit patterns start_bits, start_bits + stride, ... and copies the float results to out_host. */
 int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host);
+/* Device copy ceiling used by bench.py beside the 8 TB/s peak: `reps` copies of `bytes` bytes (rounded down to 16) between two
+ * scratch buffers by a float4-per-lane grid-stride kernel on a persistent grid (the kernel /opt/skills/guides/MI355X_MICROARCH.md
+ * quotes its 6.29 TB/s "float4 copy" with); *gb_per_s = (read + written bytes) / HIP-event time on the ctx stream. */
+int fcz_selftest_copy(fcz_ctx* ctx, uint64_t bytes, int reps, double* gb_per_s);
 
 #ifdef __cplusplus
 }

@@ -29,9 +29,26 @@ def test_traffic_table_covers_the_reported_kernels():
         assert k in t["kernels"], k
         traffic, src = b.measured_traffic(k, 350_000_000, 350)
         assert traffic and traffic > 0 and "pmc" in src
-    # other chain lengths have no measured profile: null, never a made-up number
-    assert b.measured_traffic("k_compress_angles_w", 1000, 123) == (None, None)
-    assert b.measured_traffic("no_such_kernel", 1000, 350) == (None, None)
+    # other chain lengths have no measured profile: null (and why), never a made-up number
+    assert b.measured_traffic("k_compress_angles_w", 1000, 123)[0] is None
+    assert b.measured_traffic("no_such_kernel", 1000, 350)[0] is None
+    # the mixed-length workload has counter passes of its own (round 6): per residue of THAT batch
+    mt, msrc = b.measured_traffic("k_backbone", 162_000_000, -1, "mixed")
+    assert mt and mt > 0 and "mixed" in msrc
+
+
+def test_traffic_is_only_quoted_for_the_kernels_it_was_measured_on(monkeypatch):
+    """the counter profile carries the hash of the kernel sources it was collected on (tools/pmc_summary.py): bench.py quotes its
+    figures only while the tree's hash is that one -- a kernel change makes `traffic` null until the passes are re-collected, it
+    never goes stale silently"""
+    b = _bench()
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert t["csrc_sha16"] == b.csrc_sha16(), "profiles/traffic.json describes other kernel sources than this tree: re-collect (tools/profile_gpu.sh + tools/pmc_summary.py + tools/merge_traffic.py)"
+    assert {"k_backbone", "k_compress_pack", "k_compress_pack_rows_4", "k_res_index_rows"} <= set(t["kernel_set"])
+    monkeypatch.setattr(b, "csrc_sha16", lambda: "0" * 16)
+    traffic, why = b.measured_traffic("k_backbone", 350_000_000, 350)
+    assert traffic is None and "re-collected" in why
+    assert b.controller_side_traffic("k_backbone", 350_000_000, 350) == (None, None, None)
 
 
 def test_gpus_flag_and_launcher_must_agree():

@@ -22,8 +22,8 @@ if "probes" in pr:
     ks = t["kernels"]
     tot = lambda k: ks[k]["fetch_bytes_per_residue"] + ks[k]["write_bytes_per_residue"]
     sizes = sum(tot(k) for k in ("k_entry_sizes", "k_sizes_reduce", "k_sizes_mid", "k_sizes_apply") if k in ks)   # every probed decompress call runs the sizes pass too
-    cs = {"source": "profiles/%s_hbm_busy_probe.json (tools/hbm_busy_probe.py: amdgpu mem_busy_percent, the memory controllers' activity level, "
-                    "calibrated on device copies at 100 / 50 / 25 %% duty: %s of linear)" % (tag, pr.get("linearity")),
+    cs = {"source": "profiles/%s (tools/hbm_busy_probe.py: amdgpu mem_busy_percent, the memory controllers' activity level, "
+                    "calibrated on device copies at 100 / 50 / 25 %% duty: %s of linear)" % (os.path.basename(probe_path), pr.get("linearity")),
           "bytes_per_s_per_percent": pr["bytes_per_s_per_percent"], "sizes_pass_bytes_per_residue_subtracted": round(sizes, 2), "bytes_per_residue": {}}
     for k in ("k_backbone", "k_res_index", "k_sidechain"):
         p = pr["probes"].get(k)
@@ -37,5 +37,11 @@ if "probes" in pr:
                                              "decompress_all": round(sizes + tot("k_backbone") + tot("k_res_index") + tot("k_sidechain"), 1),
                                              "compress_all": round(sum(tot(k) for k in ("k_compress_sizes", "k_compress_index", "k_compress_angles_w", "k_compress_angles", "k_compress_pack") if k in ks), 1)}
     t["controller_side"] = cs
+# the mixed-length workload (bench.py --mixed: 542 k chains of the log-normal generator), per residue of THAT batch
+mtag = os.environ.get("MIXED_TAG")
+if mtag and os.path.exists(os.path.join("gpurun_out", "prof_" + mtag, "traffic.json")):
+    tm = json.load(open(os.path.join("gpurun_out", "prof_" + mtag, "traffic.json")))
+    assert tm.get("csrc_sha16") == t.get("csrc_sha16"), "the mixed passes describe other kernels than the uniform ones"
+    t["mixed"] = {"source": tm["source"], "kernels": {k: v for k, v in tm["kernels"].items() if k.startswith(("k_compress", "k_backbone", "k_res_index", "k_sidechain", "k_entry", "k_sizes"))}}
 json.dump(t, open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(t.get("controller_side"), indent=1))

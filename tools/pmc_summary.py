@@ -60,4 +60,17 @@ for k, v in d.items():
         out["kernels"][short(k)]["valu_active_share_of_wave_cycles"] = round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"], 4)
         out["kernels"][short(k)]["valu_wave_insts_per_residue"] = round(v.get("SQ_INSTS_VALU", 0.0) / R, 3)
 if out["kernels"]:
+    # the kernels these passes describe are the ones compiled from the tree as it stands (the profile runs the tree's own .so):
+    # bench.py only quotes the figures while the hash of the kernel sources is this one
+    sys.path.insert(0, os.getcwd())
+    try:
+        import bench
+        out["csrc_sha16"] = bench.csrc_sha16(); out["kernel_sources"] = list(bench.KERNEL_SOURCES)
+    except Exception as e:   # (torch missing where the summary is made: hash by hand)
+        import hashlib
+        h = hashlib.sha256()
+        for f in ("fcz_kernels.h", "fcz_math.h", "fcz_compress.h", "fcz_sidechain.h", "aa_tables.inc"):
+            h.update(f.encode()); h.update(open(os.path.join("foldcomp_amd", "csrc", f), "rb").read())
+        out["csrc_sha16"] = h.hexdigest()[:16]
+    out["kernel_set"] = sorted(out["kernels"])
     json.dump(out, open(os.path.join("gpurun_out", "prof_" + tag, "traffic.json"), "w"), indent=1)

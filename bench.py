@@ -1167,6 +1167,11 @@ def dry_run(args, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend)
         comm = Comm(dist, dev, backend, rank, world)
+        from foldcomp_amd import shard as _shard
+        ok, pre = _shard.preflight(torch.device(dev) if backend == "nccl" else None)
+        if not ok:
+            print(f"bench.py: {pre}", file=sys.stderr); sys.stderr.flush()
+            os._exit(3)
         seen = int(comm.reduce([1.0], "max")[0] * dist.get_world_size())
         dist.barrier()
     else:
@@ -1186,6 +1191,7 @@ def dry_run(args, world, rank):
     if rank == 0:
         emit_line({"metric": "residues/sec compress+decompress, 350-aa chains; bit-exact FCZ; 1/2/4/8 GPUs", "value": None,
                    "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "cpu_baseline": cpu,
+                   "preflight": "answered" if world > 1 else None, "host_cpus": effective_cores(), "host_threads_per_rank": max(1, effective_cores() // max(1, world)),
                    "parity": {"chains_checked": n * world, "ranks_checked": world, **flags,
                               "kind": "dry run: no GPU result exists; every rank checked the oracle against itself on its own seed range"}})
     if world > 1:
@@ -1262,6 +1268,15 @@ def main():
             raise
         dist = None; group_note = f"no 1-rank RCCL group ({type(e).__name__}): the index exchange of the step is skipped at N = 1"
     comm = Comm(dist, dev, backend, rank, world)
+    preflight_note = None
+    if dist is not None:
+        # fail fast: one 1-element all_gather with a deadline BEFORE anything is generated (an 8-rank line that hangs in its first
+        # collective after minutes of generation tells nobody anything)
+        from foldcomp_amd import shard as _shard
+        ok, preflight_note = _shard.preflight(torch.device(dev) if backend == "nccl" else None)
+        if not ok:
+            print(f"bench.py: {preflight_note}", file=sys.stderr); sys.stderr.flush()
+            os._exit(3)
 
     C, n_res = args.chains, args.residues
     d = generate_resident(C, n_res, args.anchor, args.gen_chunk, dev, seed_base=args.seed_base + rank * C, mixed=args.mixed)
@@ -1593,6 +1608,7 @@ def main():
                        "chains_per_gpu": C, "residues_per_chain": round(R / C, 1) if args.mixed else n_res, "atoms_per_residue": round(A, 3),
                        "fcz_bytes_per_residue": round(fcz_per_res, 3), "parallelism": f"chain-sharded x{world}, no data-path collective",
                        "index_exchange": group_note or f"record lengths gathered on rank 0 over RCCL inside every step ({world}-rank group)",
+                       "preflight": preflight_note, "host_cpus": effective_cores(), "host_threads_per_rank": max(1, effective_cores() // max(1, world)),
                        "seed_base": args.seed_base, "backend": backend,
                        # how to read a --gpus N line of this bench, and of the product drivers, on a CPU quota that does not grow with N
                        "expected_bound_at_n_gpus": ("this step: inputs resident in HBM, no host stage, one small gather per step -> weak scaling, per-rank rate = the 1-GPU rate; "

@@ -53,6 +53,43 @@ def shard_range(n_items: int, weights: Sequence[int], rank: int, world: int) -> 
     return cuts[rank], cuts[rank + 1]
 
 
+PREFLIGHT_S = float(os.environ.get("FCZ_PREFLIGHT_S", "60"))
+
+
+def preflight(device=None, timeout_s: float = None):
+    """Fail fast instead of hanging: ONE 1-element all_gather of the ranks' numbers, given `timeout_s` seconds (FCZ_PREFLIGHT_S,
+    default 60), before any work is generated. A collective that hangs cannot be cancelled, so it runs on a thread of its own and
+    the caller decides what to kill. -> (ok, message); the message names what a maintainer checks first."""
+    import threading
+    world, rank = dist.get_world_size(), dist.get_rank()
+    timeout_s = PREFLIGHT_S if timeout_s is None else timeout_s
+    res = {}
+
+    def go():
+        try:
+            t = torch.full((1,), rank, dtype=torch.int64, device=device)
+            out = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            if device is not None:
+                torch.cuda.synchronize(device)
+            res["ranks"] = [int(x.item()) for x in out]
+        except Exception as e:   # noqa: BLE001
+            res["error"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=go, daemon=True)
+    th.start(); th.join(timeout_s)
+    env = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    where = f"rank {rank} of {world}, backend {dist.get_backend()}, device {device}, {env}"
+    if th.is_alive():
+        return False, (f"pre-flight: no answer from the {world}-rank group within {timeout_s:.0f} s ({where}). A rank that never joined, xGMI / "
+                       "IPC between the GPUs (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on this driver), or a rendezvous address the ranks do not share")
+    if "error" in res:
+        return False, f"pre-flight: the first collective failed: {res['error']} ({where})"
+    if res.get("ranks") != list(range(world)):
+        return False, f"pre-flight: the group answered {res.get('ranks')}, expected 0..{world - 1} ({where})"
+    return True, f"pre-flight: {world} ranks answered"
+
+
 def exchange_counts(records: int, nbytes: int, failed: bool, device=None, extra: Sequence[int] = ()):
     """the run's only collective: all_gather of this rank's {records, data bytes, failed, *extra} (int64).
     -> (key0, off0, any_failed, rows) with rows[r] = the list rank r sent"""

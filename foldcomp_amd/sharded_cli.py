@@ -104,9 +104,6 @@ def run(a, inputs: List[str], output: str) -> int:
     place = a.mode == "decompress" and world > 1
     part = output if (rank == 0 or place) else f"{output}.part{rank}"
     env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}     # (a launcher exports OMP_NUM_THREADS=1: the engine gets -t)
-    if place and rank == 0:
-        from . import shard as _s                     # (no torch yet: remove_db is plain file work)
-        _s.remove_db(output)                          # the ranks write INTO the final file: what an earlier run left must be gone before any of them opens it
     t_spawn = time.perf_counter()
     # (the engine takes device LOCAL_RANK modulo the device count: this process must not touch HIP before torch does -- the library
     # links the system's runtime, torch brings its own, and whichever initialises second finds no device)
@@ -132,11 +129,18 @@ def run(a, inputs: List[str], output: str) -> int:
         joined = True
         tdev = torch.device("cuda", device_index) if backend == "nccl" else None
         t_group = time.perf_counter()
-        # RCCL builds its rings on the first collective (~1 s): done here it stays off the path between the engines' end and the exchange
-        warm = torch.zeros(1, dtype=torch.int64, device=tdev)
-        dist.all_reduce(warm)
-        if tdev is not None:
-            torch.cuda.synchronize(tdev)
+        # RCCL builds its rings on the first collective (~1 s): done here it stays off the path between the engines' end and the
+        # exchange -- and it is the PRE-FLIGHT: a group that does not answer within FCZ_PREFLIGHT_S (60 s) ends the run now, with what
+        # to look at, instead of hanging in the exchange after the engines' work (a hung collective cannot be cancelled: the engine is
+        # killed and the process leaves)
+        ok, msg = shard.preflight(tdev)
+        if not ok:
+            print(f"[Error] {msg}", file=sys.stderr); sys.stderr.flush()
+            proc.kill()
+            if place and rank == 0:
+                shard.remove_db(output)
+            shard.remove_db(part); shard.remove_rank_files(output, rank)
+            os._exit(3)
         t_comm = time.perf_counter()
         if no_device:
             proc.kill()
@@ -150,22 +154,43 @@ def run(a, inputs: List[str], output: str) -> int:
                 if not line:
                     break
                 if line.startswith("{"):
-                    sizes = json.loads(line)
+                    try:
+                        sizes = json.loads(line)
+                    except ValueError:
+                        sizes = {}                    # a garbled line is this rank's failure in the exchange, not an exception that leaves the group
+                        break
                     if sizes.get("phase") == "sizes":
                         break
             t_sizes = time.perf_counter()
             failed = no_device or not sizes or bool(sizes.get("failed"))
             key0, off0, any_failed, rows0 = shard.exchange_counts(sizes.get("records", 0), sizes.get("data_bytes", 0), failed, tdev)
+            if not any_failed:
+                # the ranks write INTO the final file: what an earlier run left (the database, line files of a larger world) goes
+                # before any of them opens it -- and only now that every rank's inputs have passed their sizes pass: a run that fails
+                # at once leaves the previous database alone
+                if rank == 0:
+                    shard.remove_db(output)
+                    import glob as _glob
+                    for stale in _glob.glob(output + ".index.*") + _glob.glob(output + ".lookup.*"):
+                        try:
+                            os.remove(stale)
+                        except OSError:
+                            pass
+                dist.barrier()
             try:
                 proc.stdin.write("abort\n" if any_failed else f"{key0} {off0} {sum(r_[1] for r_ in rows0)}\n"); proc.stdin.flush(); proc.stdin.close()
             except (BrokenPipeError, OSError):
                 pass
             proc.stdin = None                         # (communicate() below must not flush a closed pipe)
-        stdout, _ = proc.communicate()
+        # (one mechanism for both phases: lines to EOF -- communicate() would read the raw descriptor past what readline buffered)
         st = {}
-        for line in (stdout or "").splitlines():
+        for line in proc.stdout:
             if line.startswith("{"):
-                st = json.loads(line)
+                try:
+                    st = json.loads(line)
+                except ValueError:
+                    st = {}
+        proc.wait()
         failed = no_device or proc.returncode != 0 or not st
         t_engine = time.perf_counter()
         extra = [st.get("residues", 0), int(st.get("wall_s", 0.0) * 1e6), int(st.get("ctx_ready_s", 0.0) * 1e6), st.get("max_rss_kb", 0),
@@ -201,6 +226,7 @@ def run(a, inputs: List[str], output: str) -> int:
             eng_wall = max(r_[4] for r_ in rows) / 1e6
             steady = max((r_[4] - r_[5]) for r_ in rows) / 1e6
             print(json.dumps({"mode": a.mode, "world": world, "backend": backend, "engine": "host/foldcomp-hip --shard R/N" + (" --place" if place else ""),
+                              "host_threads_per_rank": (a.threads if a.threads and a.threads > 1 else host_threads(world)), "cpus_of_this_process": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
                               "items": sum(r_[7] for r_ in rows), "records": sum(r_[0] for r_ in rows), "data_bytes": sum(r_[1] for r_ in rows),
                               "residues": res, "input_bytes": sum(r_[8] for r_ in rows),
                               "records_per_rank": [r_[0] for r_ in rows], "bytes_per_rank": [r_[1] for r_ in rows],

@@ -2306,7 +2306,10 @@ int run_decompress(const Options& o) {
     //                all_gather and answers `key0 off0 total` on stdin (or `abort`);
     //   real pass    the sequencer starts at key0 / off0: every job pwrites into <output> itself, index / lookup lines carry final
     //                keys and offsets (rank 0: <output>.index, rank R: <output>.index.R -- rank 0 only concatenates line files).
-    const bool place = o.place && o.db && !single;
+    // (--place is the sharded driver's handshake: without a database output there is nothing to place, and the driver would wait for a
+    //  sizes line that never comes)
+    if (o.place && (!o.db || single)) { fprintf(stderr, "[Error] --place needs `decompress -d` (--db) of a directory or database input\n"); return 1; }
+    const bool place = o.place;
     pinned_enabled() = true;
     int db_fd = -1;
     if (!o.db && !single) make_dir(output);

@@ -90,6 +90,25 @@ def test_plain_python_gpus_2_starts_two_ranks():
         assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_dry_run_of_the_eight_rank_line():
+    """the driver's first N = 8 run has no second try: the rendezvous, the pre-flight, every rank's check AND-ed into the parity flags,
+    the CPU baseline on rank 0 while seven ranks sleep on the store, ONE JSON line -- all of it at world 8 on the CPU (gloo; the codec
+    call itself is what the dry run leaves out)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--cpu-sample", "64"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["parity"]["ranks_checked"] == 8 and line["parity"]["chains_checked"] == 8 * 64
+    assert line["parity"]["fcz_bit_exact"] is True and line["parity"]["coords_bit_exact"] is True
+    assert line["preflight"] == "answered" and line["host_threads_per_rank"] >= 1 and line["host_cpus"] >= line["host_threads_per_rank"]
+    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["value"] > 0
+
+
 def test_bench_mmcif_rendering_holds_the_same_atoms():
     """the mmCIF files of bench.py's mmCIF legs are the chains of its PDB legs: cif_from_pdb_text of a PDB text reads back (host
     reader, mmCIF rules) as the atoms the PDB text reads back as (host reader, PDB rules), title = the entry id"""

@@ -65,7 +65,7 @@ def _expected(items):
     return data, idx, lk
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("mode", ["decompress", "compress"])
 def test_ranks_build_the_single_writers_database(tmp_path, world, mode):
     items = _items()
@@ -89,6 +89,73 @@ def test_a_failure_at_any_stage_leaves_nothing_behind(tmp_path, fail):
     rcs = _run(2, "decompress", str(inp), str(tmp_path / "out"), fail=fail)
     assert all(rc not in (0, None) for rc in rcs), rcs
     assert sorted(os.listdir(tmp_path)) == ["items.txt"], os.listdir(tmp_path)
+
+
+@pytest.mark.parametrize("fail", ["sizes:5", "write:0", "place:7"])
+def test_world_8_a_failure_on_any_rank_leaves_nothing_behind(tmp_path, fail):
+    """the shape of the driver's first real run (configs[3] / [4]: 8 ranks): rank 5 fails in its sizes pass, rank 0 while writing, the
+    last rank after the placement -- all eight return non-zero, no file of any rank stays"""
+    items = _items(53)
+    inp = tmp_path / "items.txt"
+    inp.write_text("".join(f"{nm} {n}\n" for nm, n in items))
+    rcs = _run(8, "decompress", str(inp), str(tmp_path / "out"), fail=fail)
+    assert len(rcs) == 8 and all(rc not in (0, None) for rc in rcs), rcs
+    assert sorted(os.listdir(tmp_path)) == ["items.txt"], os.listdir(tmp_path)
+
+
+@pytest.mark.parametrize("mode", ["decompress", "compress"])
+def test_world_8_with_empty_ranges_on_three_ranks(tmp_path, mode):
+    """five records over eight ranks: three ranks own nothing (the integer cut rule gives them an empty range) and still take part
+    in both collectives; the database is the single writer's"""
+    items = _items(5)
+    inp = tmp_path / "items.txt"
+    inp.write_text("".join(f"{nm} {n}\n" for nm, n in items))
+    sys.path.insert(0, ROOT)
+    from foldcomp_amd.shard import shard_cuts
+    cuts = shard_cuts([n for _, n in items], 8)
+    assert sum(1 for r in range(8) if cuts[r + 1] == cuts[r]) >= 3
+    out = tmp_path / "out"
+    assert _run(8, mode, str(inp), str(out)) == [0] * 8
+    data, idx, lk = _expected(items)
+    assert out.read_bytes() == data and (tmp_path / "out.index").read_text() == idx and (tmp_path / "out.lookup").read_text() == lk
+    assert sorted(os.listdir(tmp_path)) == ["items.txt", "out", "out.dbtype", "out.index", "out.lookup"]
+
+
+def test_preflight_ends_a_run_whose_group_does_not_answer(tmp_path):
+    """a rank that never reaches the first collective: the others do not hang in it -- the pre-flight gives the group
+    FCZ_PREFLIGHT_S seconds, says what it saw, kills its engine and leaves with status 3; nothing stays behind"""
+    items = _items(11)
+    inp = tmp_path / "items.txt"
+    inp.write_text("".join(f"{nm} {n}\n" for nm, n in items))
+    code = f"""
+import os, sys, time, argparse
+sys.path.insert(0, {ROOT!r})
+rank = int(os.environ["RANK"])
+import torch
+torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: 1
+from foldcomp_amd import sharded_cli, shard
+sharded_cli.ENGINE = {STANDIN!r}
+if rank == 1:
+    real = shard.preflight
+    def late(*a, **k):
+        time.sleep(30)          # this rank sits in front of its first collective: the group never answers in time
+        os._exit(0)
+    shard.preflight = late
+a = argparse.Namespace(mode="decompress", input={str(inp)!r}, threads=2, brk=25, recursive=False, skip_discontinuous=False, alt=False, check=False,
+                       id_list=None, id_mode=1, file_input=False, json_stats=False)
+sys.exit(sharded_cli.run(a, [{str(inp)!r}], {str(tmp_path / "out")!r}))
+"""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FCZ_SHARD_BACKEND="gloo", FCZ_PREFLIGHT_S="4")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE, text=True))
+    err0 = procs[0].communicate(timeout=120)[1]
+    assert procs[0].returncode == 3, (procs[0].returncode, err0[-500:])
+    assert "pre-flight: no answer from the 2-rank group within 4 s" in err0 and "MASTER_ADDR" in err0
+    procs[1].kill(); procs[1].wait()
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("out")) == []
 
 
 def test_a_failed_compress_rank_leaves_nothing_behind(tmp_path):

@@ -164,7 +164,7 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_splice_their_partial_databases_into_the_single_writers(tmp_path, world):
     rng = np.random.default_rng(3)
     (tmp_path / "files").mkdir()
@@ -239,7 +239,7 @@ def _placed_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_placed_ranks_write_once_into_the_final_database(tmp_path, world):
     rng = np.random.default_rng(4)
     (tmp_path / "files").mkdir()

@@ -489,6 +489,60 @@ def cif_from_pdb_text(pdb: bytes, entry_id: str) -> bytes:
     return ("\n".join(out) + "\n").encode("latin-1")
 
 
+ARCHIVE_STYLES = ("plain", "plain", "plain", "plain", "plain", "plain", "plain", "plain", "plain", "plain", "plain", "plain",
+                  "chains", "chains", "chains", "icode", "icode", "quoted", "quoted", "models")     # 60 / 15 / 10 / 10 / 5 %
+
+
+def cif_archive_from_pdb_text(pdb: bytes, entry_id: str, style: str) -> bytes:
+    """the ATOM records of a PDB text as an mmCIF file of the shape the PDB ARCHIVE ships (not a predicted structure): _cell /
+    _symmetry items, an _atom_site loop of 21 columns -- and, by `style`, what makes archive files differ from AFDB's:
+      chains   multi-character auth_asym_id ("AA"; label_asym_id stays "A")
+      icode    insertion codes: every 25th residue repeats its predecessor's number with pdbx_PDB_ins_code A (24, 24A, 25 ...)
+      quoted   a hetero group behind the chain whose atom names carry primes and therefore quotes ("O5'", "C1'" ...)
+      models   the chain twice, pdbx_PDB_model_num 1 and 2
+    input of the end_to_end mmcif_archive leg (how much of such a corpus the device ingest takes, how much goes to the host reader)"""
+    rows = []
+    atoms = [l for l in pdb.decode("latin-1").split("\n") if l.startswith("ATOM")]
+    asym = "AA" if style == "chains" else "A"
+    def emit(model, serial0):
+        out, serial, shift, last_seq, ins_of = [], serial0, 0, None, {}
+        for l in atoms:
+            name, res, seq = l[12:16].strip(), l[17:20].strip(), int(l[22:26])
+            ins = "?"
+            if style == "icode":
+                if seq != last_seq:
+                    last_seq = seq
+                    if seq % 25 == 0:
+                        shift += 1; ins_of[seq] = "A"
+                num = seq - shift
+                ins = ins_of.get(seq, "?")
+            else:
+                num = seq
+            serial += 1
+            out.append(f"ATOM {serial} {(l[76:78].strip() or name[:1])} {name} . {res} A 1 {seq} {ins} {l[30:38].strip()} {l[38:46].strip()} "
+                       f"{l[46:54].strip()} 1.00 {l[60:66].strip()} ? {num} {res} {asym} {name} {model}")
+        if style == "quoted":
+            x, y, z = atoms[-1][30:38].strip(), atoms[-1][38:46].strip(), atoms[-1][46:54].strip()
+            for k, (nm, el) in enumerate((("\"O5'\"", "O"), ("\"C5'\"", "C"), ("\"C4'\"", "C"), ("\"O4'\"", "O"), ("\"C1'\"", "C"), ("N9", "N"), ("PA", "P"))):
+                serial += 1
+                out.append(f"HETATM {serial} {el} {nm} . ATP B 2 . ? {x} {y} {z} 1.00 30.00 ? 900 ATP {asym if style == 'chains' else 'A'} {nm} {model}")
+        return out, serial
+    rows, last = emit(1, 0)
+    if style == "models":
+        rows2, _ = emit(2, 0)
+        rows += rows2
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_entity_id", "label_seq_id",
+            "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "pdbx_formal_charge", "auth_seq_id", "auth_comp_id",
+            "auth_asym_id", "auth_atom_id", "pdbx_PDB_model_num"]
+    out = ["data_" + entry_id, "#", "_entry.id " + entry_id, "#", "_cell.entry_id " + entry_id, "_cell.length_a 61.240", "_cell.length_b 61.240", "_cell.length_c 153.320",
+           "_cell.angle_alpha 90.00", "_cell.angle_beta 90.00", "_cell.angle_gamma 120.00", "_cell.Z_PDB 6", "#", "_symmetry.entry_id " + entry_id,
+           "_symmetry.space_group_name_H-M 'P 32 2 1'", "_symmetry.Int_Tables_number 154", "#", "loop_", "_entity.id", "_entity.type", "_entity.pdbx_description",
+           "1 polymer 'a protein of the bench generator'", "2 non-polymer \"ADENOSINE-5'-TRIPHOSPHATE\"", "#", "_struct.entry_id " + entry_id,
+           "_struct.title", ";A structure rendered in the PDB archive's mmCIF shape", "(bench.py cif_archive_from_pdb_text)", ";", "#",
+           "loop_"] + ["_atom_site." + c for c in cols] + rows + ["#"]
+    return ("\n".join(out) + "\n").encode("latin-1")
+
+
 class Comm:
     """what the ranks exchange outside the data path: reductions of clocks and check flags, the barrier, and a wait that does not
     spin (the store). `dist` None = no group (a single process). Backend "nccl" = RCCL with device tensors; "gloo" (test mode:
@@ -662,6 +716,40 @@ def end_to_end_leg(args, codec, w, dev):
             shutil.rmtree(cdir, ignore_errors=True)
         except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
             comp["mmcif"] = {"failed": str(e)[-300:]}
+        # ---- mmCIF as the PDB ARCHIVE ships it: the same chains rendered with multi-character chain names, insertion
+        #      codes, quoted atom names on a hetero group, two models (ARCHIVE_STYLES: 60 % none of these, 15 / 10 / 10 / 5 %) + the
+        #      reference's own mmCIF fixture: how much of such a corpus the device ingest takes, how much goes back to the host reader ----
+        try:
+            n_arc = min(n, 1000)
+            adir = os.path.join(tmp, "cif_archive"); os.mkdir(adir)
+            styles = {}
+            for i in range(n_arc):
+                st_ = ARCHIVE_STYLES[i % len(ARCHIVE_STYLES)]
+                styles[st_] = styles.get(st_, 0) + 1
+                with open(os.path.join(adir, f"a{i:06d}.cif"), "wb") as fh:
+                    fh.write(cif_archive_from_pdb_text(text[toff[i]:toff[i + 1]].tobytes(), f"A{i:06d}", st_))
+            try:
+                import gzip as _gz
+                fx = np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
+                with open(os.path.join(adir, "ref_test.cif"), "wb") as fh:
+                    fh.write(_gz.decompress(fx["file:test.cif.gz"].tobytes()))
+                styles["reference fixture test.cif"] = 1
+            except (OSError, KeyError):
+                pass
+            alst = os.path.join(tmp, "arc.txt")
+            with open(alst, "w") as fh:
+                fh.write((adir + "\n") * passes)
+            run_a = run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", *wpg, "--json-stats", "-f", alst, os.path.join(tmp, "dba")])
+            run_ah = run_host(["compress", "-d", "-y", "-t", str(eff), "--host-parse", "--gpus", "1", "--json-stats", "-f", alst, os.path.join(tmp, "dbah")])
+            nfa = sum(styles.values()) * passes
+            comp["mmcif_archive"] = {"files_per_pass": sum(styles.values()), "passes": passes, "styles": styles,
+                                     "gpu_host": summarise([run_a], "input_bytes", "host/foldcomp-hip compress -d -f <list of PDB-archive-style .cif> <db>"),
+                                     "gpu_host_parse": summarise([run_ah], "input_bytes", "... --host-parse"),
+                                     "host_parsed_files": run_a.get("host_parsed_files"), "hand_back_rate": round((run_a.get("host_parsed_files") or 0) / max(nfa, 1), 4),
+                                     "databases_identical": all(open(os.path.join(tmp, "dba") + ext, "rb").read() == open(os.path.join(tmp, "dbah") + ext, "rb").read() for ext in ("", ".index", ".lookup"))}
+            shutil.rmtree(adir, ignore_errors=True)
+        except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
+            comp["mmcif_archive"] = {"failed": str(e)[-300:]}
         # ---- gzipped input (AFDB ships .pdb.gz / .cif.gz): the gzip members cross the link as they are and are inflated on the
         #      device (k_inflate, round 6; reference: zlib in gemmi::MaybeGzipped / uncompressBuffer src/structure_reader.cpp:156-203),
         #      then parsed and compressed there. The first 4 096 files gzipped at level 6, both formats; `--host-inflate` (zlib on the

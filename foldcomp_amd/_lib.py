@@ -76,6 +76,7 @@ def load():
         "fcz_ingest_pdb_dev": (i32, [vp, vp, vp, u32, u64, vp, vp, vp, i32, i32, vp]),
         "fcz_ingest_pdb_begin": (i32, [vp, vp, vp, u32, vp, vp, vp, i32, i32, vp]),
         "fcz_ingest_pdb_fetch": (i32, [vp, PB, vp, vp, vp, vp]),
+        "fcz_ingest_chain_names_fetch": (i32, [vp, vp]),
         "fcz_compress_pdb_begin": (i32, [vp, vp, vp, u32, vp, vp, vp, i32, i32, vp, ctypes.POINTER(u64)]),
         "fcz_compress_pdb_fetch": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
         "fcz_inflate_sizes": (i32, [vp, vp, u32, vp, vp]),
@@ -104,7 +105,7 @@ EXPORTS = ["fcz_ctx_create", "fcz_ctx_destroy", "fcz_ctx_stream", "fcz_ctx_synch
            "fcz_compress_angles", "fcz_compress_sizes_dev", "fcz_compress_batch_dev", "fcz_decompress_sizes", "fcz_decompress_batch",
            "fcz_decompress_sizes_dev", "fcz_decompress_batch_dev", "fcz_pdb_sizes_dev", "fcz_pdb_format_dev",
            "fcz_decompress_pdb_begin", "fcz_decompress_pdb_fetch", "fcz_decompress_pdb_sizes", "fcz_extract_sizes", "fcz_extract",
-           "fcz_extract_sizes_dev", "fcz_extract_dev", "fcz_ingest_pdb_dev", "fcz_ingest_pdb_begin", "fcz_ingest_pdb_fetch",
+           "fcz_extract_sizes_dev", "fcz_extract_dev", "fcz_ingest_pdb_dev", "fcz_ingest_pdb_begin", "fcz_ingest_pdb_fetch", "fcz_ingest_chain_names_fetch",
            "fcz_compress_pdb_begin", "fcz_compress_pdb_fetch", "fcz_inflate_sizes", "fcz_inflate_dev", "fcz_inflate",
            "fcz_ingest_gz_begin", "fcz_compress_gz_begin", "fcz_check", "fcz_ctx_enable_timing",
            "fcz_ctx_kernel_time", "fcz_ctx_reset_timing", "fcz_selftest_math", "fcz_selftest_copy"]

@@ -192,6 +192,13 @@ class Codec:
         return dict(blob=blob[:int(nbytes.value)], off=off, status=st, chain_file=chain_file, chain_meta=chain_meta,
                     file_status=file_status, refused=refused, counts=counts)
 
+    def chain_names(self, n_chains: int):
+        """names of the chains of the batch the last ingest / compress_pdb / compress_gz call left in the ctx: list of str (mmCIF chain
+        names have up to four characters; chain_meta's low byte is only the first)"""
+        nm = np.zeros(max(int(n_chains), 1), np.uint32)
+        _lib.check(self.lib.fcz_ingest_chain_names_fetch(self.ctx, nm.ctypes.data), "fcz_ingest_chain_names_fetch")
+        return [int(v).to_bytes(4, "little").rstrip(b"\0").decode("latin-1") for v in nm[:int(n_chains)]]
+
     # ---- gzip members on the device ----------------------------------------------------------------
     INFLATE_STATUS = {0: "ok", 1: "header", 2: "block", 3: "code", 4: "size", 5: "input", 6: "check"}
 

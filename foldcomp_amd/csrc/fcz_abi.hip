@@ -619,7 +619,7 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
     auto need = [&](int i, size_t bytes) { return ctx->ig[i].ensure(std::max<size_t>(bytes, 16)); };
     if ((rc = need(B_CAP, 8 * F)) || (rc = need(B_ABASE, 8 * (F + 1))) || (rc = need(B_NAME, 4 * cap)) || (rc = need(B_RESN, 4 * cap)) ||
         (rc = need(B_SERIAL, 4 * cap)) || (rc = need(B_RESSEQ, 4 * cap)) || (rc = need(B_X, 4 * cap)) || (rc = need(B_Y, 4 * cap)) ||
-        (rc = need(B_Z, 4 * cap)) || (rc = need(B_B, 4 * cap)) || (rc = need(B_CHAIN, cap)) || (rc = need(B_ACODE, cap)) || (rc = need(B_RCODE, cap)) ||
+        (rc = need(B_Z, 4 * cap)) || (rc = need(B_B, 4 * cap)) || (rc = need(B_CHAIN, 4 * cap)) || (rc = need(B_ACODE, cap)) || (rc = need(B_RCODE, cap)) ||
         (rc = need(B_RFIRST, 4 * cap)) || (rc = need(B_RBFAC, 4 * cap)) || (rc = need(B_RCODE2, cap)) || (rc = need(B_TITLES, (size_t)IG_TITLE_CAP * F)) ||
         (rc = need(B_TLEN, 4 * F)) || (rc = need(B_NKEPT, 4 * F)) || (rc = need(B_STATUS, 4 * F)) || (rc = need(B_FRAGS, sizeof(ingest_frag) * IG_MAX_FRAGS * F)) ||
         (rc = need(B_NFRAGS, 4 * F)) || (rc = need(B_TOTC, 4 * F)) || (rc = need(B_TOTR, 4 * F)) || (rc = need(B_TOTA, 4 * F)) || (rc = need(B_TOTT, 4 * F)) ||
@@ -630,7 +630,7 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
     ingest_scratch T;
     T.name = (uint32_t*)P(B_NAME); T.resn = (uint32_t*)P(B_RESN); T.serial = (int32_t*)P(B_SERIAL); T.resseq = (int32_t*)P(B_RESSEQ);
     T.x = (float*)P(B_X); T.y = (float*)P(B_Y); T.z = (float*)P(B_Z); T.b = (float*)P(B_B);
-    T.chain = (uint8_t*)P(B_CHAIN); T.acode = (uint8_t*)P(B_ACODE); T.rcode = (int8_t*)P(B_RCODE);
+    T.chain = (uint32_t*)P(B_CHAIN); T.acode = (uint8_t*)P(B_ACODE); T.rcode = (int8_t*)P(B_RCODE);
     T.r_first = (uint32_t*)P(B_RFIRST); T.r_bfac = (float*)P(B_RBFAC); T.r_code = (uint8_t*)P(B_RCODE2);
     hipLaunchKernelGGL(k_ingest_caps, dim3(grid_for(n_files, 256)), dim3(256), 0, ctx->stream, file_off_dev, n_files, (uint64_t*)P(B_CAP));
     if ((rc = device_scan<uint64_t>(ctx, (const uint64_t*)P(B_CAP), (uint64_t*)P(B_ABASE), n_files))) return rc;
@@ -678,14 +678,14 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
     const size_t oa_x = 0, oa_y = 4 * (size_t)M, oa_z = 8 * (size_t)M, oa_c = 12 * (size_t)M;
     const size_t or_off = 0, or_bf = 4 * ((size_t)R + 1), or_rc = or_bf + 4 * (size_t)R;
     const size_t oc_res = 0, oc_tit = 4 * ((size_t)C + 1), oc_fr = 2 * oc_tit, oc_fa = oc_fr + 4 * (size_t)C, oc_file = oc_fa + 4 * (size_t)C,
-                 oc_meta = oc_file + 4 * (size_t)C, oc_id = oc_meta + 4 * (size_t)C;
+                 oc_meta = oc_file + 4 * (size_t)C, oc_name = oc_meta + 4 * (size_t)C, oc_id = oc_name + 4 * (size_t)C;
     if ((rc = need(B_OUT_A, 13 * (size_t)M + 16)) || (rc = need(B_OUT_R, or_rc + R + 16)) || (rc = need(B_OUT_C, oc_id + C + 16)) || (rc = need(B_OUT_T, (size_t)TB + 16))) return rc;
     char* ba = (char*)P(B_OUT_A); char* br = (char*)P(B_OUT_R); char* bc = (char*)P(B_OUT_C);
     ingest_out O;
     O.x = (float*)(ba + oa_x); O.y = (float*)(ba + oa_y); O.z = (float*)(ba + oa_z); O.atom_code = (uint8_t*)(ba + oa_c);
     O.atom_off = (uint32_t*)(br + or_off); O.bfac_ca = (float*)(br + or_bf); O.res_code = (uint8_t*)(br + or_rc);
     O.res_off = (uint32_t*)(bc + oc_res); O.title_off = (uint32_t*)(bc + oc_tit); O.first_res = (int32_t*)(bc + oc_fr); O.first_atom = (int32_t*)(bc + oc_fa);
-    O.chain_file = (uint32_t*)(bc + oc_file); O.chain_meta = (uint32_t*)(bc + oc_meta); O.chain_id = bc + oc_id;
+    O.chain_file = (uint32_t*)(bc + oc_file); O.chain_meta = (uint32_t*)(bc + oc_meta); O.chain_name4 = (uint32_t*)(bc + oc_name); O.chain_id = bc + oc_id;
     O.titles = (char*)P(B_OUT_T);
     {
         span_guard g(ctx, "ingest_fill");
@@ -703,7 +703,7 @@ int fcz_ingest_pdb_dev(fcz_ctx* ctx, const uint8_t* text_dev, const uint64_t* fi
     r.batch.atom_code = O.atom_code; r.batch.res_code = O.res_code; r.batch.bfac_ca = O.bfac_ca;
     r.batch.first_res_index = O.first_res; r.batch.first_atom_index = O.first_atom; r.batch.chain_id = O.chain_id;
     r.batch.titles = O.titles; r.batch.title_off = O.title_off;
-    r.chain_file = O.chain_file; r.chain_meta = O.chain_meta; r.file_status = (const int32_t*)P(B_STATUS); r.refused = (const uint32_t*)P(B_REFUSED);
+    r.chain_file = O.chain_file; r.chain_meta = O.chain_meta; r.chain_name4 = O.chain_name4; r.file_status = (const int32_t*)P(B_STATUS); r.refused = (const uint32_t*)P(B_REFUSED);
     r.n_files = n_files; r.n_refused = pin[5];
     ctx->ig_counts[0] = C; ctx->ig_counts[1] = R; ctx->ig_counts[2] = M; ctx->ig_counts[3] = TB; ctx->ig_counts[4] = pin[5];
     *out = r;
@@ -744,6 +744,18 @@ static int ingest_fetch_meta(fcz_ctx* ctx, uint32_t* chain_file, uint32_t* chain
     if (chain_meta && C) HIP_TRY(hipMemcpyAsync(chain_meta, r.chain_meta, 4 * (size_t)C, hipMemcpyDeviceToHost, ctx->stream));
     if (file_status && r.n_files) HIP_TRY(hipMemcpyAsync(file_status, r.file_status, 4 * (size_t)r.n_files, hipMemcpyDeviceToHost, ctx->stream));
     if (refused && r.n_refused) HIP_TRY(hipMemcpyAsync(refused, r.refused, 8 * (size_t)r.n_refused, hipMemcpyDeviceToHost, ctx->stream));
+    return FCZ_OK;
+}
+
+int fcz_ingest_chain_names_fetch(fcz_ctx* ctx, uint32_t* chain_name4) {
+    if (!ctx) return FCZ_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const fcz_ingest_result& r = ctx->ig_res;
+    if (r.batch.n_chains) {
+        if (!chain_name4) return FCZ_E_INVALID_ARG;
+        HIP_TRY(hipMemcpyAsync(chain_name4, r.chain_name4, 4 * (size_t)r.batch.n_chains, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return FCZ_OK;
 }
 

@@ -47,7 +47,7 @@ struct ingest_scratch {       // per-atom table of the kept atoms, file f at [ab
     int32_t* serial;          // atom serial number
     int32_t* resseq;          // residue sequence number
     float *x, *y, *z, *b;
-    uint8_t* chain;
+    uint32_t* chain;          // chain name: up to four characters packed (low byte = the first: the FCZ header's chain character)
     uint8_t* acode;           // codec atom code (255 = other)
     int8_t* rcode;            // codec residue code of the atom's residue name (-1 = not one the codec takes)
     // per residue, file f at [abase[f] ...): filled by k_ingest_frags
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         if (keep) {
             const size_t o = (size_t)A0 + kept + (uint32_t)__builtin_popcountll(m_keep & ((1ull << lane) - 1ull));
             T.name[o] = an; T.resn[o] = rn; T.serial[o] = serial; T.resseq[o] = resseq;
-            T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = (uint8_t)ch;
+            T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = (uint32_t)ch & 0xffu;
             T.acode[o] = (uint8_t)atom_code_of(an);
             T.rcode[o] = (int8_t)res_code_of(rn);
         }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
     uint32_t r_next = 0;                                   // next free slot of the file's residue scratch
     for (uint32_t c = 0; c < n_ch && !overflow; c++) {
         const uint32_t ca = s_cut[2 * c], cb = s_cut[2 * c + 1];
-        const uint32_t chain_char = T.chain[A0 + ca];
+        const uint32_t chain_char = T.chain[A0 + ca] & 0xffu;
         // gap cuts: positions (all N atoms) where a new fragment starts
         uint32_t fstart[IG_MAX_FRAGS + 1]; uint32_t nfr = 0;    // uniform values, small
         {
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_frags(uint32_t n_files, const u
 // ---- k_ingest_fill ------------------------------------------------------------------------------------------------------
 struct ingest_out {
     uint32_t *res_off, *atom_off, *title_off; float *x, *y, *z, *bfac_ca; uint8_t *atom_code, *res_code; int32_t *first_res, *first_atom;
-    char *chain_id, *titles; uint32_t *chain_file, *chain_meta;
+    char *chain_id, *titles; uint32_t *chain_file, *chain_meta, *chain_name4;
 };
 __global__ __launch_bounds__(WAVE) void k_ingest_fill(uint32_t n_files, const uint64_t* __restrict__ abase, ingest_scratch T,
                                                       const ingest_frag* __restrict__ frags, const uint32_t* __restrict__ n_frags,
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_fill(uint32_t n_files, const ui
         if (lane == 0) {
             O.res_off[c] = r; O.title_off[c] = t;
             O.first_res[c] = T.resseq[A0 + fr.a]; O.first_atom[c] = T.serial[A0 + fr.a];
-            O.chain_id[c] = (char)T.chain[A0 + fr.a];
+            O.chain_id[c] = (char)(T.chain[A0 + fr.a] & 0xffu); O.chain_name4[c] = T.chain[A0 + fr.a];
             O.chain_file[c] = f; O.chain_meta[c] = fr.meta;
         }
         c++; r += fr.nres; a += na; t += tl;

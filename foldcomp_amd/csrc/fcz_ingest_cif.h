@@ -25,9 +25,10 @@
 //
 // The device never guesses. It takes the shape every predicted-structure file has -- one data_ block, items one per line (or
 // a tag line followed by its value line / text field), loop rows of whole lines, `_atom_site` rows of exactly one line each
-// without quotes, single-character chain names, integer residue numbers without insertion codes, one model, residues in
-// rising order inside a chain run -- and hands EVERYTHING else back to the host reader (save_ frames, global_ / stop_, several
-// blocks, comments after values, quoted atom names, multi-letter chains, several models, '?' coordinates, exponents, lines of
+// without quotes except around the atom name ("O5'"), chain names of up to four characters, integer residue numbers with an optional
+// one-character insertion code, one model, residues in rising (number, insertion code) order inside a chain run (round 6: the PDB
+// archive's shape beside AFDB's) -- and hands EVERYTHING else back to the host reader (save_ frames, global_ / stop_, several
+// blocks, comments after values, other quoted values, longer chain names, several models, '?' coordinates, exponents, lines of
 // more than 255 characters, bytes outside printable ASCII, ...), which restates gemmi rule for rule and is held to the live
 // reference by fuzzing. tests/test_gpu_ingest.py holds this kernel to that reader on mutated files: it never builds a
 // different batch and never takes a file the reader fails.
@@ -410,8 +411,18 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
         // ---- 3. the _atom_site rows of the step leave as row records: where the line starts, the bounds of the fourteen fields ----
         if (rowmask == 0ull) return;
         const bool row = ((rowmask >> lane) & 1ull) != 0;
-        // no quoted value anywhere in a row (the host strips the quotes): such a line went through the character lexer
-        if (__any(row && slow)) { dead = true; return; }
+        // a quoted value in a row (such a line went through the character lexer): only the atom name may be one -- the primes of
+        // nucleotide and ligand atoms ("O5'") force the quotes in archive files; the reader strips them (cif::as_string). Anything
+        // else quoted (a quoted '?' is not a null, a quoted number is no number for as_number) is the host's
+        bool qname = false;
+        if (row && slow) {
+            const int pa = S.pos[CK_LATOM], pb = S.pos[CK_AATOM];
+            for (uint32_t t = 0; t < ntok; t++) {
+                const uint32_t c0 = S.buf[lo + (int)S.tok_s[t][lane]];
+                if (c0 == '\'' || c0 == '"') { if ((int)t == pa || (int)t == pb) qname = true; else bad = true; }
+            }
+        }
+        if (__any(row && bad)) { dead = true; return; }
         const uint32_t n_new = (uint32_t)__builtin_popcountll(rowmask);
         if (nrows + n_new > cap || (flen >> 32) != 0ull) { dead = true; return; }
         {
@@ -421,7 +432,8 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse_cif(const uint8_t* __rest
 #pragma unroll
             for (int q = 0; q < 14; q++) {
                 const int c = cols[q] >= 0 ? cols[q] : 0;
-                const uint32_t ts = (row && cols[q] >= 0) ? (uint32_t)S.tok_s[c][lane] : 0u, te = (row && cols[q] >= 0) ? (uint32_t)S.tok_e[c][lane] : 0u;
+                uint32_t ts = (row && cols[q] >= 0) ? (uint32_t)S.tok_s[c][lane] : 0u, te = (row && cols[q] >= 0) ? (uint32_t)S.tok_e[c][lane] : 0u;
+                if (q == 6 && qname && te >= ts + 2u) { const uint32_t c0 = S.buf[lo + (int)ts]; if (c0 == '\'' || c0 == '"') { ts++; te--; } }   // the name between its quotes
                 w[q >> 1] |= (ts | (te << 8)) << (16 * (q & 1));
             }
             if (row) {
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
     };
     const uint64_t A0 = abase[f];
     uint32_t kept = 0;
-    bool have_last = false; uint32_t last_name = 0, last_comp = 0, last_ch = 0; int32_t last_num = 0;
+    bool have_last = false; uint32_t last_name = 0, last_comp = 0, last_ch = 0, last_ic = 0; int32_t last_num = 0;
     unsigned long long model0 = 0; bool have_model = false;
     bool dead = false;
 
@@ -667,17 +679,21 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
           for (int q = 0; q < 8; q++) widest = max(widest, fn[numeric[q]]); }
         const bool narrow = !__any(widest > 8u);
         bool rbad = false;
-        uint32_t an = 0, rn = 0, ch = ' '; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
+        uint32_t an = 0, rn = 0, ch = ' ', ic = 0; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
         auto fields = [&](auto NI, auto ND, auto NWD) {
             const fld f0 = load(0, NWD), f1 = load(1, NWD), f2 = load(2, NWD), f3 = load(3, NWD), f4 = load(4, NWD), f5 = load(5, NWD);
             const fld f6 = load(6, I1{}), f7 = load(7, I1{}), f8 = load(8, I1{}), f9 = load(9, I1{}), f10 = load(10, I1{});
             const fld f11 = load(11, NWD), f12 = load(12, NWD), f13 = load(13, I2{});
             rbad = rbad | !integer(f0, &serial, NI) | !integer(f1, &num, NI) | !decimal(f2, &x, ND) | !decimal(f3, &y, ND) | !decimal(f4, &z, ND);
-            rbad = rbad | !decimal(f5, &bf, ND) | !pack(f6, &an) | !pack(f7, &rn) | (f8.n != 1u) | is_null(f8) | (!is_null(f9) & (f9.n != 1u));
-            ch = f8.w[0] & 0xffu;
+            // the chain's name: one to four characters, packed (archive files of large complexes name chains "AA", "B2" ...); a longer
+            // one is the host's. The insertion code (pdbx_PDB_ins_code): absent, null, or ONE character (cif::as_char); residue
+            // identity is (number, code) with the code's case folded (gemmi SeqId::operator==), 0 = none
+            rbad = rbad | !decimal(f5, &bf, ND) | !pack(f6, &an) | !pack(f7, &rn) | !pack(f8, &ch) | (!is_null(f9) & (f9.n != 1u));
             int32_t dummy;
             // an optional column that the loop does not have has no characters
-            rbad = rbad | ((f10.n != 0u) & !is_null(f10));
+            rbad = rbad | ((f10.n != 0u) & !is_null(f10) & (f10.n != 1u));
+            ic = ((f10.n == 1u) & !is_null(f10)) ? ((f10.w[0] & 0xffu) & ~0x20u) : 0u;
+            rbad = rbad | ((f10.n == 1u) & !is_null(f10) & (ic == 0u));                      // (a blank cannot be a token; a code that folds to nothing: not here)
             rbad = rbad | ((f11.n != 0u) & !is_null(f11) & !integer(f11, &dummy, NI));
             rbad = rbad | ((f12.n != 0u) & !is_null(f12) & !integer(f12, &dummy, NI));
             rbad = rbad | (f13.n > 8u);
@@ -691,13 +707,16 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
         const int src = pl < 64u ? (int)pl : 0;
         const int32_t s_num = __shfl(num, src, WAVE);
         const uint32_t s_rn = (uint32_t)__shfl((int)rn, src, WAVE), s_ch = (uint32_t)__shfl((int)ch, src, WAVE), s_an = (uint32_t)__shfl((int)an, src, WAVE);
+        const uint32_t s_ic = (uint32_t)__shfl((int)ic, src, WAVE);
         const bool has_p = pl < 64u ? true : have_last;
         const int32_t p_num = pl < 64u ? s_num : last_num;
-        const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name;
+        const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name, p_ic = pl < 64u ? s_ic : last_ic;
         const unsigned long long m_first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mdl >> 32), 0) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mdl, 0);
         const unsigned long long m0 = have_model ? model0 : m_first;
         if (row && mdl != m0) rbad = true;
-        if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_rn == rn) && !(num > p_num)) rbad = true;
+        // (file order is the reader's order as long as, inside a run of one chain name, every new residue has a larger (number,
+        //  insertion code) than the one before it: find_or_add_residue then never finds an earlier residue to append to)
+        if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_ic == ic && p_rn == rn) && !(num > p_num || (num == p_num && ic > p_ic))) rbad = true;
         if (__any(row && rbad)) { dead = true; break; }
         if (!have_model) { model0 = m0; have_model = true; }
         const bool keep = row && !(has_p && p_an == an);
@@ -705,14 +724,14 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
         if (keep) {
             const size_t o = (size_t)A0 + kept + (uint32_t)__builtin_popcountll(m_keep & ((1ull << lane) - 1ull));   // <= `at`: never a record still to be read
             T.name[o] = an; T.resn[o] = rn; T.serial[o] = serial; T.resseq[o] = num;
-            T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = (uint8_t)ch;
+            T.x[o] = x; T.y[o] = y; T.z[o] = z; T.b[o] = bf; T.chain[o] = ch;
             T.acode[o] = (uint8_t)atom_code_of(an);
             T.rcode[o] = (int8_t)res_code_of(rn);
         }
         kept += (uint32_t)__builtin_popcountll(m_keep);
         const int hl = 63 - __builtin_clzll(rowmask);
         last_name = (uint32_t)__builtin_amdgcn_readlane((int)an, hl); last_comp = (uint32_t)__builtin_amdgcn_readlane((int)rn, hl); last_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, hl);
-        last_num = __builtin_amdgcn_readlane(num, hl); have_last = true;
+        last_num = __builtin_amdgcn_readlane(num, hl); last_ic = (uint32_t)__builtin_amdgcn_readlane((int)ic, hl); have_last = true;
     }
     if (lane == 0 && !dead && kept != 0u) {
         n_kept[f] = kept;

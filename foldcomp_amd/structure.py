@@ -901,7 +901,8 @@ class CChainBatch(ctypes.Structure):
 class CIngestResult(ctypes.Structure):
     """fcz_ingest_result (include/fcz_hip.h): the device-resident batch of an ingest call + per-chain / per-file arrays"""
     _fields_ = [("batch", CChainBatch), ("chain_file", ctypes.c_void_p), ("chain_meta", ctypes.c_void_p),
-                ("file_status", ctypes.c_void_p), ("refused", ctypes.c_void_p), ("n_files", ctypes.c_uint32), ("n_refused", ctypes.c_uint32)]
+                ("file_status", ctypes.c_void_p), ("refused", ctypes.c_void_p), ("n_files", ctypes.c_uint32), ("n_refused", ctypes.c_uint32),
+                ("chain_name4", ctypes.c_void_p)]
 
 
 class CAtomsOut(ctypes.Structure):

@@ -1972,16 +1972,22 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                 if (rc != FCZ_OK) { fprintf(stderr, "[Error] %s: job of %u files not compressed\n", fcz_status_string(rc), n_text); failed = true; }
             }
             if (!failed && n_text) {
-                auto frag_name = [&](size_t file, uint32_t meta) {
+                // the chains' names (mmCIF: up to four characters; chain_meta keeps the first)
+                std::vector<uint32_t> name4(counts[0], 0);
+                if (counts[0] && fcz_ingest_chain_names_fetch(ctx, name4.data()) != FCZ_OK) std::fill(name4.begin(), name4.end(), 0u);
+                auto frag_name = [&](size_t file, uint32_t meta, uint32_t n4 = 0) {
                     std::string nm = stem_of(file);
                     // (a blank chain id names nothing: gemmi's read_string trims it to "", AtomTable::chain_name likewise)
-                    if ((meta & FCZ_INGEST_MULTI_CHAIN) && (char)(meta & 0xffu) != ' ') nm.push_back((char)(meta & 0xffu));
+                    if ((meta & FCZ_INGEST_MULTI_CHAIN) && (char)(meta & 0xffu) != ' ') {
+                        if (n4 == 0) n4 = meta & 0xffu;
+                        for (int b = 0; b < 4 && ((n4 >> (8 * b)) & 0xffu); b++) nm.push_back((char)((n4 >> (8 * b)) & 0xffu));
+                    }
                     if (meta & FCZ_INGEST_MULTI_FRAG) nm += "_" + std::to_string((meta >> 8) & 0xffu);
                     return nm;
                 };
                 for (uint32_t c = 0; c < counts[0]; c++) {
                     const size_t file = text_file[chain_file[c]];
-                    const std::string nm = frag_name(file, chain_meta[c]);
+                    const std::string nm = frag_name(file, chain_meta[c], name4[c]);
                     if (status[c] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s.fcz: %s\n", nm.c_str(), fcz_status_string(status[c])); continue; }
                     recs.push_back({file, (chain_meta[c] >> 8) & 0xffu, blob.data() + off[c], off[c + 1] - off[c], nm + suffix_of(file), stem_of(file), 0, 0});
                     // (sub: the order of a file's records is the order the device emitted them; see the stable sort below)
@@ -1994,10 +2000,16 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     const uint32_t reason = refused[k + 1] >> 24;
                     fprintf(stderr, "[Error] compressing %s.fcz: %s\n", frag_name(text_file[refused[k]], refused[k + 1]).c_str(), why[reason < 7 ? reason : 0]);
                 }
-                // what the device handed back: parsed here from the text that is already in memory
+                // what the device handed back: parsed here from the text that is already in memory -- on the host threads, not one file
+                // after the other on this worker's (a twentieth of an archive-style mmCIF directory comes back: round 6)
+                std::vector<uint32_t> back;
                 for (uint32_t t = 0; t < n_text; t++) {
                     if (file_status[t] == FCZ_INGEST_NO_ATOMS) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base_name(job.paths[text_file[t]]).c_str()); continue; }
-                    if (file_status[t] == FCZ_OK) continue;
+                    if (file_status[t] != FCZ_OK) back.push_back(t);
+                }
+#pragma omp parallel for schedule(dynamic, 1) if (back.size() > 1)
+                for (long long bi = 0; bi < (long long)back.size(); bi++) {
+                    const uint32_t t = back[(size_t)bi];
                     if (file_status[t] != FCZ_INGEST_HOST_GZIP) n_host_files++;      // (a member zlib has to take is counted on its own below)
                     const size_t file = text_file[t];
                     std::string stem, ext; file_parts(base_name(job.paths[file]), stem, ext);

@@ -259,11 +259,12 @@ int fcz_decompress_pdb_sizes(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
  * is read by gemmi's mmCIF rules (cif.hpp:37-148 grammar, mmcif.hpp:560-680 make_structure: the _atom_site loop's 23 columns by any
  * case, chain = auth_asym_id else label_asym_id, residue = auth_seq_id + comp id, atom name = auth_atom_id else label_atom_id,
  * title = _entry.id) when it has the shape every predicted-structure file has: one block, one item per line (or a tag line and its
- * value / text field on the following lines), loops of whole-line rows, _atom_site rows of one line each without quoted values,
- * one-character chain names, integer residue numbers without insertion codes, one model, residues rising inside a chain run,
- * coordinates as plain decimals of at most 15 digits. Every other mmCIF file comes back as FCZ_INGEST_HOST_FIELD exactly as a PDB
- * file outside the fixed layout does (save_ frames, several blocks, comments after values, quoted atom names, multi-letter chains,
- * several models, '?' coordinates, duplicate tags, a _cell angle that is not plainly non-zero, lines beyond 255 characters ...). */
+ * value / text field on the following lines), loops of whole-line rows, _atom_site rows of one line each without quoted values
+ * other than the atom name ("O5'"), chain names of up to four characters, integer residue numbers with an optional one-character
+ * insertion code, one model, residues rising by (number, insertion code) inside a chain run, coordinates as plain decimals of at
+ * most 15 digits (round 6: the PDB archive's shape beside AFDB's). Every other mmCIF file comes back as FCZ_INGEST_HOST_FIELD exactly
+ * as a PDB file outside the fixed layout does (save_ frames, several blocks, comments after values, other quoted values, longer chain
+ * names, several models, '?' coordinates, duplicate tags, a _cell angle that is not plainly non-zero, lines beyond 255 characters ...). */
 enum fcz_ingest_status { FCZ_INGEST_HOST_FIELD = 1, FCZ_INGEST_HOST_TITLE = 2, FCZ_INGEST_HOST_FRAGS = 3, FCZ_INGEST_NO_ATOMS = 4 };
 enum fcz_ingest_reason { FCZ_INGEST_REF_RESNAME = 1, FCZ_INGEST_REF_BACKBONE = 2, FCZ_INGEST_REF_TOO_LONG = 3, FCZ_INGEST_REF_SKIP_DISC = 4,
                          FCZ_INGEST_REF_BACKBONE_TWICE = 5, FCZ_INGEST_REF_LAST_NAME = 6 };
@@ -277,6 +278,10 @@ typedef struct fcz_ingest_result {        /* device pointers owned by the ctx, v
     const int32_t*  file_status;          /* [F] */
     const uint32_t* refused;              /* [2 * n_refused], in no particular order */
     uint32_t n_files, n_refused;
+    const uint32_t* chain_name4;          /* [C] the chain's NAME, up to four characters packed little-endian (mmCIF auth_asym_id of large
+                                           * complexes: "AA", "B2" ...; chain_meta's low byte is its first character, what the FCZ header
+                                           * keeps): what the reference appends to a record's name when the file holds several chains
+                                           * (src/main.cpp:489-491) */
 } fcz_ingest_result;
 /* Device-resident: text_dev / file_off_dev / names_dev / name_off_dev / stem_len_dev are device pointers; one stream
  * synchronisation (the totals). */
@@ -291,6 +296,8 @@ int fcz_ingest_pdb_begin(fcz_ctx* ctx, const uint8_t* text, const uint64_t* file
                          const uint32_t* name_off, const uint32_t* stem_len, int anchor_threshold, int flags, uint32_t counts[5]);
 int fcz_ingest_pdb_fetch(fcz_ctx* ctx, const fcz_chain_batch* host_batch, uint32_t* chain_file, uint32_t* chain_meta,
                          int32_t* file_status, uint32_t* refused);
+/* the chains' names of the resident batch (fcz_ingest_result.chain_name4) copied to chain_name4[C]; after any *_begin call */
+int fcz_ingest_chain_names_fetch(fcz_ctx* ctx, uint32_t* chain_name4);
 /* Text in, FCZ records out: ingest + fcz_compress_sizes_dev + fcz_compress_batch_dev on the resident batch.
  * begin(): counts = {chains, residues, atoms, title bytes, refused fragments}, *fcz_bytes = size of the blob; fetch(): record
  * offsets out_off[C+1], per-chain status[C] and the arrays of fcz_ingest_pdb_fetch (any may be NULL), then the blob. */

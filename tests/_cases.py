@@ -273,7 +273,10 @@ def mutated_cif(text: str, rng, max_edits=4) -> bytes:
         elif kind == 5:                                     # a column changed from this row on
             name, val = [("pdbx_PDB_model_num", "2"), ("auth_asym_id", "B"), ("label_asym_id", "B"), ("label_alt_id", "A"), ("pdbx_PDB_ins_code", "A"),
                          ("auth_comp_id", "ALA"), ("label_comp_id", "GLY"), ("auth_atom_id", "CA"), ("B_iso_or_equiv", "?"), ("occupancy", "."),
-                         ("pdbx_PDB_model_num", "1"), ("auth_seq_id", "7"), ("label_seq_id", "x")][int(rng.integers(0, 13))]
+                         ("pdbx_PDB_model_num", "1"), ("auth_seq_id", "7"), ("label_seq_id", "x"),
+                         # (round 6, the PDB archive's shapes: chain names of several characters, lower-case insertion codes, atom names in quotes)
+                         ("auth_asym_id", "BB"), ("auth_asym_id", "AB1x"), ("auth_asym_id", "ABCDE"), ("pdbx_PDB_ins_code", "b"),
+                         ("auth_atom_id", "\"O5'\""), ("label_atom_id", "\"O5'\"")][int(rng.integers(0, 19))]
             stop = rows.index(i) + int(rng.integers(1, 40))
             for j in rows[rows.index(i):stop]:
                 set_tok(j, name, val)

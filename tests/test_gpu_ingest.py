@@ -57,22 +57,23 @@ def _host_expect(texts, names, brk=25, skip_disc=False, reader=None):
             frags = identify_discontinuous(t, cs)
             for j, sl in enumerate(frags):
                 nm = stem + (t.chain[cs.start] if len(cs_all) > 1 else "") + (f"_{j}" if len(frags) > 1 else "")
+                nm_ref = stem + (t.chain[cs.start][:1] if len(cs_all) > 1 else "") + (f"_{j}" if len(frags) > 1 else "")   # (a refusal is reported with the chain's first character)
                 ch = Chain(title, t.take(sl))
                 try:
                     if skip_disc and len(frags) > 1:
                         raise StructureError("skip")
                     build_batch([ch], brk)
                 except StructureError:
-                    refused.append((fi, nm)); continue
+                    refused.append((fi, nm_ref)); continue
                 chains.append(ch); out_names.append(nm); cfile.append(fi)
     return (build_batch(chains, brk) if chains else None), out_names, cfile, refused, failed
 
 
-def _name_of(base, meta):
+def _name_of(base, meta, chain_name=None):
     stem = base.rsplit(".", 1)[0] if "." in base else base
     nm = stem
     if meta & (1 << 16):
-        nm += chr(meta & 0xff)
+        nm += chain_name if chain_name else chr(meta & 0xff)      # (mmCIF chain names have up to four characters: Codec.chain_names)
     if meta & (1 << 17):
         nm += f"_{(meta >> 8) & 0xff}"
     return nm
@@ -255,7 +256,8 @@ def test_device_ingest_fuzz_never_parses_differently(codec, golden):
     remap = {f: k for k, f in enumerate(ok)}
     exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok], reader=_read_any if names[0].endswith(".cif") else None)
     assert not failed, [names[ok[k]] for k in failed]
-    got_names = [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)]
+    cnames = codec.chain_names(b.n_chains)
+    got_names = [_name_of(names[f], int(m), cn) for f, m, cn in zip(cfile, cmeta, cnames)]
     assert got_names == exp_names
     assert [remap[int(f)] for f in cfile] == exp_file
     _same_batch(b, exp)
@@ -355,8 +357,13 @@ def test_device_mmcif_fuzz_never_parses_differently(codec, golden, ing):
     remap = {f: k for k, f in enumerate(ok)}
     exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok], reader=_read_any if names[0].endswith(".cif") else None)
     assert not failed, [names[ok[k]] for k in failed]
-    got_names = [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)]
+    cnames = codec.chain_names(b.n_chains)
+    got_names = [_name_of(names[f], int(m), cn) for f, m, cn in zip(cfile, cmeta, cnames)]
     assert got_names == exp_names
     assert [remap[int(f)] for f in cfile] == exp_file
     _same_batch(b, exp)
     assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
+    # the PDB archive's shapes are read on the device (round 6): files with chain names of several characters, insertion codes and
+    # quoted atom names are among the taken ones
+    taken = [texts[i] for i in ok]
+    assert any(b" BB " in t_ or b" AB1x " in t_ for t_ in taken) and any(b"\"O5'\"" in t_ for t_ in taken)

@@ -512,12 +512,19 @@ int fcz_compress_batch_dev(fcz_ctx* ctx, const fcz_chain_batch* in, const uint64
         // chains of 2 .. 128 residues (k_compress_pack leaves them): four to a wavefront, a persistent grid over chunks of 16 chains
         // (one launch per length class -- 2..16, 17..32, 33..64, 65..128 residues in 1, 2, 4, 8 rounds of 16 -- each a scan of the chunks' lengths)
         const uint32_t rows_blocks = std::min<uint32_t>(grid_for(grid_for(in->n_chains, CP_CHUNK), WAVES_PER_BLOCK), (uint32_t)ctx->n_cu * 4u);
+        // (every class launch is tied to the bound k_compress_pack skips by: a build with fewer rounds must not run a class twice)
+        static_assert(FCZ_PACK_ROWS_MAX_ROUNDS == 1 || FCZ_PACK_ROWS_MAX_ROUNDS == 2 || FCZ_PACK_ROWS_MAX_ROUNDS == 4 || FCZ_PACK_ROWS_MAX_ROUNDS == 8,
+                      "k_compress_pack_rows has the classes of 1, 2, 4 and 8 rounds");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<1>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+#if FCZ_PACK_ROWS_MAX_ROUNDS >= 2
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<2>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+#endif
+#if FCZ_PACK_ROWS_MAX_ROUNDS >= 4
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<4>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);
+#endif
 #if FCZ_PACK_ROWS_MAX_ROUNDS >= 8
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compress_pack_rows<8>), dim3(rows_blocks), dim3(BLOCK), 0, ctx->stream, *in, out_off_dev, out_dev, status_dev,
                            ctx->ang.as<float>(), ctx->keep_first_angle ? 1 : 0, (const uint32_t*)nonfinite);

@@ -387,7 +387,8 @@ void fcz_ctx_reset_timing(fcz_ctx* ctx);
 int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host);
 /* Device copy ceiling used by bench.py beside the 8 TB/s peak: `reps` copies of `bytes` bytes (rounded down to 16) between two
  * scratch buffers by a float4-per-lane grid-stride kernel on a persistent grid (the kernel /opt/skills/guides/MI355X_MICROARCH.md
- * quotes its 6.29 TB/s "float4 copy" with); *gb_per_s = (read + written bytes) / HIP-event time on the ctx stream. */
+ * quotes its 6.29 TB/s "float4 copy" with), in a few launch shapes (8 / 16 / 32 blocks per CU, one or four loads in flight per lane,
+ * default and non-temporal cache policy); *gb_per_s = the best (read + written bytes) / HIP-event time on the ctx stream. */
 int fcz_selftest_copy(fcz_ctx* ctx, uint64_t bytes, int reps, double* gb_per_s);
 
 #ifdef __cplusplus

@@ -791,6 +791,36 @@ def end_to_end_leg(args, codec, w, dev):
                 gzo[kind + "_gz"]["device_inflated_files"] = runs_g[0].get("device_inflated_files"); gzo[kind + "_gz"]["host_inflated_after_device_refusal"] = runs_g[0].get("host_inflated_after_device_refusal")
                 gzo[kind + "_gz"]["databases_identical"] = all(open(os.path.join(tmp, f"dbgz_{kind}_{tcounts[0]}") + ext, "rb").read() == open(os.path.join(tmp, f"dbgz_{kind}_hi") + ext, "rb").read() for ext in ("", ".index", ".lookup"))
                 gz_sets[kind] = gpaths
+                # k_inflate alone on the same members, resident in HBM (HIP events on the ctx stream; every member's status; a sample of
+                # the texts against zlib's)
+                try:
+                    import zlib as _zlib
+                    nk = min(n_gz, 2560)
+                    mem = [open(g_, "rb").read() for g_ in gpaths[:nk]]
+                    goff = np.zeros(nk + 1, np.uint64); goff[1:] = np.cumsum([len(m_) for m_ in mem])
+                    rawz = np.frombuffer(b"".join(mem), np.uint8)
+                    tzo = np.zeros(nk + 1, np.uint64)
+                    _lib.check(lib.fcz_inflate_sizes(rawz.ctypes.data, goff.ctypes.data, nk, None, tzo.ctypes.data), "fcz_inflate_sizes")
+                    d_raw = torch.from_numpy(rawz.copy()).to(dev); d_go = torch.from_numpy(goff.view(np.int64)).to(dev); d_to = torch.from_numpy(tzo.view(np.int64)).to(dev)
+                    d_tx = torch.empty(int(tzo[nk]) + 64, dtype=torch.uint8, device=dev); d_st = torch.zeros(nk, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    call_ = lambda: _lib.check(lib.fcz_inflate_dev(codec.ctx, d_raw.data_ptr(), d_go.data_ptr(), nk, None, d_to.data_ptr(), d_tx.data_ptr(), d_st.data_ptr()), "fcz_inflate_dev")
+                    call_(); codec.synchronize(); codec.enable_timing(True); codec.reset_timing()
+                    for _ in range(5):
+                        call_()
+                    codec.synchronize()
+                    ims, iln = codec.kernel_time("inflate"); ims /= max(iln, 1)
+                    got_ = d_tx[: int(tzo[nk])].cpu().numpy()
+                    same_ = all(got_[int(tzo[i_]):int(tzo[i_ + 1])].tobytes() == _zlib.decompress(mem[i_], 31) for i_ in range(0, nk, max(1, nk // 32)))
+                    gzo[kind + "_gz"]["inflate_kernel"] = {"members": nk, "gz_bytes": int(goff[nk]), "text_bytes": int(tzo[nk]), "avg_launch_ms": round(ims, 3),
+                                                           "inflated_text_GB_per_s": round(int(tzo[nk]) / ims / 1e6, 1) if ims else None,
+                                                           "residues_per_s": round((int(w.res_off_dev[nk]) & 0xFFFFFFFF) / ims * 1e3) if ims else None,
+                                                           "refused_members": int((d_st != 0).sum()), "sampled_texts_equal_zlib": bool(same_),
+                                                           "what": "k_inflate (one wavefront per gzip member, CRC-32 + ISIZE verified on the device) on members resident in HBM; "
+                                                                   "bytes moved = gz in + text out: not a bandwidth kernel (DESIGN.md 6.2)"}
+                    del d_raw, d_tx, d_st, d_go, d_to
+                except Exception as e_:   # noqa: BLE001
+                    gzo[kind + "_gz"]["inflate_kernel"] = {"failed": str(e_)[-200:]}
             plain = comp["gpu_host"]["steady_residues_per_s"]
             gzo["pdb_gz"]["steady_over_plain_pdb"] = round(gzo["pdb_gz"]["gpu_host"]["steady_residues_per_s"] / max(plain, 1), 3)
             if isinstance(comp.get("mmcif"), dict) and "gpu_host" in comp["mmcif"]:

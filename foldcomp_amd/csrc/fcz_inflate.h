@@ -465,14 +465,16 @@ __device__ __forceinline__ int32_t decode_body(const bitreader& br, sink& sk, ld
         const uint32_t ld = len | (dist << 9);
         const uint32_t pos = sk.q + ex;
         const bool okm = !is_len || (dist >= ex + len && dist <= pos - sk.q0);
-#ifdef FCZ_INFLATE_ABL_NOCOPY
+#if defined(FCZ_INFLATE_ABL_NOCOPY)
         if (false) {
+#elif defined(FCZ_INFLATE_ABL_ALLBYTE)
+        if (true) {                   // measurement build: every window takes the lane = byte form (wrong text beyond its conditions)
 #else
         if (__builtin_expect(tot <= 64u && __ballot(mine && !okm) == 0ull, 1)) {
 #endif
             L.own[lane] = 0;
             wave_fence();
-            if (mine) L.own[ex] = (uint8_t)(lane + 1u);
+            if (mine && ex < 64u) L.own[ex] = (uint8_t)(lane + 1u);
             wave_fence();
             const uint32_t k = wave_incl_max_dpp(L.own[lane]) - 1u;
             const uint32_t old = (uint32_t)__shfl((int)ld, (int)k, WAVE), oe = (uint32_t)__shfl((int)e, (int)k, WAVE);

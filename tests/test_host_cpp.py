@@ -511,3 +511,45 @@ def test_cpp_compress_device_ingest_equals_host_parse(tmp_path, golden):
     assert a == b and "f0017_multiB_1.fcz" in a and "f0043_blank.fcz" in a and "f0043_blankB.fcz" in a
     for f in a:
         assert (tmp_path / "dir_dev" / f).read_bytes() == (tmp_path / "dir_host" / f).read_bytes(), f
+
+
+@pytest.mark.gpu
+def test_cpp_compress_database_of_gzipped_entries(tmp_path, golden):
+    """`compress -d <database> <out>` where the entries are file images under names that end in .gz (StructureReader::loadFromBuffer:
+    the NAME says gzipped, the CONTENT says PDB or mmCIF, src/structure_reader.cpp:73-97): the members go to the device as they are
+    (their text's first bytes, inflated on the host in microseconds, decide the format), next to plain entries, an entry with the
+    MMseqs NUL behind its member (the device refuses bytes behind the trailer: zlib takes it, like gunzip ignores them), a member that
+    is no gzip stream and a gzipped entry that is neither PDB nor mmCIF -- the same database as with zlib on the reader threads"""
+    import gzip, json
+    from foldcomp_amd.database import DatabaseReader, DatabaseWriter
+    z, _ = golden
+    pdb = {n: _pdb_text(z, n).encode() for n in ("pdb:test_af", "syn:len129", "pdb:test")}
+    cif = _cif_text(z, "syn:len26").encode()
+    w = DatabaseWriter(str(tmp_path / "src"))
+    k = 0
+    for i in range(150):
+        n = ("pdb:test_af", "syn:len129", "pdb:test")[i % 3]
+        w.append(gzip.compress(pdb[n], 6), k, f"g{i:04d}.pdb.gz"); k += 1
+    w.append(gzip.compress(cif, 9), k, "c0001.cif.gz"); k += 1
+    w.append(pdb["syn:len129"], k, "p0001.pdb"); k += 1
+    w.append(gzip.compress(pdb["pdb:test_af"], 6) + b"\0", k, "nul01.pdb.gz"); k += 1          # an MMseqs-made entry: member + NUL
+    w.append(b"\x1f\x8b\x08 not a member at all", k, "bad01.pdb.gz"); k += 1
+    w.append(gzip.compress(b"{\"mmjson\": 1}" * 50), k, "json1.pdb.gz"); k += 1
+    w.close()
+    outs = {}
+    for tag, extra in (("dev", []), ("zlib", ["--host-inflate"])):
+        r = _run("compress", "-d", "-y", "-t", "8", "--gpus", "1", "--json-stats", *extra, str(tmp_path / "src"), str(tmp_path / f"db_{tag}"))
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stderr)
+    assert outs["dev"][0]["records"] == outs["zlib"][0]["records"] == 150 + 1 + 1 + 1
+    # 150 + 1 members inflated on the device; the NUL-terminated one went there too and came back to zlib (which ignores what follows
+    # a member); the broken one and the mmJSON one never left the host (their first bytes do not inflate to PDB / mmCIF text)
+    assert outs["dev"][0]["device_inflated_files"] == 151 and outs["dev"][0]["host_inflated_after_device_refusal"] == 1
+    assert outs["zlib"][0]["device_inflated_files"] == 0
+    for tag in ("dev", "zlib"):
+        assert "bad01" in outs[tag][1] and "json1" in outs[tag][1]
+    for ext in ("", ".index", ".lookup", ".dbtype"):
+        assert (tmp_path / f"db_dev{ext}").read_bytes() == (tmp_path / f"db_zlib{ext}").read_bytes(), ext
+    rd = DatabaseReader(str(tmp_path / "db_dev"))
+    assert rd.id_of_name("nul01.pdb") >= 0 and rd.id_of_name("c0001.cif") >= 0
+    rd.close()

@@ -1264,6 +1264,7 @@ struct Options {
     bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
     bool single = false;        // one structure / FCZ file in, one file out
     bool host_parse = false;    // --host-parse: compress parses on the host threads even where the device could (A/B, debugging)
+    int job_files = 0;          // --job-files N: files per device job of `compress` (0: the default rule)
     bool host_inflate = false;  // --host-inflate: gzipped inputs are inflated by the reader threads (zlib) instead of on the device (A/B)
     bool check = false;         // --check: decompress skips entries that fail Foldcomp::checkValidity (src/main.cpp:629-636)
     bool merge = true;          // --no-merge: extract writes one file per entry instead of one merged file (src/main.cpp:171-195)
@@ -2080,7 +2081,9 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
     //      (src/input_processor.h:237-257 hands `name, data, length` to the same lambda as a directory's files) ----
     double t_read = 0.0; uint64_t in_bytes = 0;
     try {
-        const size_t JOB = std::max<size_t>(64, std::min<size_t>(2048, (size_t)plan.n_mine / (4 * (size_t)n_workers) + 1));
+        // files per job: enough wavefronts for the wavefront-per-file kernels (k_inflate, k_ingest_parse*: 256 CUs x 8-11 resident), few
+        // enough for several jobs in flight per worker. --job-files N overrides (measurement)
+        const size_t JOB = o.job_files > 0 ? (size_t)o.job_files : std::max<size_t>(64, std::min<size_t>(2048, (size_t)plan.n_mine / (4 * (size_t)n_workers) + 1));
         size_t job_index = 0;
         std::vector<InputItem> cur;
         auto make_job = [&]() {
@@ -2858,6 +2861,7 @@ int main(int argc, char** argv) {
         else if (a == "--check") o.check = true;
         else if (a == "--host-parse") o.host_parse = true;
         else if (a == "--host-inflate") o.host_inflate = true;
+        else if (a == "--job-files") next_int(o.job_files);
         else if (a == "--no-merge") o.merge = false;
         else if (a == "-f" || a == "--file") o.file_input = true;
         else if (a == "-l" || a == "--id-list") { if (i + 1 < argc) o.id_list = argv[++i]; }

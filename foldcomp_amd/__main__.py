@@ -15,10 +15,8 @@ from __future__ import annotations
 
 import argparse
 import gzip
-import io
 import os
 import sys
-import tarfile
 from typing import Iterable, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -60,6 +58,64 @@ def file_parts(base: str) -> Tuple[str, str]:
     return (base, "") if i < 0 else (base[:i], base[i + 1:])
 
 
+# ---- tar archives as the reference's microtar reads and writes them ----------------------------------------
+def iter_tar(path: str) -> Iterator[Tuple[str, bytes]]:
+    """TarProcessor (src/input_processor.h:109-198) over lib/microtar: 512-byte headers; a header whose checksum field starts with
+    a NUL ends the archive; the member's name is the NAME FIELD ONLY, cut to 99 characters (no ustar prefix, no pax records); a GNU
+    long-name record ('L', 'K') carries the next member's name; types '0', '7' and NUL are files, every other type is skipped.
+    A gzipped archive is told by its NAME (.gz / .tgz). The same rules as host/foldcomp_hip.cpp (TarStream)."""
+    f = gzip.open(path, "rb") if path.endswith((".gz", ".tgz")) else open(path, "rb")
+    last, long_name = "", None
+
+    def octal(b: bytes) -> int:
+        if b[:1] and b[0] & 0x80:
+            return int.from_bytes(bytes([b[0] & 0x7F]) + b[1:], "big")
+        t = b.lstrip(b" \t\n\v\f\r"); n = 0
+        while n < len(t) and 0x30 <= t[n] <= 0x37:
+            n += 1
+        return int(t[:n], 8) if n else 0
+
+    with f:
+        while True:
+            h = f.read(512)
+            if len(h) < 512:
+                print(f"[Error] tar truncated after entry {last}", file=sys.stderr); return
+            if h[148] == 0:
+                return
+            if 256 + sum(h[:148]) + sum(h[156:]) != octal(h[148:156]):
+                print(f"[Error] {os.path.basename(path)}: bad tar header checksum after entry {last}", file=sys.stderr); return
+            size, typ = octal(h[124:136]), h[156:157]
+            padded = size + (512 - size % 512) % 512
+            if typ in (b"L", b"K"):
+                d = f.read(padded)
+                if len(d) < padded:
+                    print(f"[Error] cannot read entry {last}", file=sys.stderr); return
+                long_name = d[:size].split(b"\0")[0].decode("latin-1"); continue
+            name = long_name if long_name is not None else h[:99].split(b"\0")[0].decode("latin-1")
+            long_name, last = None, name
+            d = f.read(padded)
+            if len(d) < padded:
+                print(f"[Error] cannot read entry {name}", file=sys.stderr); return
+            if typ in (b"0", b"7", b"\0"):
+                yield name, d[:size]
+
+
+def tar_header(name: str, size: int) -> bytes:
+    """mtar_write_file_header (lib/microtar): zeros; name; mode 644, owner 0, size, mtime 0 printed with %o; type '0'; the checksum as
+    "%06o", a NUL and a blank -- no ustar magic, no times"""
+    h = bytearray(512)
+    nb = name.encode("latin-1")[:99]
+    h[:len(nb)] = nb
+    h[100:103] = b"644"; h[108:109] = b"0"
+    sz = b"%o" % size
+    h[124:124 + len(sz)] = sz
+    h[136:137] = b"0"; h[156:157] = b"0"
+    cs = b"%06o" % (256 + sum(h[:148]) + sum(h[156:]))
+    h[148:148 + len(cs)] = cs
+    h[155:156] = b" "
+    return bytes(h)
+
+
 # ---- entry sources -------------------------------------------------------------------------------------
 def iter_entries(inp: str, recursive: bool, id_list: Optional[str], id_mode: int) -> Iterator[Tuple[str, bytes]]:
     if os.path.exists(inp + ".dbtype"):
@@ -74,11 +130,8 @@ def iter_entries(inp: str, recursive: bool, id_list: Optional[str], id_mode: int
             # itself end in zero bytes, so nothing is stripped here)
             yield r.name(i), r.data(i)
         r.close()
-    elif inp.endswith((".tar", ".tar.gz", ".tgz")):
-        with tarfile.open(inp) as tf:
-            for m in tf:
-                if m.isfile():
-                    yield m.name, tf.extractfile(m).read()
+    elif inp.endswith((".tar", ".tar.gz", ".tgz")) and not os.path.isdir(inp):
+        yield from iter_tar(inp)
     elif os.path.isdir(inp):
         for root, dirs, files in os.walk(inp):
             dirs.sort()
@@ -100,7 +153,7 @@ class Sink:
         if kind == "db":
             self.db = DatabaseWriter(output)
         elif kind == "tar":
-            self.tar = tarfile.open(output, "w")
+            self.tar = open(output, "wb")
         elif kind == "dir":
             os.makedirs(output, exist_ok=True)
 
@@ -108,8 +161,7 @@ class Sink:
         if self.kind == "db":
             self.db.append(data + (b"\0" if nul else b""), self.key, db_name or name); self.key += 1
         elif self.kind == "tar":
-            ti = tarfile.TarInfo(os.path.basename(name)); ti.size = len(data)
-            self.tar.addfile(ti, io.BytesIO(data))
+            self.tar.write(tar_header(os.path.basename(name), len(data)) + data + b"\0" * ((512 - len(data) % 512) % 512))
         else:
             path = name if self.kind == "file" else os.path.join(self.output, os.path.basename(name))
             if os.path.exists(path) and not self.overwrite:
@@ -122,6 +174,7 @@ class Sink:
         if self.kind == "db":
             self.db.close()
         elif self.kind == "tar":
+            self.tar.write(b"\0" * 1024)     # mtar_write_finalize: two NUL records
             self.tar.close()
 
 
@@ -154,7 +207,7 @@ def host_fragments(name: str, data: bytes, a, kind: str, single: bool, output) -
             if len(frags) > 1:
                 fname += f"_{j}"
             if kind != "db":
-                fname += ".fcz" if is_compressible(out_file, ext) else ("." + ext if ext else "")
+                fname += ".fcz" if is_compressible(out_file, ext) else "." + ext     # (src/main.cpp:498-502: the dot also without an extension)
             out.append((fname, out_file, Chain(title, t.take(sl))))
     return out
 
@@ -211,9 +264,7 @@ def run_decompress(a, inputs, output, kind, single):
             if r is None:
                 print(f"[Error] decompressing {nm}", file=sys.stderr); continue
             stem, ext = file_parts(os.path.basename(nm))
-            fname = file_parts(output)[0] + ".pdb" if single and kind == "file" else stem + (".pdb" if ext in ("fcz", "") else "." + ext)
-            if single and kind == "file":
-                fname = output
+            fname = output if single and kind == "file" else stem + ".pdb"      # src/main.cpp:646-653
             sink.put(fname, r[1].encode("latin-1"), db_name=stem, nul=True)
         names.clear(); ents.clear()
 
@@ -233,7 +284,8 @@ def run_decompress(a, inputs, output, kind, single):
 
 def run_extract(a, inputs, output, kind, single):
     """pLDDT / sequence strings come from the device (k_extract); the FASTA-like / TSV wrapping is host text"""
-    merged = [] if (a.merge and not single) else None
+    merged = [] if (a.merge and not single and kind not in ("db", "tar")) else None     # src/main.cpp:738-741
+    sink = Sink(output.rstrip("/"), kind, True) if kind in ("db", "tar") else None
     out_dir_made = False
     pend: List[Tuple[str, bytes, fczfile.FczRecord]] = []
 
@@ -244,7 +296,11 @@ def run_extract(a, inputs, output, kind, single):
             text = fczfile.fasta_like(title, s) if a.plddt_digits == 1 else fczfile.tsv_line(title, rec.n_residues, s)
         else:
             text = fczfile.fasta_like(title, s)
-        if single:
+        if sink is not None:
+            # a tar member <stem>.<suffix>, or a database record under <stem> with the MMseqs terminator (src/main.cpp:790-844)
+            stem = file_parts(os.path.basename(name))[0]
+            sink.put(stem + "." + a.suffix, text.encode("latin-1"), db_name=stem, nul=True)
+        elif single:
             open(output, "w").write(text)
         elif merged is not None:
             merged.append(text)
@@ -277,6 +333,8 @@ def run_extract(a, inputs, output, kind, single):
             if len(pend) >= BATCH_CHAINS:
                 flush()
     flush()
+    if sink is not None:
+        sink.close()
     if merged is not None:
         open(output.rstrip("/") if not output.endswith("/") else output.rstrip("/") + "." + a.suffix, "w").write("".join(merged))
 

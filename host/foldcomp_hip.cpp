@@ -1,13 +1,15 @@
 // foldcomp_hip.cpp -- the C++ host of the MI355X codec: a `foldcomp`-style command line over the C-ABI of include/fcz_hip.h.
 //
-//   foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d] [--skip-discontinuous] [--json-stats] <pdb file|dir> [<fcz file|dir|db>]
-//   foldcomp-hip decompress [--gpus N] [-a] [-y] [-r] [-d] [--json-stats] <fcz file|dir|db> [<pdb file|dir|db>]
-//   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [-r] <fcz file|dir|db> [<out file>]
-//   foldcomp-hip check      [-r] <fcz file|dir|db>
+//   foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d|-z] [--skip-discontinuous] [--json-stats] <pdb|cif file|dir|tar(.gz)|db> [<fcz file|dir|tar|db>]
+//   foldcomp-hip decompress [--gpus N] [-a] [-y] [-r] [-d|-z] [--json-stats] <fcz file|dir|tar(.gz)|db> [<pdb file|dir|tar|db>]
+//   foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--use-title] [--no-merge] [-d|-z] [-r] <fcz file|dir|tar(.gz)|db> [<out>]
+//   foldcomp-hip check      [-r] <fcz file|dir|tar(.gz)|db>
 //   foldcomp-hip rmsd       <pdb|cif> <pdb|cif>
 //   no GPU needed (used by the tests):
 //   foldcomp-hip dump-batch [-b N] <pdb file>          the host-side batch of a file as text
+//   foldcomp-hip plan-dump [--shard R/N] <input>       the items of a run's input (files, database entries, tar members), one per line
 //   foldcomp-hip db-pack <dir> <db> / db-unpack <db> <dir>   files <-> database container
+//   foldcomp-hip tar-pack <dir> <tar>                  files -> tar archive with the reference writer's headers
 //   foldcomp-hip db-splice --shard R/N [--key0 K --off0 B] <part db> <final db>   exchange step of a sharded run (see run_db_splice)
 //   sharded runs:  compress|decompress -d --shard R/N --device D ...   rank R of N takes its byte-balanced range of the inputs
 //
@@ -23,7 +25,7 @@
 //   getFileParts / isCompressible       src/utility.cpp:118-140
 //   database container (-d)            src/database_reader.cpp, src/database_writer.cpp
 //   mmCIF _atom_site loop, .gz         src/structure_reader.cpp:31-61 (gemmi), zlib
-// tar inputs are handled by the Python host (python -m foldcomp_amd).
+//   tar archives in and out (-z)       src/input_processor.h:109-198 (TarProcessor), lib/microtar, src/main.cpp:333-342, :519-523, :666-674
 #include <dirent.h>
 #include <fcntl.h>
 #include <sched.h>
@@ -1258,10 +1260,129 @@ struct DbWriter {
 };
 bool is_db(const std::string& p) { return exists(p + ".dbtype"); }
 
+// ---- tar archives, in and out (the reference: lib/microtar driven by TarProcessor, src/input_processor.h:109-198, and by the
+//      writers of src/main.cpp:519-523, :666-674, :832-844, src/foldcomp.cpp:1122). AFDB ships its bulk downloads as a plain tar
+//      of .pdb.gz / .cif.gz members: the members of a plain tar are byte ranges of one file (InputPlan reads them like database
+//      entries, a gzip member goes to the device as it lies in the archive); a gzipped tar (.tar.gz / .tgz, by the NAME as
+//      TarProcessor decides) is one DEFLATE stream and is inflated by zlib on the producer thread as the run walks it.
+//      What microtar reads and this reader keeps: 512-byte headers; a header whose checksum field starts with a NUL ends the
+//      archive; the checksum is the byte sum of the header with its checksum field read as eight blanks, compared with the
+//      field's octal number; the size is the octal number of its field; the member's name is the NAME FIELD ONLY, cut to 99
+//      characters (the ustar prefix and pax records are not read); a GNU long-name record ('L', 'K') carries the next member's
+//      name as its data; members of type '0', '7' and NUL are files, every other type is skipped with its data.
+//      Where microtar goes on with stale state (a header that fails its checksum, an archive that ends without a NUL record)
+//      this reader stops with an [Error] line: what was read before it is processed. ----
+bool is_tar_name(const std::string& p) { return ends_with(p, ".tar") || ends_with(p, ".tar.gz") || ends_with(p, ".tgz"); }   // src/main.cpp:341
+struct TarMember { std::string name; uint64_t off = 0, len = 0; };   // off: position of the member's bytes in the (inflated) archive
+struct TarStream {
+    int fd = -1; gzFile gz = nullptr; uint64_t pos = 0; std::string path, last; bool failed = false;
+    ~TarStream() { if (gz) gzclose(gz); if (fd >= 0) close(fd); }
+    bool open_path(const std::string& p) {
+        path = p;
+        if (ends_with(p, ".gz") || ends_with(p, ".tgz")) { gz = gzopen(p.c_str(), "rb"); if (gz) gzbuffer(gz, 1u << 20); return gz != nullptr; }
+        fd = open(p.c_str(), O_RDONLY);
+        return fd >= 0;
+    }
+    bool read_exact(void* dst, uint64_t n) {
+        uint8_t* d = (uint8_t*)dst; uint64_t got = 0;
+        while (got < n) {
+            const size_t want = (size_t)std::min<uint64_t>(n - got, 1u << 30);
+            const long k = gz ? (long)gzread(gz, d + got, (unsigned)want) : (long)pread(fd, d + got, want, (off_t)(pos + got));
+            if (k <= 0) return false;
+            got += (uint64_t)k;
+        }
+        pos += n;
+        return true;
+    }
+    bool skip(uint64_t n) {
+        if (gz) { if (n && gzseek(gz, (z_off_t)n, SEEK_CUR) < 0) return false; }
+        pos += n;
+        return true;
+    }
+    static uint64_t pad(uint64_t len) { return (512 - len % 512) % 512; }
+    static uint64_t octal(const char* f, size_t n) {                // strtoul(field, NULL, 8); GNU's base-256 form for what octal cannot hold
+        if ((unsigned char)f[0] & 0x80u) { uint64_t v = (unsigned char)f[0] & 0x7fu; for (size_t i = 1; i < n; i++) v = (v << 8) | (unsigned char)f[i]; return v; }
+        size_t i = 0; while (i < n && (f[i] == ' ' || (unsigned)(f[i] - 9) < 5u)) i++;
+        uint64_t v = 0; while (i < n && f[i] >= '0' && f[i] <= '7') v = v * 8 + (uint64_t)(f[i++] - '0');
+        return v;
+    }
+    // the next file member: 1 (name and size set; its bytes start at `pos`: the caller reads or skips them, then the padding),
+    // 0 at the end of the archive, -1 after an [Error] line
+    int next(TarMember& m) {
+        std::string long_name; bool have_long = false;
+        for (;;) {
+            unsigned char h[512];
+            if (!read_exact(h, 512)) { fprintf(stderr, "[Error] tar truncated after entry %s\n", last.c_str()); failed = true; return -1; }
+            if (h[148] == '\0') return 0;                             // a NUL record
+            unsigned sum = 256;
+            for (int i = 0; i < 148; i++) sum += h[i];
+            for (int i = 156; i < 512; i++) sum += h[i];
+            if (sum != (unsigned)octal((const char*)h + 148, 8)) { fprintf(stderr, "[Error] %s: bad tar header checksum after entry %s\n", base_name(path).c_str(), last.c_str()); failed = true; return -1; }
+            const uint64_t len = octal((const char*)h + 124, 12);
+            const char type = (char)h[156];
+            if (type == 'L' || type == 'K') {
+                std::string d((size_t)len, '\0');
+                if ((len && !read_exact(&d[0], len)) || !skip_pad(len)) { fprintf(stderr, "[Error] cannot read entry %s\n", last.c_str()); failed = true; return -1; }
+                long_name.assign(d.c_str()); have_long = true;       // (the name as a C string: the record carries its terminator)
+                continue;
+            }
+            m.name = have_long ? long_name : std::string((const char*)h, strnlen((const char*)h, 99));
+            m.len = len; m.off = pos; last = m.name;
+            if (type == '0' || type == '7' || type == '\0') return 1;
+            if (len && (!skip(len) || !skip_pad(len))) { fprintf(stderr, "[Error] cannot skip entry %s\n", m.name.c_str()); failed = true; return -1; }
+            have_long = false;
+        }
+    }
+    bool skip_pad(uint64_t len) { return skip(pad(len)); }
+    bool skip_member(const TarMember& m) { return skip(m.len) && skip_pad(m.len); }
+};
+
+// a member's header as mtar_write_file_header makes it (lib/microtar: zeros; name; mode 644, owner 0, size, mtime 0 as "%o"; type
+// '0'; checksum "%06o" + NUL + blank): no ustar magic, no times -- the same bytes, so the same archive for the same members
+void tar_header(uint8_t* h, const std::string& name, uint64_t size) {
+    memset(h, 0, 512);
+    memcpy(h, name.data(), std::min<size_t>(name.size(), 99));
+    snprintf((char*)h + 100, 8, "%o", 0644u);
+    snprintf((char*)h + 108, 8, "%o", 0u);
+    snprintf((char*)h + 124, 12, "%llo", (unsigned long long)size);
+    snprintf((char*)h + 136, 12, "%o", 0u);
+    h[156] = '0';
+    unsigned sum = 256;
+    for (int i = 0; i < 148; i++) sum += h[i];
+    for (int i = 156; i < 512; i++) sum += h[i];
+    snprintf((char*)h + 148, 8, "%06o", sum);
+    h[155] = ' ';
+}
+inline uint64_t tar_record_bytes(uint64_t len) { return 512 + len + TarStream::pad(len); }
+
+// the members of one job, header + bytes + padding each, back to back in `out` (what mtar_write_file_header + mtar_write_data leave
+// in the archive): a job's members are one contiguous range of the archive, placed by the Sequencer like a database's records
+template <class Vec, class GetName, class GetPtr, class GetLen>
+uint64_t tar_pack_members(Vec& out, size_t n, GetName name, GetPtr ptr, GetLen len) {
+    uint64_t total = 0;
+    for (size_t q = 0; q < n; q++) total += tar_record_bytes(len(q));
+    out.resize(total);
+    uint64_t pos = 0;
+    for (size_t q = 0; q < n; q++) {
+        const uint64_t l = len(q), pd = TarStream::pad(l);
+        tar_header(out.data() + pos, name(q), l);
+        if (l) memcpy(out.data() + pos + 512, ptr(q), l);
+        if (pd) memset(out.data() + pos + 512 + l, 0, pd);
+        pos += 512 + l + pd;
+    }
+    return total;
+}
+// the end of an archive: two NUL records (mtar_write_finalize)
+bool tar_finalize(int fd, uint64_t at) {
+    uint8_t z[1024]; memset(z, 0, sizeof z);
+    return pwrite(fd, z, sizeof z, (off_t)at) == (ssize_t)sizeof z;
+}
+
 struct Options {
     std::string mode, input, output;
     int brk = 25, digits = 1, ext_mode = 0;
     bool alt = false, overwrite = false, recursive = false, skip_discontinuous = false, use_title = false, db = false;
+    bool tar = false;           // -z / --tar, or an output that ends in .tar: the outputs become the members of one tar archive (src/main.cpp:333-335)
     bool single = false;        // one structure / FCZ file in, one file out
     bool host_parse = false;    // --host-parse: compress parses on the host threads even where the device could (A/B, debugging)
     int job_files = 0;          // --job-files N: files per device job of `compress` (0: the default rule)
@@ -1377,23 +1498,28 @@ struct DbScan {
     }
 };
 
-struct InputItem { int kind = 0; std::string name; uint64_t off = 0, len = 0; int src = 0; };   // kind 0: a file (name = path, len = its size or UINT64_MAX: not asked yet); 1: a database entry (name = lookup name)
+struct InputItem { int kind = 0; std::string name; uint64_t off = 0, len = 0; int src = 0; };   // kind 0: a file (name = path, len = its size or UINT64_MAX: not asked yet); 1: a database entry (name = lookup name) or a tar member (name = the member's name)
 
 struct InputPlan {
     struct Src {
-        int kind = 0;                          // 0 files, 1 database streamed, 2 database through DbReader
+        int kind = 0;                          // 0 files, 1 database streamed, 2 database through DbReader, 3 tar (members listed up front), 4 gzipped tar (walked as it inflates)
         std::string path;
+        std::vector<TarMember> members;        // kind 3
+        std::vector<uint8_t> arena; uint64_t arena0 = 0;   // kind 4: the bytes of the members handed out since the last release(); arena[0] is stream position arena0
         std::vector<std::string> files; std::vector<uint64_t> fsize;
         DbScan scan;
         std::unique_ptr<DbReader> db; std::vector<size_t> ids;
         int dfd = -1; uint64_t dsize = 0;
         uint64_t n = 0, bytes = 0, lo = 0, hi = 0;   // items, their bytes, this process's items [lo, hi)
         ~Src() { if (dfd >= 0) close(dfd); }
-        uint64_t weight(uint64_t i) const { return kind == 0 ? fsize[i] : (uint64_t)db->rows[ids[i]].len; }   // kinds 0 and 2
+        uint64_t weight(uint64_t i) const { return kind == 0 ? fsize[i] : kind == 3 ? members[i].len : (uint64_t)db->rows[ids[i]].len; }   // kinds 0, 2 and 3
     };
     std::vector<std::unique_ptr<Src>> srcs;
     uint64_t n_items = 0, n_mine = 0, bytes_total = 0;
     bool streamed_all = true;
+    bool unsized = false;                      // a gzipped tar among the inputs: its members are counted as the run walks it
+    bool hold = false;                         // the consumer reads the entries of a gzipped tar after for_each's callback returned: it calls release()
+    void release() { for (auto& sp : srcs) if (sp->kind == 4) { sp->arena0 += sp->arena.size(); sp->arena.clear(); } }
 
     // first item e of a source with (bytes of the items before it) >= t; n when there is none
     static uint64_t first_at_least(Src& s, uint64_t t) {
@@ -1427,7 +1553,23 @@ struct InputPlan {
         for (const std::string& input : o.inputs) {
             std::unique_ptr<Src> sp(new Src()); Src& s = *sp;
             s.path = input;
-            if (is_db(input)) {
+            if (!is_dir(input) && is_tar_name(input)) {
+                if (ends_with(input, ".gz") || ends_with(input, ".tgz")) {
+                    // one DEFLATE stream: no member can be reached without inflating what lies before it
+                    if (o.shard_world > 1) throw std::runtime_error(input + ": a gzipped tar cannot be cut into ranges (inflate it to a plain .tar for a sharded run)");
+                    s.kind = 4; unsized = true;
+                } else {
+                    s.kind = 3;
+                    TarStream ts;
+                    if (!ts.open_path(input)) throw std::runtime_error("open tar " + input + " failed.");
+                    TarMember m;
+                    while (ts.next(m) == 1) { s.bytes += m.len; s.members.push_back(m); if (!ts.skip_member(m)) break; }
+                    s.n = s.members.size();
+                    s.dfd = open(input.c_str(), O_RDONLY);
+                    if (s.dfd < 0) throw std::runtime_error("cannot open " + input);
+                    struct stat st; fstat(s.dfd, &st); s.dsize = (uint64_t)st.st_size;
+                }
+            } else if (is_db(input)) {
                 if (o.id_list.empty() && s.scan.scan(input)) { s.kind = 1; s.n = s.scan.n; s.bytes = s.scan.bytes; }
                 else {
                     if (o.id_list.empty() && !quiet) fprintf(stderr, "[Info] %s is read into memory (%s)\n", input.c_str(), s.scan.why.c_str());
@@ -1488,6 +1630,7 @@ struct InputPlan {
         std::vector<uint64_t> a, b;
         cut(R, a); cut(R + 1, b);
         for (size_t k = 0; k < srcs.size(); k++) { srcs[k]->lo = a[k]; srcs[k]->hi = std::max(a[k], b[k]); n_mine += srcs[k]->hi - srcs[k]->lo; }
+        for (auto& sp : srcs) if (sp->kind == 4) { sp->lo = 0; sp->hi = UINT64_MAX; }
     }
 
     // this process's items in order: f(const InputItem&)
@@ -1496,7 +1639,24 @@ struct InputPlan {
             Src& s = *srcs[k];
             if (s.lo >= s.hi) continue;
             InputItem it; it.src = (int)k;
-            if (s.kind == 0) {
+            if (s.kind == 3) {
+                it.kind = 1;
+                for (uint64_t i = s.lo; i < s.hi; i++) { it.name = s.members[i].name; it.off = s.members[i].off; it.len = s.members[i].len; f(it); }
+            } else if (s.kind == 4) {
+                it.kind = 1;
+                TarStream ts;
+                if (!ts.open_path(s.path)) throw std::runtime_error("open tar " + s.path + " failed.");
+                TarMember m;
+                while (ts.next(m) == 1) {
+                    if (!hold) release();
+                    const size_t at = s.arena.size();
+                    s.arena.resize(at + m.len);
+                    if ((m.len && !ts.read_exact(s.arena.data() + at, m.len)) || !ts.skip_pad(m.len)) { s.arena.resize(at); fprintf(stderr, "[Error] cannot read entry %s\n", m.name.c_str()); break; }
+                    it.name = m.name; it.off = s.arena0 + at; it.len = m.len;
+                    s.n++; n_items++; n_mine++; s.bytes += m.len; bytes_total += m.len;
+                    f(it);
+                }
+            } else if (s.kind == 0) {
                 it.kind = 0;
                 for (uint64_t i = s.lo; i < s.hi; i++) { it.name = s.files[i]; it.len = s.fsize.empty() ? UINT64_MAX : s.fsize[i]; f(it); }
             } else if (s.kind == 2) {
@@ -1528,6 +1688,7 @@ struct InputPlan {
     // become a bad_alloc that ends the run; off + len cannot wrap this way -- an index number may have 19 digits)
     bool entry_in_range(const InputItem& it) const {
         const Src& s = *srcs[(size_t)it.src];
+        if (s.kind == 4) return it.off >= s.arena0 && it.len <= s.arena.size() && it.off - s.arena0 <= s.arena.size() - it.len;
         const uint64_t size = s.kind == 2 ? (uint64_t)s.db->size : s.dsize;
         return it.len <= size && it.off <= size - it.len;
     }
@@ -1535,6 +1696,7 @@ struct InputPlan {
         const Src& s = *srcs[(size_t)it.src];
         if (!entry_in_range(it)) return false;
         if (s.kind == 2) { memcpy(dst, s.db->data + it.off, it.len); return true; }
+        if (s.kind == 4) { memcpy(dst, s.arena.data() + (it.off - s.arena0), it.len); return true; }
         uint64_t got = 0;
         while (got < it.len) { const ssize_t k = pread(s.dfd, dst + got, it.len - got, (off_t)(it.off + got)); if (k <= 0) return false; got += (uint64_t)k; }
         return true;
@@ -1581,7 +1743,8 @@ void fragments_from_memory(const char* data, size_t size, const std::string& bas
             std::string fname = out_stem;
             if (chains.size() > 1) fname += t.chain_name(cs.a);
             if (frags.size() > 1) fname += "_" + std::to_string(j);
-            if (to_dir_or_file) fname += is_compressible(out_stem, ext) ? ".fcz" : (ext.empty() ? "" : "." + ext);
+            // (src/main.cpp:498-502: "." + the extension also when there is none -- a file `d1asha_` becomes `d1asha_.`)
+            if (to_dir_or_file) fname += is_compressible(out_stem, ext) ? ".fcz" : "." + ext;
             // the usual file is one chain in one piece: its table moves into the fragment instead of being copied
             Fragment f;
             f.out_name = fname; f.db_name = out_stem; f.title = title;
@@ -1702,6 +1865,21 @@ struct Sequencer {
     }
 };
 
+// many pieces, one after the other, from file position `off` on (pwritev in runs of at most 512 pieces; partial writes resumed)
+void pwritev_all(int fd, std::vector<iovec>& iov, uint64_t off) {
+    size_t i = 0;
+    while (i < iov.size()) {
+        if (iov[i].iov_len == 0) { i++; continue; }
+        const int cnt = (int)std::min<size_t>(iov.size() - i, 512);
+        ssize_t w = pwritev(fd, iov.data() + i, cnt, (off_t)off);
+        if (w <= 0) throw std::runtime_error("pwritev failed");
+        off += (uint64_t)w;
+        while (w > 0 && i < iov.size()) {
+            if ((size_t)w >= iov[i].iov_len) { w -= (ssize_t)iov[i].iov_len; i++; }
+            else { iov[i].iov_base = (char*)iov[i].iov_base + w; iov[i].iov_len -= (size_t)w; w = 0; }
+        }
+    }
+}
 void pwrite_all(int fd, const uint8_t* p, uint64_t n, uint64_t off) {
     while (n) {
         const ssize_t w = pwrite(fd, p, (size_t)std::min<uint64_t>(n, 1u << 30), (off_t)off);
@@ -1735,7 +1913,8 @@ int run_compress(const Options& o) {
     const int n_workers = gpus * std::max(1, o.workers_per_gpu);
     pinned_enabled() = true;
     int db_fd = -1;
-    if (o.db) {
+    const bool placed = o.db || o.tar;          // one output file: a job's records are placed in it by the Sequencer
+    if (placed) {
         db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
         if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
     } else if (!single) make_dir(output);
@@ -1781,7 +1960,7 @@ int run_compress(const Options& o) {
             if (v.n_chains) fcz_compress_sizes(&v, off.data());
             // a job claims its byte range of the database AFTER its GPU call, with the records that compressed packed back to
             // back (the reference's writer appends only what compressed); every job claims, also an empty or failed one
-            if (kept.empty() || !ctx) { if (o.db) seq.claim(job.index, 0); continue; }
+            if (kept.empty() || !ctx) { if (placed) seq.claim(job.index, 0); continue; }
             blob.resize(off.back());
             const int32_t UNSET = INT32_MIN;                              // a status the library never writes
             std::vector<int32_t> status(v.n_chains, UNSET);
@@ -1794,9 +1973,19 @@ int run_compress(const Options& o) {
             for (uint32_t q = 0; q < v.n_chains && !call_failed; q++) if (status[q] == UNSET) call_failed = true;
             if (call_failed) {
                 fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size());
-                hard_fail = true; if (o.db) seq.claim(job.index, 0); continue;
+                hard_fail = true; if (placed) seq.claim(job.index, 0); continue;
             }
             try {
+                if (o.tar) {
+                    // the records that compressed as members of the archive, named as a directory's files would be (src/main.cpp:519-523)
+                    std::vector<size_t> okq;
+                    for (size_t q = 0; q < kept.size(); q++) if (status[q] == FCZ_OK) okq.push_back(q);
+                    std::vector<uint8_t> members;
+                    const uint64_t bytes = tar_pack_members(members, okq.size(), [&](size_t k) { return base_name(job.frags[kept[okq[k]]].out_name); },
+                                                            [&](size_t k) { return blob.data() + off[okq[k]]; }, [&](size_t k) { return off[okq[k] + 1] - off[okq[k]]; });
+                    const uint64_t at = seq.claim(job.index, bytes);
+                    if (bytes) pwrite_all(db_fd, members.data(), bytes, at);
+                }
                 uint64_t packed = 0;                                      // bytes of the records that compressed
                 std::vector<uint64_t> lens; std::vector<std::string> names;
                 for (size_t q = 0; q < kept.size(); q++) {
@@ -1813,7 +2002,7 @@ int run_compress(const Options& o) {
                     if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), fcz_status_string(status[q])); continue; }
                     n_frag_ok++; n_res += v.res_off[q + 1] - v.res_off[q]; n_bytes += off[q + 1] - off[q];
                     n_atoms += v.atom_off[v.res_off[q + 1]] - v.atom_off[v.res_off[q]];
-                    if (o.db) continue;
+                    if (placed) continue;
                     const std::string path = single ? output : output + "/" + f.out_name;
                     write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
                 }
@@ -1845,7 +2034,8 @@ int run_compress(const Options& o) {
         for (size_t f0 = 0; f0 < files.size(); f0 += FILE_CHUNK) {
             const auto t0 = clk::now();
             const size_t f1 = std::min(files.size(), f0 + FILE_CHUNK);
-            fragments_of_files(files, f0, f1, single, output, !o.db, o, pending, true);
+            // (a single file into a database or a tar is named by the INPUT, src/main.cpp:447-456)
+            fragments_of_files(files, f0, f1, single && !placed, output, !o.db, o, pending, true);
             t_parse += std::chrono::duration<double>(clk::now() - t0).count();
             in_bytes = g_bytes_read.load();
             cut(false);
@@ -1862,6 +2052,10 @@ int run_compress(const Options& o) {
         close(db_fd);
         seq.finish(output, !hard_fail);
         if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
+    } else if (o.tar) {
+        if (!hard_fail && !tar_finalize(db_fd, seq.pos)) hard_fail = true;
+        close(db_fd);
+        if (hard_fail) { unlink(output.c_str()); fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str()); }
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -1919,7 +2113,8 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
     const int n_workers = gpus * std::max(1, o.workers_per_gpu);
     pinned_enabled() = true;
     int db_fd = -1;
-    if (o.db) {
+    const bool placed = o.db || o.tar;          // one output file: a job's records are placed in it by the Sequencer
+    if (placed) {
         db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
         if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
     } else make_dir(output);
@@ -1952,7 +2147,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
             for (size_t i = 0; i < job.paths.size(); i++) if (job.slot[i] >= 0) text_file[(size_t)job.slot[i]] = i;
             auto stem_of = [&](size_t i) { std::string stem, ext; file_parts(base_name(job.paths[i]), stem, ext); return stem; };
             // the suffix of a fragment's file (src/main.cpp:498-502): ".fcz" for what isCompressible knows, else the input's own
-            auto suffix_of = [&](size_t i) { std::string stem, ext; file_parts(base_name(job.paths[i]), stem, ext); return is_compressible(stem, ext) ? std::string(".fcz") : (ext.empty() ? std::string() : "." + ext); };
+            auto suffix_of = [&](size_t i) { std::string stem, ext; file_parts(base_name(job.paths[i]), stem, ext); return is_compressible(stem, ext) ? std::string(".fcz") : "." + ext; };
             if (!failed && n_text) {
                 uint64_t fcz_bytes = 0;
                 const auto t0 = clk::now();
@@ -2050,7 +2245,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     }
                 }
             }
-            if (failed) { hard_fail = true; if (o.db) seq.claim(job.index, 0); pool.put(job.text); continue; }
+            if (failed) { hard_fail = true; if (placed) seq.claim(job.index, 0); pool.put(job.text); continue; }
             try {
                 // records of the job in file order (a file's own records keep the order they were emitted in)
                 std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.file != b.file ? a.file < b.file : a.sub < b.sub; });
@@ -2063,6 +2258,11 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     for (size_t q = 0; q < recs.size(); q++) { lens[q] = recs[q].len; names[q] = recs[q].db_name; }
                     const uint64_t at = seq.claim(job.index, total, &lens, &names);
                     if (total) pwrite_all(db_fd, packed.data(), total, at);
+                } else if (o.tar) {
+                    // members named as the files of a directory output would be (writeTar(tar_out, baseName(filename), ...), src/main.cpp:519-523)
+                    const uint64_t bytes = tar_pack_members(packed, recs.size(), [&](size_t q) { return base_name(recs[q].out_name); }, [&](size_t q) { return recs[q].p; }, [&](size_t q) { return recs[q].len; });
+                    const uint64_t at = seq.claim(job.index, bytes);
+                    if (bytes) pwrite_all(db_fd, packed.data(), bytes, at);
                 } else {
                     for (const Rec& r : recs) write_out(output + "/" + r.out_name, (const char*)r.p, r.len, o.overwrite);
                 }
@@ -2083,9 +2283,11 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
     try {
         // files per job: enough wavefronts for the wavefront-per-file kernels (k_inflate, k_ingest_parse*: 256 CUs x 8-11 resident), few
         // enough for several jobs in flight per worker. --job-files N overrides (measurement)
-        const size_t JOB = o.job_files > 0 ? (size_t)o.job_files : std::max<size_t>(64, std::min<size_t>(2048, (size_t)plan.n_mine / (4 * (size_t)n_workers) + 1));
+        const size_t JOB = o.job_files > 0 ? (size_t)o.job_files : plan.unsized ? (size_t)2048
+                         : std::max<size_t>(64, std::min<size_t>(2048, (size_t)plan.n_mine / (4 * (size_t)n_workers) + 1));
         size_t job_index = 0;
         std::vector<InputItem> cur;
+        plan.hold = true;                       // (a gzipped tar's members stay in memory until their job has copied them: release() below)
         auto make_job = [&]() {
             if (cur.empty()) return;
             const auto t0 = clk::now();
@@ -2218,6 +2420,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
             in_bytes = g_bytes_read.load();
             queue.put(std::move(j));
             cur.clear();
+            plan.release();
         };
         plan.for_each([&](const InputItem& it) { cur.push_back(it); if (cur.size() >= JOB) make_job(); });
         make_job();
@@ -2230,6 +2433,10 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
         close(db_fd);
         seq.finish(output, !hard_fail);
         if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
+    } else if (o.tar) {
+        if (!hard_fail && !tar_finalize(db_fd, seq.pos)) hard_fail = true;
+        close(db_fd);
+        if (hard_fail) { unlink(output.c_str()); fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str()); }
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -2264,7 +2471,18 @@ struct Entries {
 template <class F>
 void for_each_entry(const Options& o, Entries& ents, F&& flush, size_t batch = BATCH_CHAINS) {
     for (const std::string& input : o.inputs) {
-        if (is_db(input)) {
+        if (!is_dir(input) && is_tar_name(input)) {
+            // the members of a tar archive, plain or gzipped, in archive order (TarProcessor, src/input_processor.h:109-198)
+            TarStream ts;
+            if (!ts.open_path(input)) { fprintf(stderr, "[Error] open tar %s failed.\n", input.c_str()); continue; }
+            TarMember m;
+            while (ts.next(m) == 1) {
+                std::string d((size_t)m.len, '\0');
+                if ((m.len && !ts.read_exact(&d[0], m.len)) || !ts.skip_pad(m.len)) { fprintf(stderr, "[Error] cannot read entry %s\n", m.name.c_str()); break; }
+                ents.add(m.name, d);
+                if (ents.n() >= batch) flush();
+            }
+        } else if (is_db(input)) {
             DbReader r(input);
             std::vector<size_t> ids;
             if (!o.id_list.empty()) {
@@ -2327,7 +2545,7 @@ int run_decompress(const Options& o) {
     const bool place = o.place;
     pinned_enabled() = true;
     int db_fd = -1;
-    if (!o.db && !single) make_dir(output);
+    if (!o.db && !o.tar && !single) make_dir(output);
 
     InputPlan plan;
     Sequencer seq;
@@ -2397,7 +2615,15 @@ int run_decompress(const Options& o) {
                     std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
                     lens.push_back(text_off[i + 1] - text_off[i]); dbnames.push_back(stem);
                 }
-                const uint64_t at = o.db ? seq.claim(job.index, rc == FCZ_OK ? bytes : 0, &lens, &dbnames) : 0;     // every job claims, also a failed one
+                // -z: an entry's text becomes the member <stem>.pdb (src/main.cpp:646-647, :666-674)
+                std::vector<std::string> members; uint64_t tar_bytes = 0;
+                if (o.tar && rc == FCZ_OK) for (uint32_t i = 0; i < n; i++) {
+                    if (status[i] != FCZ_OK) continue;
+                    std::string stem, ext; file_parts(base_name(job.ents.names[i]), stem, ext);
+                    members.push_back(stem + ".pdb"); tar_bytes += tar_record_bytes(text_off[i + 1] - text_off[i]);
+                }
+                const uint64_t at = o.db ? seq.claim(job.index, rc == FCZ_OK ? bytes : 0, &lens, &dbnames)     // every job claims, also a failed one
+                                  : o.tar ? seq.claim(job.index, tar_bytes) : 0;
                 if (rc == FCZ_OK) {
                     const auto ta = clk::now();
                     if (text.size() < text_off[n]) text.resize(text_off[n] + text_off[n] / 8);     // grows, never shrinks (a resize zero-fills what it adds)
@@ -2417,6 +2643,22 @@ int run_decompress(const Options& o) {
                         // tools/dbg/write_bench.cpp; more writer threads only add contention.)
                         for (uint32_t i = 0; i < n; i++) if (status[i] != FCZ_OK) fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str());
                         pwrite_all(db_fd, text.data(), bytes, at);
+                    } else if (o.tar) {
+                        // header, text, padding per member, gathered by the kernel from where they lie (no second copy of the text)
+                        static const uint8_t zeros[512] = {0};
+                        std::vector<uint8_t> heads(512 * members.size());
+                        std::vector<iovec> iov; iov.reserve(3 * members.size());
+                        size_t k = 0;
+                        for (uint32_t i = 0; i < n; i++) {
+                            if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
+                            const uint64_t len = text_off[i + 1] - text_off[i];
+                            tar_header(heads.data() + 512 * k, members[k], len);
+                            iov.push_back({heads.data() + 512 * k, 512});
+                            iov.push_back({text.data() + text_off[i], (size_t)len});
+                            iov.push_back({(void*)zeros, (size_t)TarStream::pad(len)});
+                            k++;
+                        }
+                        pwritev_all(db_fd, iov, at);
                     } else {
                         // one file per entry, written by several threads (open / write / close per file is what takes the time)
                         const int pieces = (int)std::min<size_t>(std::max<size_t>(n / 64, 1), (size_t)std::max(1, o.write_threads));
@@ -2426,7 +2668,7 @@ int run_decompress(const Options& o) {
                                 if (status[i] != FCZ_OK) { fprintf(stderr, "[Error] decompressing %s\n", job.ents.names[i].c_str()); continue; }
                                 std::string stem, ext;
                                 file_parts(base_name(job.ents.names[i]), stem, ext);
-                                const std::string fname = stem + ((ext == "fcz" || ext.empty()) ? ".pdb" : "." + ext);
+                                const std::string fname = stem + ".pdb";      // getFileParts(baseName(name)).first + ".pdb" (src/main.cpp:646-653)
                                 write_out(single ? output : output + "/" + fname, (const char*)text.data() + text_off[i], text_off[i + 1] - text_off[i], o.overwrite);
                             }
                         });
@@ -2506,6 +2748,9 @@ int run_decompress(const Options& o) {
         db_fd = open(output.c_str(), place ? (O_CREAT | O_WRONLY) : (O_CREAT | O_TRUNC | O_WRONLY), 0666);
         if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
         if (!seq.open_index(output, place && o.shard_rank > 0 ? "." + std::to_string(o.shard_rank) : "")) { fprintf(stderr, "[Error] cannot write %s.index\n", output.c_str()); return 1; }
+    } else if (o.tar) {
+        db_fd = open(output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+        if (db_fd < 0) { fprintf(stderr, "[Error] cannot write %s\n", output.c_str()); return 1; }
     }
     const uint64_t pos0 = seq.pos;
     run_pass(false);
@@ -2526,6 +2771,10 @@ int run_decompress(const Options& o) {
             else if (o.shard_rank == 0) { std::ofstream t(output + ".dbtype", std::ios::binary); const int32_t twelve = 12; t.write((const char*)&twelve, 4); }
         } else seq.finish(output, !hard_fail);
         if (hard_fail) fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str());
+    } else if (o.tar) {
+        if (!hard_fail && !tar_finalize(db_fd, seq.pos)) hard_fail = true;
+        close(db_fd);
+        if (hard_fail) { unlink(output.c_str()); fprintf(stderr, "[Error] the run failed: %s was not written\n", output.c_str()); }
     }
     if (o.json_stats) {
         const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
@@ -2566,11 +2815,17 @@ int run_extract(const Options& o) {
     const int digits = std::min(std::max(o.digits, 1), 4);
     const std::string suffix = extract_suffix(o);
     const std::string output = o.output;
-    const bool per_entry = !single && !o.merge;                      // --no-merge: <output>/<stem>.<suffix> per entry (src/main.cpp:790-800)
+    // where an entry's text goes (src/main.cpp:738-741, :790-850): a tar member <stem>.<suffix> (-z), a database record under <stem>
+    // with the MMseqs terminator (-d), the one output file of a single input, one merged file, or -- --no-merge -- <output>/<stem>.<suffix>
+    const bool per_entry = !o.tar && !o.db && !single && !o.merge;
     if (per_entry) make_dir(output);
     fcz_ctx* ctx = nullptr;
     if (need_ctx(&ctx)) return 1;
     std::string merged;
+    std::vector<uint8_t> archive;
+    std::unique_ptr<DbWriter> dbw;
+    long long key = 0;
+    if (o.db) { try { dbw.reset(new DbWriter(output)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); fcz_ctx_destroy(ctx); return 1; } }
     Entries ents;
     auto flush = [&]() {
         if (!ents.n()) return;
@@ -2590,16 +2845,23 @@ int run_extract(const Options& o) {
             std::string text;
             if (o.ext_mode == 0 && digits > 1) text = title + "\t" + std::to_string(n_res) + "\t" + s + "\n";   // writeTSV
             else text = ">" + title + "\n" + s + "\n";                                                       // writeFASTALike
-            if (per_entry) {
-                std::string stem, ext; file_parts(base_name(ents.names[i]), stem, ext);
-                write_out(output + "/" + stem + "." + suffix, text.data(), text.size(), true);
-            } else merged += text;
+            std::string stem, ext; file_parts(base_name(ents.names[i]), stem, ext);
+            if (o.tar) {
+                const size_t at = archive.size();
+                archive.resize(at + tar_record_bytes(text.size()), 0);
+                tar_header(archive.data() + at, stem + "." + suffix, text.size());
+                memcpy(archive.data() + at + 512, text.data(), text.size());
+            } else if (o.db) dbw->append(text.data(), text.size(), key++, stem, true);
+            else if (per_entry) write_out(output + "/" + stem + "." + suffix, text.data(), text.size(), true);
+            else merged += text;
         }
         ents.clear();
     };
     for_each_entry(o, ents, flush);
     fcz_ctx_destroy(ctx);
-    if (!per_entry) write_out(output, merged.data(), merged.size(), true);
+    if (o.tar) { archive.resize(archive.size() + 1024, 0); write_out(output, (const char*)archive.data(), archive.size(), true); }
+    else if (o.db) dbw->close();
+    else if (!per_entry) write_out(output, merged.data(), merged.size(), true);
     return 0;
 }
 
@@ -2635,6 +2897,18 @@ int run_db_pack(const Options& o) {
     }
     w.close();
     return 0;
+}
+// files of a directory -> tar archive with the reference writer's headers (no GPU; what the -z outputs are made of)
+int run_tar_pack(const Options& o) {
+    if (o.output.empty()) { fprintf(stderr, "[Error] tar-pack needs an output archive.\n"); return 1; }
+    std::vector<std::string> files;
+    list_files(o.input, o.recursive, files);
+    std::vector<std::string> data(files.size());
+    for (size_t i = 0; i < files.size(); i++) data[i] = read_file(files[i]);
+    std::vector<uint8_t> archive;
+    tar_pack_members(archive, files.size(), [&](size_t q) { return base_name(files[q]); }, [&](size_t q) { return data[q].data(); }, [&](size_t q) { return (uint64_t)data[q].size(); });
+    archive.resize(archive.size() + 1024, 0);
+    return write_out(o.output, (const char*)archive.data(), archive.size(), true) ? 0 : 1;
 }
 int run_db_unpack(const Options& o) {
     if (o.output.empty()) { fprintf(stderr, "[Error] db-unpack needs an output directory.\n"); return 1; }
@@ -2795,11 +3069,12 @@ int run_rmsd(const Options& o) {
 
 void usage() {
     fprintf(stderr,
-            "usage: foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d] [--skip-discontinuous] [--json-stats] <pdb|cif file|dir> [<fcz file|dir|db>]\n"
-            "       foldcomp-hip decompress [--gpus N] [-a] [-y] [-r] [-d] [--check] [-l ids [-m 0|1]] [--json-stats] <fcz file|dir|db> [<pdb file|dir|db>]\n"
-            "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--no-merge] [--use-title] [-r] [-l ids [-m 0|1]] <fcz file|dir|db> [<out>]\n"
-            "       foldcomp-hip check      [-r] [-l ids [-m 0|1]] <fcz file|dir|db>\n"
+            "usage: foldcomp-hip compress   [-t threads] [--gpus N] [-b N] [-y] [-r] [-d|-z] [--skip-discontinuous] [--json-stats] <pdb|cif file|dir|tar(.gz)|db> [<fcz file|dir|tar|db>]\n"
+            "       foldcomp-hip decompress [--gpus N] [-a] [-y] [-r] [-d|-z] [--check] [-l ids [-m 0|1]] [--json-stats] <fcz file|dir|tar(.gz)|db> [<pdb file|dir|tar|db>]\n"
+            "       foldcomp-hip extract    [--plddt|--fasta|--amino-acid] [-p digits] [--no-merge] [--use-title] [-d|-z] [-r] [-l ids [-m 0|1]] <fcz file|dir|tar(.gz)|db> [<out>]\n"
+            "       foldcomp-hip check      [-r] [-l ids [-m 0|1]] <fcz file|dir|tar(.gz)|db>\n"
             "       -f / --file: <input> is a text file listing the inputs, one per line (any mode)\n"
+            "       -d / --db: the outputs become one database; -z / --tar (or an output named *.tar): one tar archive\n"
             "       foldcomp-hip rmsd       <pdb|cif> <pdb|cif>\n");
 }
 
@@ -2858,6 +3133,7 @@ int main(int argc, char** argv) {
         else if (a == "--use-title") o.use_title = true;
         else if (a == "--skip-discontinuous") o.skip_discontinuous = true;
         else if (a == "-d" || a == "--db") o.db = true;
+        else if (a == "-z" || a == "--tar") o.tar = true;
         else if (a == "--check") o.check = true;
         else if (a == "--host-parse") o.host_parse = true;
         else if (a == "--host-inflate") o.host_inflate = true;
@@ -2890,10 +3166,16 @@ int main(int argc, char** argv) {
         }
         o.inputs.insert(o.inputs.end(), singles.begin(), singles.end());
     } else o.inputs.push_back(o.input);
-    { struct stat st; o.single = !o.file_input && stat(o.input.c_str(), &st) == 0 && S_ISREG(st.st_mode) && !is_db(o.input); }
-    if (o.output.empty() && (o.mode == "compress" || o.mode == "decompress" || o.mode == "extract")) {   // src/main.cpp:356-369
+    // a tar archive is a container by its NAME (src/main.cpp:341-342), an output that ends in .tar asks for one (:333-335)
+    { struct stat st; o.single = !o.file_input && stat(o.input.c_str(), &st) == 0 && S_ISREG(st.st_mode) && !is_db(o.input) && !is_tar_name(o.input); }
+    const bool writes_members = o.mode == "compress" || o.mode == "decompress" || o.mode == "extract";
+    if (writes_members && ends_with(o.output, ".tar")) o.tar = true;
+    if (o.tar && o.db) { fprintf(stderr, "[Error] -z and -d name two different outputs: one of them.\n"); return 1; }
+    if (o.tar && (o.shard_world > 1 || o.place)) { fprintf(stderr, "[Error] a sharded run writes a database (-d), not a tar archive.\n"); return 1; }
+    if (o.output.empty() && writes_members) {   // src/main.cpp:356-369
         const std::string suffix = o.mode == "compress" ? "fcz" : (o.mode == "decompress" ? "pdb" : extract_suffix(o));
         if (o.db) o.output = o.input + "_db";
+        else if (o.tar) o.output = o.input + "." + suffix + ".tar";
         else if (o.single) { const size_t i = o.input.rfind('.'); o.output = (i == std::string::npos ? o.input : o.input.substr(0, i)) + "." + suffix; }
         else o.output = o.input + "_" + suffix;
     }
@@ -2930,6 +3212,7 @@ int main(int argc, char** argv) {
     }
     if (o.mode == "db-splice") return run_db_splice(o);
     if (o.mode == "db-pack") return run_db_pack(o);
+    if (o.mode == "tar-pack") return run_tar_pack(o);
     if (o.mode == "db-unpack") return run_db_unpack(o);
     usage();
     return 1;

@@ -28,3 +28,17 @@ wait
 g++ -shared -fopenmp -o "$OUT/libfoldcomp_ref.so" $OBJS "$OUT/ref_shim.o" -lz
 rm -f "$OUT"/*.o
 echo "built $OUT/libfoldcomp_ref.so"
+# the reference's own command line (src/main.cpp over the same sources + its vendored microtar; the definitions its CMakeLists.txt
+# gives the executable target): the checker of the drivers' container handling -- tar archives in and out, output naming -- in
+# tests/test_tar_vs_reference.py
+COBJS=""
+for s in $SRCS main; do
+  g++ -O3 -DNDEBUG -std=c++17 -fopenmp -DOPENMP -DFOLDCOMP_EXECUTABLE -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" -I"$REF/lib/microtar" \
+      -c "$REF/src/$s.cpp" -o "$OUT/cli_$s.o" &
+  COBJS="$COBJS $OUT/cli_$s.o"
+done
+gcc -O2 -w -c "$REF/lib/microtar/microtar.c" -o "$OUT/cli_microtar.o" &
+wait
+g++ -fopenmp -o "$OUT/foldcomp_ref" $COBJS "$OUT/cli_microtar.o" -lz
+rm -f "$OUT"/*.o
+echo "built $OUT/foldcomp_ref"

@@ -120,15 +120,19 @@ def tar_header(name: str, size: int) -> bytes:
 def iter_entries(inp: str, recursive: bool, id_list: Optional[str], id_mode: int) -> Iterator[Tuple[str, bytes]]:
     if os.path.exists(inp + ".dbtype"):
         r = DatabaseReader(inp)
-        ids = range(len(r))
+        ids = [(i, None) for i in range(len(r))]
         if id_list:
+            # an entry of an id list goes by the list's own line -- with --id-mode 0 that is its KEY (src/input_processor.h:262-278)
             want = [l.strip() for l in open(id_list) if l.strip()]
-            ids = [r.id_of_key(int(w)) if id_mode == 0 else r.id_of_name(w) for w in want]
-            ids = [i for i in ids if i >= 0]
-        for i in ids:
+            ids = [(r.id_of_key(int(w)) if id_mode == 0 else r.id_of_name(w), w) for w in want]
+            for i, w in ids:
+                if i < 0:
+                    print(f"[Warning] {w} not found in database.", file=sys.stderr)
+            ids = [(i, w) for i, w in ids if i >= 0]
+        for i, w in ids:
             # the stored bytes, MMseqs NUL terminator included: the codec takes the record length from the header (a record may
             # itself end in zero bytes, so nothing is stripped here)
-            yield r.name(i), r.data(i)
+            yield (r.name(i) if w is None else w), r.data(i)
         r.close()
     elif inp.endswith((".tar", ".tar.gz", ".tgz")) and not os.path.isdir(inp):
         yield from iter_tar(inp)
@@ -291,7 +295,7 @@ def run_extract(a, inputs, output, kind, single):
 
     def emit(name, rec, s):
         nonlocal out_dir_made
-        title = rec.title if a.use_title else os.path.basename(name)
+        title = rec.title if a.use_title else name      # the entry's name as the run met it -- a directory's file with its path (src/main.cpp:780-781)
         if a.ext_mode == 0:
             text = fczfile.fasta_like(title, s) if a.plddt_digits == 1 else fczfile.tsv_line(title, rec.n_residues, s)
         else:

@@ -1509,6 +1509,7 @@ struct InputPlan {
         std::vector<std::string> files; std::vector<uint64_t> fsize;
         DbScan scan;
         std::unique_ptr<DbReader> db; std::vector<size_t> ids;
+        std::vector<std::string> id_names;     // --id-list: an entry goes by the list's own line -- with --id-mode 0 that is its KEY (src/input_processor.h:262-278)
         int dfd = -1; uint64_t dsize = 0;
         uint64_t n = 0, bytes = 0, lo = 0, hi = 0;   // items, their bytes, this process's items [lo, hi)
         ~Src() { if (dfd >= 0) close(dfd); }
@@ -1584,7 +1585,7 @@ struct InputPlan {
                             if (line.empty()) continue;
                             const long long id = o.id_mode == 0 ? s.db->id_of_key(atoll(line.c_str())) : s.db->id_of_name(line);
                             if (id < 0) { if (!quiet) fprintf(stderr, "[Warning] %s not found in database.\n", line.c_str()); continue; }
-                            s.ids.push_back((size_t)id);
+                            s.ids.push_back((size_t)id); s.id_names.push_back(line);
                         }
                     } else { s.ids.resize(s.db->n()); for (size_t i = 0; i < s.db->n(); i++) s.ids[i] = i; }
                     s.n = s.ids.size();
@@ -1663,7 +1664,7 @@ struct InputPlan {
                 it.kind = 1;
                 for (uint64_t i = s.lo; i < s.hi; i++) {
                     const auto& r = s.db->rows[s.ids[i]];
-                    it.name = s.db->name(s.ids[i]); it.off = (uint64_t)r.off; it.len = (uint64_t)r.len; f(it);
+                    it.name = s.id_names.empty() ? s.db->name(s.ids[i]) : s.id_names[i]; it.off = (uint64_t)r.off; it.len = (uint64_t)r.len; f(it);
                 }
             } else {
                 it.kind = 1;
@@ -2484,7 +2485,7 @@ void for_each_entry(const Options& o, Entries& ents, F&& flush, size_t batch = B
             }
         } else if (is_db(input)) {
             DbReader r(input);
-            std::vector<size_t> ids;
+            std::vector<size_t> ids; std::vector<std::string> id_names;   // (an entry of an id list goes by the list's own line, src/input_processor.h:262-278)
             if (!o.id_list.empty()) {
                 std::ifstream f(o.id_list);
                 if (!f) fprintf(stderr, "[Error] user id '%s' does not exist.\n", o.id_list.c_str());
@@ -2494,11 +2495,12 @@ void for_each_entry(const Options& o, Entries& ents, F&& flush, size_t batch = B
                     if (line.empty()) continue;
                     const long long id = o.id_mode == 0 ? r.id_of_key(atoll(line.c_str())) : r.id_of_name(line);
                     if (id < 0) { fprintf(stderr, "[Warning] %s not found in database.\n", line.c_str()); continue; }
-                    ids.push_back((size_t)id);
+                    ids.push_back((size_t)id); id_names.push_back(line);
                 }
             } else { ids.resize(r.n()); for (size_t i = 0; i < r.n(); i++) ids[i] = i; }
-            for (size_t i : ids) {
-                try { ents.add(r.name(i), r.entry(i)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
+            for (size_t q = 0; q < ids.size(); q++) {
+                const size_t i = ids[q];
+                try { ents.add(id_names.empty() ? r.name(i) : id_names[q], r.entry(i)); } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); }
                 if (ents.n() >= batch) flush();
             }
         } else {
@@ -2840,7 +2842,7 @@ int run_extract(const Options& o) {
             if (!fcz_header(ents.blob.data() + ents.off[i], len, title, n_res) || (data_off[i + 1] == data_off[i] && n_res)) {
                 fprintf(stderr, "[Error] reading %s\n", ents.names[i].c_str()); continue;
             }
-            if (!o.use_title) title = base_name(ents.names[i]);
+            if (!o.use_title) title = ents.names[i];        // the entry's name as the run met it -- a directory's file with its path (src/main.cpp:780-781)
             const std::string s = data.substr(data_off[i], data_off[i + 1] - data_off[i]);
             std::string text;
             if (o.ext_mode == 0 && digits > 1) text = title + "\t" + std::to_string(n_res) + "\t" + s + "\n";   // writeTSV

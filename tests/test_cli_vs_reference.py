@@ -1,0 +1,239 @@
+"""The command line, option by option, against the reference's OWN command line on the same inputs (oracle/_ref/foldcomp_ref:
+src/main.cpp compiled from where it lies by oracle/build_ref.sh -- test infrastructure only): both hosts (host/foldcomp-hip =
+host/foldcomp, python -m foldcomp_amd) must leave the same files under the same names with the same bytes (FCZ records: the four
+header bytes the reference leaves uninitialised masked; databases: the same name -> record pairs -- the reference numbers its keys in
+directory-listing order, the hosts in sorted order).
+
+Covers: default output names of every mode, single files, directories (-r), input lists (-f), databases in and out (-d), -b,
+--skip-discontinuous, -a, --check, --id-list / --id-mode, extract (--plddt -p 1..4, --fasta, --no-merge, --use-title), -y, rmsd."""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "host", "foldcomp")            # the drop-in name (the same binary as foldcomp-hip)
+REF = os.path.join(ROOT, "oracle", "_ref", "foldcomp_ref")
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/foldcomp_ref not built")]
+
+
+def _run(cmd, cwd):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=cwd, env=env)
+
+
+HOSTS = {"ref": [REF], "cpp": [BIN], "py": [sys.executable, "-m", "foldcomp_amd"]}
+
+
+def _mask(b: bytes) -> bytes:
+    if b[:4] != b"FCMP":
+        return b
+    a = bytearray(b)
+    for i in (14, 15, 22, 23):
+        if i < len(a):
+            a[i] = 0
+    return bytes(a)
+
+
+def _records(b: bytes) -> bytes:
+    """a merged extract output as its records in sorted order (FASTA-like: two lines per entry; TSV: one): the reference walks a
+    directory in the file system's listing order, the hosts in sorted order"""
+    lines = b.split(b"\n")
+    if b.startswith(b">"):
+        recs = [b"\n".join(lines[i:i + 2]) for i in range(0, len(lines) - 1, 2)]
+    else:
+        recs = lines[:-1]
+    return b"\n".join(sorted(recs)) + b"\n" + lines[-1]
+
+
+def _tree(path):
+    """every file under a directory (or the one file): relative name -> bytes (FCZ records masked)"""
+    if os.path.isfile(path):
+        b = _mask(open(path, "rb").read())
+        return {os.path.basename(path): _records(b) if os.path.basename(path) == "merged.txt" else b}
+    out = {}
+    for root, _, fs in os.walk(path):
+        for f in fs:
+            p = os.path.join(root, f)
+            out[os.path.relpath(p, path)] = _mask(open(p, "rb").read())
+    return out
+
+
+def _db(path):
+    from foldcomp_amd.database import DatabaseReader
+    r = DatabaseReader(str(path))
+    out = sorted((r.name(i), _mask(r.data(i))) for i in range(len(r)))
+    r.close()
+    assert open(str(path) + ".dbtype", "rb").read() == b"\x0c\0\0\0"
+    return out
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    """a directory of the shapes the drivers meet: PDB, gzipped PDB, mmCIF, gzipped mmCIF, a file without an extension, one with
+    an unknown extension, a two-chain file with a numbering gap, and a sub-directory"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
+    f = {k[5:]: z[k].tobytes() for k in z.keys() if k.startswith("file:") and not k.startswith("file:example_db")}
+    base = tmp_path_factory.mktemp("cli_inputs")
+    d = base / "in"
+    d.mkdir()
+    (d / "test.pdb").write_bytes(f["test.pdb"])
+    (d / "test_af.pdb.gz").write_bytes(gzip.compress(f["test_af.pdb"], mtime=0))
+    (d / "model.cif").write_bytes(gzip.decompress(f["test.cif.gz"]))
+    (d / "model2.cif.gz").write_bytes(f["test.cif.gz"])
+    (d / "d1asha_").write_bytes(f["test_af.pdb"])
+    (d / "other.ent").write_bytes(f["test_af.pdb"])
+    (d / "multichain.pdb").write_bytes(f["multichain.pdb"])
+    (d / "sub").mkdir()
+    (d / "sub" / "deep.pdb").write_bytes(f["test_af.pdb"])
+    (base / "one.pdb").write_bytes(f["test_af.pdb"])
+    (base / "two.pdb").write_bytes(f["test.pdb"])
+    return base
+
+
+def _each(base, tmp_path, args_of, outputs, hosts=("ref", "cpp", "py"), setup=None):
+    """run `args_of(workdir)` with every host in its own copy of the inputs; -> {host: {output: tree or db}}"""
+    got = {}
+    for h in hosts:
+        w = tmp_path / h
+        shutil.copytree(base, w)
+        if setup:
+            setup(w)
+        r = _run(HOSTS[h] + [str(a) for a in args_of(w)], cwd=str(w))
+        assert r.returncode == 0, (h, r.stderr[-2000:])
+        res = {}
+        for o in outputs:
+            p = w / o
+            if os.path.exists(str(p) + ".dbtype"):
+                res[o] = _db(p)
+            else:
+                assert p.exists(), (h, o, r.stdout[-500:], r.stderr[-2000:])
+                res[o] = _tree(str(p))
+        got[h] = res
+    return got
+
+
+def _assert_same(got):
+    ref = got["ref"]
+    for h, res in got.items():
+        if h == "ref":
+            continue
+        for o in ref:
+            if isinstance(ref[o], dict):
+                assert sorted(res[o]) == sorted(ref[o]), (h, o, sorted(res[o]), sorted(ref[o]))
+                for n in ref[o]:
+                    assert res[o][n] == ref[o][n], (h, o, n)
+            else:
+                assert [n for n, _ in res[o]] == [n for n, _ in ref[o]], (h, o)
+                assert res[o] == ref[o], (h, o)
+
+
+@pytest.mark.parametrize("extra", [[], ["-r"], ["-b", "10"], ["-b", "200"], ["--skip-discontinuous"]])
+def test_compress_directory(inputs, tmp_path, extra):
+    _assert_same(_each(inputs, tmp_path, lambda w: ["compress", *extra, "in", "out"], ["out"]))
+
+
+def test_compress_default_names(inputs, tmp_path):
+    # no output given: <dir>_fcz/, <file stem>.fcz, <input>_db (src/main.cpp:356-369)
+    _assert_same(_each(inputs, tmp_path, lambda w: ["compress", "in"], ["in_fcz"]))
+    _assert_same(_each(inputs, tmp_path / "s", lambda w: ["compress", "one.pdb"], ["one.fcz"]))
+    _assert_same(_each(inputs, tmp_path / "d", lambda w: ["compress", "-d", "in"], ["in_db"]))
+
+
+def test_compress_single_file_named_output_and_overwrite(inputs, tmp_path):
+    _assert_same(_each(inputs, tmp_path, lambda w: ["compress", "one.pdb", "renamed.fcz"], ["renamed.fcz"]))
+    # an existing output is left alone without -y and replaced with it
+    def pre(w):
+        (w / "kept.fcz").write_bytes(b"old")
+    _assert_same(_each(inputs, tmp_path / "n", lambda w: ["compress", "one.pdb", "kept.fcz"], ["kept.fcz"], setup=pre))
+    _assert_same(_each(inputs, tmp_path / "y", lambda w: ["compress", "-y", "one.pdb", "kept.fcz"], ["kept.fcz"], setup=pre))
+
+
+def test_compress_database_and_lists(inputs, tmp_path):
+    _assert_same(_each(inputs, tmp_path, lambda w: ["compress", "-d", "in", "db"], ["db"]))
+    # -f: a list that names a directory and two single files (src/main.cpp:304-325)
+    def pre(w):
+        (w / "list.txt").write_text("in\none.pdb\ntwo.pdb\n")
+    _assert_same(_each(inputs, tmp_path / "f", lambda w: ["compress", "-f", "list.txt", "out"], ["out"], setup=pre))
+    _assert_same(_each(inputs, tmp_path / "fd", lambda w: ["compress", "-d", "-f", "list.txt", "db"], ["db"], setup=pre))
+
+
+def test_compress_database_and_tar_inputs_in_one_list(inputs, tmp_path):
+    """a database of structure files (MMseqs layout; entries gzipped or not by their lookup NAME) and a tar archive, alone and named
+    together in one -f list (src/main.cpp:405-436: every container kind goes through the same lambda)"""
+    import tarfile
+    def pre(w):
+        r = _run([os.path.join(ROOT, "host", "foldcomp-hip"), "db-pack", "in", "srcdb"], cwd=str(w))
+        assert r.returncode == 0, r.stderr
+        # (db-pack names an entry by its file's stem; the reference decides "gzipped" by the NAME: give the gzipped entries theirs back)
+        look = (w / "srcdb.lookup").read_text().replace("\ttest_af.pdb\t", "\ttest_af.pdb.gz\t").replace("\tmodel2.cif\t", "\tmodel2.cif.gz\t")
+        (w / "srcdb.lookup").write_text(look)
+        with tarfile.open(w / "more.tar", "w", format=tarfile.GNU_FORMAT) as tf:
+            tf.add(w / "one.pdb", arcname="x/one_in_tar.pdb"); tf.add(w / "in" / "model2.cif.gz", arcname="two_in_tar.cif.gz")
+        (w / "list.txt").write_text("srcdb\nmore.tar\nin\ntwo.pdb\n")
+    _assert_same(_each(inputs, tmp_path, lambda w: ["compress", "-d", "srcdb", "db"], ["db"], setup=pre))
+    _assert_same(_each(inputs, tmp_path / "dir", lambda w: ["compress", "srcdb", "out"], ["out"], setup=pre))
+    _assert_same(_each(inputs, tmp_path / "f", lambda w: ["compress", "-d", "-f", "list.txt", "db"], ["db"], setup=pre))
+
+
+@pytest.fixture(scope="module")
+def fcz_inputs(inputs, tmp_path_factory):
+    """the reference's own FCZ outputs as the inputs of decompress / extract / check: a directory, a database, one file"""
+    base = tmp_path_factory.mktemp("cli_fcz")
+    shutil.copytree(inputs / "in", base / "in")
+    assert _run([REF, "compress", "-r", "in", "fcz"], cwd=str(base)).returncode == 0
+    assert _run([REF, "compress", "-d", "in", "fdb"], cwd=str(base)).returncode == 0
+    shutil.copy(base / "fcz" / "test.fcz", base / "one.fcz")
+    shutil.rmtree(base / "in")
+    (base / "names.txt").write_text("test\nmultichain\nabsent\nmodel\n")
+    return base
+
+
+@pytest.mark.parametrize("extra", [[], ["-a"], ["--check"]])
+def test_decompress_directory_and_database(fcz_inputs, tmp_path, extra):
+    _assert_same(_each(fcz_inputs, tmp_path, lambda w: ["decompress", *extra, "fcz", "out"], ["out"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "db", lambda w: ["decompress", *extra, "fdb", "out"], ["out"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "dd", lambda w: ["decompress", *extra, "-d", "fdb", "odb"], ["odb"]))
+
+
+def test_decompress_default_names_and_single_file(fcz_inputs, tmp_path):
+    _assert_same(_each(fcz_inputs, tmp_path, lambda w: ["decompress", "fcz"], ["fcz_pdb"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "s", lambda w: ["decompress", "one.fcz"], ["one.pdb"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "n", lambda w: ["decompress", "-a", "one.fcz", "named.pdb"], ["named.pdb"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "d", lambda w: ["decompress", "-d", "fcz"], ["fcz_db"]))
+
+
+def test_decompress_id_list(fcz_inputs, tmp_path):
+    _assert_same(_each(fcz_inputs, tmp_path, lambda w: ["decompress", "--id-list", "names.txt", "fdb", "out"], ["out"]))
+    def pre(w):
+        (w / "keys.txt").write_text("0\n3\n99\n")
+    _assert_same(_each(fcz_inputs, tmp_path / "k", lambda w: ["decompress", "--id-list", "keys.txt", "--id-mode", "0", "-d", "fdb", "odb"], ["odb"], setup=pre))
+
+
+@pytest.mark.parametrize("flags", [["--plddt"], ["--plddt", "-p", "2"], ["--plddt", "-p", "3"], ["--plddt", "-p", "4"], ["--fasta"], ["--amino-acid", "--use-title"]])
+def test_extract(fcz_inputs, tmp_path, flags):
+    _assert_same(_each(fcz_inputs, tmp_path, lambda w: ["extract", *flags, "fcz", "merged.txt"], ["merged.txt"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "db", lambda w: ["extract", *flags, "fdb", "merged.txt"], ["merged.txt"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "nm", lambda w: ["extract", *flags, "--no-merge", "fcz", "per_entry"], ["per_entry"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "s", lambda w: ["extract", *flags, "one.fcz", "one.txt"], ["one.txt"]))
+
+
+def test_extract_default_names(fcz_inputs, tmp_path):
+    _assert_same(_each(fcz_inputs, tmp_path, lambda w: ["extract", "--plddt", "one.fcz"], ["one.plddt"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "t", lambda w: ["extract", "--plddt", "-p", "3", "one.fcz"], ["one.plddt.tsv"]))
+    _assert_same(_each(fcz_inputs, tmp_path / "f", lambda w: ["extract", "--fasta", "one.fcz"], ["one.fasta"]))
+
+
+def test_rmsd_line(inputs, tmp_path):
+    out = {}
+    for h in HOSTS:
+        r = _run(HOSTS[h] + ["rmsd", "one.pdb", "one.pdb"], cwd=str(inputs))
+        assert r.returncode == 0, (h, r.stderr)
+        out[h] = [l for l in r.stdout.splitlines() if "\t" in l]
+    assert out["cpp"] == out["ref"] and out["py"] == out["ref"] and len(out["ref"]) == 1

@@ -133,7 +133,10 @@ def test_cpp_cli_files_and_directories(tmp_path, golden):
         assert [l for l in back.splitlines() if l.startswith(("ATOM", "TER"))] == [l for l in ref.splitlines() if l.startswith(("ATOM", "TER"))], n
     r = _run("extract", "--plddt", "-p", "2", str(tmp_path / "fcz"), str(tmp_path / "out.tsv"))
     assert r.returncode == 0, r.stderr
-    rows = {l.split("\t")[0]: l.split("\t") for l in (tmp_path / "out.tsv").read_text().splitlines()}
+    # (an entry goes by its name as the run met it -- a directory's file with its path, src/main.cpp:780-781; held against the
+    #  reference's own command line in tests/test_cli_vs_reference.py)
+    rows = {os.path.basename(l.split("\t")[0]): l.split("\t") for l in (tmp_path / "out.tsv").read_text().splitlines()}
+    assert rows["test_af.fcz"][0] == str(tmp_path / "fcz" / "test_af.fcz")
     assert rows["test_af.fcz"][2] == z["pdb:test_af/plddt2"].tobytes().decode()
     r = _run("extract", "--fasta", str(tmp_path / "fcz" / "test.fcz"), str(tmp_path / "seq.fasta"))
     assert (tmp_path / "seq.fasta").read_text().splitlines()[1] == z["pdb:test/fasta"].tobytes().decode()

@@ -821,6 +821,61 @@ def end_to_end_leg(args, codec, w, dev):
                     del d_raw, d_tx, d_st, d_go, d_to
                 except Exception as e_:   # noqa: BLE001
                     gzo[kind + "_gz"]["inflate_kernel"] = {"failed": str(e_)[-200:]}
+            # ---- the same .pdb.gz members as ONE plain tar archive -- how AFDB ships a proteome -- through `compress -d <tar> <db>`: the
+            #      members are byte ranges of the archive, read into the job buffers and inflated on the device like the files of
+            #      the directory above; beside it the reference's own command line on the same archive (oracle/_ref/foldcomp_ref =
+            #      src/main.cpp + lib/microtar compiled as they lie; TarProcessor reads the members under `omp critical`) ----
+            try:
+                import tarfile as _tarfile
+                tarp = os.path.join(tmp, "afdb_like.tar")
+                with _tarfile.open(tarp, "w", format=_tarfile.GNU_FORMAT) as tf_:
+                    for gp_ in gz_sets["pdb"]:
+                        tf_.add(gp_, arcname="afdb/" + os.path.basename(gp_))
+                tlst = os.path.join(tmp, "tars.txt")
+                with open(tlst, "w") as fh:
+                    fh.write((tarp + "\n") * passes)
+                run_t = run_host(["compress", "-d", "-y", "-t", str(eff), "--gpus", "1", *wpg, "--json-stats", "-f", tlst, os.path.join(tmp, "dbtar")])
+                smt = summarise([run_t], "input_bytes", "host/foldcomp-hip compress -d -f <list naming one tar of .pdb.gz members> <db>   (members read from the archive, inflate + parse + codec on the device)")
+                tr = {"archive_bytes": os.path.getsize(tarp), "members": len(gz_sets["pdb"]), "passes": passes, "gpu_host": smt,
+                      "device_inflated_files": run_t.get("device_inflated_files"),
+                      "steady_over_directory_of_the_same_members": round(smt["steady_residues_per_s"] / max(gzo["pdb_gz"]["gpu_host"]["steady_residues_per_s"], 1), 3),
+                      "databases_identical_to_the_directory_run": all(open(os.path.join(tmp, "dbtar") + ext, "rb").read() == open(os.path.join(tmp, f"dbgz_pdb_{tcounts[0]}") + ext, "rb").read() for ext in ("", ".index", ".lookup"))}
+                refcli = os.path.join(ROOT, "oracle", "_ref", "foldcomp_ref")
+                if os.path.exists(refcli):
+                    best_ = None
+                    for t_ in tcounts:
+                        for ext in ("", ".index", ".lookup", ".dbtype"):
+                            if os.path.exists(os.path.join(tmp, "dbtar_ref") + ext):
+                                os.remove(os.path.join(tmp, "dbtar_ref") + ext)
+                        t0_ = time.perf_counter()
+                        r_ = subprocess.run([refcli, "compress", "-t", str(t_), "-d", tarp, os.path.join(tmp, "dbtar_ref")], capture_output=True, text=True, timeout=900)
+                        dt_ = time.perf_counter() - t0_
+                        if r_.returncode == 0 and (best_ is None or dt_ < best_[0]):
+                            best_ = (dt_, t_)
+                    if best_:
+                        res_pass_ = gzo["pdb_gz"]["residues_per_pass"]
+                        tr["cpu_reference"] = {"what": "oracle/_ref/foldcomp_ref compress -t <threads> -d <the same tar> <db> (the reference's own command line, one walk, process wall time, best thread count)",
+                                               "wall_s": round(best_[0], 4), "threads": best_[1], "residues_per_s": round(res_pass_ / best_[0])}
+                        tr["steady_speedup_vs_cpu_reference"] = round(smt["steady_residues_per_s"] / max(tr["cpu_reference"]["residues_per_s"], 1), 2)
+                        # every record of the reference's database (by name; its key order is thread-schedule dependent) == ours, pad bytes masked
+                        try:
+                            from foldcomp_amd.database import DatabaseReader as _DR
+                            ra_, rb_ = _DR(os.path.join(tmp, "dbtar_ref")), _DR(os.path.join(tmp, "dbtar"))
+                            def mk_(b_):
+                                a_ = bytearray(b_)
+                                for i_ in (14, 15, 22, 23):
+                                    a_[i_] = 0
+                                return bytes(a_)
+                            mine_ = {rb_.name(i_): mk_(rb_.data(i_)) for i_ in range(len(gz_sets["pdb"]))}     # the first walk
+                            eq_ = sum(1 for i_ in range(len(ra_)) if mine_.get(ra_.name(i_)) == mk_(ra_.data(i_)))
+                            tr["records_equal_reference"] = f"{eq_}/{len(ra_)}"
+                            ra_.close(); rb_.close()
+                        except Exception as e_:   # noqa: BLE001
+                            tr["records_equal_reference"] = "failed: " + str(e_)[-120:]
+                gzo["pdb_gz"]["tar"] = tr
+                os.remove(tarp)
+            except (RuntimeError, subprocess.TimeoutExpired, OSError, KeyError) as e:
+                gzo["pdb_gz"]["tar"] = {"failed": str(e)[-300:]}
             plain = comp["gpu_host"]["steady_residues_per_s"]
             gzo["pdb_gz"]["steady_over_plain_pdb"] = round(gzo["pdb_gz"]["gpu_host"]["steady_residues_per_s"] / max(plain, 1), 3)
             if isinstance(comp.get("mmcif"), dict) and "gpu_host" in comp["mmcif"]:

@@ -106,7 +106,7 @@ def decompress_many(entries: Sequence[bytes], *, alt_order: bool = False, codec:
 
 def decompress(fcz: bytes) -> Tuple[str, str]:
     if not isinstance(fcz, (bytes, bytearray, memoryview)):
-        raise TypeError("a bytes-like object is required")
+        raise TypeError(f"a bytes-like object is required, not '{type(fcz).__name__}'")      # ("y#", foldcomp.cxx:204)
     return decompress_many([bytes(fcz)])[0]
 
 
@@ -114,8 +114,10 @@ def decompress(fcz: bytes) -> Tuple[str, str]:
 def get_data(input) -> dict:  # noqa: A002
     if isinstance(input, str):
         raw = input.encode("latin-1")
-    else:
+    elif isinstance(input, (bytes, bytearray, memoryview)):
         raw = bytes(input)
+    else:
+        raise TypeError(f"a bytes-like object is required, not '{type(input).__name__}'")
     if len(raw) == 0:
         raise ValueError("Input is empty")
     if len(raw) >= 4 and raw[:4] == b"FCMP":
@@ -205,6 +207,8 @@ class FoldcompDatabase:
 
     def __getitem__(self, index):
         index = int(index)
+        if index < 0:
+            index += len(self)                        # the sequence protocol of the reference's type (sq_item behind PySequence_GetItem): db[-1] is the last entry
         if not self._decompress:
             return self._entry(index)
         if index < 0 or index >= len(self):

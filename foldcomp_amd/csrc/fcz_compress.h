@@ -916,7 +916,7 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
     }
 
     // ---- validation (the reference aborts on these inputs) + total side-chain torsion count ----
-    int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
+    int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 1 ? FCZ_E_INVALID_ARG : 0);
     // nResidue is a uint16 and nAnchor a uint8 in the header (src/foldcomp.h:120-125): a chain beyond them would get a record
     // whose layout uses the full values and whose header holds wrapped ones (the reference writes exactly that, unreadable)
     if (!bad && (n > 65535u || n / thr + 2u > 255u)) bad = FCZ_E_INVALID_ARG;
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, co
     }
 
     // ---- validation, as compress_pack_chain orders it ----
-    int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 2 ? FCZ_E_INVALID_ARG : 0);
+    int bad = (n < 2) ? FCZ_E_TOO_SHORT : (thr < 1 ? FCZ_E_INVALID_ARG : 0);
     if (!bad && (n > 65535u || n / thr + 2u > 255u)) bad = FCZ_E_INVALID_ARG;
     if (!bad && ((nonfinite[c >> 5] >> (c & 31u)) & 1u)) bad = FCZ_E_NONFINITE;
     uint32_t nsc = 0;

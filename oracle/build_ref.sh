@@ -42,3 +42,21 @@ wait
 g++ -fopenmp -o "$OUT/foldcomp_ref" $COBJS "$OUT/cli_microtar.o" -lz
 rm -f "$OUT"/*.o
 echo "built $OUT/foldcomp_ref"
+# the reference's own Python module (foldcomp/foldcomp.cxx over the same sources, against this interpreter's headers): the checker of
+# the Python surface in tests/test_api_vs_reference_module.py. It is called `foldcomp` like the drop-in, so it lives in a directory of
+# its own that only the checker's subprocess puts on its path.
+PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])' 2>/dev/null || true)"
+PYEXT="$(python3 -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))' 2>/dev/null || true)"
+if [ -n "$PYINC" ] && [ -f "$PYINC/Python.h" ] && [ -f "$REF/foldcomp/foldcomp.cxx" ]; then
+  POBJS=""
+  for s in $SRCS; do
+    g++ -O3 -DNDEBUG -std=c++17 -fPIC -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" -c "$REF/src/$s.cpp" -o "$OUT/py_$s.o" &
+    POBJS="$POBJS $OUT/py_$s.o"
+  done
+  g++ -O3 -DNDEBUG -std=c++17 -fPIC -D_USE_MATH_DEFINES=1 -w -I"$REF/src" -I"$REF/lib" -I"$PYINC" -c "$REF/foldcomp/foldcomp.cxx" -o "$OUT/py_module.o" &
+  wait
+  mkdir -p "$OUT/pymod"
+  g++ -shared -o "$OUT/pymod/foldcomp$PYEXT" $POBJS "$OUT/py_module.o" -lz
+  rm -f "$OUT"/*.o
+  echo "built $OUT/pymod/foldcomp$PYEXT"
+fi

@@ -50,9 +50,11 @@ def test_atom_richest_tiles(codec):
     _check(codec, both)
 
 
-@pytest.mark.parametrize("thr", [2, 7, 200, 5000])
+@pytest.mark.parametrize("thr", [1, 2, 7, 200, 5000])
 def test_anchor_thresholds(codec, thr):
-    lens = [30, 64, 350, 700 if thr > 2 else 506]   # n / thr + 2 anchors must fit the header's uint8 (next test)
+    # n / thr + 2 anchors must fit the header's uint8 (next test). -b 1: an anchor per residue and two more, every interval 0 --
+    # the reference writes and reads such records (tests/test_api_vs_reference_module.py: compress_b1)
+    lens = [30, 64, 350, 700 if thr > 2 else 506] if thr > 1 else [2, 3, 16, 30, 64, 129, 253]
     b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=5, anchor_threshold=thr))
     _check(codec, b)
 

@@ -3146,6 +3146,11 @@ int main(int argc, char** argv) {
         else if (a == "-m" || a == "--id-mode") { next_int(o.id_mode); if (o.id_mode != 0 && o.id_mode != 1) { fprintf(stderr, "[Error] Invalid id mode. Please use 0 or 1.\n"); usage(); return 1; } }
         else if (a == "-v" || a == "--version") { printf("foldcomp (MI355X / libfcz_hip) 1.0\n"); return 0; }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
+        // --time (per-entry timers of the reference's one-entry-at-a-time loop, src/main.cpp:439) and --use-cache (a cached sorted index
+        // for --id-list runs, src/input_processor.h:209-216) have nothing to switch here -- entries go through the device in jobs, the
+        // index is streamed -- and are accepted so that a command line written for the reference runs unchanged
+        else if (a == "--time" || a == "--use-cache") {}
+        else if (a.size() > 1 && a[0] == '-' && pos.size() < 3 && !(a[1] >= '0' && a[1] <= '9')) { fprintf(stderr, "[Error] unknown option %s\n", a.c_str()); usage(); return 1; }
         else pos.push_back(a);
     }
     if (pos.size() < 2) { usage(); return 0; }

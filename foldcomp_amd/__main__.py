@@ -218,14 +218,15 @@ def host_fragments(name: str, data: bytes, a, kind: str, single: bool, output) -
 
 def run_compress(a, inputs, output, kind, single):
     sink = Sink(output, kind, a.overwrite)
-    pending: List[Tuple[str, str, Chain]] = []   # (file name, db name, chain)
+    pending: List[list] = []   # [file name, db name, chain, input ordinal, record or None]
 
     def flush():
         if not pending:
             return
+        good = list(pending)
         try:
-            batch = build_batch([p[2] for p in pending], a.brk)
-        except StructureError as e:
+            batch = build_batch([p[2] for p in good], a.brk)
+        except StructureError:
             # isolate the offending chains one by one
             good = []
             for p in pending:
@@ -233,21 +234,50 @@ def run_compress(a, inputs, output, kind, single):
                     build_batch([p[2]], a.brk); good.append(p)
                 except StructureError as ee:
                     print(f"[Error] compressing {p[0]}: {ee}", file=sys.stderr)
-            pending[:] = good
-            if not pending:
-                return
-            batch = build_batch([p[2] for p in pending], a.brk)
-        blob, off, st = default_codec().compress_batch(batch, strict=False)
-        for i, (fname, dbname, _) in enumerate(pending):
-            if st[i] != 0:
-                print(f"[Error] compressing {fname}: {_lib.load().fcz_status_string(int(st[i])).decode()}", file=sys.stderr); continue
-            sink.put(fname, blob[off[i]:off[i + 1]].tobytes(), db_name=dbname)
+            batch = build_batch([p[2] for p in good], a.brk) if good else None
+        if batch is not None:
+            blob, off, st = default_codec().compress_batch(batch, strict=False)
+            for i, p in enumerate(good):
+                if st[i] != 0:
+                    print(f"[Error] compressing {p[0]}: {_lib.load().fcz_status_string(int(st[i])).decode()}", file=sys.stderr); continue
+                p[4] = blob[off[i]:off[i + 1]].tobytes()
+        if kind in ("db", "tar"):
+            for fname, dbname, _, _, rec in pending:
+                if rec is not None:
+                    sink.put(fname, rec, db_name=dbname)
+        else:
+            # files of a directory, in the order the reference's lambda meets the fragments of an input (src/main.cpp:466-531): it
+            # RETURNS at the first output name that already exists -- from an earlier run, or an earlier fragment of the same input
+            # (chain A, chain B, chain A again) -- unless -y, where the later fragment replaces the earlier one. A fragment refused
+            # here (the reference writes its shifted record) keeps its place in that order: under a name stands what the reference
+            # writes under it, or nothing (host/foldcomp_hip.cpp write_fragments_in_order)
+            cur, seen, stopped = None, set(), False
+            for fname, dbname, _, fidx, rec in pending:
+                if fidx != cur:
+                    cur, seen, stopped = fidx, set(), False
+                if stopped:
+                    continue
+                path = fname if kind == "file" else os.path.join(output, os.path.basename(fname))
+                if not a.overwrite:
+                    if fname in seen or os.path.exists(path):
+                        print(f"[Error] Output file already exists: {os.path.basename(path)}", file=sys.stderr); stopped = True; continue
+                    seen.add(fname)
+                    if rec is not None:
+                        open(path, "wb").write(rec)
+                else:
+                    if rec is not None:
+                        open(path, "wb").write(rec)
+                    elif fname in seen and os.path.exists(path):
+                        os.remove(path)
+                    seen.add(fname)
         pending.clear()
 
+    fidx = 0
     for inp in inputs:
         for name, data in iter_entries(inp, a.recursive, None, 1):
+            fidx += 1
             try:
-                pending.extend(host_fragments(name, data, a, kind, single, output))
+                pending.extend([fn, dbn, ch, fidx, None] for fn, dbn, ch in host_fragments(name, data, a, kind, single, output))
             except Exception as e:  # noqa: BLE001 - parse errors are reported and skipped like the reference
                 print(f"[Error] {os.path.basename(name)}: {e}", file=sys.stderr); continue
             if len(pending) >= BATCH_CHAINS:

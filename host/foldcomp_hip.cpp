@@ -1706,6 +1706,7 @@ struct InputPlan {
 
 struct Fragment {
     std::string out_name, db_name; AtomTable atoms; std::string title;   // db_name: lookup name = the input file's stem
+    size_t file = 0;                           // which input of the run it came from (fragments of one input are written in order, write_fragments_in_order)
     // filled by the parse threads of the compress pipeline (Batch::prepare): what the batch needs besides the atoms, or why not
     bool prepared = false; Batch::Prepared prep; std::string prep_err;
 };
@@ -1777,7 +1778,7 @@ void fragments_of_files(const std::vector<std::string>& files, size_t a, size_t 
     }
     for (size_t i = 0; i < b - a; i++) {
         if (!err[i].empty()) fputs(err[i].c_str(), stderr);
-        for (Fragment& f : per[i]) out.push_back(std::move(f));
+        for (Fragment& f : per[i]) { f.file = a + i; out.push_back(std::move(f)); }
     }
 
 }
@@ -1878,6 +1879,31 @@ void pwritev_all(int fd, std::vector<iovec>& iov, uint64_t off) {
         while (w > 0 && i < iov.size()) {
             if ((size_t)w >= iov[i].iov_len) { w -= (ssize_t)iov[i].iov_len; i++; }
             else { iov[i].iov_base = (char*)iov[i].iov_base + w; iov[i].iov_len -= (size_t)w; w = 0; }
+        }
+    }
+}
+// The fragments of the inputs as files of a directory, in the order the reference's lambda meets them (src/main.cpp:466-531): it walks
+// a file's fragments in order and RETURNS at the first output name that already exists -- a file of an earlier run, or an earlier
+// fragment of the same file under the same name (chain A, chain B, chain A again) -- unless -y, where a later fragment replaces the
+// earlier one. A fragment this host REFUSES (p == nullptr; the reference writes its shifted record) still takes
+// its place in that order: what stands under a name here is what the reference writes under it, or nothing -- never another fragment.
+struct FragOut { size_t file; uint32_t sub; std::string name; const uint8_t* p; uint64_t len; };
+template <class PathOf>
+void write_fragments_in_order(std::vector<FragOut>& ev, PathOf path_of, bool overwrite) {
+    std::stable_sort(ev.begin(), ev.end(), [](const FragOut& a, const FragOut& b) { return a.file != b.file ? a.file < b.file : a.sub < b.sub; });
+    std::unordered_set<std::string> seen; bool stopped = false; size_t cur = SIZE_MAX;
+    for (const FragOut& f : ev) {
+        if (f.file != cur) { cur = f.file; seen.clear(); stopped = false; }
+        if (stopped) continue;
+        const std::string path = path_of(f);
+        if (!overwrite) {
+            if (seen.count(f.name) || exists(path)) { fprintf(stderr, "[Error] Output file already exists: %s\n", base_name(path).c_str()); stopped = true; continue; }
+            seen.insert(f.name);
+            if (f.p) write_out(path, (const char*)f.p, f.len, true);
+        } else {
+            if (f.p) write_out(path, (const char*)f.p, f.len, true);
+            else if (seen.count(f.name)) unlink(path.c_str());
+            seen.insert(f.name);
         }
     }
 }
@@ -1998,15 +2024,17 @@ int run_compress(const Options& o) {
                 }
                 const uint64_t at = o.db ? seq.claim(job.index, packed, &lens, &names) : 0;
                 if (o.db && packed) pwrite_all(db_fd, blob.data(), packed, at);
+                std::vector<FragOut> ev;                                  // directory / single-file output: every fragment of the job in input order
+                if (!placed) for (size_t i = 0; i < job.frags.size(); i++) ev.push_back({job.frags[i].file, (uint32_t)i, job.frags[i].out_name, nullptr, 0});
                 for (size_t q = 0; q < kept.size(); q++) {
                     const Fragment& f = job.frags[kept[q]];
                     if (status[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), fcz_status_string(status[q])); continue; }
                     n_frag_ok++; n_res += v.res_off[q + 1] - v.res_off[q]; n_bytes += off[q + 1] - off[q];
                     n_atoms += v.atom_off[v.res_off[q + 1]] - v.atom_off[v.res_off[q]];
                     if (placed) continue;
-                    const std::string path = single ? output : output + "/" + f.out_name;
-                    write_out(path, (const char*)blob.data() + off[q], off[q + 1] - off[q], o.overwrite);
+                    ev[kept[q]].p = blob.data() + off[q]; ev[kept[q]].len = off[q + 1] - off[q];
                 }
+                if (!placed) write_fragments_in_order(ev, [&](const FragOut& f) { return single ? output : output + "/" + f.name; }, o.overwrite);
             } catch (const std::exception& e) { fprintf(stderr, "[Error] %s\n", e.what()); hard_fail = true; }
         }
         if (ctx) fcz_ctx_destroy(ctx);
@@ -2182,8 +2210,21 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     if (meta & FCZ_INGEST_MULTI_FRAG) nm += "_" + std::to_string((meta >> 8) & 0xffu);
                     return nm;
                 };
+                // A file whose fragments do not all have names of their own (chain A, chain B, chain A again) written into a DIRECTORY: the
+                // reference's lambda stops at the second use of a name (write_fragments_in_order). The device reports a file's fragments
+                // without their order among the refused ones, so such a file -- rare -- goes through the host reader, whose fragments are
+                // in order; nothing of it is taken from the device's batch.
+                std::vector<char> collide(job.paths.size(), 0);
+                if (!placed) {
+                    std::vector<std::pair<size_t, std::string>> nm_of;
+                    for (uint32_t c = 0; c < counts[0]; c++) nm_of.push_back({text_file[chain_file[c]], frag_name(text_file[chain_file[c]], chain_meta[c], name4[c])});
+                    for (size_t k = 0; k + 1 < refused.size(); k += 2) nm_of.push_back({text_file[refused[k]], frag_name(text_file[refused[k]], refused[k + 1])});
+                    std::sort(nm_of.begin(), nm_of.end());
+                    for (size_t k = 1; k < nm_of.size(); k++) if (nm_of[k] == nm_of[k - 1]) collide[nm_of[k].first] = 1;
+                }
                 for (uint32_t c = 0; c < counts[0]; c++) {
                     const size_t file = text_file[chain_file[c]];
+                    if (collide[file]) continue;
                     const std::string nm = frag_name(file, chain_meta[c], name4[c]);
                     if (status[c] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s.fcz: %s\n", nm.c_str(), fcz_status_string(status[c])); continue; }
                     recs.push_back({file, (chain_meta[c] >> 8) & 0xffu, blob.data() + off[c], off[c + 1] - off[c], nm + suffix_of(file), stem_of(file), 0, 0});
@@ -2195,6 +2236,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                                                 "chain does not fit the FCZ header (65535 residues, 255 anchors)", "discontinuous chain skipped",
                                                 "residue with a second N, CA or C atom", "the chain's last atom carries another residue name than its residue"};
                     const uint32_t reason = refused[k + 1] >> 24;
+                    if (collide[text_file[refused[k]]]) continue;
                     fprintf(stderr, "[Error] compressing %s.fcz: %s\n", frag_name(text_file[refused[k]], refused[k + 1]).c_str(), why[reason < 7 ? reason : 0]);
                 }
                 // what the device handed back: parsed here from the text that is already in memory -- on the host threads, not one file
@@ -2202,7 +2244,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                 std::vector<uint32_t> back;
                 for (uint32_t t = 0; t < n_text; t++) {
                     if (file_status[t] == FCZ_INGEST_NO_ATOMS) { fprintf(stderr, "[Error] No atoms found in the input file: %s\n", base_name(job.paths[text_file[t]]).c_str()); continue; }
-                    if (file_status[t] != FCZ_OK) back.push_back(t);
+                    if (file_status[t] != FCZ_OK || collide[text_file[t]]) back.push_back(t);
                 }
 #pragma omp parallel for schedule(dynamic, 1) if (back.size() > 1)
                 for (long long bi = 0; bi < (long long)back.size(); bi++) {
@@ -2212,19 +2254,21 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     std::string stem, ext; file_parts(base_name(job.paths[file]), stem, ext);
                     // (a member the device did not inflate, FCZ_INGEST_HOST_GZIP, or one whose text it handed back: zlib here, then the reader)
                     if (file_status[t] == FCZ_INGEST_HOST_GZIP) n_host_gz++;
+                    // (the job's buffer holds what was READ: a gzip member the device inflated elsewhere is still a gzip member here)
                     try { fragments_from_memory((const char*)job.text->data() + job.file_off[t], job.file_off[t + 1] - job.file_off[t], base_name(job.paths[file]), stem, ext, !o.db, o, job.host_frags[file], /*inflated=*/!(job.any_gz && job.is_gz[t])); }
                     catch (const std::exception& e) { fprintf(stderr, "[Error] %s: %s\n", base_name(job.paths[file]).c_str(), e.what()); }
                 }
             }
             // host-parsed fragments (mmCIF, gzip, and what the device handed back): one fcz_compress_batch for the job
             std::vector<uint64_t> hoff; std::vector<int32_t> hstatus;
+            std::vector<FragOut> host_refused;                        // fragments of host-parsed files this host refuses: their place in the file's order of names
             if (!failed) {
                 hb.clear();
                 std::vector<std::pair<size_t, size_t>> kept;          // (file, fragment)
                 for (size_t i = 0; i < job.host_frags.size(); i++) for (size_t j = 0; j < job.host_frags[i].size(); j++) {
                     Fragment& f = job.host_frags[i][j];
                     try { hb.add(f.atoms, f.title, o.brk); kept.push_back({i, j}); }
-                    catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), e.what()); }
+                    catch (const std::exception& e) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), e.what()); host_refused.push_back({i, (uint32_t)j, f.out_name, nullptr, 0}); }
                 }
                 if (!kept.empty()) {
                     fcz_chain_batch v = hb.view(o.brk);
@@ -2241,7 +2285,7 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     if (call_failed) { fprintf(stderr, "[Error] %s: %zu chains not compressed\n", fcz_status_string(rc), kept.size()); failed = true; }
                     for (size_t q = 0; q < kept.size() && !failed; q++) {
                         const Fragment& f = job.host_frags[kept[q].first][kept[q].second];
-                        if (hstatus[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), fcz_status_string(hstatus[q])); continue; }
+                        if (hstatus[q] != FCZ_OK) { fprintf(stderr, "[Error] compressing %s: %s\n", f.out_name.c_str(), fcz_status_string(hstatus[q])); host_refused.push_back({kept[q].first, (uint32_t)kept[q].second, f.out_name, nullptr, 0}); continue; }
                         recs.push_back({kept[q].first, (uint32_t)kept[q].second, blob_host.data() + hoff[q], hoff[q + 1] - hoff[q], f.out_name, f.db_name, 0, 0});
                     }
                 }
@@ -2265,7 +2309,9 @@ int run_compress_device(const Options& o, InputPlan& plan, const std::string& ou
                     const uint64_t at = seq.claim(job.index, bytes);
                     if (bytes) pwrite_all(db_fd, packed.data(), bytes, at);
                 } else {
-                    for (const Rec& r : recs) write_out(output + "/" + r.out_name, (const char*)r.p, r.len, o.overwrite);
+                    std::vector<FragOut> ev = host_refused;
+                    for (const Rec& r : recs) ev.push_back({r.file, r.sub, r.out_name, r.p, r.len});
+                    write_fragments_in_order(ev, [&](const FragOut& f) { return output + "/" + f.name; }, o.overwrite);
                 }
                 for (const Rec& r : recs) {
                     n_frag_ok++; n_bytes += r.len;

@@ -237,3 +237,87 @@ def test_rmsd_line(inputs, tmp_path):
         assert r.returncode == 0, (h, r.stderr)
         out[h] = [l for l in r.stdout.splitlines() if "\t" in l]
     assert out["cpp"] == out["ref"] and out["py"] == out["ref"] and len(out["ref"]) == 1
+
+
+def test_compress_of_mutated_files_beside_the_reference(tmp_path):
+    """Seeded mutations of the reference's own test files (characters replaced, lines cut / doubled / swapped, chain ids and residue
+    numbers changed from some line on, mmCIF values nulled / quoted / re-cased, rows moved, columns rewritten), one run of
+    `foldcomp compress <dir> <out>` over all of them beside the reference's command line file by file (a file of its own directory
+    each: the reference spins or aborts on some of these). Every file this host writes must be a file the reference writes, with
+    the same name and bytes; what only the reference writes must be a fragment this host REFUSED by name on stderr (the shifted
+    records of malformed chains) -- never a silent difference."""
+    import gzip as _gz
+    from _cases import mutated_cif, mutated_pdb
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_ingest.npz"))
+    rng = np.random.default_rng(20261001)
+    af = z["file:test_af.pdb"].tobytes().decode("latin-1").splitlines()
+    big = z["file:test.pdb"].tobytes().decode("latin-1").splitlines()
+    big = [l for l in big if not l.startswith("ATOM") or int(l[22:26]) < 520]             # (the first 70-odd residues: small files, many of them)
+    cif = _gz.decompress(z["file:test.cif.gz"].tobytes()).decode("latin-1")
+    rows = [i for i, l in enumerate(cif.split("\n")) if l.startswith("ATOM")]
+    cif_small = "\n".join(l for i, l in enumerate(cif.split("\n")) if not l.startswith("ATOM") or i < rows[0] + 400)
+    mut = tmp_path / "mut"
+    mut.mkdir()
+    names = []
+    for i in range(200):
+        nm = f"m{i:03d}.pdb"
+        (mut / nm).write_bytes(mutated_pdb(af if i % 2 else big, rng, max_edits=3)); names.append(nm)
+    for i in range(80):
+        nm = f"c{i:03d}.cif"
+        (mut / nm).write_bytes(mutated_cif(cif_small, rng, max_edits=2)); names.append(nm)
+    r = _run([BIN, "compress", str(mut), str(tmp_path / "mine")], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    mine = _tree(str(tmp_path / "mine"))
+    said = r.stderr
+    ref_out, ref_failed = {}, []
+    (tmp_path / "ro").mkdir()
+    for nm in names:
+        d = tmp_path / "one" / nm
+        d.mkdir(parents=True)
+        shutil.copy(mut / nm, d / nm)
+        try:
+            rr = subprocess.run([REF, "compress", str(d), str(tmp_path / "ro" / nm)], capture_output=True, text=True, timeout=10)
+            ok = rr.returncode == 0
+        except subprocess.TimeoutExpired:
+            ok = False
+        if not ok:
+            ref_failed.append(nm); continue
+        if os.path.isdir(tmp_path / "ro" / nm):
+            for k, v in _tree(str(tmp_path / "ro" / nm)).items():
+                ref_out[k] = (nm, v)
+    stem_failed = {n.rsplit(".", 1)[0] for n in ref_failed}
+    same = 0; only_mine = []; differ = []
+    for k, v in mine.items():
+        if k in ref_out:
+            if ref_out[k][1] == v:
+                same += 1
+            else:
+                differ.append(k)
+        elif not any(k.startswith(s) for s in stem_failed):
+            only_mine.append(k)
+    unexplained = []
+    for k, (nm, _) in ref_out.items():
+        if k not in mine:
+            frag = k[:-4] if k.endswith(".fcz") else k
+            if frag not in said and nm not in said:
+                unexplained.append(k)
+    stats = {"files": len(names), "reference_spun_or_aborted": len(ref_failed), "written_by_both_and_equal": same, "reference_only_refused_here_by_name": len(ref_out) - same - len(differ) - 0}
+    print(stats)
+    if os.environ.get("FCZ_FUZZ_REPORT"):
+        import json
+        with open(os.environ["FCZ_FUZZ_REPORT"], "w") as fh:
+            json.dump({"stats": stats, "differ": differ, "only_mine": only_mine, "unexplained": unexplained, "ref_failed": ref_failed,
+                       "stderr": said[-20000:]}, fh, indent=1)
+    assert not differ, differ[:10]
+    assert not only_mine, only_mine[:10]
+    assert not unexplained, unexplained[:10]
+    assert same >= len(names) // 3, stats
+    # the Python host leaves the same directory as the C++ host (and with -y both replace an earlier fragment by a later one of its name)
+    r = _run(HOSTS["py"] + ["compress", str(mut), str(tmp_path / "mine_py")], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _tree(str(tmp_path / "mine_py")) == mine
+    for h in ("cpp", "py"):
+        r = _run(HOSTS[h] + ["compress", "-y", str(mut), str(tmp_path / f"y_{h}")], cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+    ty = _tree(str(tmp_path / "y_cpp"))
+    assert ty == _tree(str(tmp_path / "y_py")) and set(mine) <= set(ty) | {k for k in mine}

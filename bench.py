@@ -243,13 +243,29 @@ def cpu_baseline(hb, anchor, gpu=None):
 KERNEL_SOURCES = ("fcz_kernels.h", "fcz_math.h", "fcz_compress.h", "fcz_sidechain.h", "aa_tables.inc")   # the codec kernels' device code (fcz_abi.hip holds their launches among much host code: not hashed)
 
 
+def _code_only(text: bytes) -> bytes:
+    """a kernel source without what the compiler does not see of it: full-line and trailing // comments (not on lines that hold a
+    string literal), trailing blanks, empty lines"""
+    out = []
+    for line in text.split(b"\n"):
+        if b'"' not in line:
+            k = line.find(b"//")
+            if k >= 0:
+                line = line[:k]
+        line = line.rstrip()
+        if line:
+            out.append(line)
+    return b"\n".join(out)
+
+
 def csrc_sha16():
-    """what the codec kernels are compiled from, hashed: a counter profile describes the kernels of ONE state of these files"""
+    """what the codec kernels are compiled from, hashed: a counter profile describes the kernels of ONE state of these files (their
+    code: a reworded comment does not make a profile stale, a changed token does)"""
     import hashlib
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "foldcomp_amd", "csrc", f), "rb") as fh:
-            h.update(f.encode()); h.update(fh.read())
+            h.update(f.encode()); h.update(_code_only(fh.read()))
     return h.hexdigest()[:16]
 
 

@@ -1177,7 +1177,6 @@ template <int G> __device__ __forceinline__ uint32_t grp_sum_u32(uint32_t v) {
     return v;
 }
 // std::min_element / max_element over the group's values with their positions (first occurrence wins): only when an extremum is a zero
-// std::min_element / max_element over the group's values with their positions (first occurrence wins): only when an extremum is a zero
 template <int G> __device__ __forceinline__ lo_hi grp_first_extrema(ext mn, ext mx) {
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) {
@@ -1417,17 +1416,15 @@ __global__ __launch_bounds__(BLOCK, 3) void k_compress_pack(fcz_chain_batch in, 
     compress_pack_chain<6>(in, c, r0, n, out_off, out, status, ang, keep_first_angle, nonfinite);
 }
 
-// Short chains (2 .. 64 residues: peptides, fragments, the low end of a metagenomic set). One wavefront per chain costs a short
-// chain what it costs a long one -- a handful of dependent memory round trips (offsets -> codes -> anchor atoms -> record) with the
-// wavefront idle in between -- so what matters is how many chains are in flight: this kernel keeps a third of the registers
-// (one round of values instead of six) and therefore more than twice the wavefronts per SIMD. A persistent grid: wavefront w takes
-// the chunks of CP_CHUNK consecutive chains w, w + W, ...; one coalesced load gives the chunk's lengths, a ballot the short ones.
-// A batch without short chains costs one load per 16 chains.
+// Short chains (2 .. CP_SHORT residues: peptides, fragments, the low end of a metagenomic set). One wavefront per chain costs a
+// short chain what it costs a long one -- ~1 250 VALU wave-instructions of validation, anchors, reductions, layout and header before
+// its first residue -- so k_compress_pack_rows<U> puts FOUR chains into a wavefront (below); k_compress_pack leaves them alone.
 constexpr int CP_CHUNK = 16;
-// Chains of 2 .. 64 residues, FOUR to a wavefront: one chain per 16-lane DPP row, in 1, 2 or 4 rounds of 16 residues by length class
-// (2..16, 17..32, 33..64). A persistent grid: wavefront w takes the chunks of CP_CHUNK consecutive chains w, w + W, ...; one
-// coalesced load gives the chunk's lengths, a ballot per class the chains, which are handed to the rows four at a time. A batch
-// without short chains costs one load per 16 chains.
+// Chains of 2 .. CP_SHORT (= 16 x FCZ_PACK_ROWS_MAX_ROUNDS = 128) residues, FOUR to a wavefront: one chain per 16-lane DPP row, in
+// U = 1, 2, 4 or 8 rounds of 16 residues by length class (2..16, 17..32, 33..64, 65..128; one launch per class). A persistent grid:
+// wavefront w takes the chunks of CP_CHUNK consecutive chains w, w + W, ...; one coalesced load gives the chunk's lengths, a ballot
+// the chains of the launch's class, which are handed to the rows four at a time. A batch without short chains costs one load per
+// 16 chains per launch.
 template <int U>
 __device__ __forceinline__ void pack_rows_class(unsigned long long todo, const uint32_t c0, const uint32_t ro, const uint32_t nn, const fcz_chain_batch& in,
                                                 const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out, int32_t* __restrict__ status,

@@ -26,9 +26,9 @@
 // The device never guesses. It takes the shape every predicted-structure file has -- one data_ block, items one per line (or
 // a tag line followed by its value line / text field), loop rows of whole lines, `_atom_site` rows of exactly one line each
 // without quotes except around the atom name ("O5'"), chain names of up to four characters, integer residue numbers with an optional
-// one-character insertion code, one model, residues in rising (number, insertion code) order inside a chain run (round 6: the PDB
-// archive's shape beside AFDB's) -- and hands EVERYTHING else back to the host reader (save_ frames, global_ / stop_, several
-// blocks, comments after values, other quoted values, longer chain names, several models, '?' coordinates, exponents, lines of
+// one-character insertion code, models one after the other under rising plain numbers, residues in rising (number, insertion code)
+// order inside a chain run (round 6: the PDB archive's shape beside AFDB's) -- and hands EVERYTHING else back to the host reader (save_ frames, global_ / stop_, several
+// blocks, comments after values, other quoted values, longer chain names, a model that comes back or is not a plain number, '?' coordinates, exponents, lines of
 // more than 255 characters, bytes outside printable ASCII, ...), which restates gemmi rule for rule and is held to the live
 // reference by fuzzing. tests/test_gpu_ingest.py holds this kernel to that reader on mutated files: it never builds a
 // different batch and never takes a file the reader fails.
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
     const uint64_t A0 = abase[f];
     uint32_t kept = 0;
     bool have_last = false; uint32_t last_name = 0, last_comp = 0, last_ch = 0, last_ic = 0; int32_t last_num = 0;
-    unsigned long long model0 = 0; bool have_model = false;
+    unsigned long long last_mdl = 0; uint32_t last_mdl_n = 0;
     bool dead = false;
 
     struct fld { uint32_t w[4]; uint32_t n; };
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
           for (int q = 0; q < 8; q++) widest = max(widest, fn[numeric[q]]); }
         const bool narrow = !__any(widest > 8u);
         bool rbad = false;
-        uint32_t an = 0, rn = 0, ch = ' ', ic = 0; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0;
+        uint32_t an = 0, rn = 0, ch = ' ', ic = 0; int32_t serial = 0, num = 0; float x = 0.f, y = 0.f, z = 0.f, bf = 0.f; unsigned long long mdl = 0; uint32_t mdl_n = 0;
         auto fields = [&](auto NI, auto ND, auto NWD) {
             const fld f0 = load(0, NWD), f1 = load(1, NWD), f2 = load(2, NWD), f3 = load(3, NWD), f4 = load(4, NWD), f5 = load(5, NWD);
             const fld f6 = load(6, I1{}), f7 = load(7, I1{}), f8 = load(8, I1{}), f9 = load(9, I1{}), f10 = load(10, I1{});
@@ -698,11 +698,12 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
             rbad = rbad | ((f12.n != 0u) & !is_null(f12) & !integer(f12, &dummy, NI));
             rbad = rbad | (f13.n > 8u);
             const unsigned long long v8 = (unsigned long long)f13.w[0] | ((unsigned long long)f13.w[1] << 32);
-            mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull));
+            mdl = f13.n >= 8u ? v8 : (v8 & ((1ull << (8u * f13.n)) - 1ull)); mdl_n = f13.n;
         };
         if (narrow) fields(I8{}, I8{}, I2{}); else fields(I10{}, I16{}, I4{});
         rbad = rbad & row;
-        // one model; residues of a chain run in rising order (the reader regroups anything else); keep rule of removeAlternativePosition
+        // models one after the other (below); residues of a chain run in rising order (the reader regroups anything else); keep rule
+        // of removeAlternativePosition
         const uint32_t pl = ig_prev_lane(rowmask, lane);
         const int src = pl < 64u ? (int)pl : 0;
         const int32_t s_num = __shfl(num, src, WAVE);
@@ -711,14 +712,33 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
         const bool has_p = pl < 64u ? true : have_last;
         const int32_t p_num = pl < 64u ? s_num : last_num;
         const uint32_t p_rn = pl < 64u ? s_rn : last_comp, p_ch = pl < 64u ? s_ch : last_ch, p_an = pl < 64u ? s_an : last_name, p_ic = pl < 64u ? s_ic : last_ic;
-        const unsigned long long m_first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mdl >> 32), 0) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mdl, 0);
-        const unsigned long long m0 = have_model ? model0 : m_first;
-        if (row && mdl != m0) rbad = true;
+        // Several models (NMR ensembles of the archive): the reader gives every model name an ordinal at its first row and sorts the
+        // atoms by (model, chain, residue) -- file order as long as no row returns to an EARLIER model. Here: the model's name may
+        // change where the new one is a plain number larger than the one before it (1, 2, 3 ...: no name can come twice then); a
+        // chain starts anew there, whatever its name (make_structure_from_block: `chain = nullptr` at a new model,
+        // lib/gemmi/mmcif.hpp:560-680), so the order rule below does not look across the step. Anything else: the host's.
+        const unsigned long long s_mdl = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(mdl >> 32), src, WAVE) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)mdl, src, WAVE);
+        const uint32_t s_mn = (uint32_t)__shfl((int)mdl_n, src, WAVE);
+        const unsigned long long p_mdl = pl < 64u ? s_mdl : last_mdl;
+        const uint32_t p_mn = pl < 64u ? s_mn : last_mdl_n;
+        const bool new_model = row && has_p && (p_mdl != mdl || p_mn != mdl_n);
+        if (__any(new_model)) {
+            auto plain_number = [](unsigned long long v, uint32_t n) -> bool {          // digits only, no leading zero: name <-> number one to one
+                if (n == 0u || n > 8u) return false;
+                bool ok = n == 1u || (v & 0xffull) != '0';
+                for (uint32_t i = 0; i < n; i++) { const uint32_t c = (uint32_t)(v >> (8u * i)) & 0xffu; ok = ok && c >= '0' && c <= '9'; }
+                return ok;
+            };
+            auto rises = [](unsigned long long a, uint32_t na, unsigned long long b, uint32_t nb) -> bool {   // number(a) < number(b)
+                if (na != nb) return na < nb;
+                return __builtin_bswap64(a) < __builtin_bswap64(b);            // the first character is the low byte: most significant after the swap
+            };
+            if (new_model && !(plain_number(p_mdl, p_mn) && plain_number(mdl, mdl_n) && rises(p_mdl, p_mn, mdl, mdl_n))) rbad = true;
+        }
         // (file order is the reader's order as long as, inside a run of one chain name, every new residue has a larger (number,
         //  insertion code) than the one before it: find_or_add_residue then never finds an earlier residue to append to)
-        if (row && !rbad && has_p && p_ch == ch && !(p_num == num && p_ic == ic && p_rn == rn) && !(num > p_num || (num == p_num && ic > p_ic))) rbad = true;
+        if (row && !rbad && has_p && !new_model && p_ch == ch && !(p_num == num && p_ic == ic && p_rn == rn) && !(num > p_num || (num == p_num && ic > p_ic))) rbad = true;
         if (__any(row && rbad)) { dead = true; break; }
-        if (!have_model) { model0 = m0; have_model = true; }
         const bool keep = row && !(has_p && p_an == an);
         const unsigned long long m_keep = __ballot(keep);
         if (keep) {
@@ -732,6 +752,8 @@ __global__ __launch_bounds__(WAVE) void k_ingest_rows_cif(const uint8_t* __restr
         const int hl = 63 - __builtin_clzll(rowmask);
         last_name = (uint32_t)__builtin_amdgcn_readlane((int)an, hl); last_comp = (uint32_t)__builtin_amdgcn_readlane((int)rn, hl); last_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, hl);
         last_num = __builtin_amdgcn_readlane(num, hl); last_ic = (uint32_t)__builtin_amdgcn_readlane((int)ic, hl); have_last = true;
+        last_mdl = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mdl >> 32), hl) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mdl, hl);
+        last_mdl_n = (uint32_t)__builtin_amdgcn_readlane((int)mdl_n, hl);
     }
     if (lane == 0 && !dead && kept != 0u) {
         n_kept[f] = kept;

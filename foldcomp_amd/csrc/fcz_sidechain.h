@@ -7,8 +7,9 @@
 //
 //   k_res_index      one wavefront per chain: resolves everything that hangs off the chain's header into flat
 //                    per-residue arrays (first output atom, residue code, torsion bytes) and emits the outputs
-//                    that need no geometry (B-factors, residue codes, OXT). Entries beyond 64 residues.
-//   k_res_index_rows the same for entries of up to 64 residues, four to a wavefront (one entry per 16-lane group, 1 / 2 / 4
+//                    that need no geometry (B-factors, residue codes, OXT). Entries beyond RI_ROWS (= 16 x
+//                    FCZ_INDEX_ROWS_MAX_ROUNDS = 64) residues.
+//   k_res_index_rows the same for entries of up to RI_ROWS residues, four to a wavefront (one entry per 16-lane group, 1 / 2 / 4
 //                    rounds of 16 residues by length class).
 //   k_sidechain      persistent blocks over 256-residue tiles.
 //                    phase 0 (thread = residue): load the residue's index entry and backbone atoms (prefetched one

@@ -261,10 +261,10 @@ int fcz_decompress_pdb_sizes(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
  * title = _entry.id) when it has the shape every predicted-structure file has: one block, one item per line (or a tag line and its
  * value / text field on the following lines), loops of whole-line rows, _atom_site rows of one line each without quoted values
  * other than the atom name ("O5'"), chain names of up to four characters, integer residue numbers with an optional one-character
- * insertion code, one model, residues rising by (number, insertion code) inside a chain run, coordinates as plain decimals of at
+ * insertion code, models one after the other under rising plain numbers (1, 2, 3 ...), residues rising by (number, insertion code) inside a chain run, coordinates as plain decimals of at
  * most 15 digits (round 6: the PDB archive's shape beside AFDB's). Every other mmCIF file comes back as FCZ_INGEST_HOST_FIELD exactly
  * as a PDB file outside the fixed layout does (save_ frames, several blocks, comments after values, other quoted values, longer chain
- * names, several models, '?' coordinates, duplicate tags, a _cell angle that is not plainly non-zero, lines beyond 255 characters ...). */
+ * names, a model that comes back or is not a plain number, '?' coordinates, duplicate tags, a _cell angle that is not plainly non-zero, lines beyond 255 characters ...). */
 enum fcz_ingest_status { FCZ_INGEST_HOST_FIELD = 1, FCZ_INGEST_HOST_TITLE = 2, FCZ_INGEST_HOST_FRAGS = 3, FCZ_INGEST_NO_ATOMS = 4 };
 enum fcz_ingest_reason { FCZ_INGEST_REF_RESNAME = 1, FCZ_INGEST_REF_BACKBONE = 2, FCZ_INGEST_REF_TOO_LONG = 3, FCZ_INGEST_REF_SKIP_DISC = 4,
                          FCZ_INGEST_REF_BACKBONE_TWICE = 5, FCZ_INGEST_REF_LAST_NAME = 6 };

@@ -276,7 +276,10 @@ def mutated_cif(text: str, rng, max_edits=4) -> bytes:
                          ("pdbx_PDB_model_num", "1"), ("auth_seq_id", "7"), ("label_seq_id", "x"),
                          # (round 6, the PDB archive's shapes: chain names of several characters, lower-case insertion codes, atom names in quotes)
                          ("auth_asym_id", "BB"), ("auth_asym_id", "AB1x"), ("auth_asym_id", "ABCDE"), ("pdbx_PDB_ins_code", "b"),
-                         ("auth_atom_id", "\"O5'\""), ("label_atom_id", "\"O5'\"")][int(rng.integers(0, 19))]
+                         ("auth_atom_id", "\"O5'\""), ("label_atom_id", "\"O5'\""),
+                         # (ensembles: models numbered upwards are read where they lie; a model that comes back, or is not a plain number, is sorted by the reader)
+                         ("pdbx_PDB_model_num", "3"), ("pdbx_PDB_model_num", "10"), ("pdbx_PDB_model_num", "02"), ("pdbx_PDB_model_num", "A"),
+                         ("pdbx_PDB_model_num", "0")][int(rng.integers(0, 24))]
             stop = rows.index(i) + int(rng.integers(1, 40))
             for j in rows[rows.index(i):stop]:
                 set_tok(j, name, val)

@@ -9,6 +9,7 @@ PDB text in, fcz_chain_batch out, every step on the GPU. Parity:
   * what the device does not decide (fields outside the fixed-column layout) is handed back (file_status), never guessed;
   * text -> FCZ in one call (fcz_compress_pdb_*) == host parse + fcz_compress_batch, byte for byte."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -367,3 +368,47 @@ def test_device_mmcif_fuzz_never_parses_differently(codec, golden, ing):
     # quoted atom names are among the taken ones
     taken = [texts[i] for i in ok]
     assert any(b" BB " in t_ or b" AB1x " in t_ for t_ in taken) and any(b"\"O5'\"" in t_ for t_ in taken)
+
+
+def test_device_mmcif_reads_model_ensembles(codec, ing):
+    """files of several models (NMR ensembles of the PDB archive; bench.py's `models` style and longer ones): models that follow each
+    other under rising plain numbers are read on the device -- the same batch, names and refusals as the host reader's, which keeps
+    every model (make_structure_from_block, lib/gemmi/mmcif.hpp:560-680) --; a model that comes back, a name with a leading zero or
+    a letter goes to the host reader"""
+    sys.path.insert(0, ROOT)
+    from bench import cif_archive_from_pdb_text
+    pdbs = [ing["file:test_af.pdb"].tobytes(), ing["file:multichain.pdb"].tobytes()]
+    two = cif_archive_from_pdb_text(pdbs[0], "E2", "models")
+    def renumber(text, how):
+        """the rows of the two-model file under other model names: how(k, model) -> name of row k"""
+        out, k = [], 0
+        for l in text.decode("latin-1").split("\n"):
+            if l.startswith(("ATOM ", "HETATM ")):
+                p = l.split(" ")
+                p[-1] = how(k, p[-1]); k += 1
+                l = " ".join(p)
+            out.append(l)
+        return "\n".join(out).encode("latin-1")
+    n_rows = sum(1 for l in two.decode("latin-1").split("\n") if l.startswith("ATOM "))
+    texts = [two,
+             renumber(two, lambda k, m: {"1": "9", "2": "10"}[m]),                       # 9 -> 10: one character more
+             renumber(two, lambda k, m: str(1 + k * 5 // n_rows)),                       # five models of a fifth of the rows each
+             renumber(two, lambda k, m: {"1": "2", "2": "1"}[m]),                        # 2 -> 1: taken by the reader's order
+             renumber(two, lambda k, m: ("1", "2", "1")[k * 3 // n_rows]),               # model 1 comes back
+             renumber(two, lambda k, m: {"1": "01", "2": "02"}[m]),
+             renumber(two, lambda k, m: {"1": "A", "2": "B"}[m]),
+             cif_archive_from_pdb_text(pdbs[1], "E3", "models")]
+    names = [f"ens{i}.cif" for i in range(len(texts))]
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    assert [int(v) for v in fstat[:3]] == [0, 0, 0] and int(fstat[7]) == 0, list(fstat)           # read on the device
+    assert all(int(v) != 0 for v in fstat[3:7]), list(fstat)                                     # handed back
+    ok = [i for i in range(len(texts)) if fstat[i] == 0]
+    remap = {f: k for k, f in enumerate(ok)}
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok], reader=_read_any)
+    assert not failed
+    cnames = codec.chain_names(b.n_chains)
+    assert [_name_of(names[f], int(m), cn) for f, m, cn in zip(cfile, cmeta, cnames)] == exp_names
+    assert [remap[int(f)] for f in cfile] == exp_file
+    _same_batch(b, exp)
+    assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
+    # (what the host reader makes of the handed-back ones is its own affair: test_ingest_vs_reference.py holds it to the live reference)

@@ -66,11 +66,7 @@ if out["kernels"]:
     try:
         import bench
         out["csrc_sha16"] = bench.csrc_sha16(); out["kernel_sources"] = list(bench.KERNEL_SOURCES)
-    except Exception as e:   # (torch missing where the summary is made: hash by hand)
-        import hashlib
-        h = hashlib.sha256()
-        for f in ("fcz_kernels.h", "fcz_math.h", "fcz_compress.h", "fcz_sidechain.h", "aa_tables.inc"):
-            h.update(f.encode()); h.update(open(os.path.join("foldcomp_amd", "csrc", f), "rb").read())
-        out["csrc_sha16"] = h.hexdigest()[:16]
+    except Exception as e:   # (bench.py does not import where the summary is made: no hash, and bench.py will not quote the figures)
+        print("warning: bench.csrc_sha16 unavailable (%s): traffic.json carries no source hash" % e, file=sys.stderr)
     out["kernel_set"] = sorted(out["kernels"])
     json.dump(out, open(os.path.join("gpurun_out", "prof_" + tag, "traffic.json"), "w"), indent=1)

@@ -260,7 +260,10 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     int32_t last_seq = 0; uint32_t last_rn = 0, last_seg = 0, last_icch = 0;   // its residue (number, name, segment, insertion code | chain << 8)
     uint32_t tlen = 0, hdr_id = 0, hdr_n = 0;             // title state (uniform): TITLE text so far, the last HEADER id code
     bool ended = false;                                   // an END record was read
-    bool seen_model = false, seen_endm = false;           // MODEL / ENDMDL records read
+    // MODEL / ENDMDL records (uniform): where the reader stands -- 0 nothing read, 1 atoms without a MODEL record, 2 a model is open,
+    // 3 the last model was closed --, whether the open model has atoms, the last MODEL number (-2: none yet, -1: not a plain number),
+    // and whether a MODEL / ENDMDL record came after the last ATOM / HETATM record (the next one starts a new chain whatever its name)
+    int mstate = 0; bool open_has_atoms = false; int32_t last_mnum = -2; bool boundary_since_rec = false;
     int32_t status = FCZ_OK;
     uint64_t line_start = 0;               // file-relative start of the line that is open at the chunk's beginning (uniform)
 
@@ -270,11 +273,11 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     // The rules are gemmi's (lib/gemmi/pdb.hpp:262-365, restated in foldcomp_amd/structure.py parse_pdb_gemmi): records are
     // matched on four letters case-insensitively, END stops the reading, `len` below is the reader's line length (line end
     // included, at most 120). What the fixed-column fast path cannot promise to read as that reader would -- a field outside the
-    // fixed layout, a two-character chain name, ANISOU / MODEL records, a residue whose lines are apart (the reader regroups them)
+    // fixed layout, a two-character chain name, ANISOU records, models that are not numbered upwards, a residue whose lines are apart
+    // (the reader regroups them)
     // -- marks the file for the host, which implements every rule.
     auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo, bool has_nl) {
         if (ended) return;
-        const bool seen_endm_before = seen_endm;
         bool cryst_bad = false;
         const uint32_t raw = on ? (uint32_t)(le - ls) : 0u;
         const uint32_t glen = raw + (has_nl ? 1u : 0u) < 120u ? raw + (has_nl ? 1u : 0u) : 120u;       // gemmi's len
@@ -300,16 +303,29 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         const bool rec = on && (up4 == (0x4d4f5441u & ~0x20202020u) || up4 == (0x41544548u & ~0x20202020u));     // ATOM, HETA(TM)
         // a step of nothing but ATOM / HETATM lines (all but two or three steps of a file) skips what the other records need
         const bool any_other = __any(on && !rec);
-        bool is_end = false, foreign = false, is_model = false, is_endm = false;
+        bool is_end = false, foreign = false, is_model = false, is_endm = false; int32_t mnum = -1;
         if (any_other) {
             is_end = on && !rec && (up4 & 0x00ffffffu) == 0x00444e45u && ((up4 >> 24) & 0xf0u) == 0u;          // END, not ENDMDL
             // records this path does not model: ANISOU (attached to atoms, can fail the file), data_
             foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_') ||
                                                 (up4 == (0x6164227bu & ~0x20202020u) && ((L.w[1] & 0x00ffffffu) & ~0x00202020u) == (0x005f6174u & ~0x00202020u)));   // ANISOU, data_, {"data_
             // MODEL / ENDMDL: one MODEL record before the first atom and ENDMDL records after the last one (the single-model file every
-            // predicted structure is) change nothing; atoms after an ENDMDL or a second MODEL start new models, with rules of their own
+            // predicted structure is) change nothing. Ensembles (NMR entries of the archive): MODEL n / atoms / ENDMDL, again and again.
+            // The reader (lib/gemmi/pdb.hpp:262-365) keeps the models in file order, names them by the number in columns 11-14, fails
+            // a MODEL record that finds atoms in an open model or a name that already has atoms, names atoms that follow an ENDMDL
+            // without a MODEL record by the count of models, and starts a new chain at every MODEL / ENDMDL whatever the chain's name.
+            // Here: every MODEL after the first carries a plain number larger than the one before it (no name comes twice), stands
+            // where no model is open, and atoms stand inside a model or before any -- then file order is the reader's order and the
+            // only thing a model boundary changes is that the residue-order rule below does not look across it. Anything else: the host's.
             is_model = on && !rec && up4 == (0x45444f4du & ~0x20202020u);
             is_endm = on && !rec && up4 == (0x4d444e45u & ~0x20202020u);
+            if (is_model && staged && len >= 14u) {
+                const uint32_t c[4] = {ig_b<10>(L), ig_b<11>(L), ig_b<12>(L), ig_b<13>(L)};
+                int i = 0; while (i < 4 && c[i] == ' ') i++;
+                bool ok = i < 4; int32_t v = 0;
+                for (; i < 4; i++) { ok = ok && (c[i] - '0' < 10u); v = v * 10 + (int32_t)(c[i] - '0'); }
+                mnum = ok ? v : -1;
+            }
             // CRYST1: the reader fails a file whose cell has a gamma and an alpha or beta of exactly zero (UnitCell::set). Decided here
             // only for fields that start (after blanks) with a digit 1-9 -- certainly not zero; anything else goes to the host
             if (on && !rec && up4 == (0x53595243u & ~0x20202020u) && glen > 54u) {
@@ -410,13 +426,25 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         // code) than the one before it; anything else goes to the host, which regroups.
         const unsigned long long m_rec = __ballot(arec);
         const uint32_t pl = ig_prev_lane(m_rec, lane);
-        if (m_model | m_endm) {
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (live && is_model && (have_last || seen_model || ((m_rec | m_model) & below))) bad = true;
-            if (arec && (m_endm & below)) bad = true;
-            seen_model = seen_model || m_model != 0; seen_endm = seen_endm || m_endm != 0;
-        }
-        if (arec && seen_endm_before) bad = true;
+        const unsigned long long m_ev = m_model | m_endm;
+        bool brk = pl < 64u ? false : boundary_since_rec;     // a MODEL / ENDMDL record between this record and the one before it
+        if (m_ev) {
+            const unsigned long long below = (1ull << lane) - 1ull, evb = m_ev & below;
+            // where the reader stands when it comes to this lane's line
+            int st = mstate;
+            if (evb) st = ((m_model >> (63 - __builtin_clzll(evb))) & 1ull) ? 2 : 3;
+            else if (st == 0 && (m_rec & below)) st = 1;
+            const unsigned long long mb = m_model & below;
+            const int32_t s_mnum = __shfl(mnum, mb ? 63 - __builtin_clzll(mb) : 0, WAVE);      // (outside every condition)
+            const int32_t prev_mnum = mb ? s_mnum : last_mnum;
+            if (arec && st == 3) bad = true;                                          // atoms behind an ENDMDL: a model named by the count
+            if (live && is_model) {
+                if (!(st == 0 || st == 3)) bad = true;                                // atoms without a model before it, or a model still open
+                if (prev_mnum != -2 && !(prev_mnum >= 0 && mnum > prev_mnum)) bad = true;   // (the first MODEL record may say anything ...
+                if (prev_mnum == -2 && (have_last || (m_rec & below))) bad = true;          //  ... but stands before every atom: atoms without
+            }                                                                                //  one are the model "1" already)
+            brk = pl < 64u ? (evb & ~((2ull << pl) - 1ull)) != 0 : (boundary_since_rec || evb != 0);
+        } else if (arec && mstate == 3) bad = true;
         {
             const int src = pl < 64u ? (int)pl : 0;
             // (the shuffles stand outside every condition: a lane that sits one out would hand its neighbour nothing)
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
             const uint32_t p_seg = pl < 64u ? s_seg : last_seg;
             const uint32_t p_ic = pl < 64u ? s_ic : last_icch;
             const bool has_p = pl < 64u ? true : have_last;
-            if (arec && !bad && has_p && (p_ic >> 8) == ch) {
+            if (arec && !bad && has_p && !brk && (p_ic >> 8) == ch) {
                 const bool same_res = p_seq == resseq && p_rn == rn && p_seg == seg && (p_ic & 0xffu) == icode;
                 if (!same_res && !(resseq > p_seq || (resseq == p_seq && icode > (p_ic & 0xffu)))) bad = true;
             }
@@ -450,6 +478,13 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
             T.rcode[o] = (int8_t)res_code_of(rn);
         }
         kept += (uint32_t)__builtin_popcountll(m_keep);
+        if (m_ev) {
+            const int t = 63 - __builtin_clzll(m_ev);
+            mstate = ((m_model >> t) & 1ull) ? 2 : 3;
+            open_has_atoms = ((m_rec >> t) >> 1) != 0;
+            if (m_model) last_mnum = __shfl(mnum, 63 - __builtin_clzll(m_model), WAVE);
+            boundary_since_rec = ((m_ev >> (m_rec ? 63 - __builtin_clzll(m_rec) : 0)) >> (m_rec ? 1 : 0)) != 0;
+        } else if (m_rec) { if (mstate == 0) mstate = 1; open_has_atoms = true; boundary_since_rec = false; }
         if (m_rec) {
             const int hl = 63 - __builtin_clzll(m_rec);
             last_name = (uint32_t)__shfl((int)an, hl, WAVE); have_last = true;

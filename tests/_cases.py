@@ -58,7 +58,8 @@ _FOREIGN = ["ANISOU    2  CA  MET A   1     2406   1892   1614    198    519   -
             "ORIGX1      1.000000  0.000000  0.000000        0.00000", "REMARK 350   BIOMT1   1  1.000000  0.000000  0.000000        0.00000", "REMARK 350 APPLY THE FOLLOWING TO CHAINS: A, B",
             "REMARK   2 RESOLUTION.    1.74 ANGSTROMS.", "REMARK   3   R VALUE            (WORKING SET) : 0.18", "CONECT  413  412  414", "COMPND    MOL_ID: 1;", "EXPDTA    X-RAY DIFFRACTION",
             "NUMMDL    2", "MASTER      351    0    0    4    8    0    0    6 1215    1    0   11", "HETNAM     HOH WATER", "MODRES 1ABC MSE A    1  MET  SELENOMETHIONINE", "TER     216      PRO A  26",
-            "SIGATM    1  N   MET A   1       0.010   0.010   0.010  0.00  0.00           N", "JRNL        AUTH   A.B.C", "KEYWDS    X"]
+            "SIGATM    1  N   MET A   1       0.010   0.010   0.010  0.00  0.00           N", "JRNL        AUTH   A.B.C", "KEYWDS    X",
+            "MODEL        3", "MODEL       10", "ENDMDL", "MODEL 4"]
 
 
 def mutated_pdb(base_lines, rng, max_edits=5):

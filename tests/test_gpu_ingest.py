@@ -390,9 +390,20 @@ def test_device_mmcif_reads_model_ensembles(codec, ing):
             out.append(l)
         return "\n".join(out).encode("latin-1")
     n_rows = sum(1 for l in two.decode("latin-1").split("\n") if l.startswith("ATOM "))
+    def ensemble(n_models):
+        """the first model's rows n_models times, under the model numbers 1 .. n_models"""
+        head, rows, tail = [], [], []
+        for l in two.decode("latin-1").split("\n"):
+            if l.startswith(("ATOM ", "HETATM ")):
+                if l.endswith(" 1"):
+                    rows.append(l)
+            else:
+                (tail if rows else head).append(l)
+        body = [" ".join(r.split(" ")[:-1] + [str(m)]) for m in range(1, n_models + 1) for r in rows]
+        return "\n".join(head + body + tail).encode("latin-1")
     texts = [two,
              renumber(two, lambda k, m: {"1": "9", "2": "10"}[m]),                       # 9 -> 10: one character more
-             renumber(two, lambda k, m: str(1 + k * 5 // n_rows)),                       # five models of a fifth of the rows each
+             ensemble(5),                                                                 # five models
              renumber(two, lambda k, m: {"1": "2", "2": "1"}[m]),                        # 2 -> 1: taken by the reader's order
              renumber(two, lambda k, m: ("1", "2", "1")[k * 3 // n_rows]),               # model 1 comes back
              renumber(two, lambda k, m: {"1": "01", "2": "02"}[m]),
@@ -400,7 +411,8 @@ def test_device_mmcif_reads_model_ensembles(codec, ing):
              cif_archive_from_pdb_text(pdbs[1], "E3", "models")]
     names = [f"ens{i}.cif" for i in range(len(texts))]
     b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
-    assert [int(v) for v in fstat[:3]] == [0, 0, 0] and int(fstat[7]) == 0, list(fstat)           # read on the device
+    assert [int(v) for v in fstat[:3]] == [0, 0, 0], list(fstat)                                 # read on the device
+    # (the last file -- two chains rendered under one chain name, numbers starting over -- is whatever the order rule makes of it: compared below if taken)
     assert all(int(v) != 0 for v in fstat[3:7]), list(fstat)                                     # handed back
     ok = [i for i in range(len(texts)) if fstat[i] == 0]
     remap = {f: k for k, f in enumerate(ok)}
@@ -412,3 +424,45 @@ def test_device_mmcif_reads_model_ensembles(codec, ing):
     _same_batch(b, exp)
     assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
     # (what the host reader makes of the handed-back ones is its own affair: test_ingest_vs_reference.py holds it to the live reference)
+
+
+def test_device_pdb_reads_model_ensembles(codec, ing):
+    """PDB files of several models (MODEL n / atoms / ENDMDL, the NMR entries of the archive): groups under rising plain numbers are
+    read on the device in file order with a new chain at every group -- the same batch, names and refusals as the host reader's
+    (gemmi's read_pdb keeps the models in file order, lib/gemmi/pdb.hpp:262-365) --; models out of order or named twice, atoms
+    outside a model, a MODEL record inside an open model go to the host reader, which fails some of them as the reference does"""
+    def atoms_of(key):
+        return [l for l in ing[key].tobytes().decode("latin-1").split("\n") if l.startswith(("ATOM", "HETATM", "TER"))]
+    one, multi = atoms_of("file:test_af.pdb"), atoms_of("file:multichain.pdb")
+    def pdb(*parts):
+        out = ["HEADER    ENSEMBLE                                01-JAN-00   1ENS"]
+        for p_ in parts:
+            out += p_ if isinstance(p_, list) else [p_]
+        return ("\n".join(out + ["END"]) + "\n").encode("latin-1")
+    M = lambda n: "MODEL     %4d" % n
+    E_ = "ENDMDL"
+    texts = [pdb(M(1), one, E_, M(2), one, E_),                                       # 0  two models
+             pdb(M(9), one, E_, M(10), one, E_),                                      # 1
+             pdb(*[x for m in range(1, 6) for x in (M(m), one, E_)]),                 # 2  five
+             pdb(M(1), multi, E_, M(2), multi, E_, M(7), multi, E_),                  # 3  chains A and B in every model
+             pdb(M(1), one[:40], E_, M(2), one, E_),                                  # 4  the first model ends inside a residue
+             pdb(M(2), one, E_, M(1), one, E_),                                       # 5  falling numbers
+             pdb(M(1), one, E_, M(1), one, E_),                                       # 6  a number twice: the reader fails the file
+             pdb(one, E_, M(1), one, E_),                                             # 7  atoms before the first MODEL
+             pdb(M(1), one, M(2), one, E_),                                           # 8  MODEL inside an open model
+             pdb(M(1), one, E_, one),                                                 # 9  atoms behind an ENDMDL
+             pdb("MODEL 1", one, E_, "MODEL 2", one, E_),                             # 10 numbers outside their columns
+             pdb(M(1), one, E_, "MODEL       2A", one, E_)]                           # 11 not a plain number
+    names = [f"ens{i}.pdb" for i in range(len(texts))]
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    assert [int(v) for v in fstat[:5]] == [0] * 5, list(fstat)                       # read on the device
+    assert all(int(v) != 0 for v in fstat[5:]), list(fstat)                          # handed back
+    ok = [i for i in range(len(texts)) if fstat[i] == 0]
+    remap = {f: k for k, f in enumerate(ok)}
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect([texts[i] for i in ok], [names[i] for i in ok])
+    assert not failed
+    cnames = codec.chain_names(b.n_chains)
+    assert [_name_of(names[f], int(m), cn) for f, m, cn in zip(cfile, cmeta, cnames)] == exp_names
+    assert [remap[int(f)] for f in cfile] == exp_file
+    _same_batch(b, exp)
+    assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--residues", type=int, default=350)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--repeats", type=int, default=3, help="runs per command; the fastest is reported")
+    ap.add_argument("--decompress-entries", type=int, default=0, help="also: decompress the first N entries into a directory and into a database, both hosts")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -62,6 +63,49 @@ def main():
             lb = sorted(open(os.path.join(tmp, f"{tag}_reference.out"), "rb").read().split(b">" if tag != "extract_plddt_p3" else b"\n"))
             row["same_records"] = la == lb
         out[tag] = row
+    if a.decompress_entries:
+        # decompress into a directory (the reference's default output: one .pdb per entry) and into a database, the first N entries
+        ids = os.path.join(tmp, "ids.txt")
+        with open(ids, "w") as fh:
+            fh.write("".join(f"AF-{k:08d}-F1-model_v4\n" for k in range(min(a.decompress_entries, a.chains))))
+        n = min(a.decompress_entries, a.chains)
+        for tag, extra in (("decompress_dir", []), ("decompress_db", ["-d"])):
+            row = {}
+            for who, exe in (("host", host), ("reference", ref)):
+                if not os.path.exists(exe):
+                    continue
+                o = os.path.join(tmp, f"{tag}_{who}")
+                cmd = [exe, "decompress", "-y", "-t", str(a.threads), "--id-list", ids, *extra, db, o]
+                if who == "host":
+                    cmd.insert(2, "--json-stats")
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                if os.path.isdir(o):
+                    nb = sum(os.path.getsize(os.path.join(o, f)) for f in os.listdir(o)); nf = len(os.listdir(o))
+                else:
+                    nb = os.path.getsize(o) if os.path.exists(o) else None; nf = 1
+                row[who] = {"wall_s": round(dt, 3), "entries_per_s": round(n / dt), "residues_per_s": round(n * a.residues / dt), "rc": r.returncode, "out_bytes": nb, "out_files": nf,
+                            "text_GB_per_s": round((nb or 0) / dt / 1e9, 2)}
+                if who == "host":
+                    try:
+                        row[who]["stats"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                    except Exception:
+                        row[who]["stats"] = r.stdout[-300:] + r.stderr[-300:]
+            if tag == "decompress_dir" and "host" in row and "reference" in row:
+                da, dbb = os.path.join(tmp, f"{tag}_host"), os.path.join(tmp, f"{tag}_reference")
+                names = sorted(os.listdir(da))
+                row["same_files"] = names == sorted(os.listdir(dbb)) and all(open(os.path.join(da, f), "rb").read() == open(os.path.join(dbb, f), "rb").read() for f in names[::max(1, len(names) // 500)])
+            out[tag] = row
+            import shutil
+            for who in ("host", "reference"):
+                o = os.path.join(tmp, f"{tag}_{who}")
+                if os.path.isdir(o):
+                    shutil.rmtree(o, ignore_errors=True)
+                else:
+                    for ext in ("", ".index", ".lookup", ".dbtype"):
+                        if os.path.exists(o + ext):
+                            os.remove(o + ext)
     print(json.dumps(out))
 
 

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     // 3 the last model was closed --, whether the open model has atoms, the last MODEL number (-2: none yet, -1: not a plain number),
     // and whether a MODEL / ENDMDL record came after the last ATOM / HETATM record (the next one starts a new chain whatever its name)
     int mstate = 0; bool open_has_atoms = false; int32_t last_mnum = -2; bool boundary_since_rec = false;
+    bool last_line_rec = false;                           // the last line read was an ATOM / HETATM record (an ANISOU may follow it)
     int32_t status = FCZ_OK;
     uint64_t line_start = 0;               // file-relative start of the line that is open at the chunk's beginning (uniform)
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
     // The rules are gemmi's (lib/gemmi/pdb.hpp:262-365, restated in foldcomp_amd/structure.py parse_pdb_gemmi): records are
     // matched on four letters case-insensitively, END stops the reading, `len` below is the reader's line length (line end
     // included, at most 120). What the fixed-column fast path cannot promise to read as that reader would -- a field outside the
-    // fixed layout, a two-character chain name, ANISOU records, models that are not numbered upwards, a residue whose lines are apart
+    // fixed layout, a two-character chain name, an ANISOU record that does not follow its atom, models that are not numbered upwards, a residue whose lines are apart
     // (the reader regroups them)
     // -- marks the file for the host, which implements every rule.
     auto do_lines = [&](bool on, uint64_t ls, uint64_t le, int lo, bool has_nl) {
@@ -303,12 +304,16 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         const bool rec = on && (up4 == (0x4d4f5441u & ~0x20202020u) || up4 == (0x41544548u & ~0x20202020u));     // ATOM, HETA(TM)
         // a step of nothing but ATOM / HETATM lines (all but two or three steps of a file) skips what the other records need
         const bool any_other = __any(on && !rec);
-        bool is_end = false, foreign = false, is_model = false, is_endm = false; int32_t mnum = -1;
+        bool is_end = false, foreign = false, is_model = false, is_endm = false, is_anis = false; int32_t mnum = -1;
         if (any_other) {
             is_end = on && !rec && (up4 & 0x00ffffffu) == 0x00444e45u && ((up4 >> 24) & 0xf0u) == 0u;          // END, not ENDMDL
-            // records this path does not model: ANISOU (attached to atoms, can fail the file), data_
-            foreign = on && !rec && (up4 == (0x53494e41u & ~0x20202020u) || (up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_') ||
-                                                (up4 == (0x6164227bu & ~0x20202020u) && ((L.w[1] & 0x00ffffffu) & ~0x00202020u) == (0x005f6174u & ~0x00202020u)));   // ANISOU, data_, {"data_
+            // records this path does not model: data_ / {"data_ (another format)
+            foreign = on && !rec && ((up4 == (0x61746164u & ~0x20202020u) && (L.w[1] & 0xffu) == '_') ||
+                                                (up4 == (0x6164227bu & ~0x20202020u) && ((L.w[1] & 0x00ffffffu) & ~0x00202020u) == (0x005f6174u & ~0x00202020u)));   // data_, {"data_
+            // ANISOU: the reader attaches it to the last atom read of the current residue and fails the file when there is none or when
+            // that atom already has one with a non-zero U11 (lib/gemmi/pdb.hpp:262-365). A record that stands directly behind an ATOM /
+            // HETATM line -- where every file of the archive has it -- finds that fresh atom: nothing to decide. Any other place: the host's.
+            is_anis = on && !rec && up4 == (0x53494e41u & ~0x20202020u);
             // MODEL / ENDMDL: one MODEL record before the first atom and ENDMDL records after the last one (the single-model file every
             // predicted structure is) change nothing. Ensembles (NMR entries of the archive): MODEL n / atoms / ENDMDL, again and again.
             // The reader (lib/gemmi/pdb.hpp:262-365) keeps the models in file order, names them by the number in columns 11-14, fails
@@ -346,6 +351,14 @@ __global__ __launch_bounds__(WAVE) void k_ingest_parse(const uint8_t* __restrict
         const int end_lane = m_end ? __builtin_ctzll(m_end) : 64;
         const bool live = on && lane < end_lane;                 // what follows an END record is not read
         if (__any(live && (foreign || cryst_bad))) status = FCZ_INGEST_HOST_FIELD;
+        {
+            const unsigned long long m_live = __ballot(live), m_recs = __ballot(rec && live);
+            if (any_other) {
+                const bool prev_rec = lane ? ((m_recs >> (lane - 1)) & 1ull) != 0 : last_line_rec;
+                if (__any(live && is_anis && !prev_rec)) status = FCZ_INGEST_HOST_FIELD;
+            }
+            if (m_live) last_line_rec = ((m_recs >> (63 - __builtin_clzll(m_live))) & 1ull) != 0;
+        }
         const unsigned long long m_model = __ballot(live && is_model), m_endm = __ballot(live && is_endm);
         // ---- title: the last HEADER record's id code (columns 63-66, right-trimmed), else the TITLE records' text concatenated ----
         if (any_other) {

@@ -249,7 +249,7 @@ int fcz_decompress_pdb_sizes(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* 
  * file order with a new chain at every group, as the reader keeps them.
  * file_status[i]: FCZ_OK, FCZ_INGEST_NO_ATOMS, or FCZ_INGEST_HOST_*: something this path does not decide the way that reader
  * would on its own (a number field the exact fixed-point rule does not cover, a blank or hybrid-36 number, a two-character chain
- * name, an ATOM record shorter than its coordinates, ANISOU records, models not numbered upwards or atoms outside them, a NUL byte, a residue whose (number,
+ * name, an ATOM record shorter than its coordinates, an ANISOU record that does not stand directly behind its atom, models not numbered upwards or atoms outside them, a NUL byte, a residue whose (number,
  * insertion code) does not grow inside its run of one chain name -- the reader regroups such lines --, a title beyond 512 bytes,
  * more than 32 fragments) -- nothing of that file is in the batch and the caller's own reader has to take it (the hosts of this
  * repository restate every rule: foldcomp_amd/structure.py parse_pdb_gemmi, host/foldcomp_hip.cpp parse_pdb_gemmi). refused[2k], refused[2k+1] = file, chain_meta | reason << 24 of the

@@ -466,3 +466,38 @@ def test_device_pdb_reads_model_ensembles(codec, ing):
     assert [remap[int(f)] for f in cfile] == exp_file
     _same_batch(b, exp)
     assert sorted((remap[int(f)], _name_of(names[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
+
+
+def test_device_pdb_reads_anisou_records_behind_their_atoms(codec, ing):
+    """ANISOU records where every file of the archive has them -- directly behind the ATOM / HETATM line of their atom -- change
+    nothing the codec sees (the reader attaches the record to the atom it has just read, lib/gemmi/pdb.hpp:262-365): read on the
+    device, same batch as the host reader's. A record anywhere else (before the first atom, behind a TER or another ANISOU, which
+    the reader may fail the file for) goes to the host reader"""
+    lines = [l for l in ing["file:test_af.pdb"].tobytes().decode("latin-1").split("\n") if l.startswith(("ATOM", "HETATM", "TER"))]
+    def anis(l, u11=2406):
+        return "ANISOU" + l[6:28] + "%7d%7d%7d%7d%7d%7d" % (u11, 1892, 1614, 198, 519, -328) + l[70:80].ljust(10)
+    every = [x for l in lines for x in ([l, anis(l)] if l.startswith(("ATOM", "HETATM")) else [l])]
+    some = [x for i, l in enumerate(lines) for x in ([l, anis(l, 0)] if l.startswith("ATOM") and i % 7 == 3 else [l])]
+    first_atom = next(i for i, l in enumerate(lines) if l.startswith("ATOM"))
+    ter = next((i for i, l in enumerate(lines) if l.startswith("TER")), len(lines) - 1)
+    def pdb(ls, tail=()):
+        return ("\n".join(["HEADER    ANISOTROPIC                             01-JAN-00   1ANI"] + list(ls) + ["END"] + list(tail)) + "\n").encode("latin-1")
+    texts = [pdb(every),                                                              # 0  the archive's shape (lines and steps end anywhere)
+             pdb(some),                                                               # 1
+             pdb(every, tail=[anis(lines[first_atom])]),                              # 2  behind END: not read
+             pdb([anis(lines[first_atom])] + lines),                                  # 3  before any atom: the reader fails the file
+             pdb(lines[:first_atom + 1] + [anis(lines[first_atom])] * 2 + lines[first_atom + 1:]),      # 4  twice: fails
+             pdb(lines[:ter + 1] + [anis(lines[first_atom])] + lines[ter + 1:]),      # 5  behind a TER
+             pdb(lines[:5] + ["REMARK   1"] + [anis(lines[4])] + lines[5:])]          # 6  a record between the atom and its ANISOU
+    names = [f"ani{i}.pdb" for i in range(len(texts))]
+    b, cfile, cmeta, fstat, refused = codec.ingest_pdb(texts, names)
+    assert [int(v) for v in fstat[:3]] == [0] * 3, list(fstat)                       # read on the device
+    assert all(int(v) != 0 for v in fstat[3:]), list(fstat)                          # handed back
+    exp, exp_names, exp_file, exp_ref, failed = _host_expect(texts[:3], names[:3])
+    assert not failed and not exp_ref and not len(refused)
+    _same_batch(b, exp)
+    assert [_name_of(names[f], int(m)) for f, m in zip(cfile, cmeta)] == exp_names and list(cfile) == exp_file
+    # the host reader on two of the others: it fails the records that find no fresh atom
+    for i in (3, 4):
+        with pytest.raises(StructureError):
+            parse_pdb_gemmi(texts[i])

@@ -154,6 +154,14 @@ def degenerate_cases():
     def one_point(b, x, y, z):
         x[:] = 1.0; y[:] = 2.0; z[:] = 3.0
 
+    def neg_zero(b, x, y, z):
+        # "-0.000" is a coordinate PDB files hold (strtod keeps the sign): anchors, ordinary atoms, whole residues in a plane
+        x[::5] = -0.0; y[::7] = -0.0; z[::11] = -0.0
+        for ch in range(b.n_chains):
+            n = int(b.res_off[ch + 1] - b.res_off[ch])
+            for r in range(0, n, 25):
+                a = _first_atom(b, ch, r); x[a] = -0.0; y[a + 1] = -0.0; z[a + 2] = -0.0
+
     def n1_on_c0(b, x, y, z):
         for ch in range(b.n_chains):
             a, a1 = _first_atom(b, ch, 0), _first_atom(b, ch, 1); x[a1], y[a1], z[a1] = x[a + 2], y[a + 2], z[a + 2]
@@ -172,7 +180,7 @@ def degenerate_cases():
 
     return [("N of residue 1 on C of residue 0", n1_on_c0)] + [(f"random coincidences {k}", coincidences(k)) for k in range(6)] + [("CA on N, residue 5", ca_on_n(5)), ("CA on N, first residue", ca_on_n(0)), ("C on CA, first residue", c_on_ca),
             ("three atoms in a line", straight), ("a residue at the origin", residue_at_origin), ("an atom 1e30 away", far_away),
-            ("noise", noise), ("integer lattice", lattice), ("every atom at one point", one_point)]
+            ("noise", noise), ("integer lattice", lattice), ("every atom at one point", one_point), ("coordinates of -0.0", neg_zero)]
 
 
 def degenerate_batch(mutate, lens=(40, 350, 90), seed=3):
@@ -181,6 +189,20 @@ def degenerate_batch(mutate, lens=(40, 350, 90), seed=3):
     x, y, z = b.x.copy(), b.y.copy(), b.z.copy()
     mutate(b, x, y, z)
     b.x, b.y, b.z = x, y, z
+    return b
+
+
+def distorted_batch(n_chains, sigma, seed, lo=16, hi=700):
+    """chains of the generator with every atom moved by N(0, sigma) in x, y and z and written at PDB precision (three decimals):
+    bond lengths and angles as far from ideal as refined experimental models (sigma 0.02-0.05), poor ones (0.3) and wrecks (1.5)
+    have them -- the generator alone has ideal bond lengths. Lengths log-uniform in [lo, hi]"""
+    from foldcomp_amd import synthetic
+    rng = np.random.default_rng(seed)
+    lens = np.exp(rng.uniform(np.log(lo), np.log(hi), n_chains)).astype(np.int64)
+    b = synthetic.to_chain_batch(synthetic.generate(n_chains, lens, seed=seed))
+    for k in ("x", "y", "z"):
+        v = getattr(b, k).astype(np.float64) + rng.normal(0.0, sigma, len(getattr(b, k)))
+        setattr(b, k, (np.round(v * 1000.0) / 1000.0).astype(np.float32))
     return b
 
 

@@ -43,3 +43,24 @@ def test_restatement_equals_live_reference_on_bench_chains(mixed):
     assert r["failed_chains"] == 0
     assert lr["records_equal"] == n, lr
     assert lr["coords_equal"] == n, lr
+
+
+@pytest.mark.parametrize("sigma", [0.02, 0.3, 1.5])
+def test_restatement_equals_live_reference_on_distorted_chains(sigma):
+    """the same pin on chains whose bond lengths and angles are not ideal (every atom moved by N(0, sigma), three decimals):
+    what tests/test_gpu_edge_cases.py::test_distorted_geometry holds the GPU path to"""
+    import bench
+    from _cases import distorted_batch
+    n = 256
+    hb = distorted_batch(n, sigma, seed=int(sigma * 1000) + 11)
+    threads = bench.effective_cores()
+    blob, off, st = H.oracle_compress(hb, n_threads=threads)
+    assert (st == 0).all()
+    o = H.oracle_decompress(blob, off, n_threads=threads)
+    side = {"blob": np.ascontiguousarray(blob), "off": np.ascontiguousarray(off.astype(np.uint64)), "x": o["x"], "y": o["y"], "z": o["z"],
+            "atom_off": np.ascontiguousarray(o["atom_off"].astype(np.uint32)), "bfac_res": o["bfac_res"],
+            "res_off": np.ascontiguousarray(o["res_off"].astype(np.uint32))}
+    r = bench.cpu_baseline(hb, 25, gpu=side)
+    lr = r["live_reference"]
+    assert r["failed_chains"] == 0
+    assert lr["records_equal"] == n and lr["coords_equal"] == n, lr

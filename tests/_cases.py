@@ -206,6 +206,66 @@ def distorted_batch(n_chains, sigma, seed, lo=16, hi=700):
     return b
 
 
+# ---- input variants for the differential fuzz -------------------------------------------------------------------------------------
+def _variant_base(rng, n, lo=16, hi=600):
+    from foldcomp_amd import synthetic
+    lens = np.exp(rng.uniform(np.log(lo), np.log(hi), n)).astype(np.int64)
+    return synthetic.to_chain_batch(synthetic.generate(n, lens, seed=int(rng.integers(1, 1 << 30))))
+
+
+def _variant_xyz(b, f):
+    for k in ("x", "y", "z"):
+        setattr(b, k, np.ascontiguousarray(f(getattr(b, k).astype(np.float64), k), dtype=np.float32))
+    return b
+
+
+def input_variants(rng, n):
+    """(name, batch) pairs: chains of the generator put through what real inputs have and the generator does not -- distortions at PDB
+    precision and as raw floats, translations to the edge of the PDB columns and beyond, scalings, reflections, coarse precision,
+    signed zeros and denormals, odd B-factors, every short length, one residue type per batch, numbering and chain ids. Used by
+    tests/test_gpu_parity_fuzz.py (GPU == restatement) and tools/dbg/parity_fuzz.py (the same at any size and seed)"""
+    from foldcomp_amd import synthetic
+    base = lambda rng_: _variant_base(rng_, n)
+    xyz = _variant_xyz
+    r3 = lambda v: np.round(v * 1000.0) / 1000.0
+    yield "plain", base(rng)
+    for s in (0.01, 0.05, 0.2, 0.6, 3.0, 10.0):
+        yield f"noise {s} (3 decimals)", xyz(base(rng), lambda v, k: r3(v + rng.normal(0, s, len(v))))
+    for s in (0.001, 0.05, 0.5):
+        yield f"noise {s} (raw float)", xyz(base(rng), lambda v, k: v + rng.normal(0, s, len(v)))
+    for t in (100.0, 999.0, 5000.0, 9000.0, -9999.0, 1e5, 1e7):
+        yield f"moved by {t}", xyz(base(rng), lambda v, k: r3(v + t))
+    yield "moved by (1000, -2000, 3000) + noise", xyz(base(rng), lambda v, k: r3(v + {"x": 1000.0, "y": -2000.0, "z": 3000.0}[k] + rng.normal(0, 0.1, len(v))))
+    for sc in (0.5, 0.9, 1.1, 2.0, 1e-3, 1e3):
+        yield f"scaled by {sc}", xyz(base(rng), lambda v, k: r3(v * sc) if sc >= 0.5 else v * sc)
+    yield "mirrored", xyz(base(rng), lambda v, k: -v if k == "x" else v)
+    yield "two decimals", xyz(base(rng), lambda v, k: np.round(v * 100.0) / 100.0)
+    yield "one decimal", xyz(base(rng), lambda v, k: np.round(v * 10.0) / 10.0)
+    yield "integers", xyz(base(rng), lambda v, k: np.round(v))
+    yield "-0.0 sprinkled + noise", xyz(base(rng), lambda v, k: np.where(rng.random(len(v)) < 0.05, -0.0, r3(v + rng.normal(0, 0.05, len(v)))))
+    yield "zeros sprinkled + noise", xyz(base(rng), lambda v, k: np.where(rng.random(len(v)) < 0.05, 0.0, r3(v + rng.normal(0, 0.05, len(v)))))
+    yield "one coordinate plane (z = -0.0)", xyz(base(rng), lambda v, k: np.full_like(v, -0.0) if k == "z" else v)
+    yield "one coordinate plane (y = 0)", xyz(base(rng), lambda v, k: np.zeros_like(v) if k == "y" else v)
+    yield "-0.0 sprinkled", xyz(base(rng), lambda v, k: np.where(rng.random(len(v)) < 0.02, -0.0, v))
+    yield "tiny values sprinkled", xyz(base(rng), lambda v, k: np.where(rng.random(len(v)) < 0.02, rng.choice([1e-38, -1e-38, 1e-45, 1e-30, -1e-20, 1e-10], len(v)), v))
+    # B-factors
+    for name, f in (("B constant", lambda v: np.full_like(v, 50.0)), ("B zero", lambda v: np.zeros_like(v)), ("B negative", lambda v: -v), ("B huge", lambda v: v * 1e4),
+                    ("B two values", lambda v: np.where(rng.random(len(v)) < 0.5, 10.0, 90.0).astype(np.float32)), ("B with -0.0", lambda v: np.where(rng.random(len(v)) < 0.1, -0.0, v).astype(np.float32)),
+                    ("B raw floats", lambda v: rng.normal(50, 30, len(v)).astype(np.float32))):
+        b = base(rng); b.bfac_ca = np.ascontiguousarray(f(b.bfac_ca.copy()), dtype=np.float32); yield name, b
+    # short chains, one length each
+    for k in (1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 25, 26, 27, 49, 50, 51, 52, 63, 64, 65, 75, 76, 77):
+        yield f"chains of {k}", synthetic.to_chain_batch(synthetic.generate(min(n, 64), [k] * min(n, 64), seed=int(rng.integers(1, 1 << 30))))
+    # all of one residue type
+    for rc in range(20):
+        yield f"all residues of type {rc}", xyz(synthetic.to_chain_batch(synthetic.generate(min(n, 48), [int(v) for v in rng.integers(20, 200, min(n, 48))], seed=int(rng.integers(1, 1 << 30)), res_code=rc)),
+                                                 lambda v, k: r3(v + rng.normal(0, 0.05, len(v))))
+    # first / chain numbering
+    b = base(rng); b.first_res_index = rng.integers(-500, 9000, b.n_chains).astype(b.first_res_index.dtype); b.first_atom_index = rng.integers(0, 90000, b.n_chains).astype(b.first_atom_index.dtype); yield "numbering", b
+    b = base(rng); b.chain_id = rng.integers(32, 127, b.n_chains).astype(np.uint8); yield "chain ids", b
+
+
+
 # ---- FCZ records with random payloads (the header, the residue codes and the anchors stay) ----------------------------------
 def payload_mutations(records, per_record=10, seed=20260927, temp_params=False):
     """random angle words (every one / a tenth / all bits set or clear / one residue / bond-angle bytes only), side-chain torsion

@@ -501,3 +501,43 @@ def test_device_pdb_reads_anisou_records_behind_their_atoms(codec, ing):
     for i in (3, 4):
         with pytest.raises(StructureError):
             parse_pdb_gemmi(texts[i])
+
+
+def test_device_readers_keep_the_sign_of_a_zero(codec, golden, ing):
+    """"-0.000" is a coordinate real files hold; the reference's reader (fast_float / strtod) keeps the sign and the codec carries it
+    through anchors into the decoded atoms. PDB columns and mmCIF fields with -0.000 / -0.0 / -0 / 0.000 and a B-factor of -0.00:
+    the device's batch equals the host reader's bit for bit (_same_batch compares bit patterns)"""
+    from test_host_cpp import _cif_text
+    z, _ = golden
+    pdb_lines = ing["file:test_af.pdb"].tobytes().decode("latin-1").split("\n")
+    out = []
+    k = 0
+    for l in pdb_lines:
+        if l.startswith("ATOM") and len(l) >= 66:
+            k += 1
+            if k % 9 == 1: l = l[:30] + "  -0.000" + l[38:]
+            if k % 9 == 4: l = l[:38] + "  -0.000" + l[46:54] + l[54:]
+            if k % 9 == 7: l = l[:46] + "   0.000" + l[54:]
+            if k % 13 == 2: l = l[:60] + " -0.00" + l[66:]
+        out.append(l)
+    pdb = "\n".join(out).encode("latin-1")
+    cif_lines = _cif_text(z, "pdb:test_af").split("\n")
+    k0 = next(i for i, l in enumerate(cif_lines) if l.startswith("ATOM"))
+    head = [l for l in cif_lines[:k0] if l.startswith("_atom_site.")]
+    cx, cb = head.index("_atom_site.Cartn_x"), head.index("_atom_site.B_iso_or_equiv")
+    for i in range(k0, len(cif_lines)):
+        if not cif_lines[i].startswith("ATOM"):
+            continue
+        t = cif_lines[i].split()
+        j = i - k0
+        if j % 7 == 0: t[cx] = "-0.000"
+        if j % 7 == 2: t[cx + 1] = "-0.0"
+        if j % 7 == 4: t[cx + 2] = "-0"
+        if j % 7 == 5: t[cx] = "0.000"
+        if j % 11 == 3: t[cb] = "-0.00"
+        cif_lines[i] = " ".join(t)
+    cif = "\n".join(cif_lines).encode()
+    b, cfile, cmeta, fstat, refused = _check(codec, [pdb, cif], ["z.pdb", "z.cif"], reader=_read_any)
+    assert list(fstat) == [0, 0]
+    sign = lambda v: int((v.view(np.uint32) == 0x80000000).sum())
+    assert sign(b.x) > 20 and sign(b.y) > 10 and sign(b.z) > 5              # (the zeros with a sign are there)

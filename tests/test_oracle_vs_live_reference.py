@@ -64,3 +64,27 @@ def test_restatement_equals_live_reference_on_distorted_chains(sigma):
     lr = r["live_reference"]
     assert r["failed_chains"] == 0
     assert lr["records_equal"] == n and lr["coords_equal"] == n, lr
+
+
+def test_restatement_equals_live_reference_on_input_variants():
+    """and on every input variant of the differential fuzz (_cases.input_variants: what tests/test_gpu_parity_fuzz.py holds the GPU
+    path to the restatement on) -- the variants the reference compresses (it refuses one-residue chains)"""
+    import bench
+    from _cases import input_variants
+    rng = np.random.default_rng(20261001)
+    threads = bench.effective_cores()
+    checked = 0
+    for name, hb in input_variants(rng, 12):
+        blob, off, st = H.oracle_compress(hb, n_threads=threads)
+        if not (st == 0).all():
+            continue
+        o = H.oracle_decompress(blob, off, n_threads=threads)
+        side = {"blob": np.ascontiguousarray(blob), "off": np.ascontiguousarray(off.astype(np.uint64)), "x": o["x"], "y": o["y"], "z": o["z"],
+                "atom_off": np.ascontiguousarray(o["atom_off"].astype(np.uint32)), "bfac_res": o["bfac_res"],
+                "res_off": np.ascontiguousarray(o["res_off"].astype(np.uint32))}
+        r = bench.cpu_baseline(hb, 25, gpu=side)
+        lr = r["live_reference"]
+        assert r["failed_chains"] == 0, name
+        assert lr["records_equal"] == hb.n_chains and lr["coords_equal"] == hb.n_chains, (name, lr)
+        checked += 1
+    assert checked > 75, checked

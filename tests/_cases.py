@@ -260,6 +260,11 @@ def input_variants(rng, n):
     for rc in range(20):
         yield f"all residues of type {rc}", xyz(synthetic.to_chain_batch(synthetic.generate(min(n, 48), [int(v) for v in rng.integers(20, 200, min(n, 48))], seed=int(rng.integers(1, 1 << 30)), res_code=rc)),
                                                  lambda v, k: r3(v + rng.normal(0, 0.05, len(v))))
+    # chains long enough for the segment-parallel decode (1 024 residues and more), alone and among short ones
+    m = min(n, 24)
+    yield "long chains + noise + -0.0", xyz(_variant_base(rng, m, 1024, 3000), lambda v, k: np.where(rng.random(len(v)) < 0.02, -0.0, r3(v + rng.normal(0, 0.05, len(v)))))
+    lens = [int(v) for v in np.where(rng.random(m) < 0.3, rng.integers(1024, 2600, m), rng.integers(2, 300, m))]
+    yield "long and short chains in one batch", xyz(synthetic.to_chain_batch(synthetic.generate(m, lens, seed=int(rng.integers(1, 1 << 30)))), lambda v, k: r3(v + rng.normal(0, 0.1, len(v))))
     # first / chain numbering
     b = base(rng); b.first_res_index = rng.integers(-500, 9000, b.n_chains).astype(b.first_res_index.dtype); b.first_atom_index = rng.integers(0, 90000, b.n_chains).astype(b.first_atom_index.dtype); yield "numbering", b
     b = base(rng); b.chain_id = rng.integers(32, 127, b.n_chains).astype(np.uint8); yield "chain ids", b

@@ -16,23 +16,38 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def _tool(name):
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", "dbg", name + ".py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
 @pytest.mark.parametrize("seed", [20261001])
 def test_input_variants_bit_exact(codec, seed):
+    """statuses, record bytes, decoded coordinates of both atom orders; anchor thresholds 25 and, for every third variant, 200 and 7
+    (tools/dbg/parity_fuzz.py holds the comparison: chains whose anchor count does not fit the header are refused here, see there)"""
+    m = _tool("parity_fuzz")
     rng = np.random.default_rng(seed)
-    n = 0
+    n = 0; bad = 0
     for name, b in input_variants(rng, 64):
         for thr in ((25,) if n % 3 else (25, 200, 7)):
-            b.anchor_threshold = thr
-            blob, off, st = codec.compress_batch(b, strict=False)
-            oblob, ooff, ost = H.oracle_compress(b, n_threads=8)
-            assert np.array_equal(st, ost), (name, thr)
-            assert np.array_equal(off, ooff) and blob.tobytes() == oblob.tobytes(), (name, thr)
-            if int(off[-1]) == 0:
-                continue
-            for alt in (False, True):
-                d = codec.decompress_batch(blob, off, alt_order=alt)
-                o = H.oracle_decompress(oblob, ooff, alt_order=alt, n_threads=8)
-                for k in ("x", "y", "z", "bfac_res"):
-                    assert np.all((_bits(d[k]) == _bits(o[k])) | (np.isnan(d[k]) & np.isnan(o[k]))), (name, thr, alt, k)
+            bad += m.compare(codec, f"{name} (-b {thr})", b, thr)
         n += 1
-    assert n > 80
+    assert n > 80 and bad == 0
+
+
+def test_pdb_text_and_extract_on_input_variants(codec):
+    """k_pdb_format / k_extract on the same variants (columns that overflow, negative and huge B-factors, numbering beyond the
+    columns): device text == the host restatement of the reference's writer (pinned to the live reference in
+    tests/test_host_formats.py), pLDDT strings of 1-4 digits == the host's (tools/dbg/pdb_text_fuzz.py holds the loop)"""
+    n, bad = _tool("pdb_text_fuzz").run(6, 20261001, codec)
+    assert n > 80 and bad == 0
+
+
+def test_ingest_of_rendered_input_variants(codec):
+    """the variants as TEXT -- PDB (overflowing columns and all), AFDB-shaped and archive-shaped mmCIF -- through the device ingest:
+    every file is read into the batch the host reader builds or handed back (tools/dbg/ingest_variants_fuzz.py)"""
+    n, bad = _tool("ingest_variants_fuzz").run(4, 20261001, codec)
+    assert n > 80 and bad == 0

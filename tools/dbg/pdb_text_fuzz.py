@@ -13,32 +13,41 @@ from foldcomp_amd import fczfile
 from foldcomp_amd.codec import Codec
 from host_text import pdb_from_result, extract_plddt
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bad = 0; n = 0
-with Codec(0) as codec:
-    for name, b in input_variants(rng, N):
-        n += 1
-        blob, off, st = codec.compress_batch(b, strict=False)
-        keep = [i for i in range(b.n_chains) if st[i] == 0]
-        if not keep:
-            continue
-        entries = [blob[off[i]:off[i + 1]].tobytes() for i in keep]
-        eoff = np.zeros(len(entries) + 1, np.uint64); eoff[1:] = np.cumsum([len(e) for e in entries])
-        eblob = np.frombuffer(b"".join(entries), np.uint8).copy()
-        for digits in (1, 2, 3, 4):
-            got = codec.extract(eblob, eoff, mode=0, digits=digits)
-            for i, e in enumerate(entries):
-                if got[i].decode("latin-1") != extract_plddt(fczfile.parse(e), digits):
-                    print(f"[{name}] extract -p {digits} chain {i}: device {got[i][:60]!r} host {extract_plddt(fczfile.parse(e), digits)[:60]!r}"); bad += 1; break
-        for alt in (False, True):
-            texts, status = codec.decompress_pdb(eblob, eoff, alt_order=alt)
-            o = H.oracle_decompress(eblob, eoff, alt_order=alt, n_threads=16)
-            for i, (t, e) in enumerate(zip(texts, entries)):
-                exp = pdb_from_result(fczfile.parse(e), o, i, alt).encode("latin-1")
-                if status[i] != 0 or t != exp:
-                    k = next((k for k in range(min(len(t), len(exp))) if t[k] != exp[k]), None)
-                    print(f"[{name}] alt={alt} chain {i}: status {status[i]}, first difference at byte {k}: device {t[max(0, (k or 0) - 40):(k or 0) + 40]!r} host {exp[max(0, (k or 0) - 40):(k or 0) + 40]!r}")
-                    bad += 1
-                    break
-print(f"{n} variants, {bad} differences")
+def run(N, seed, codec=None):
+    rng = np.random.default_rng(seed)
+    own = codec is None
+    if own: codec = Codec(0)
+    bad = 0; n = 0
+    if True:
+        for name, b in input_variants(rng, N):
+            n += 1
+            blob, off, st = codec.compress_batch(b, strict=False)
+            keep = [i for i in range(b.n_chains) if st[i] == 0]
+            if not keep:
+                continue
+            entries = [blob[off[i]:off[i + 1]].tobytes() for i in keep]
+            eoff = np.zeros(len(entries) + 1, np.uint64); eoff[1:] = np.cumsum([len(e) for e in entries])
+            eblob = np.frombuffer(b"".join(entries), np.uint8).copy()
+            for digits in (1, 2, 3, 4):
+                got = codec.extract(eblob, eoff, mode=0, digits=digits)
+                for i, e in enumerate(entries):
+                    if got[i].decode("latin-1") != extract_plddt(fczfile.parse(e), digits):
+                        print(f"[{name}] extract -p {digits} chain {i}: device {got[i][:60]!r} host {extract_plddt(fczfile.parse(e), digits)[:60]!r}"); bad += 1; break
+            for alt in (False, True):
+                texts, status = codec.decompress_pdb(eblob, eoff, alt_order=alt)
+                o = H.oracle_decompress(eblob, eoff, alt_order=alt, n_threads=16)
+                for i, (t, e) in enumerate(zip(texts, entries)):
+                    exp = pdb_from_result(fczfile.parse(e), o, i, alt).encode("latin-1")
+                    if status[i] != 0 or t != exp:
+                        k = next((k for k in range(min(len(t), len(exp))) if t[k] != exp[k]), None)
+                        print(f"[{name}] alt={alt} chain {i}: status {status[i]}, first difference at byte {k}: device {t[max(0, (k or 0) - 40):(k or 0) + 40]!r} host {exp[max(0, (k or 0) - 40):(k or 0) + 40]!r}")
+                        bad += 1
+                        break
+    if own: codec.close()
+    print(f"{n} variants, {bad} differences")
+    return n, bad
+
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 1)

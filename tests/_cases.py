@@ -219,6 +219,33 @@ def _variant_xyz(b, f):
     return b
 
 
+def _variant_atoms(b, rng, mode):
+    """a batch with its side chains edited residue by residue (N, CA, C stay where they are): mode "drop" removes each side-chain
+    atom with probability 0.15 (and whole side chains with 0.03), "shuffle" permutes the atoms behind the backbone, "extra" inserts
+    up to three unnamed atoms (code 255: hydrogens, ligand atoms) anywhere behind the backbone"""
+    x, y, z, code, aoff = [], [], [], [], [0]
+    for r in range(b.n_residues):
+        s, e = int(b.atom_off[r]), int(b.atom_off[r + 1])
+        idx = np.arange(s, e)
+        head, tail = idx[:3], idx[3:]
+        if mode == "drop":
+            tail = tail[rng.random(len(tail)) >= 0.15] if rng.random() >= 0.03 else tail[:0]
+        elif mode == "shuffle":
+            tail = rng.permutation(tail)
+        idx = np.concatenate((head, tail))
+        xs, ys, zs, cs = b.x[idx], b.y[idx], b.z[idx], b.atom_code[idx]
+        if mode == "extra":
+            for _ in range(int(rng.integers(0, 4))):
+                at = int(rng.integers(3, len(xs) + 1))
+                p3 = np.round((np.asarray([xs[1], ys[1], zs[1]], np.float64) + rng.normal(0, 2, 3)) * 1000.0) / 1000.0
+                xs = np.insert(xs, at, np.float32(p3[0])); ys = np.insert(ys, at, np.float32(p3[1])); zs = np.insert(zs, at, np.float32(p3[2])); cs = np.insert(cs, at, np.uint8(255))
+        x.append(xs); y.append(ys); z.append(zs); code.append(cs); aoff.append(aoff[-1] + len(xs))
+    return ChainBatch(res_off=b.res_off, atom_off=np.asarray(aoff, np.uint32), x=np.concatenate(x).astype(np.float32), y=np.concatenate(y).astype(np.float32),
+                      z=np.concatenate(z).astype(np.float32), atom_code=np.concatenate(code).astype(np.uint8), res_code=b.res_code, bfac_ca=b.bfac_ca,
+                      first_res_index=b.first_res_index, first_atom_index=b.first_atom_index, chain_id=b.chain_id,
+                      titles=b.titles, title_off=b.title_off, anchor_threshold=b.anchor_threshold)
+
+
 def input_variants(rng, n):
     """(name, batch) pairs: chains of the generator put through what real inputs have and the generator does not -- distortions at PDB
     precision and as raw floats, translations to the edge of the PDB columns and beyond, scalings, reflections, coarse precision,
@@ -265,6 +292,9 @@ def input_variants(rng, n):
     yield "long chains + noise + -0.0", xyz(_variant_base(rng, m, 1024, 3000), lambda v, k: np.where(rng.random(len(v)) < 0.02, -0.0, r3(v + rng.normal(0, 0.05, len(v)))))
     lens = [int(v) for v in np.where(rng.random(m) < 0.3, rng.integers(1024, 2600, m), rng.integers(2, 300, m))]
     yield "long and short chains in one batch", xyz(synthetic.to_chain_batch(synthetic.generate(m, lens, seed=int(rng.integers(1, 1 << 30)))), lambda v, k: r3(v + rng.normal(0, 0.1, len(v))))
+    # side chains as deposited models have them: atoms missing, in another order, hydrogens and other unnamed atoms among them
+    for mode in ("drop", "shuffle", "extra"):
+        yield f"side chains: {mode}", _variant_atoms(xyz(_variant_base(rng, min(n, 48), 16, 300), lambda v, k: r3(v + rng.normal(0, 0.05, len(v)))), rng, mode)
     # first / chain numbering
     b = base(rng); b.first_res_index = rng.integers(-500, 9000, b.n_chains).astype(b.first_res_index.dtype); b.first_atom_index = rng.integers(0, 90000, b.n_chains).astype(b.first_atom_index.dtype); yield "numbering", b
     b = base(rng); b.chain_id = rng.integers(32, 127, b.n_chains).astype(np.uint8); yield "chain ids", b

@@ -1018,8 +1018,10 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
     // what the fminf / fmaxf reductions give
     auto finish_q = [&](int q, float first, float lo, float hi, const float* src, uint32_t cntq, int mode) {
         if (__builtin_expect(lo == 0.0f || hi == 0.0f, 0)) { const lo_hi e = first_extrema(src, cntq, lane, mode); lo = e.lo; hi = e.hi; }
-        if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+        // a NaN at the head is minimum and maximum at once, and x86-64 hands its bits through the subtraction and the division
+        // (NaN - NaN = the first operand, quiet already): the record's header holds those bits twice (acos_deg_exact makes them)
+        if (__builtin_expect(first != first, 0)) { qmin[q] = first; qdisc[q] = first; qcont[q] = first; }
     };
     if (small) {
         // everything of the chain is in registers already: no reload for the quantisation pass
@@ -1124,10 +1126,9 @@ __device__ __forceinline__ void compress_pack_chain(const fcz_chain_batch& in, c
         h[17] = (uint8_t)fcz_res1[h_rc_last];
         h[18] = 0; h[19] = 0;
         st_u32(h + 20, title_len);
-        // a NaN among the angle parameters (a zero-length bond at the first window: 0 / 0 in getCosineTheta) is one the arithmetic
-        // made, and the reference's x86-64 arithmetic makes the negative quiet NaN (the "real indefinite", 0xFFC00000) and carries
-        // it unchanged through acos, the degree conversion and the quantiser's subtraction and division; gfx950 makes 0x7FC00000
-        auto x86_nan = [](float v) { return v != v ? __uint_as_float(0xFFC00000u) : v; };
+        // a NaN among the angle parameters is the NaN of the chain's first angle with the bits x86-64 / glibc give it (acos_deg_exact:
+        // negative from a NaN cosine, positive from a cosine beyond +-1), carried unchanged through the quantiser (finish_q)
+        auto x86_nan = [](float v) { return v; };
 #pragma unroll
         for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, x86_nan(qmin[q])); st_f32(h + 48 + 4 * q, x86_nan(qcont[q])); }
         // OXT (src/foldcomp.cpp:474-482): the last atom of the span
@@ -1323,8 +1324,10 @@ __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, co
             const lo_hi e = grp_first_extrema<G>(mn, mx);
             if (lo == 0.0f || hi == 0.0f) { lo = e.lo; hi = e.hi; }
         }
-        if (__builtin_expect(first != first, 0)) { lo = first; hi = first; }
         qmin[q] = lo; qdisc[q] = nbins[q] / (hi - lo); qcont[q] = (hi - lo) / nbins[q];
+        // a NaN at the head is minimum and maximum at once, and x86-64 hands its bits through the subtraction and the division
+        // (NaN - NaN = the first operand, quiet already): the record's header holds those bits twice (acos_deg_exact makes them)
+        if (__builtin_expect(first != first, 0)) { qmin[q] = first; qdisc[q] = first; qcont[q] = first; }
     }
     // ---- the packed words (src/foldcomp.cpp:582-601, convertBackboneChainToBytes :33-52) + B-factor bytes ----
 #pragma unroll
@@ -1373,7 +1376,7 @@ __device__ __forceinline__ void compress_pack_rows(const fcz_chain_batch& in, co
         h[17] = (uint8_t)fcz_res1[h_rc_last];
         h[18] = 0; h[19] = 0;
         st_u32(h + 20, title_len);
-        auto x86_nan = [](float v) { return v != v ? __uint_as_float(0xFFC00000u) : v; };
+        auto x86_nan = [](float v) { return v; };          // (the bits acos_deg_exact gave the chain's first angle: see k_compress_pack)
 #pragma unroll
         for (int q = 0; q < 6; q++) { st_f32(h + 24 + 4 * q, x86_nan(qmin[q])); st_f32(h + 48 + 4 * q, x86_nan(qcont[q])); }
         const uint32_t la = a_end - 1;

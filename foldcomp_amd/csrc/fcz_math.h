@@ -180,7 +180,14 @@ __device__ __noinline__ double acos_correctly_rounded(float c, double a0) {
 
 // (float)(acos((double)c) * 180.0 / M_PI), the only way the reference observes acos.
 // Returns NaN for |c| > 1 or NaN input (callers apply the reference's NaN guard where it has one).
+// NaN results carry the bits x86-64 / glibc give them, because the quantiser writes a NaN minimum into the record's header as it
+// is (src/discretizer.cpp:22-33): a NaN cosine -- made by the arithmetic from finite coordinates (0 / 0 of a zero-length bond,
+// inf - inf of an overflow): x86-64's "real indefinite", the NEGATIVE quiet NaN -- comes back from acos as it went in
+// (0xFFC00000 as a float); a finite cosine beyond +-1 (float rounding of nearly collinear bonds: 1.0000001) is glibc's domain
+// error, the POSITIVE quiet NaN (0x7FC00000). gfx950 would make the positive one in both cases.
 __device__ __noinline__ float acos_deg_exact(float c) {
+    if (c != c) return __uint_as_float(0xFFC00000u);
+    if (__builtin_fabsf(c) > 1.0f) return __uint_as_float(0x7FC00000u);
     const double kPi = 3.14159265358979323846;
     double A = __ocml_acos_f64((double)c);
     double D = A * 180.0 / kPi;

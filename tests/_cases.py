@@ -265,6 +265,11 @@ def input_variants(rng, n):
     yield "moved by (1000, -2000, 3000) + noise", xyz(base(rng), lambda v, k: r3(v + {"x": 1000.0, "y": -2000.0, "z": 3000.0}[k] + rng.normal(0, 0.1, len(v))))
     for sc in (0.5, 0.9, 1.1, 2.0, 1e-3, 1e3):
         yield f"scaled by {sc}", xyz(base(rng), lambda v, k: r3(v * sc) if sc >= 0.5 else v * sc)
+    # nearly collinear bonds: what a reader makes of columns that ran together ("-1999.7482999.922": z = 82999.92 for some atoms,
+    # 3000.03 for others) -- cosines that round beyond +-1, acos domain errors, NaN bond angles at the head of a chain
+    yield "z of half the atoms + 80 000", xyz(_variant_base(rng, 6 * n, 16, 40), lambda v, k: r3(v + (np.where(rng.random(len(v)) < 0.5, 80000.0, 0.0) if k == "z" else 0.0)))
+    yield "x of a tenth of the atoms + 1e6", xyz(base(rng), lambda v, k: r3(v + (np.where(rng.random(len(v)) < 0.1, 1e6, 0.0) if k == "x" else 0.0)))
+    yield "atoms on a line + noise 1e-3", xyz(base(rng), lambda v, k: r3(np.arange(len(v)) * {"x": 1.5, "y": 0.0, "z": 0.0}[k] + rng.normal(0, 1e-3, len(v))))
     yield "mirrored", xyz(base(rng), lambda v, k: -v if k == "x" else v)
     yield "two decimals", xyz(base(rng), lambda v, k: np.round(v * 100.0) / 100.0)
     yield "one decimal", xyz(base(rng), lambda v, k: np.round(v * 10.0) / 10.0)
@@ -284,7 +289,7 @@ def input_variants(rng, n):
     for k in (1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 25, 26, 27, 49, 50, 51, 52, 63, 64, 65, 75, 76, 77):
         yield f"chains of {k}", synthetic.to_chain_batch(synthetic.generate(min(n, 64), [k] * min(n, 64), seed=int(rng.integers(1, 1 << 30))))
     # all of one residue type
-    for rc in range(20):
+    for rc in range(24):                                   # (20-22: ASX, GLX, STP are refused by both; 23 = UNK)
         yield f"all residues of type {rc}", xyz(synthetic.to_chain_batch(synthetic.generate(min(n, 48), [int(v) for v in rng.integers(20, 200, min(n, 48))], seed=int(rng.integers(1, 1 << 30)), res_code=rc)),
                                                  lambda v, k: r3(v + rng.normal(0, 0.05, len(v))))
     # chains long enough for the segment-parallel decode (1 024 residues and more), alone and among short ones

@@ -321,3 +321,74 @@ def test_compress_of_mutated_files_beside_the_reference(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
     ty = _tree(str(tmp_path / "y_cpp"))
     assert ty == _tree(str(tmp_path / "y_py")) and set(mine) <= set(ty) | {k for k in mine}
+
+
+def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_path):
+    """The input variants of the differential fuzz (_cases.input_variants: distorted geometry, "-0.000", coordinates that overflow
+    their columns, odd B-factors, every short length, UNK residues, long chains, side chains with atoms missing or reordered ...)
+    written as PDB files, three chains per variant, through `foldcomp compress <dir> <out>` and `foldcomp decompress <out> <dir>`
+    beside the reference's own command line file by file: every .fcz written here is a file the reference writes with the same
+    bytes (what only it writes was refused here by name), and the two command lines decode OUR records to the same text"""
+    from _cases import input_variants
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import host_text
+    rng = np.random.default_rng(20261001)
+    src = tmp_path / "in"; src.mkdir()
+    names = []
+    for vi, (name, b) in enumerate(input_variants(rng, 6)):
+        if name.startswith("side chains: extra"):                            # (unnamed atoms have no name to write)
+            continue
+        res_of_atom = np.repeat(np.arange(b.n_residues), np.diff(b.atom_off.astype(np.int64)))
+        picked = 0
+        for c in range(b.n_chains):
+            r0, r1 = int(b.res_off[c]), int(b.res_off[c + 1])
+            if r1 - r0 > 400 and picked:
+                continue
+            a0, a1 = int(b.atom_off[r0]), int(b.atom_off[r1])
+            sl = slice(a0, a1)
+            text = host_text.format_pdb(f"V{vi}", b.atom_code[sl], b.res_code[res_of_atom[sl]], int(b.first_res_index[c]) + res_of_atom[sl] - r0,
+                                        chr(b.chain_id[c]) if 32 < b.chain_id[c] < 127 else "A", int(b.first_atom_index[c]), b.x[sl], b.y[sl], b.z[sl], b.bfac_ca[res_of_atom[sl]])
+            nm = f"v{vi:02d}_{c}.pdb"
+            (src / nm).write_bytes(text.encode("latin-1")); names.append(nm)
+            picked += 1
+            if picked == 3:
+                break
+    assert len(names) > 200
+    r = _run([BIN, "compress", str(src), str(tmp_path / "mine")], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    mine = _tree(str(tmp_path / "mine")); said = r.stderr
+    ref_out, ref_failed = {}, []
+    (tmp_path / "ro").mkdir()
+    for nm in names:
+        d = tmp_path / "one" / nm
+        d.mkdir(parents=True)
+        shutil.copy(src / nm, d / nm)
+        try:
+            rr = subprocess.run([REF, "compress", str(d), str(tmp_path / "ro" / nm)], capture_output=True, text=True, timeout=20)
+            ok = rr.returncode == 0
+        except subprocess.TimeoutExpired:
+            ok = False
+        if not ok:
+            ref_failed.append(nm); continue
+        if os.path.isdir(tmp_path / "ro" / nm):
+            for k, v in _tree(str(tmp_path / "ro" / nm)).items():
+                ref_out[k] = (nm, v)
+    stem_failed = {n.rsplit(".", 1)[0] for n in ref_failed}
+    differ = [k for k, v in mine.items() if k in ref_out and ref_out[k][1] != v]
+    only_mine = [k for k in mine if k not in ref_out and not any(k.startswith(s) for s in stem_failed)]
+    unexplained = [k for k, (nm, _) in ref_out.items() if k not in mine and (k[:-4] if k.endswith(".fcz") else k) not in said and nm not in said]
+    same = sum(1 for k, v in mine.items() if k in ref_out and ref_out[k][1] == v)
+    print({"files": len(names), "reference_spun_or_aborted": len(ref_failed), "written_by_both_and_equal": same, "reference_only": len(ref_out) - same})
+    assert not differ, differ[:10]
+    assert not only_mine, only_mine[:10]
+    assert not unexplained, unexplained[:10]
+    assert same >= len(names) * 3 // 4, (same, len(names))
+    # our records decoded by both command lines: the same text, file by file
+    r = _run([BIN, "decompress", str(tmp_path / "mine"), str(tmp_path / "dec_mine")], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rr = _run([REF, "decompress", str(tmp_path / "mine"), str(tmp_path / "dec_ref")], cwd=str(tmp_path))
+    assert rr.returncode == 0, rr.stderr[-2000:]
+    tm, tr = _tree(str(tmp_path / "dec_mine")), _tree(str(tmp_path / "dec_ref"))
+    assert set(tm) == set(tr) and len(tm) >= same
+    bad = [k for k in tm if tm[k] != tr[k]]
+    assert not bad, bad[:10]

@@ -306,6 +306,58 @@ def input_variants(rng, n):
 
 
 
+def composite_pdb(rng, b, title="COMPOSITE") -> bytes:
+    """a PDB file as depositions look, made of chains of a batch: two to four chains under different names, TER records, residues
+    missing in the middle (the reference splits the chain into fragments), alternative locations (A kept, B dropped), insertion
+    codes, numbering from below zero, waters and a ligand as HETATM behind the chains, CRLF line ends now and then"""
+    import sys as _sys, os as _os
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "oracle"))
+    import host_text
+    res_of_atom = np.repeat(np.arange(b.n_residues), np.diff(b.atom_off.astype(np.int64)))
+    short = [c for c in range(b.n_chains) if 4 <= int(b.res_off[c + 1] - b.res_off[c]) <= 160] or [0]
+    out = ["HEADER    TEST                                    01-JAN-00   1CMP", "TITLE     " + title]
+    serial = 1
+    for ci, c in enumerate(rng.choice(short, size=min(len(short), int(rng.integers(2, 5))), replace=False)):
+        r0, r1 = int(b.res_off[c]), int(b.res_off[c + 1])
+        a0, a1 = int(b.atom_off[r0]), int(b.atom_off[r1]); sl = slice(a0, a1)
+        first = int(rng.choice([1, 1, -7, 95, 990]))
+        lines = host_text.format_pdb("", b.atom_code[sl], b.res_code[res_of_atom[sl]], first + res_of_atom[sl] - r0, "ABCDEFG"[ci], 1,
+                                     b.x[sl], b.y[sl], b.z[sl], b.bfac_ca[res_of_atom[sl]]).split("\n")
+        lines = [l for l in lines if l.startswith("ATOM")]
+        n = r1 - r0
+        mode = int(rng.integers(0, 5))
+        if mode == 1 and n > 12:                                                # residues missing in the middle
+            g0 = int(rng.integers(3, n - 6)); g1 = g0 + int(rng.integers(1, 4))
+            lines = [l for l in lines if not (first + g0 <= int(l[22:26]) < first + g1)]
+        elif mode == 2:                                                         # alternative locations on some side-chain atoms
+            new = []
+            for l in lines:
+                if l[12:16].strip() not in ("N", "CA", "C", "O") and rng.random() < 0.15:
+                    new.append(l[:16] + "A" + l[17:]); new.append(l[:16] + "B" + l[17:30] + "%8.3f" % (float(l[30:38]) + 0.5) + l[38:])
+                else:
+                    new.append(l)
+            lines = new
+        elif mode == 3 and n > 8:                                               # insertion codes: 7, 7A, 7B, 8 ...
+            k = first + int(rng.integers(2, n - 4))
+            def renum(l):
+                q = int(l[22:26])
+                if q == k + 1: return l[:22] + "%4d" % k + "A" + l[27:]
+                if q == k + 2: return l[:22] + "%4d" % k + "B" + l[27:]
+                if q > k + 2: return l[:22] + "%4d" % (q - 2) + l[26:]
+                return l
+            lines = [renum(l) for l in lines]
+        for l in lines:
+            out.append(l[:6] + "%5d" % serial + l[11:]); serial += 1
+        last = lines[-1]
+        out.append("TER   %5d      %s %s%s" % (serial, last[17:20], last[21], last[22:27])); serial += 1
+    wch = last[21] if rng.random() < 0.8 else "W"           # (a chain of their own behind the last chain: the reference's identifyChains never returns)
+    for w in range(int(rng.integers(0, 6))):
+        out.append("HETATM%5d  O   HOH %s%4d    %8.3f%8.3f%8.3f  1.00 30.00           O  " % (serial, wch, 2000 + w, *rng.normal(0, 20, 3))); serial += 1
+    out.append("END")
+    eol = "\r\n" if rng.random() < 0.1 else "\n"
+    return (eol.join(out) + eol).encode("latin-1")
+
+
 # ---- FCZ records with random payloads (the header, the residue codes and the anchors stay) ----------------------------------
 def payload_mutations(records, per_record=10, seed=20260927, temp_params=False):
     """random angle words (every one / a tenth / all bits set or clear / one residue / bond-angle bytes only), side-chain torsion

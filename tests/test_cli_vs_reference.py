@@ -323,6 +323,18 @@ def test_compress_of_mutated_files_beside_the_reference(tmp_path):
     assert ty == _tree(str(tmp_path / "y_py")) and set(mine) <= set(ty) | {k for k in mine}
 
 
+def _would_spin(path) -> bool:
+    """the reference's identifyChains loops forever on some files (_cases.reference_would_spin): those are not put to its command
+    line (each would cost the test its timeout)"""
+    from _cases import reference_would_spin
+    from foldcomp_amd.structure import StructureError, parse_pdb_gemmi, remove_alternative_position
+    try:
+        t, _ = parse_pdb_gemmi(open(path, "rb").read())
+        return reference_would_spin(remove_alternative_position(t))
+    except StructureError:
+        return False
+
+
 def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_path):
     """The input variants of the differential fuzz (_cases.input_variants: distorted geometry, "-0.000", coordinates that overflow
     their columns, odd B-factors, every short length, UNK residues, long chains, side chains with atoms missing or reordered ...)
@@ -354,6 +366,14 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
             if picked == 3:
                 break
     assert len(names) > 200
+    # and files as depositions look (_cases.composite_pdb): several chains, gaps, alternative locations, insertion codes, waters
+    from _cases import composite_pdb, _variant_base
+    pool = _variant_base(rng, 48, 5, 150)
+    for k in ("x", "y", "z"):
+        setattr(pool, k, (np.round((getattr(pool, k).astype(np.float64) + rng.normal(0, 0.05, pool.n_atoms)) * 1000.0) / 1000.0).astype(np.float32))
+    for i in range(40):
+        nm = f"w{i:02d}.pdb"
+        (src / nm).write_bytes(composite_pdb(rng, pool, f"COMPOSITE {i}")); names.append(nm)
     r = _run([BIN, "compress", str(src), str(tmp_path / "mine")], cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     mine = _tree(str(tmp_path / "mine")); said = r.stderr
@@ -363,9 +383,10 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
         d = tmp_path / "one" / nm
         d.mkdir(parents=True)
         shutil.copy(src / nm, d / nm)
+        ok = not _would_spin(src / nm)
         try:
-            rr = subprocess.run([REF, "compress", str(d), str(tmp_path / "ro" / nm)], capture_output=True, text=True, timeout=20)
-            ok = rr.returncode == 0
+            rr = subprocess.run([REF, "compress", str(d), str(tmp_path / "ro" / nm)], capture_output=True, text=True, timeout=4) if ok else None
+            ok = ok and rr.returncode == 0
         except subprocess.TimeoutExpired:
             ok = False
         if not ok:

@@ -1277,7 +1277,7 @@ int fcz_decompress_batch(fcz_ctx* ctx, const uint8_t* blob, const uint64_t* off,
 // self-test hooks: run the device numerics over caller-chosen float bit patterns so tests can pin
 // them against the host libm (tests/test_device_math.py). mode 0: acos_deg, 1: sinf, 2: cosf, 3: deg2rad, 4: norm,
 // 5: getCosineTheta, 6-8: place_atom x/y/z, 9/10: sine / cosine of sincosf_pair (the form the kernels call),
-// 11: acos_deg_f32 (the float approximation behind the side-chain torsion byte)
+// 11: acos_deg_f32 (the float approximation behind the side-chain torsion byte), 12/13: sine / cosine of sincosf_pair_any (any float)
 // ------------------------------------------------------------------------------------------------
 }  // extern "C"
 
@@ -1302,6 +1302,7 @@ __global__ void k_selftest_math(int mode, uint32_t start_bits, uint32_t stride, 
     else if (mode == 3) r = deg2rad(x);
     else if (mode == 11) r = acos_deg_f32(x);
     else if (mode == 9 || mode == 10) { float sn, cs; sincosf_pair(x, &sn, &cs); r = mode == 9 ? sn : cs; }
+    else if (mode == 12 || mode == 13) { float sn, cs; sincosf_pair_any(x, &sn, &cs); r = mode == 12 ? sn : cs; }
     else if (mode == 4) r = vnorm(v3{st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)});
     else if (mode == 5) r = vcos_theta(v3{st_hash_float(u, 1, sc), st_hash_float(u, 2, sc), st_hash_float(u, 3, sc)},
                                        v3{st_hash_float(u, 4, sc), st_hash_float(u, 5, sc), st_hash_float(u, 6, sc)});
@@ -1376,7 +1377,7 @@ extern "C" int fcz_selftest_copy(fcz_ctx* ctx, uint64_t bytes, int reps, double*
 }
 
 extern "C" int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host) {
-    if (!ctx || !out_host || mode < 0 || mode > 11) return FCZ_E_INVALID_ARG;
+    if (!ctx || !out_host || mode < 0 || mode > 13) return FCZ_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (count == 0) return FCZ_OK;
     int rc = ctx->stage[17].ensure(sizeof(float) * (size_t)count); if (rc) return rc;

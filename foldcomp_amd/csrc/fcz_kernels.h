@@ -605,6 +605,16 @@ __device__ __forceinline__ void backbone_group(
     entry_view v; v.n = 0; v.n_anchor = 1; v.e = e; v.L = make_layout(0, 0, 0, 0);
     bb_params P{};
     if (valid) { v = view_entry(e); if (MODE != 2) P = load_params(e); }
+    // can the parameters make an angle whose radians reach glibc's large-argument reduction (|x| >= 120 = 6 875 degrees)? An angle
+    // is minimum + q * step with q in [0, bins]: its bounds are the two ends. Anything not certainly below 6 000 degrees -- NaN and
+    // infinite parameters with it -- sends the wavefront through the sine / cosine that takes any float
+    bool wild = false;
+    if (MODE != 2 && valid) {
+        const float bins[6] = {4095.0f, 4095.0f, 2047.0f, 255.0f, 255.0f, 255.0f};
+#pragma unroll
+        for (int q = 0; q < 6; q++) wild = wild || !(__builtin_fabsf(P.mn[q]) < 6000.0f && __builtin_fabsf(P.mn[q] + bins[q] * P.cf[q]) < 6000.0f);
+    }
+    const bool any_wild = MODE != 2 && __any(wild);
     const uint8_t* words = e + v.L.o_words;
     const uint8_t* last_word = words + 8 * (size_t)(v.n ? v.n - 1 : 0);
     const uint32_t nseg = valid ? v.n_anchor - 1 : 0;
@@ -684,24 +694,29 @@ __device__ __forceinline__ void backbone_group(
         }
         BB_STAMP(1)
         // ---- forward NeRF of the segment ----
-        for (int i = 0; MODE != 2 && i + 1 < maxlen; i++) {
-            if (i + 1 >= len) continue;
+        // (ANY: a chain of the wavefront has quantiser parameters that can make an angle of 120 radians or more -- a record no
+        //  compressor writes --: the same step with the sine / cosine that takes any float, any_wild is wave-uniform)
+        auto forward_step = [&](int i, auto any_tag) {
+            constexpr bool ANY = decltype(any_tag)::value;
             const uint8_t* pf = wp + 16;
             const uint64_t w_pre = ld_u64(pf <= last_word ? pf : last_word);
             const bb_word w = decode_word(w_cur, P);
             float s_psi, c_psi, s_om, c_om, s_phi, c_phi;
-            sincosf_pair(deg2rad(w.psi), &s_psi, &c_psi);
-            sincosf_pair(deg2rad(w.omega), &s_om, &c_om);
-            sincosf_pair(deg2rad(w.phi), &s_phi, &c_phi);
+            if (ANY) { sincosf_pair_any(deg2rad(w.psi), &s_psi, &c_psi); sincosf_pair_any(deg2rad(w.omega), &s_om, &c_om); sincosf_pair_any(deg2rad(w.phi), &s_phi, &c_phi); }
+            else { sincosf_pair(deg2rad(w.psi), &s_psi, &c_psi); sincosf_pair(deg2rad(w.omega), &s_om, &c_om); sincosf_pair(deg2rad(w.phi), &s_phi, &c_phi); }
             float* Tw = Tg + (size_t)BB_TROW(6 * i) * WAVE;
             Tw[0] = c_psi; Tw[WAVE] = s_psi; Tw[2 * WAVE] = c_om; Tw[3 * WAVE] = s_om; Tw[4 * WAVE] = c_phi; Tw[5 * WAVE] = s_phi;
-            const v3 N = place_atom_d2(p0, p1, p2, nerf_d2_trig((float)1.3311, w.can, c_psi, s_psi));
+            const v3 N = place_atom_d2(p0, p1, p2, nerf_d2_trig_t<ANY>((float)1.3311, w.can, c_psi, s_psi));
             const float l_nca = (w.res != FCZ_RES_PRO) ? (float)1.4581 : (float)1.353;  // src/foldcomp.cpp:204-212
-            const v3 CA = place_atom_d2(p1, p2, N, nerf_d2_trig(l_nca, w.cna, c_om, s_om));
-            const v3 C = place_atom_d2(p2, N, CA, nerf_d2_trig((float)1.5281, w.nca, c_phi, s_phi));
+            const v3 CA = place_atom_d2(p1, p2, N, nerf_d2_trig_t<ANY>(l_nca, w.cna, c_om, s_om));
+            const v3 C = place_atom_d2(p2, N, CA, nerf_d2_trig_t<ANY>((float)1.5281, w.nca, c_phi, s_phi));
             Rg[(size_t)BB_RROW(3 * i + 3) * WAVE] = N; Rg[(size_t)BB_RROW(3 * i + 4) * WAVE] = CA; Rg[(size_t)BB_RROW(3 * i + 5) * WAVE] = C;
             p0 = N; p1 = CA; p2 = C;
             w_cur = w_nxt; w_nxt = w_pre; wp += 8;
+        };
+        for (int i = 0; MODE != 2 && i + 1 < maxlen; i++) {
+            if (i + 1 >= len) continue;
+            if (__builtin_expect(any_wild, 0)) forward_step(i, std::true_type{}); else forward_step(i, std::false_type{});
         }
         BB_STAMP(2)
         // ---- reverse NeRF + blend of the same segment ----

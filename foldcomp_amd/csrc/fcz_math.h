@@ -383,6 +383,46 @@ __device__ __forceinline__ void sincosf_pair(float y, float* sn, float* cs) {
     *cs = tiny ? 1.0f : __uint_as_float(c0);
 }
 
+// ---- the same for ANY float: |y| >= 120 (glibc's reduce_large, sysdeps/ieee754/flt-32/sincosf.h), infinities, NaN ------
+// No compressor writes such angles (they come from quantiser parameters of a record that was made by hand or damaged: minimum +
+// q * step of thousands of degrees), but the reference decodes those records to numbers, and so does this. reduce_large
+// multiplies the 24-bit mantissa by a 96-bit window of 4/pi chosen by the exponent: the quadrant is the top two bits of the
+// product, the reduced argument its remaining 62 bits as a signed fraction of pi/2. Out of line, behind a test the decoder makes
+// once per chain (backbone_group: chains whose parameters cannot reach 120 radians never look).
+__device__ __constant__ uint32_t fcz_inv_pio4[24] = {
+    0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u, 0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u,
+    0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u, 0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+__device__ __noinline__ void sincosf_any_slow(float y, float* sn, float* cs) {
+    uint32_t xi = __float_as_uint(y);
+    if ((xi & 0x7f800000u) == 0x7f800000u) {
+        // __math_invalidf: (y - y) / (y - y) -- a NaN goes through, an infinity makes x86-64's negative quiet NaN
+        const float r = (xi & 0x007fffffu) ? __uint_as_float(xi | 0x00400000u) : __uint_as_float(0xFFC00000u);
+        *sn = r; *cs = r;
+        return;
+    }
+    const int sign = (int)(xi >> 31);
+    const uint32_t* arr = &fcz_inv_pio4[(xi >> 26) & 15u];
+    const int shift = (int)((xi >> 23) & 7u);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    unsigned long long res0 = (unsigned long long)(uint32_t)(xi * arr[0]);           // (a 32-bit product, as the reference computes it)
+    const unsigned long long res1 = (unsigned long long)xi * arr[4], res2 = (unsigned long long)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const unsigned long long nq = (res0 + (1ull << 61)) >> 62;
+    res0 -= nq << 62;
+    const double x = (double)(long long)res0 * 0x1.921FB54442D18p-62;
+    const int n = (int)nq, m = n + sign;
+    const double sg = ((m + 1) & 2) ? -1.0 : 1.0;                                    // sign table {1, -1, -1, 1}[(n + sign) & 3]
+    const bool negc = (m & 2) != 0;
+    *sn = sc_poly(x * sg, x * x, n, negc);
+    *cs = sc_poly(x * sg, x * x, n ^ 1, negc);
+}
+__device__ __forceinline__ void sincosf_pair_any(float y, float* sn, float* cs) {
+    if (__builtin_expect(abstop12(y) >= 0x42fu, 0)) sincosf_any_slow(y, sn, cs);     // abstop12(120.0f)
+    else sincosf_pair(y, sn, cs);
+}
+
 // degrees -> radians as Nerf::place_atom does (src/nerf.cpp:63-64): double multiply, double divide,
 // rounded to float on assignment. Fast path: one multiply by pi/180 + the float-rounding safety test.
 __device__ __noinline__ float deg2rad_exact(float deg) {
@@ -488,6 +528,19 @@ __device__ __forceinline__ v3 nerf_d2_trig(float L, float bond_angle_deg_, float
     const float ba = deg2rad(bond_angle_deg_);
     float sb, cb;
     sincosf_pair(ba, &sb, &cb);
+    v3 d2;
+    d2.x = -1.0f * L * cb;
+    d2.y = L * ct * sb;
+    d2.z = L * st * sb;
+    return d2;
+}
+
+// (ANY: the bond angle may be any float -- see sincosf_pair_any)
+template <bool ANY>
+__device__ __forceinline__ v3 nerf_d2_trig_t(float L, float bond_angle_deg_, float ct, float st) {
+    const float ba = deg2rad(bond_angle_deg_);
+    float sb, cb;
+    if (ANY) sincosf_pair_any(ba, &sb, &cb); else sincosf_pair(ba, &sb, &cb);
     v3 d2;
     d2.x = -1.0f * L * cb;
     d2.y = L * ct * sb;

@@ -81,6 +81,20 @@ def test_sincos_pair_sweep(codec, is_cos):
             assert len(bad) == 0, (len(bad), [(hex(sign + start + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])
 
 
+@pytest.mark.parametrize("is_cos", [0, 1])
+def test_sincos_of_any_float(codec, is_cos):
+    """sincosf_pair_any (the decoder's form for chains whose quantiser parameters can reach 120 radians: records made by hand or
+    damaged) against libm over the whole float range, both signs: every 997th float from 0 to infinity (glibc's three
+    reductions: none, fast, large), every float around 120.0 where they switch, the infinities and NaNs (NaN on both sides)"""
+    for sign in (0, 0x80000000):
+        for start, stride, count in ((0, 997, 0x7f800000 // 997 + 1), (_b(119.99), 1, _b(120.01) - _b(119.99)), (_b(3e38), 1, 0x7f800010 - _b(3e38)), (0x7fc00000, 1, 4)):
+            dev = codec.selftest_math(12 + is_cos, sign + start, stride, count)
+            host = _host_sincos(is_cos, sign + start, stride, count)
+            a, b = dev.view(np.uint32), host.view(np.uint32)
+            bad = np.nonzero((a != b) & ~(np.isnan(dev) & np.isnan(host)))[0]
+            assert len(bad) == 0, (len(bad), [(hex(sign + start + int(i) * stride), float(dev[i]), float(host[i])) for i in bad[:8]])
+
+
 def _host_math(mode, start, stride, count):
     lib = H.load_oracle()
     lib.fcz_oracle_math_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]

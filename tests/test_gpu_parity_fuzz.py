@@ -51,3 +51,11 @@ def test_ingest_of_rendered_input_variants(codec):
     every file is read into the batch the host reader builds or handed back (tools/dbg/ingest_variants_fuzz.py)"""
     n, bad = _tool("ingest_variants_fuzz").run(4, 20261001, codec)
     assert n > 80 and bad == 0
+
+
+def test_records_with_any_quantiser_parameters_decode_like_the_restatement(codec):
+    """the twelve angle parameters of a record's header set to anything -- huge, tiny, negative, zero, NaN, infinite (angles of
+    thousands of radians: glibc's large-argument sine / cosine, NaN and infinite angles): the device decodes every record to the
+    restatement's bits, both atom orders (tools/dbg/param_fuzz.py; round 6: such angles used to decode to NaN here)"""
+    n, bad = _tool("param_fuzz").run(20261001, codec, per_record=8)
+    assert n > 400 and bad == 0

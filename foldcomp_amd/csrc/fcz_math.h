@@ -460,17 +460,18 @@ __device__ __forceinline__ v3 vdiv3(v3 n, float d) {
         float t = n.z * r; float e2 = __builtin_fmaf(-d, t, n.z); t = __builtin_fmaf(e2, r, t);
         const float e3 = __builtin_fmaf(-d, t, n.z); q.z = __builtin_fmaf(e3, r, t);
     }
-    // safe iff the denominator is comfortably normal and no quotient is zero, tiny or huge. A ZERO quotient is not safe: the
-    // refinement steps lose its sign (fma(-d, -0, -0) = +0, then fma(+0, r, -0) = +0) where '/' keeps it -- a numerator of -0 is
-    // what the blend of a segment's first atom makes of an anchor coordinate written "-0.000" (round 6: found by
-    // tests/test_gpu_edge_cases.py::test_distorted_geometry, the decoded 0.0 had the wrong sign bit). On the bit patterns with
-    // the sign shifted out one unsigned minimum covers "above 2^-90" for all three components; one float maximum (NaN quotients
-    // only come from NaN / zero / infinite operands: den_ok, or NaN either way) covers the upper bound.
+    // safe iff the denominator is comfortably normal and every quotient is a number between 2^-90 and 2^90. A ZERO quotient is not
+    // safe: the refinement steps lose its sign (fma(-d, -0, -0) = +0, then fma(+0, r, -0) = +0) where '/' keeps it -- a numerator
+    // of -0 is what the blend of a segment's first atom makes of an anchor coordinate written "-0.000" (round 6: found by
+    // tests/test_gpu_edge_cases.py::test_distorted_geometry, the decoded 0.0 had the wrong sign bit). Nor is an INFINITE one: an
+    // infinite numerator (an anchor of a damaged record) leaves the refinement as NaN (inf - inf) where '/' gives the infinity
+    // (tools/dbg/param_fuzz.py). On the bit patterns with the sign shifted out one unsigned minimum and one unsigned maximum
+    // cover all three components: exponent fields 37 .. 216 pass, zeros, denormals, infinities and NaNs do not.
     const bool den_ok = (ed - 32u) < 192u;                                   // 2^-95 <= |d| < 2^97
     const uint32_t ux = __float_as_uint(q.x) << 1, uy = __float_as_uint(q.y) << 1, uz = __float_as_uint(q.z) << 1;
     const uint32_t lo2 = ux < uy ? ux : uy, lo3 = lo2 < uz ? lo2 : uz;                                          // v_min3_u32
-    const float hi3 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)), __builtin_fabsf(q.z));   // v_max3_f32
-    const bool q_ok = lo3 >= (37u << 24) && hi3 < 0x1p90f;                   // 2^-90 = exponent field 37
+    const uint32_t hi2 = ux > uy ? ux : uy, hi3 = hi2 > uz ? hi2 : uz;                                          // v_max3_u32
+    const bool q_ok = lo3 >= (37u << 24) && hi3 < (217u << 24);              // 2^-90 = exponent field 37, 2^90 = 217
     if (__builtin_expect(!(den_ok && q_ok), 0)) q = vdiv3_plain(n, d);
     return q;
 }

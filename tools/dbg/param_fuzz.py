@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FCZ records whose angle quantiser parameters (the twelve floats of the header: minimum and step of phi, psi, omega and the three
-bond angles) are not what a compressor writes -- huge, tiny, negative, zero, NaN, infinite: angles of thousands of radians
+bond angles) -- and, for a third of them, anchor coordinates and the OXT atom -- are not what a compressor writes -- huge, tiny, negative, zero, NaN, infinite: angles of thousands of radians
 (glibc's sinf / cosf switch to their large-argument reduction at |x| >= 120), NaN and infinite angles. Device decode against the
 restatement (libm on the host), both atom orders. usage (GPU box): python tools/dbg/param_fuzz.py [seed]"""
 import os, struct, sys
@@ -20,6 +20,14 @@ def mutated(records, rng, per_record=24):
     for e in records:
         for _ in range(per_record):
             b = bytearray(e)
+            n_anchor = b[12]; tl = struct.unpack_from("<I", b, 24)[0]; o_anchor = 76 + 4 * n_anchor + tl
+            if rng.random() < 0.35:                                                # anchor coordinates and the OXT atom: any float as well
+                for _ in range(int(rng.integers(1, 4))):
+                    k = int(rng.integers(0, 9 * n_anchor + 3))
+                    at = o_anchor + 4 * k if k < 9 * n_anchor else o_anchor + 36 * n_anchor + 1 + 4 * (k - 9 * n_anchor)
+                    struct.pack_into("<f", b, at, VALUES[int(rng.integers(0, len(VALUES)))])
+                if rng.random() < 0.5:
+                    out.append(bytes(b)); continue
             for _ in range(int(rng.integers(1, 4))):
                 q = int(rng.integers(0, 12))                                   # mins at 28 + 4q (q < 6), steps at 52 + 4(q - 6)
                 v = VALUES[int(rng.integers(0, len(VALUES)))] if rng.random() < 0.7 else float(np.float32(rng.normal(0, 1) * 10.0 ** rng.integers(-6, 9)))

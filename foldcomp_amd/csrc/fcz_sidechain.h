@@ -429,8 +429,14 @@ void k_sidechain(uint32_t n_res, uint32_t n_tiles, uint32_t tile_res, const uint
         const res_in cur = nxt;
         nxt = load_res(unit_tile(unit + gridDim.x < n_units ? unit + gridDim.x : unit));
         const uint32_t A0 = cur.a_first, A1 = cur.a_end;
-        if (A1 - A0 > (uint32_t)SC_CAP) {
-            // does not fit the staging buffer: both halves go to the 128-residue launch (never happens there: 128 * 14 + OXT)
+        // the work-item list: a residue's N, CA, C are never items and of the rest at most 10 in 11 are (TRP: 14 atoms, 10 items),
+        // so items <= 10 / 11 (atoms - 3 rows). For a full tile that fits SC_CAP the static_assert above bounds it; the batch's
+        // LAST tile has fewer rows, and when nearly all of them are TRP / TYR / ARG (157 TRP: 2 199 atoms fit, 1 570 items do not)
+        // its items overran the list (round 6: found by the differential fuzz, the tile's side chains came out as garbage)
+        const uint32_t rows_here = (size_t)tile * tile_res < (size_t)n_res ? ((size_t)n_res - (size_t)tile * tile_res < tile_res ? (uint32_t)((size_t)n_res - (size_t)tile * tile_res) : tile_res) : 0u;
+        if (A1 - A0 > (uint32_t)SC_CAP || 10u * (A1 - A0 - 3u * rows_here) > 11u * (uint32_t)SC_LIST) {
+            // does not fit the staging buffer or the item list: both halves go to the 128-residue launch (never happens there:
+            // 128 * 14 + OXT atoms, 128 * 10 items)
             if (t == 0 && punt_list) { const uint32_t k = atomicAdd(punt_count, 2u); punt_list[k] = 2u * tile; punt_list[k + 1] = 2u * tile + 1u; }
             null_stores();
             continue;

@@ -283,7 +283,9 @@ def input_variants(rng, n):
     # B-factors
     for name, f in (("B constant", lambda v: np.full_like(v, 50.0)), ("B zero", lambda v: np.zeros_like(v)), ("B negative", lambda v: -v), ("B huge", lambda v: v * 1e4),
                     ("B two values", lambda v: np.where(rng.random(len(v)) < 0.5, 10.0, 90.0).astype(np.float32)), ("B with -0.0", lambda v: np.where(rng.random(len(v)) < 0.1, -0.0, v).astype(np.float32)),
-                    ("B raw floats", lambda v: rng.normal(50, 30, len(v)).astype(np.float32))):
+                    ("B raw floats", lambda v: rng.normal(50, 30, len(v)).astype(np.float32)),
+                    ("B at the ends of the float range", lambda v: rng.choice(np.asarray([3e38, -3e38, 1e38, 0.0, 1e-38, 50.0], np.float32), len(v))),
+                    ("B tiny", lambda v: (v * 1e-40).astype(np.float32))):
         b = base(rng); b.bfac_ca = np.ascontiguousarray(f(b.bfac_ca.copy()), dtype=np.float32); yield name, b
     # short chains, one length each
     for k in (1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 25, 26, 27, 49, 50, 51, 52, 63, 64, 65, 75, 76, 77):

@@ -229,3 +229,16 @@ def test_distorted_geometry(codec, sigma):
         o = H.oracle_decompress(oblob, ooff, alt_order=alt, n_threads=8)
         for k in ("x", "y", "z", "bfac_res"):
             assert np.all((_bits(d[k]) == _bits(o[k])) | (np.isnan(d[k]) & np.isnan(o[k]))), (sigma, alt, k)
+
+
+def test_atom_rich_last_tile(codec):
+    """the batch's LAST side-chain tile has fewer than 256 residues: when nearly all of them are TRP its atoms fit the staging
+    buffer (up to 164 x 14) while its work items (10 per TRP) do not fit the item list -- such a tile goes to the 128-residue
+    launch like a tile whose atoms do not fit (round 6: it did not, and its side chains decoded to garbage; found by the
+    differential fuzz). Every size around the two limits, the last chain starting on a tile boundary and inside a tile"""
+    for rc, sizes in ((17, list(range(136, 170)) + [2, 64, 128, 200, 255, 256]), (18, range(150, 200, 7)), (1, range(160, 257, 12))):
+        for last in sizes:
+            for pre in ([256], [100, 193]):
+                lens = pre + [int(last)]
+                b = synthetic.to_chain_batch(synthetic.generate(len(lens), lens, seed=rc * 1000 + int(last), res_code=rc))
+                _check(codec, b, alt=bool(last & 1))

@@ -555,10 +555,22 @@ __device__ __forceinline__ v3 place_atom(v3 a, v3 b, v3 c, float L, float ba_deg
 
 // ---- quantisers, reference src/discretizer.cpp ----------------------------------------------------
 // vector discretize (:43-53): float product, double +0.5, truncation; NaN -> 0 like x86-64 gcc
+// `(unsigned int)d` of x86-64 gcc is cvttsd2si into a 64-bit register, low half taken: values of [2^32, 2^63) wrap, negative ones
+// wrap as two's complement, NaN, infinities and everything from 2^63 on give the "integer indefinite" 0x8000000000000000 = 0.
+// The hardware conversion here saturates. Out of line: a quantiser's operand is in [0.5, bins + 1) unless its step is degenerate
+// (a chain whose B-factors are all denormal: 255 / (max - min) is infinite -- round 6, the differential fuzz; the reference
+// writes bytes of 0 there, the saturating conversion wrote 255)
+__device__ __noinline__ uint32_t cvt_u32_x86_slow(double d) {
+    if (!(__builtin_fabs(d) < 9223372036854775808.0)) return 0u;
+    return (uint32_t)(unsigned long long)(long long)d;
+}
 __device__ __forceinline__ uint32_t quant_round(float v, float mn, float disc_f) {
-    // operand is in [0.5, n_bins + 1): the direct unsigned conversion equals gcc's cvttsd2si+truncate
-    double d = (double)((v - mn) * disc_f) + 0.5;
-    return (d != d) ? 0u : __double2uint_rz(d);
+    const double d = (double)((v - mn) * disc_f) + 0.5;
+    // v lies in [min, max] and disc = bins / (max - min): the operand is in [0.5, bins + 1) -- or a NaN (a NaN angle; inf * 0 of a
+    // range that overflowed) -- unless disc itself is not finite. That test is the chain's, not the residue's (loop-invariant)
+    uint32_t q = (d != d) ? 0u : __double2uint_rz(d);
+    if (__builtin_expect(!(__builtin_fabsf(disc_f) < __builtin_huge_valf()), 0)) q = cvt_u32_x86_slow(d);
+    return q;
 }
 // scalar discretize (:55-57): truncation of the float product
 __device__ __forceinline__ uint32_t quant_trunc(float v, float mn, float disc_f) {

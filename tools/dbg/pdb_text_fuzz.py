@@ -31,8 +31,12 @@ def run(N, seed, codec=None):
             for digits in (1, 2, 3, 4):
                 got = codec.extract(eblob, eoff, mode=0, digits=digits)
                 for i, e in enumerate(entries):
-                    if got[i].decode("latin-1") != extract_plddt(fczfile.parse(e), digits):
-                        print(f"[{name}] extract -p {digits} chain {i}: device {got[i][:60]!r} host {extract_plddt(fczfile.parse(e), digits)[:60]!r}"); bad += 1; break
+                    try:
+                        exp_p = extract_plddt(fczfile.parse(e), digits)
+                    except ValueError:                       # (a NaN B-factor: the reference converts it to a char, which C leaves undefined)
+                        continue
+                    if got[i].decode("latin-1") != exp_p:
+                        print(f"[{name}] extract -p {digits} chain {i}: device {got[i][:60]!r} host {exp_p[:60]!r}"); bad += 1; break
             for alt in (False, True):
                 texts, status = codec.decompress_pdb(eblob, eoff, alt_order=alt)
                 o = H.oracle_decompress(eblob, eoff, alt_order=alt, n_threads=16)

@@ -53,6 +53,30 @@ def run(N, seed, codec=None):
                 assert sorted((remap[int(f)], T._name_of(fnames[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
             except AssertionError as e:
                 print(f"[{name}] {str(e)[:300]}"); bad += 1
+    # files as depositions look (_cases.composite_pdb: several chains, gaps, alternative locations, insertion codes, waters, CRLF)
+    from _cases import composite_pdb, _variant_base
+    pool = _variant_base(rng, 40, 4, 160)
+    for k in ("x", "y", "z"):
+        setattr(pool, k, (np.round((getattr(pool, k).astype(np.float64) + rng.normal(0, 0.05, pool.n_atoms)) * 1000.0) / 1000.0).astype(np.float32))
+    ftexts = [composite_pdb(rng, pool, f"C{i}") for i in range(10 * N)]; fnames = [f"c{i}.pdb" for i in range(10 * N)]
+    for skip in (False, True):
+        bdev, cfile, cmeta, fstat, refused = codec.ingest_pdb(ftexts, fnames, 25, skip)
+        ok = [i for i in range(len(ftexts)) if fstat[i] in (0, 4)]
+        taken += len(ok); handed += len(ftexts) - len(ok)
+        remap = {f: k for k, f in enumerate(ok)}
+        try:
+            exp, exp_names, exp_file, exp_ref, failed = T._host_expect([ftexts[i] for i in ok], [fnames[i] for i in ok], 25, skip, reader=T._read_any)
+            assert not failed, ("the device took files the host reader fails", failed)
+            if exp is None:
+                assert bdev.n_chains == 0
+            else:
+                T._same_batch(bdev, exp)
+                cn = codec.chain_names(bdev.n_chains)
+                assert [T._name_of(fnames[f], int(m), c) for f, m, c in zip(cfile, cmeta, cn)] == exp_names
+                assert [remap[int(f)] for f in cfile] == exp_file
+            assert sorted((remap[int(f)], T._name_of(fnames[int(f)], int(m))) for f, m in refused) == sorted(exp_ref)
+        except AssertionError as e:
+            print(f"[composite files, skip_discontinuous={skip}] {str(e)[:300]}"); bad += 1
     if own: codec.close()
     print(f"{n} variants, {taken} files read on the device, {handed} handed back, {bad} differences")
     return n, bad

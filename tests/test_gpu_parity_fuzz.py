@@ -59,3 +59,11 @@ def test_records_with_any_quantiser_parameters_decode_like_the_restatement(codec
     restatement's bits, both atom orders (tools/dbg/param_fuzz.py; round 6: such angles used to decode to NaN here)"""
     n, bad = _tool("param_fuzz").run(20261001, codec, per_record=8)
     assert n > 400 and bad == 0
+
+
+def test_inflate_of_rendered_variants_and_noise(codec):
+    """k_inflate on texts the fixtures do not hold (the variants as PDB / mmCIF text, composite files, noise, runs, every size around
+    the kernel's windows), each member made with a random level, strategy, window and memory level: zlib's bytes, none refused
+    (tools/dbg/inflate_fuzz.py)"""
+    n, bad = _tool("inflate_fuzz").run(2, 20261001, codec)
+    assert n > 150 and bad == 0

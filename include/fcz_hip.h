@@ -382,8 +382,8 @@ int  fcz_ctx_kernel_time(fcz_ctx* ctx, const char* name, double* ms, uint64_t* l
 void fcz_ctx_reset_timing(fcz_ctx* ctx);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */
-/* Device numerics self-test used by tests/test_device_math.py: evaluates one math primitive of the codec (mode 0..8:
- * acos->degrees, glibc sinf / cosf restatements, norm, cosine, NeRF placement ...) on `count` inputs generated from
+/* Device numerics self-test used by tests/test_device_math.py: evaluates one math primitive of the codec (mode 0..13:
+ * acos->degrees, glibc sinf / cosf restatements, norm, cosine, NeRF placement, the kernels' paired and any-float sine / cosine ...) on `count` inputs generated from
  * the float bit patterns start_bits, start_bits + stride, ... and copies the float results to out_host. */
 int fcz_selftest_math(fcz_ctx* ctx, int mode, uint32_t start_bits, uint32_t stride, uint32_t count, float* out_host);
 /* Device copy ceiling used by bench.py beside the 8 TB/s peak: `reps` copies of `bytes` bytes (rounded down to 16) between two

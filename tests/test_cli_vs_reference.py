@@ -413,3 +413,13 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
     assert set(tm) == set(tr) and len(tm) >= same
     bad = [k for k in tm if tm[k] != tr[k]]
     assert not bad, bad[:10]
+    # and extracted by both: pLDDT strings of one to four digits (B-factors negative, huge, denormal, constant among them), sequences
+    for flags in (["--plddt"], ["--plddt", "-p", "2"], ["--plddt", "-p", "3"], ["--plddt", "-p", "4"], ["--fasta"]):
+        tag = "x" + "".join(f.strip("-") for f in flags)
+        r = _run([BIN, "extract", *flags, "--no-merge", str(tmp_path / "mine"), str(tmp_path / (tag + "_mine"))], cwd=str(tmp_path))
+        rr = _run([REF, "extract", *flags, "--no-merge", str(tmp_path / "mine"), str(tmp_path / (tag + "_ref"))], cwd=str(tmp_path))
+        assert r.returncode == 0 and rr.returncode == 0, (flags, r.stderr[-500:], rr.stderr[-500:])
+        tm, tr = _tree(str(tmp_path / (tag + "_mine"))), _tree(str(tmp_path / (tag + "_ref")))
+        assert set(tm) == set(tr) and len(tm) >= same, (flags, len(tm), len(tr))
+        bad = [k for k in tm if tm[k] != tr[k]]
+        assert not bad, (flags, bad[:10])

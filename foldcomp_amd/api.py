@@ -22,7 +22,7 @@ from ._aa_tables import RES1, RES3
 from . import _lib
 from .codec import Codec
 from .database import DatabaseReader
-from .structure import (Chain, StructureError, build_batch, parse_pdb, remove_alternative_position)
+from .structure import (Chain, MultipleChainsError, StructureError, build_batch, parse_pdb, remove_alternative_position)
 
 DEFAULT_ANCHOR_THRESHOLD = 25
 
@@ -51,8 +51,11 @@ def set_codec(c: Optional[Codec]):
 def _chain_from_pdb(name: str, pdb_content: str) -> Chain:
     try:
         t = parse_pdb(pdb_content, single_chain=True)
-    except StructureError:
+    except MultipleChainsError:
         raise error("Multiple chains found. Please provide a single chain using 'foldcomp.split_pdb_by_chain'")
+    except StructureError as e:
+        # (std::stoi / std::stof / substr throw inside the reference's extension and end the interpreter: an exception here)
+        raise error(f"Error parsing the PDB string: {e}")
     if len(t) == 0:
         raise error("No ATOM lines found")
     return Chain(name, remove_alternative_position(t))

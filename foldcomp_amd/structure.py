@@ -14,6 +14,8 @@ import ctypes
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
+import re
+
 import numpy as np
 
 from ._aa_tables import ATOM_NAMES, RES3
@@ -54,31 +56,83 @@ class AtomTable:
                          self.xyz[idx], self.bfac[idx])
 
 
-def parse_pdb(text: str, *, hetatm: bool = False, single_chain: bool = False) -> AtomTable:
-    """Fixed-column PDB ATOM parser (foldcomp/foldcomp.cxx:259-278).
+_C_SPACE = "[ \\t\\n\\v\\f\\r]*"
+_STOI = re.compile(_C_SPACE + r"([+-]?[0-9]+)")
+_STOF = re.compile(_C_SPACE + r"([+-]?(?:infinity|inf|nan(?:\([0-9A-Za-z_]*\))?|0[xX](?:[0-9a-fA-F]+\.?[0-9a-fA-F]*|\.[0-9a-fA-F]+)(?:[pP][+-]?[0-9]+)?"
+                               r"|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?))", re.I)
 
-    single_chain=True reproduces the Python binding: a second chain id raises
-    StructureError("multiple chains") (flag 2 at foldcomp.cxx:264-266).
+
+class MultipleChainsError(StructureError):
+    """the binding's flag 2: a second chain name among the ATOM lines of a string given to compress"""
+
+
+def _field(line: str, pos: int, n: int) -> str:
+    """std::string::substr(pos, n): the characters that are there; a position beyond the end throws (std::out_of_range)"""
+    if pos > len(line):
+        raise StructureError("ATOM line too short")
+    return line[pos:pos + n]
+
+
+def _stoi(field: str) -> int:
+    """std::stoi: blanks, a sign, digits -- the longest such prefix; none, or a value beyond int, throws"""
+    m = _STOI.match(field)
+    if not m or not -2 ** 31 <= int(m.group(1)) < 2 ** 31:
+        raise StructureError("ATOM line: a field that is no integer")
+    return int(m.group(1))
+
+
+def _stof(field: str) -> float:
+    """std::stof (strtof): the longest prefix that is a number -- decimal or hexadecimal, with an exponent, inf / nan --; none, or a
+    value beyond float's range (ERANGE), throws. "0-9999.0" is 0, "1.00 5" is 1, "12.5A" is 12.5"""
+    m = _STOF.match(field)
+    if not m:
+        raise StructureError("ATOM line: a field that is no number")
+    t = m.group(1)
+    low = t.lower().lstrip("+-")
+    if low.startswith("0x"):
+        v = float.fromhex(t)
+    elif low.startswith("nan"):
+        v = float("nan")
+    else:
+        v = float(t)
+    with np.errstate(over="ignore"):
+        f = float(np.float32(v)) if v == v and abs(v) != float("inf") else v
+    if (abs(f) == float("inf") and not low.startswith("inf")) or (v != 0.0 and v == v and abs(f) < 1.1754943508222875e-38):
+        raise StructureError("ATOM line: a number beyond float's range")
+    return v
+
+
+def parse_pdb(text: str, *, hetatm: bool = False, single_chain: bool = False) -> AtomTable:
+    """The Python binding's reader of a PDB STRING (foldcomp/foldcomp.cxx:252-278, :636-652), field by field: lines end at '\\n'
+    only (std::getline), a line that starts with ATOM gives an atom from fixed columns -- std::stoi / std::stof of the substrings:
+    the longest numeric prefix of each field counts, blanks in front of it are skipped --, the occupancy is parsed as well. Where
+    the reference's call THROWS (a line that ends before column 61, a field without a number, a value out of range) its extension
+    ends the interpreter (the exception crosses a C frame); here that is a StructureError (foldcomp.error).
+
+    single_chain=True reproduces `compress`: a second chain id raises StructureError("multiple chains") (flag 2 at
+    foldcomp.cxx:264-266); get_data takes every ATOM line.
     """
     atom, residue, chain = [], [], []
     ai, ri, xyz, bf = [], [], [], []
     first_chain = None
-    for line in text.splitlines():
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    for line in lines:
         if line.startswith("ATOM") or (hetatm and line.startswith("HETATM")):
-            ch = line[21:22]
+            ch = _field(line, 21, 1)
             if first_chain is None:
                 first_chain = ch
             if single_chain and ch != first_chain:
-                raise StructureError("multiple chains")
-            atom.append(line[12:16].strip())
-            residue.append(line[17:20].strip())
-            chain.append(ch)
-            ai.append(int(line[6:11]))
-            ri.append(int(line[22:26]))
-            xyz.append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
-            b = line[60:66].strip()
-            bf.append(float(b) if b else 0.0)
-    return AtomTable(atom, residue, chain, np.asarray(ai, np.int32), np.asarray(ri, np.int32),
+                raise MultipleChainsError("multiple chains")
+            a_name, r_name = _field(line, 12, 4).strip(" \t"), _field(line, 17, 3).strip(" \t")
+            serial, resi = _stoi(_field(line, 6, 5)), _stoi(_field(line, 22, 4))
+            x, y, z = _stof(_field(line, 30, 8)), _stof(_field(line, 38, 8)), _stof(_field(line, 46, 8))
+            _stof(_field(line, 54, 6))                                      # the occupancy: read, not used
+            b = _stof(_field(line, 60, 6))
+            atom.append(a_name); residue.append(r_name); chain.append(ch)
+            ai.append(serial); ri.append(resi); xyz.append((x, y, z)); bf.append(b)
+    return AtomTable(atom, residue, chain, np.asarray(ai, np.int64).astype(np.int32), np.asarray(ri, np.int64).astype(np.int32),
                      np.asarray(xyz, np.float64).astype(np.float32).reshape(-1, 3),
                      np.asarray(bf, np.float64).astype(np.float32))
 
@@ -97,7 +151,6 @@ def parse_pdb(text: str, *, hetatm: bool = False, single_chain: bool = False) ->
 #     (number, insertion code, name, segment) was seen before joins THAT residue, wherever its line stands;
 #   * the title is the HEADER id code (columns 63-66 of the last HEADER record long enough to hold it, right-trimmed), else the
 #     TITLE records' columns 11.. right-trimmed and concatenated.
-import re
 
 _NUM_PREFIX = re.compile(rb"-?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?")
 _SPACES = b" \t\n\v\f\r"

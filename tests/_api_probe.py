@@ -111,6 +111,44 @@ def main():
     out["random_access"] = cap(lambda: [d[7][0], d[2][0], d[3][0], d[3][0], d[0][0]])
     out["close"] = cap(lambda: d.close())
     out["close_twice"] = cap(lambda: d.close())
+    # ---- extra inputs (tests/test_api_vs_reference_module.py: the differential fuzz's variants rendered as PDB text, composite files):
+    #      compress, decompress of the result, get_data of the text and of the record
+    if len(sys.argv) > 3:
+        x = np.load(sys.argv[3])
+        forked = len(sys.argv) > 4 and sys.argv[4] == "fork"      # (the reference's module ends the PROCESS on some texts -- std::stof throws
+        for k in sorted(x.keys()):                                #  through a noexcept frame --: each input in a child of its own)
+            text = x[k].tobytes().decode("latin-1")
+
+            def one():
+                res = {}
+                rec = cap(lambda: foldcomp.compress(k, text))
+                res["x_compress:" + k] = rec
+                res["x_get_data_text:" + k] = cap(lambda: foldcomp.get_data(text))
+                if rec[0] == "ok":
+                    raw = foldcomp.compress(k, text)
+                    res["x_decompress:" + k] = cap(lambda: foldcomp.decompress(raw))
+                    res["x_get_data_fcz:" + k] = cap(lambda: foldcomp.get_data(raw))
+                return res
+            if not forked:
+                out.update(one())
+                continue
+            r, w = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                os.close(r)
+                try:
+                    with os.fdopen(w, "w") as fh:
+                        json.dump(one(), fh)
+                finally:
+                    os._exit(0)
+            os.close(w)
+            with os.fdopen(r) as fh:
+                data = fh.read()
+            _, status = os.waitpid(pid, 0)
+            try:
+                out.update(json.loads(data) if status == 0 else {"x_compress:" + k: ["process ended", status]})
+            except ValueError:
+                out["x_compress:" + k] = ["process ended", status]
     json.dump(out, sys.stdout)
 
 

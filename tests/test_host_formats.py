@@ -182,3 +182,32 @@ def test_pdb_text_of_degenerate_records_equals_live_reference():
                 assert _pdb_from_result(fczfile.parse(e), o, i, alt) == ref, (name, alt, i)
                 seen_nan = seen_nan or "(.00(" in ref
     assert seen_nan, "the cases must reach the NaN text"
+
+
+def test_module_reader_takes_numbers_as_stoi_and_stof_do():
+    """the Python binding reads ATOM lines with std::stoi / std::stof of fixed substrings (foldcomp/foldcomp.cxx:259-277): the
+    longest numeric prefix counts (columns that overflowed: "0-9999.0" is 0, "1.00 5" is 1), a field without a number or a line that
+    ends before column 61 makes the reference's extension end the interpreter -- an exception here. Held to the reference's module
+    on 226 rendered inputs in tests/test_api_vs_reference_module.py (GPU); this is the CPU half"""
+    from foldcomp_amd.structure import MultipleChainsError, StructureError, _stof, _stoi, parse_pdb
+    for f, v in (("0-9999.0", 0.0), ("1.00 5", 1.0), ("0 35.1", 0.0), ("  12.5A", 12.5), (".5", 0.5), ("5.", 5.0), ("1e3", 1000.0), ("1e", 1.0), ("0x1A", 26.0),
+                 ("0x", 0.0), ("  +7.25 ", 7.25), ("1_0", 1.0), ("\t-3.5e-1x", -0.35)):
+        assert _stof(f) == v, f
+    assert str(_stof(" -0.000")) == "-0.0" and _stof("inf") == float("inf") and _stof("-nan(x)") != _stof("-nan(x)")
+    for f in ("", "   ", "abc", "-", "1e99", "1e-60", "e5"):
+        with pytest.raises(StructureError):
+            _stof(f)
+    assert _stoi("  12A") == 12 and _stoi("-5 ") == -5 and _stoi("+007") == 7
+    for f in ("", " x1", "99999999999"):
+        with pytest.raises(StructureError):
+            _stoi(f)
+    line = "ATOM      1  N   MET A   1     -20.714   0.344  16.577  1.00 56.93           N  "
+    t = parse_pdb(line + "\n" + line[:62] + "\n")                       # the second line ends inside the B-factor: " 5" is 5
+    assert len(t) == 2 and float(t.bfac[1]) == 5.0
+    with pytest.raises(StructureError):
+        parse_pdb(line[:60] + "\n")                                      # ends before column 61: substr(60) of a 60-character line is empty
+    with pytest.raises(StructureError):
+        parse_pdb(line[:54] + "      " + line[60:] + "\n")              # a blank occupancy: std::stof throws though nobody uses the value
+    with pytest.raises(MultipleChainsError):
+        parse_pdb(line + "\n" + line[:21] + "B" + line[22:] + "\n", single_chain=True)
+    assert len(parse_pdb(line + "\r\n" + line + "\r")) == 2              # lines end at '\n' only; a '\r' stays in the line

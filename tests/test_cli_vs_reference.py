@@ -327,9 +327,10 @@ def _would_spin(path) -> bool:
     """the reference's identifyChains loops forever on some files (_cases.reference_would_spin): those are not put to its command
     line (each would cost the test its timeout)"""
     from _cases import reference_would_spin
-    from foldcomp_amd.structure import StructureError, parse_pdb_gemmi, remove_alternative_position
+    from foldcomp_amd.structure import StructureError, parse_pdb_gemmi, parse_structure_gemmi, remove_alternative_position
     try:
-        t, _ = parse_pdb_gemmi(open(path, "rb").read())
+        raw = open(path, "rb").read()
+        t, _ = parse_structure_gemmi(raw) if str(path).endswith(".cif") else parse_pdb_gemmi(raw)
         return reference_would_spin(remove_alternative_position(t))
     except StructureError:
         return False
@@ -362,6 +363,16 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
                                         chr(b.chain_id[c]) if 32 < b.chain_id[c] < 127 else "A", int(b.first_atom_index[c]), b.x[sl], b.y[sl], b.z[sl], b.bfac_ca[res_of_atom[sl]])
             nm = f"v{vi:02d}_{c}.pdb"
             (src / nm).write_bytes(text.encode("latin-1")); names.append(nm)
+            if picked == 0 and r1 - r0 <= 400:
+                # the same chain as mmCIF: AFDB's shape for even variants, the archive's (chain names of two characters, insertion
+                # codes, quoted atom names, two models) for odd ones -- where the text's columns let the converter split it
+                try:
+                    import bench
+                    cif = bench.cif_from_pdb_text(text.encode("latin-1"), f"V{vi}") if vi % 2 == 0 else \
+                        bench.cif_archive_from_pdb_text(text.encode("latin-1"), f"V{vi}", bench.ARCHIVE_STYLES[(7 * vi) % len(bench.ARCHIVE_STYLES)])
+                    (src / f"x{vi:02d}.cif").write_bytes(cif); names.append(f"x{vi:02d}.cif")
+                except Exception:
+                    pass
             picked += 1
             if picked == 3:
                 break
@@ -404,6 +415,11 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
     assert not only_mine, only_mine[:10]
     assert not unexplained, unexplained[:10]
     assert same >= len(names) * 3 // 4, (same, len(names))
+    # the Python host leaves the same directory as the C++ host
+    r = _run(HOSTS["py"] + ["compress", str(src), str(tmp_path / "mine_py")], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    tp = _tree(str(tmp_path / "mine_py"))
+    assert set(tp) == set(mine) and not [k for k in mine if tp[k] != mine[k]], (sorted(set(tp) ^ set(mine))[:10], [k for k in mine if k in tp and tp[k] != mine[k]][:10])
     # our records decoded by both command lines: the same text, file by file
     r = _run([BIN, "decompress", str(tmp_path / "mine"), str(tmp_path / "dec_mine")], cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]

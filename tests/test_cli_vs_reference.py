@@ -415,6 +415,28 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
     assert not only_mine, only_mine[:10]
     assert not unexplained, unexplained[:10]
     assert same >= len(names) * 3 // 4, (same, len(names))
+    # the files the reference took, as one directory -> one database by both command lines (-d), and back to a database of texts
+    safe = tmp_path / "safe"; safe.mkdir()
+    for nm in names:
+        if nm not in ref_failed:
+            shutil.copy(src / nm, safe / nm)
+    r = _run([BIN, "compress", "-d", str(safe), str(tmp_path / "db_mine")], cwd=str(tmp_path))
+    rr = subprocess.run([REF, "compress", "-d", str(safe), str(tmp_path / "db_ref")], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0 and rr.returncode == 0, (r.stderr[-1000:], rr.stderr[-1000:])
+    lm, lr = _db(tmp_path / "db_mine"), _db(tmp_path / "db_ref")                  # sorted (name, record) pairs: a name may come twice
+    from collections import Counter
+    cm, cr = Counter(lm), Counter(lr)
+    only_mine_db = sorted((cm - cr).elements())
+    assert not only_mine_db, [(k, len(v), [len(x) for n2, x in lr if n2 == k]) for k, v in only_mine_db[:10]]
+    dm = dict(lm)
+    r = _run([BIN, "decompress", "-d", str(tmp_path / "db_mine"), str(tmp_path / "tdb_mine")], cwd=str(tmp_path))
+    rr = _run([REF, "decompress", "-d", str(tmp_path / "db_mine"), str(tmp_path / "tdb_ref")], cwd=str(tmp_path))
+    assert r.returncode == 0 and rr.returncode == 0, (r.stderr[-1000:], rr.stderr[-1000:])
+    from foldcomp_amd.database import DatabaseReader
+    def texts(path):
+        d = DatabaseReader(str(path)); out = {d.name(i): bytes(d.data(i)) for i in range(len(d))}; d.close(); return out
+    tm_, tr_ = texts(tmp_path / "tdb_mine"), texts(tmp_path / "tdb_ref")
+    assert set(tm_) == set(tr_) and len(tm_) == len(dm) and not [k for k in tm_ if tm_[k] != tr_[k]], [k for k in tm_ if tm_.get(k) != tr_.get(k)][:10]
     # the Python host leaves the same directory as the C++ host
     r = _run(HOSTS["py"] + ["compress", str(src), str(tmp_path / "mine_py")], cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]

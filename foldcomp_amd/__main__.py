@@ -307,8 +307,18 @@ def run_decompress(a, inputs, output, kind, single):
             if a.check:
                 from . import _lib
                 arr = np.frombuffer(data, np.uint8)
-                if _lib.load().fcz_check(arr.ctypes.data, len(arr)) != 0:
-                    print(f"[Error] invalid FCZ entry skipped: {name}", file=sys.stderr); continue
+                rc = _lib.load().fcz_check(arr.ctypes.data, len(arr))
+                if rc != 0:
+                    # the reference prints printValidityError's line with the record's TITLE (src/main.cpp:630-635)
+                    what = {1: "Number of backbone angles does not match header", 2: "Number of sidechain angles does not match header",
+                            3: "Number of temperature factors does not match header", 4: "All backbone angles are empty",
+                            5: "All sidechain angles are empty", 6: "All temperature factors are empty"}
+                    if rc in what and len(data) >= 76:
+                        o_title = 76 + 4 * data[12]; tl = int.from_bytes(data[24:28], "little")
+                        print(f"[Error] {what[rc]}: {bytes(data[o_title:o_title + tl]).decode('latin-1') if o_title + tl <= len(data) else ''}", file=sys.stderr)
+                    else:
+                        print(f"[Error] invalid FCZ entry skipped: {name}", file=sys.stderr)
+                    continue
             names.append(name); ents.append(data)
             if len(ents) >= BATCH_CHAINS:
                 flush()
@@ -376,8 +386,10 @@ def run_extract(a, inputs, output, kind, single):
 def run_check(a, inputs):
     from . import _lib
     lib = _lib.load()
-    msgs = {1: "backbone count mismatch", 2: "side chain count mismatch", 3: "temperature factor count mismatch",
-            4: "empty backbone angles", 5: "empty side chain angles", 6: "empty temperature factors"}
+    # the lines of printValidityError (src/foldcomp.cpp:1534-1560), word for word: "[Error] <what>: <name>"
+    msgs = {1: "Number of backbone angles does not match header", 2: "Number of sidechain angles does not match header",
+            3: "Number of temperature factors does not match header", 4: "All backbone angles are empty",
+            5: "All sidechain angles are empty", 6: "All temperature factors are empty"}
     for inp in inputs:
         for name, data in iter_entries(inp, a.recursive, a.id_list, a.id_mode):
             arr = np.frombuffer(data, np.uint8)
@@ -385,7 +397,7 @@ def run_check(a, inputs):
             if rc == 0:
                 print(f"[Info] {name} is valid.")
             else:
-                print(f"[Error] {name}: {msgs.get(rc, 'not a valid FCZ entry')}", file=sys.stderr)
+                print(f"[Error] {msgs[rc]}: {name}" if rc in msgs else f"[Error] {name}: not a valid FCZ entry", file=sys.stderr)
 
 
 def run_rmsd(a, p1, p2):

@@ -2835,7 +2835,21 @@ int run_decompress(const Options& o) {
                     for (uint32_t i = 0; i < ents.n(); i++) {
                         const uint64_t len = ents.off[i + 1] - ents.off[i];
                         const int rc = len ? fcz_check(ents.blob.data() + ents.off[i], len) : FCZ_E_TRUNCATED;
-                        if (rc != 0) { if (!sizes_only) fprintf(stderr, "[Error] invalid FCZ entry skipped: %s\n", ents.names[i].c_str()); continue; }
+                        if (rc != 0) {
+                            // the reference prints printValidityError's line with the record's TITLE (src/main.cpp:630-635)
+                            static const char* what[] = {"", "Number of backbone angles does not match header", "Number of sidechain angles does not match header",
+                                                         "Number of temperature factors does not match header", "All backbone angles are empty",
+                                                         "All sidechain angles are empty", "All temperature factors are empty"};
+                            if (!sizes_only) {
+                                if (rc >= 1 && rc <= 6 && len >= 76) {
+                                    const uint8_t* e = ents.blob.data() + ents.off[i];
+                                    const uint64_t o_title = 76 + 4 * (uint64_t)e[12], tl = (uint64_t)e[24] | ((uint64_t)e[25] << 8) | ((uint64_t)e[26] << 16) | ((uint64_t)e[27] << 24);
+                                    const std::string title = o_title + tl <= len ? std::string((const char*)e + o_title, (size_t)tl) : std::string();
+                                    fprintf(stderr, "[Error] %s: %s\n", what[rc], title.c_str());
+                                } else fprintf(stderr, "[Error] invalid FCZ entry skipped: %s\n", ents.names[i].c_str());
+                            }
+                            continue;
+                        }
                         ok.add(ents.names[i], std::string((const char*)ents.blob.data() + ents.off[i], len));
                     }
                     ents = std::move(ok);
@@ -3129,8 +3143,10 @@ int run_extract(const Options& o) {
 }
 
 int run_check(const Options& o) {
-    static const char* msgs[] = {"", "backbone count mismatch", "side chain count mismatch", "temperature factor count mismatch",
-                                 "empty backbone angles", "empty side chain angles", "empty temperature factors"};
+    // the lines of printValidityError (src/foldcomp.cpp:1534-1560), word for word: "[Error] <what>: <name>"
+    static const char* msgs[] = {"", "Number of backbone angles does not match header", "Number of sidechain angles does not match header",
+                                 "Number of temperature factors does not match header", "All backbone angles are empty",
+                                 "All sidechain angles are empty", "All temperature factors are empty"};
     // checkValidity of every entry on all host threads (the reference: process_entry_func under `omp parallel for`,
     // src/main.cpp:911-930); the lines of a batch are printed in input order, one write per stream
     Entries ents;
@@ -3147,7 +3163,8 @@ int run_check(const Options& o) {
         for (uint32_t i = 0; i < n; i++) {
             const int rc = rcs[i];
             if (rc == 0) { out += "[Info] "; out += ents.names[i]; out += " is valid.\n"; }
-            else { err += "[Error] "; err += ents.names[i]; err += ": "; err += (rc >= 1 && rc <= 6) ? msgs[rc] : "not a valid FCZ entry"; err += "\n"; }
+            else if (rc >= 1 && rc <= 6) { err += "[Error] "; err += msgs[rc]; err += ": "; err += ents.names[i]; err += "\n"; }
+            else { err += "[Error] "; err += ents.names[i]; err += ": not a valid FCZ entry\n"; }      // (the reference: "[Error] File is not a valid fcz file", without the name)
         }
         if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);
         if (!err.empty()) fwrite(err.data(), 1, err.size(), stderr);

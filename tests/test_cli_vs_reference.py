@@ -451,6 +451,21 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
     assert set(tm) == set(tr) and len(tm) >= same
     bad = [k for k in tm if tm[k] != tr[k]]
     assert not bad, bad[:10]
+    # `check` of our records by both: the same [Error] lines (records whose B-factor bytes are all zero -- constant, zero, denormal
+    # B-factors --, chains without a side-chain torsion: all GLY)
+    def errors(r):                                     # (this host also says "[Info] <name> is valid." on stdout; the reference is silent about valid entries)
+        return sorted(l.strip() for l in (r.stderr + r.stdout).splitlines() if l.startswith("[Error]"))
+    r = _run([BIN, "check", "mine"], cwd=str(tmp_path)); rr = _run([REF, "check", "mine"], cwd=str(tmp_path))
+    assert r.returncode == rr.returncode, (r.returncode, rr.returncode)
+    em, er = errors(r), errors(rr)
+    assert em == er, (len(em), len(er), sorted(set(em) ^ set(er))[:6])
+    assert any("temperature factors are empty" in l for l in er) and any("sidechain angles are empty" in l for l in er), er[:5]
+    # decompress --check: the records `check` complains about are reported (with their titles) and left out by both
+    r = _run([BIN, "decompress", "--check", "mine", "chk_mine"], cwd=str(tmp_path)); rr = _run([REF, "decompress", "--check", "mine", "chk_ref"], cwd=str(tmp_path))
+    assert r.returncode == 0 and rr.returncode == 0, (r.stderr[-500:], rr.stderr[-500:])
+    assert errors(r) == errors(rr) and len(errors(r)) == len(er), (errors(r)[:3], errors(rr)[:3])
+    tm, tr = _tree(str(tmp_path / "chk_mine")), _tree(str(tmp_path / "chk_ref"))
+    assert set(tm) == set(tr) and len(tm) == len(mine) - len(er) and not [k for k in tm if tm[k] != tr[k]]
     # and extracted by both: pLDDT strings of one to four digits (B-factors negative, huge, denormal, constant among them), sequences
     for flags in (["--plddt"], ["--plddt", "-p", "2"], ["--plddt", "-p", "3"], ["--plddt", "-p", "4"], ["--fasta"]):
         tag = "x" + "".join(f.strip("-") for f in flags)

@@ -419,7 +419,7 @@ def test_cpp_cli_flags_equal_the_python_cli(tmp_path, golden):
         return {f: (p / f).read_bytes() for f in sorted(os.listdir(p))}
     # decompress --check: the invalid entry is skipped by both hosts, the others decompress to the same text
     r = _run("decompress", "--check", "-y", str(tmp_path / "bad"), str(tmp_path / "c_chk"))
-    assert r.returncode == 0 and "invalid FCZ entry skipped" in r.stderr, r.stderr
+    assert r.returncode == 0 and "[Error] All backbone angles are empty: " in r.stderr, r.stderr    # (printValidityError's line, with the record's title)
     py_main(["decompress", "--check", "-y", str(tmp_path / "bad"), str(tmp_path / "p_chk")])
     assert len(os.listdir(tmp_path / "c_chk")) == len(names) - 1 and tree(tmp_path / "c_chk") == tree(tmp_path / "p_chk")
     # --id-list by name into a database; the texts are the reference's

@@ -482,6 +482,18 @@ def main(argv=None):
         if a.gpus > 1 and "RANK" not in os.environ:
             return sharded_cli.launch(list(argv) if argv is not None else sys.argv[1:], a.gpus)
         return sharded_cli.run(a, inputs, output.rstrip("/"))
+    # the reference's announcement of what it is about to do (src/main.cpp:392-403, :564-575, :717-734, :870-875), word for word
+    verb = {"compress": "Compressing", "decompress": "Decompressing", "extract": "Extracting", "check": "Checking"}[a.mode]
+    shown = (output or "").rstrip("/")
+    if a.mode == "check":
+        print(f"Checking {inp}" if len(inputs) == 1 else f"Checking files in {inp} using {a.threads} threads")
+    elif single:
+        print(f"{verb} {inp} to {shown}")
+    else:
+        print(f"{verb} files in {inp} using {a.threads} threads")
+        print(f"Output database: {shown}" if a.db else f"Output tar file: {shown}" if a.tar else
+              f"Output directory: {shown}" if (a.mode != "extract" or not a.merge) else f"Output: {shown}")
+    sys.stdout.flush()
     if a.mode == "compress":
         run_compress(a, inputs, output.rstrip("/") if kind != "file" else output, kind, single)
     elif a.mode == "decompress":

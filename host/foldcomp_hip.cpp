@@ -1462,6 +1462,7 @@ struct Options {
     int workers_per_gpu = 2;    // host threads (each with its own ctx and stream) per device
     int write_threads = 8;      // threads a decompress worker writes its job's text with (set from -t: threads / workers)
     bool json_stats = false;    // --json-stats: one JSON line with counts and wall times on stdout
+    int threads_said = 1;       // -t as given (the reference's default: 1): only for the announcement lines
     int shard_rank = 0, shard_world = 1;   // --shard R/N: this process is rank R of N of a sharded database run (see InputPlan)
     int device = 0;             // --device D: first HIP device of this process (a rank of a sharded run drives device LOCAL_RANK)
     bool place = false;         // --place: decompress -d as a rank of a sharded run: sizes pass over the range, counts on stdout, then the
@@ -3407,7 +3408,7 @@ int main(int argc, char** argv) {
         else if (a == "-r" || a == "--recursive") o.recursive = true;
         else if (a == "-b" || a == "--break") next_int(o.brk);
         else if (a == "-p" || a == "--plddt-digits") next_int(o.digits);
-        else if (a == "-t" || a == "--threads") { int t = 0; next_int(t); if (t > 0) omp_set_num_threads(t); }   // host parse threads
+        else if (a == "-t" || a == "--threads") { int t = 0; next_int(t); if (t > 0) { omp_set_num_threads(t); o.threads_said = t; } }   // host parse threads
         else if (a == "--gpus") next_int(o.gpus);
         else if (a == "--workers-per-gpu") next_int(o.workers_per_gpu);
         else if (a == "--json-stats") o.json_stats = true;
@@ -3477,6 +3478,23 @@ int main(int argc, char** argv) {
         else o.output = o.input + "_" + suffix;
     }
     if (device_mod && (o.mode == "compress" || o.mode == "decompress")) { const int nd = fcz_device_count(); if (nd > 0) o.device %= nd; }
+    // the reference's announcement of what it is about to do (src/main.cpp:392-403, :564-575, :717-734, :870-875), word for word --
+    // not from an engine of a sharded run or with --json-stats, whose stdout is read by a program
+    if (!o.json_stats && o.shard_world <= 1 && !o.place && (writes_members || o.mode == "check")) {
+        const char* verb = o.mode == "compress" ? "Compressing" : o.mode == "decompress" ? "Decompressing" : o.mode == "extract" ? "Extracting" : "Checking";
+        if (o.mode == "check") {
+            if (o.inputs.size() == 1) printf("Checking %s\n", o.input.c_str());
+            else printf("Checking files in %s using %d threads\n", o.input.c_str(), o.threads_said);
+        } else if (o.single) printf("%s %s to %s\n", verb, o.input.c_str(), o.output.c_str());
+        else {
+            printf("%s files in %s using %d threads\n", verb, o.input.c_str(), o.threads_said);
+            if (o.db) printf("Output database: %s\n", o.output.c_str());
+            else if (o.tar) printf("Output tar file: %s\n", o.output.c_str());
+            else if (o.mode != "extract" || !o.merge) printf("Output directory: %s\n", o.output.c_str());
+            else printf("Output: %s\n", o.output.c_str());
+        }
+        fflush(stdout);
+    }
     if (o.mode == "compress") return run_compress(o);
     o.write_threads = std::max(1, omp_get_max_threads() / std::max(1, (o.gpus <= 0 ? 1 : o.gpus) * std::max(1, o.workers_per_gpu)));
     if (o.mode == "decompress") return run_decompress(o);

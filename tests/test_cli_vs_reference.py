@@ -437,6 +437,15 @@ def test_compress_and_decompress_of_rendered_variants_beside_the_reference(tmp_p
         d = DatabaseReader(str(path)); out = {d.name(i): bytes(d.data(i)) for i in range(len(d))}; d.close(); return out
     tm_, tr_ = texts(tmp_path / "tdb_mine"), texts(tmp_path / "tdb_ref")
     assert set(tm_) == set(tr_) and len(tm_) == len(dm) and not [k for k in tm_ if tm_[k] != tr_[k]], [k for k in tm_ if tm_.get(k) != tr_.get(k)][:10]
+    # what the command lines SAY on stdout before they start: the reference's lines, word for word, from both hosts
+    for cmd in (["compress", "safe", "say_c"], ["compress", "-d", "safe", "say_db"], ["decompress", "mine", "say_d"], ["extract", "--plddt", "mine", "say_e"],
+                ["extract", "--fasta", "--no-merge", "mine", "say_n"], ["check", "mine"], ["compress", "-t", "3", "-z", "safe", "say_t.tar"]):
+        said_by = {}
+        for h in ("ref", "cpp", "py"):
+            out_name = [c + "_" + h if c.startswith("say_") else c for c in cmd]
+            rr_ = _run(HOSTS[h] + out_name, cwd=str(tmp_path))
+            said_by[h] = [l.replace("_" + h, "") for l in rr_.stdout.splitlines() if l.split(" ")[0] in ("Compressing", "Decompressing", "Extracting", "Checking", "Output")]
+        assert said_by["cpp"] == said_by["ref"] and said_by["py"] == said_by["ref"] and said_by["ref"], (cmd, said_by)
     # the Python host leaves the same directory as the C++ host
     r = _run(HOSTS["py"] + ["compress", str(src), str(tmp_path / "mine_py")], cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]

@@ -162,3 +162,38 @@ def test_oracle_decode_of_mutated_records_equals_live_reference(golden):
             assert t[0] == "ok" and extract_plddt(fczfile.parse(e), digits) == t[1], (i, digits)
     ref.close()
     assert same > 150 and crashed < same // 4, (same, crashed)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_decode_of_records_with_any_header_floats_equals_live_reference(golden):
+    """the twelve angle parameters, anchor coordinates and the OXT atom of golden records set to anything (tools/dbg/param_fuzz.py:
+    huge, tiny, negative, NaN, infinite -- angles of thousands of radians go through glibc's large-argument sine / cosine): the
+    restatement's decode == Foldcomp::decompress of the live reference, both atom orders. The device is held to the restatement on
+    the same kind of records in tests/test_gpu_parity_fuzz.py"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("param_fuzz", os.path.join(root, "tools", "dbg", "param_fuzz.py"))
+    pf = importlib.util.module_from_spec(spec); spec.loader.exec_module(pf)
+    from _cases import golden_records
+    recs = pf.mutated(golden_records(golden), np.random.default_rng(20261001), per_record=3)
+    blob, off = entries_blob(recs)
+    ref = H.RefWorker()
+    same = crashed = 0
+    for alt in (False, True):
+        o = H.oracle_decompress(blob, off, alt_order=alt, n_threads=4)
+        for i, e in enumerate(recs):
+            if o["info"][i].status != 0:
+                continue
+            got_r = ref.call("ref_decompress", e, alt)
+            if got_r[0] != "ok":
+                crashed += 1; continue
+            r = got_r[1]
+            a0, a1 = o["atom_off"][i], o["atom_off"][i + 1]
+            assert a1 - a0 == len(r["x"]), i
+            for k in "xyz":
+                got, exp = o[k][a0:a1], np.asarray(r[k], np.float32)
+                assert np.all((_bits(got) == _bits(exp)) | (np.isnan(got) & np.isnan(exp))), (i, alt, k, np.frombuffer(e, np.float32, 12, 28))
+            same += 1
+    ref.close()
+    assert same > 200 and crashed < same // 4, (same, crashed)
